@@ -1,0 +1,211 @@
+/*
+ * pqv.h -- C ABI of the MI355X-native pq-vector hot path (libpqv_hip.so).
+ *
+ * This is the drop-in boundary.  The reference (pure Rust, no FFI of its own) would bind
+ * these symbols from a `extern "C"` block where its L1 "IVF core" meets its callers; each
+ * entry point cites the reference interface it replaces (paths relative to the reference
+ * repo).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - return 0 (PQV_OK) or a negative pqv_status; the message for the calling thread is
+ *     returned by pqv_last_error().  Validation messages are the reference's own strings
+ *     (src/ivf/index.rs:24,89,158,169; src/ivf/mod.rs:59,86; src/ivf/parquet.rs:90,93;
+ *     src/ivf/search.rs:67,72,92-97) so a Rust shim can surface identical errors.
+ *   - inputs are borrowed for the duration of the call (mirrors `&[f32]`); outputs are
+ *     either caller-allocated fixed-size arrays or library buffers released with the
+ *     matching pqv_*_free.  Opaque handles own host + device memory.
+ *   - every entry point is blocking and callable from any thread.  A handle may be shared
+ *     across threads; calls on one pqv_searcher serialise on its internal scratch.
+ *   - there is NO CPU fallback: every compute entry point fails with PQV_ERR_NO_DEVICE
+ *     when no gfx950 device is usable.
+ *   - row ids are file-global u32 row ordinals, as in the reference (src/ivf/index.rs:13).
+ */
+#ifndef PQV_H
+#define PQV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pqv_status {
+    PQV_OK              = 0,
+    PQV_ERR_INVALID     = -1,  /* argument validation (reference's message texts)      */
+    PQV_ERR_NO_DEVICE   = -2,  /* no usable HIP device / device index out of range      */
+    PQV_ERR_HIP         = -3,  /* a HIP runtime call failed                              */
+    PQV_ERR_OOM         = -4,  /* host or device allocation failed                       */
+    PQV_ERR_UNSUPPORTED = -5,  /* outside the implemented envelope (e.g. k > 1024)       */
+    PQV_ERR_FORMAT      = -6   /* malformed index blob                                   */
+} pqv_status;
+
+/* Summation order of the squared-L2 distance. */
+typedef enum pqv_metric {
+    PQV_L2SQ_REF4 = 0, /* src/ivf/index.rs:461-480: sum += ((d0^2+d1^2)+d2^2)+d3^2 per 4 */
+    PQV_L2SQ_SEQ  = 1  /* src/df_vector/exec.rs:529-533: dist += d^2, element by element */
+} pqv_metric;
+
+/* pqv_searcher_create flags */
+#define PQV_LAYOUT_IVF_ORDERED   0x0u /* copy rows into cluster-contiguous order in HBM (default) */
+#define PQV_LAYOUT_ROW_ORDER     0x1u /* keep file row order; re-rank gathers rows by id          */
+#define PQV_RELEASE_ROW_ORDER    0x2u /* with IVF_ORDERED: let the corpus drop its row-order copy */
+
+typedef struct pqv_index    pqv_index;    /* IvfIndex: dim, n_clusters, centroids, inverted lists */
+typedef struct pqv_corpus   pqv_corpus;   /* the embedding column, resident in one GPU's HBM     */
+typedef struct pqv_searcher pqv_searcher; /* (index, corpus) bound for querying on one GPU       */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *pqv_last_error(void);
+/* Number of usable HIP devices (0 on a machine without a GPU; never an error). */
+int pqv_device_count(void);
+/* Library ABI version (major*100 + minor). */
+int pqv_abi_version(void);
+
+/* ---- embedding column -> HBM ---------------------------------------------------------
+ * Replaces the materialised `Embeddings{data: Vec<f32>, dim}` that
+ * read_parquet_with_embeddings hands to build_ivf_index (src/ivf/parquet.rs:216-305,
+ * src/ivf/mod.rs:72-102) and the per-query read_embeddings_for_rows gather
+ * (src/ivf/search.rs:155-244): the column is uploaded once and stays resident. */
+
+/* rows: host [n, dim] row-major f32.  n may be 0 (build then fails like the reference). */
+int pqv_corpus_upload(int device, const float *rows, uint64_t n, uint32_t dim,
+                      pqv_corpus **out);
+/* Append-style upload for streaming row groups: create empty with capacity, then append. */
+int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t dim, pqv_corpus **out);
+int pqv_corpus_append(pqv_corpus *corpus, const float *rows, uint64_t n_rows);
+/* Same, narrowing a Float64 column to f32 first (src/ivf/parquet.rs:246-256). */
+int pqv_corpus_append_f64(pqv_corpus *corpus, const double *rows, uint64_t n_rows);
+/* Adopt an existing device buffer [n, dim] f32 on `device` (borrowed; caller keeps it
+ * alive and frees it). */
+int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,
+                           pqv_corpus **out);
+uint64_t pqv_corpus_rows(const pqv_corpus *corpus);
+uint32_t pqv_corpus_dim(const pqv_corpus *corpus);
+int      pqv_corpus_device(const pqv_corpus *corpus);
+/* Gather rows (file row ordinals) back to the host: out [m, dim]. */
+int pqv_corpus_fetch_rows(const pqv_corpus *corpus, const uint32_t *rows, uint64_t m,
+                          float *out);
+void pqv_corpus_free(pqv_corpus *corpus);
+
+/* ---- index build ---------------------------------------------------------------------
+ * Replaces build_ivf_index(&Embeddings, IvfBuildConfig{n_clusters, max_iters, seed})
+ * (src/ivf/index.rs:152-214) including k_means (:323-457), sample_embeddings (:222-242)
+ * and the final assignment (:189-206).
+ *   n_clusters == 0  => ceil(sqrt(n))                     (:161-167)
+ *   workers          => the `available_parallelism()` the reference would see; it fixes the
+ *                       f32 partial-sum chunking of k-means++ (:259-265,:356-370).
+ *                       0 => this host's online CPU count. */
+int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
+                    uint64_t seed, uint32_t workers, pqv_index **out);
+/* Host-pointer form with the reference's exact argument shape: uploads, builds, frees. */
+int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
+                         uint32_t n_clusters, uint32_t max_iters, uint64_t seed,
+                         uint32_t workers, pqv_index **out);
+/* k_means alone (src/ivf/index.rs:323-457) over a resident matrix; centroids [k*dim] and
+ * assignments [n] are host outputs; iters_run may be NULL. */
+int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_iters, uint64_t seed,
+               uint32_t workers, float *centroids, uint32_t *assignments,
+               uint32_t *iters_run);
+
+/* ---- index blob ----------------------------------------------------------------------
+ * IvfIndex::to_bytes / from_bytes (src/ivf/index.rs:65-128); byte-identical layout. */
+int  pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index **out);
+int  pqv_index_to_bytes(const pqv_index *index, uint8_t **buf, size_t *len);
+void pqv_bytes_free(uint8_t *buf);
+/* Assemble from parts (what IvfIndex{..} literal construction does in index.rs:497-502). */
+int  pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const float *centroids,
+                          const uint64_t *list_off /*[n_clusters+1]*/,
+                          const uint32_t *list_rows, pqv_index **out);
+uint32_t pqv_index_dim(const pqv_index *index);              /* IvfIndex::dim() :53 */
+uint32_t pqv_index_n_clusters(const pqv_index *index);
+uint64_t pqv_index_n_rows(const pqv_index *index);           /* sum of list lengths   */
+const float    *pqv_index_centroids(const pqv_index *index); /* [n_clusters*dim]      */
+const uint64_t *pqv_index_list_offsets(const pqv_index *index); /* [n_clusters+1]     */
+const uint32_t *pqv_index_list_rows(const pqv_index *index); /* lists, concatenated   */
+void pqv_index_free(pqv_index *index);
+
+/* ---- searching -----------------------------------------------------------------------
+ * Binds an index to the resident column on the corpus' GPU: uploads centroids + lists and
+ * (by default) lays the rows out cluster-contiguously so that a probed inverted list is
+ * one sequential HBM range. */
+int  pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
+                         pqv_searcher **out);
+void pqv_searcher_free(pqv_searcher *searcher);
+
+/* IvfIndex::find_closest_centroids (src/ivf/index.rs:130-149): clusters_out has room for
+ * min(nprobe, n_clusters); *n_out receives the count. */
+int pqv_probe(const pqv_searcher *searcher, const float *query, uint32_t query_len,
+              uint32_t nprobe, uint32_t *clusters_out, uint32_t *n_out);
+/* IvfIndex::candidate_rows (src/ivf/index.rs:57-63): library buffer, probe-rank major. */
+int  pqv_candidate_rows(const pqv_searcher *searcher, const float *query, uint32_t query_len,
+                        uint32_t nprobe, uint32_t **rows, uint64_t *n_rows);
+void pqv_rows_free(uint32_t *rows);
+
+/* topk() (src/ivf/search.rs:83-142) for nq queries at once: probe, re-rank every
+ * candidate, keep the k smallest by (d2, candidate position), order ascending.
+ *   queries      host [nq, query_len]; query_len must equal the index dim (:91-98)
+ *   max_candidates  0 => none; else the CandidateCursor cap (src/df_vector/access.rs:
+ *                   214-242, single file): only the first max_candidates candidates in
+ *                   probe-rank order are considered
+ *   metric       PQV_L2SQ_REF4 (TopkBuilder) or PQV_L2SQ_SEQ (VectorTopKExec)
+ *   sqrt_out     nonzero => dist = sqrt(d2) as TopkBuilder returns (:133); 0 => d2
+ *   row_idx/dist host [nq*k]; entries past n_found[q] are 0xFFFFFFFF / +inf
+ *   n_found      host [nq] (may be NULL)
+ *   n_candidates host [nq] (may be NULL): sum of the probed lists' lengths, before the cap */
+int pqv_topk(const pqv_searcher *searcher, const float *queries, uint32_t nq,
+             uint32_t query_len, uint32_t k, uint32_t nprobe, uint64_t max_candidates,
+             int metric, int sqrt_out, uint32_t *row_idx, float *dist, uint32_t *n_found,
+             uint64_t *n_candidates);
+
+/* Device-resident form: queries and outputs are device pointers on the searcher's GPU,
+ * work is enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = the searcher's
+ * own stream) and the call returns without synchronising.  d_n_found / d_n_candidates
+ * may be NULL.  This is what bench.py times. */
+int pqv_topk_device(const pqv_searcher *searcher, const void *d_queries, uint32_t nq,
+                    uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric,
+                    int sqrt_out, void *d_row_idx, void *d_dist, void *d_n_found,
+                    void *d_n_candidates, void *hip_stream);
+
+/* update_topk_heap / compute_distance_values (src/df_vector/exec.rs:457-550) for one
+ * RecordBatch worth of rows: cand host [m, dim] values buffer, ids[m] the payload to return
+ * (e.g. batch row numbers; NULL => 0..m), valid[m] optional bytes (0 = null row or length
+ * mismatch => skipped, exec.rs:496-498,526-528).  Folds the batch into the running top-k
+ * state (io_rows/io_d2/io_count, caller-owned, capacity k, kept sorted ascending by
+ * (d2, arrival)); pass *io_count = 0 for the first batch. */
+int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
+               const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+               uint32_t *io_rows, float *io_d2, uint32_t *io_count);
+
+/* Merge per-shard top-k lists (one list per file/shard, as topk_from_batches does for
+ * multi-file tables, src/df_vector/exec.rs:264-267): lists [n_lists, nq, k] of d2 (or
+ * distance) and row ids, counts [n_lists, nq]; ties resolve by (value, list index,
+ * position in list).  Host arrays. out_list receives the source list of each result. */
+int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *counts,
+                   uint32_t n_lists, uint32_t nq, uint32_t k, float *out_dist,
+                   uint32_t *out_rows, uint32_t *out_list, uint32_t *out_count);
+
+/* Counters mirroring the reference's plan metrics (src/df_vector/index_exec.rs:289-299,
+ * src/df_vector/exec.rs:411-427), accumulated per searcher since creation. */
+typedef struct pqv_counters_t {
+    uint64_t queries;            /* top-k queries served                                 */
+    uint64_t candidate_rows;     /* sum over queries of probed list lengths              */
+    uint64_t embeddings_fetched; /* rows whose distance was computed (after the cap)     */
+    uint64_t kernel_launches;    /* device kernels enqueued                              */
+} pqv_counters_t;
+int pqv_counters(const pqv_searcher *searcher, pqv_counters_t *out);
+
+/* Kernel timing for bench.py's roofline line.  While enabled, every pqv_topk /
+ * pqv_topk_device call records HIP events on the stream its kernels run on: around the
+ * whole call and around the re-rank kernel alone.  pqv_timing_read synchronises those
+ * events, returns the summed milliseconds and the number of calls since the last read,
+ * and clears them. */
+int pqv_set_timing(pqv_searcher *searcher, int enabled);
+int pqv_timing_read(const pqv_searcher *searcher, double *rerank_ms, double *total_ms,
+                    uint32_t *n_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQV_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libpqv_hip.so (the C ABI declared in include/pqv.h).
+
+The library is built in-tree by `make -C pq-vector_amd/csrc` (see __graft_entry__.build)
+and must be present: there is no CPU or pure-Python fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpqv_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+PQV_OK = 0
+PQV_ERR_INVALID = -1
+PQV_ERR_NO_DEVICE = -2
+PQV_ERR_HIP = -3
+PQV_ERR_OOM = -4
+PQV_ERR_UNSUPPORTED = -5
+PQV_ERR_FORMAT = -6
+
+PQV_L2SQ_REF4 = 0
+PQV_L2SQ_SEQ = 1
+
+PQV_LAYOUT_IVF_ORDERED = 0x0
+PQV_LAYOUT_ROW_ORDER = 0x1
+PQV_RELEASE_ROW_ORDER = 0x2
+
+
+class Counters(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("candidate_rows", C.c_uint64),
+                ("embeddings_fetched", C.c_uint64), ("kernel_launches", C.c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol include/pqv.h declares
+SIGNATURES = {
+    "pqv_last_error": (C.c_char_p, []),
+    "pqv_device_count": (C.c_int, []),
+    "pqv_abi_version": (C.c_int, []),
+    "pqv_corpus_upload": (C.c_int, [C.c_int, f32p, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "pqv_corpus_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "pqv_corpus_append": (C.c_int, [vp, f32p, C.c_uint64]),
+    "pqv_corpus_append_f64": (C.c_int, [vp, f64p, C.c_uint64]),
+    "pqv_corpus_from_device": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "pqv_corpus_rows": (C.c_uint64, [vp]),
+    "pqv_corpus_dim": (C.c_uint32, [vp]),
+    "pqv_corpus_device": (C.c_int, [vp]),
+    "pqv_corpus_fetch_rows": (C.c_int, [vp, u32p, C.c_uint64, f32p]),
+    "pqv_corpus_free": (None, [vp]),
+    "pqv_index_build": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "pqv_index_build_host": (C.c_int, [C.c_int, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "pqv_kmeans": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, f32p, u32p, u32p]),
+    "pqv_index_from_bytes": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(vp)]),
+    "pqv_index_to_bytes": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(C.c_size_t)]),
+    "pqv_bytes_free": (None, [u8p]),
+    "pqv_index_from_parts": (C.c_int, [C.c_uint32, C.c_uint32, f32p, u64p, u32p, C.POINTER(vp)]),
+    "pqv_index_dim": (C.c_uint32, [vp]),
+    "pqv_index_n_clusters": (C.c_uint32, [vp]),
+    "pqv_index_n_rows": (C.c_uint64, [vp]),
+    "pqv_index_centroids": (f32p, [vp]),
+    "pqv_index_list_offsets": (u64p, [vp]),
+    "pqv_index_list_rows": (u32p, [vp]),
+    "pqv_index_free": (None, [vp]),
+    "pqv_searcher_create": (C.c_int, [vp, vp, C.c_uint32, C.POINTER(vp)]),
+    "pqv_searcher_free": (None, [vp]),
+    "pqv_probe": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, u32p, u32p]),
+    "pqv_candidate_rows": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, C.POINTER(u32p), u64p]),
+    "pqv_rows_free": (None, [u32p]),
+    "pqv_topk": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                           C.c_int, C.c_int, u32p, f32p, u32p, u64p]),
+    "pqv_topk_device": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
+                                  C.c_int, vp, vp, vp, vp, vp]),
+    "pqv_rerank": (C.c_int, [C.c_int, f32p, f32p, u32p, u8p, C.c_uint64, C.c_uint32, C.c_uint32,
+                             C.c_int, u32p, f32p, u32p]),
+    "pqv_merge_topk": (C.c_int, [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p,
+                                 u32p, u32p]),
+    "pqv_counters": (C.c_int, [vp, C.POINTER(Counters)]),
+    "pqv_set_timing": (C.c_int, [vp, C.c_int]),
+    "pqv_timing_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u32p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpqv_hip.so; raises loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C pq-vector_amd/csrc). "
+                "pq_vector_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,418 @@
+"""Host-side mirror of the reference's builder API over the C ABI (include/pqv.h).
+
+Names, argument meaning and error texts follow src/ivf/parquet.rs:23-103 (IndexBuilder),
+src/ivf/search.rs:41-81 (TopkBuilder, SearchResult) and src/ivf/index.rs:9-14 (IvfIndex).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import f32p, f64p, u8p, u32p, u64p, vp
+
+
+class PqvError(Exception):
+    """Carries the library's status code and the reference's message text."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+        self.message = message
+
+
+def _check(rc):
+    if rc != _ffi.PQV_OK:
+        raise PqvError(rc, _ffi.lib().pqv_last_error().decode())
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    return _ffi.lib().pqv_device_count()
+
+
+# ---------------------------------------------------------------------------------------
+class Corpus:
+    """The embedding column resident in one GPU's HBM (row-major [n, dim] f32)."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keepalive = keepalive
+
+    @classmethod
+    def upload(cls, rows, device=0):
+        rows = np.asarray(rows)
+        if rows.ndim != 2:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding data length must be a multiple of dimension")
+        n, dim = rows.shape
+        h = vp()
+        if rows.dtype == np.float64:  # narrowed like src/ivf/parquet.rs:246-256
+            _check(_ffi.lib().pqv_corpus_create(device, n, dim, C.byref(h)))
+            c = cls(h)
+            r64 = np.ascontiguousarray(rows)
+            _check(_ffi.lib().pqv_corpus_append_f64(h, r64.ctypes.data_as(f64p), n))
+            return c
+        r = _f32(rows)
+        _check(_ffi.lib().pqv_corpus_upload(device, r.ctypes.data_as(f32p), n, dim, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create(cls, capacity_rows, dim, device=0):
+        h = vp()
+        _check(_ffi.lib().pqv_corpus_create(device, capacity_rows, dim, C.byref(h)))
+        return cls(h)
+
+    def append(self, rows):
+        rows = np.asarray(rows)
+        if rows.dtype == np.float64:
+            r = np.ascontiguousarray(rows)
+            _check(_ffi.lib().pqv_corpus_append_f64(self._h, r.ctypes.data_as(f64p), r.shape[0]))
+        else:
+            r = _f32(rows)
+            _check(_ffi.lib().pqv_corpus_append(self._h, r.ctypes.data_as(f32p), r.shape[0]))
+
+    @classmethod
+    def from_device_ptr(cls, ptr, n, dim, device=0, keepalive=None):
+        """Adopt a device buffer (e.g. a torch tensor's data_ptr()); `keepalive` pins its owner."""
+        h = vp()
+        _check(_ffi.lib().pqv_corpus_from_device(device, vp(ptr), n, dim, C.byref(h)))
+        return cls(h, keepalive)
+
+    @property
+    def rows(self):
+        return _ffi.lib().pqv_corpus_rows(self._h)
+
+    @property
+    def dim(self):
+        return _ffi.lib().pqv_corpus_dim(self._h)
+
+    @property
+    def device(self):
+        return _ffi.lib().pqv_corpus_device(self._h)
+
+    def fetch_rows(self, row_ids):
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint32)
+        out = np.empty((ids.size, self.dim), dtype=np.float32)
+        _check(_ffi.lib().pqv_corpus_fetch_rows(self._h, ids.ctypes.data_as(u32p), ids.size,
+                                                out.ctypes.data_as(f32p)))
+        return out
+
+    def close(self):
+        if self._h:
+            _ffi.lib().pqv_corpus_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------
+class Index:
+    """IvfIndex{dim, n_clusters, centroids, inverted_lists} (src/ivf/index.rs:9-14)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_bytes(cls, blob):
+        h = vp()
+        blob = bytes(blob)
+        _check(_ffi.lib().pqv_index_from_bytes(blob, len(blob), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_parts(cls, dim, centroids, lists):
+        cent = _f32(centroids).reshape(-1)
+        k = len(lists)
+        off = np.zeros(k + 1, dtype=np.uint64)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        rows = (np.concatenate([np.asarray(l, dtype=np.uint32) for l in lists])
+                if k and off[-1] else np.zeros(0, dtype=np.uint32))
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        h = vp()
+        _check(_ffi.lib().pqv_index_from_parts(dim, k, cent.ctypes.data_as(f32p),
+                                               off.ctypes.data_as(u64p), rows.ctypes.data_as(u32p),
+                                               C.byref(h)))
+        return cls(h)
+
+    def to_bytes(self):
+        buf = u8p()
+        n = C.c_size_t(0)
+        _check(_ffi.lib().pqv_index_to_bytes(self._h, C.byref(buf), C.byref(n)))
+        try:
+            return C.string_at(buf, n.value)
+        finally:
+            _ffi.lib().pqv_bytes_free(buf)
+
+    @property
+    def dim(self):
+        return _ffi.lib().pqv_index_dim(self._h)
+
+    @property
+    def n_clusters(self):
+        return _ffi.lib().pqv_index_n_clusters(self._h)
+
+    @property
+    def n_rows(self):
+        return _ffi.lib().pqv_index_n_rows(self._h)
+
+    @property
+    def centroids(self):
+        p = _ffi.lib().pqv_index_centroids(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n_clusters, self.dim)).copy()
+
+    @property
+    def list_offsets(self):
+        p = _ffi.lib().pqv_index_list_offsets(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n_clusters + 1,)).copy()
+
+    @property
+    def list_rows(self):
+        n = self.n_rows
+        if n == 0:
+            return np.zeros(0, dtype=np.uint32)
+        p = _ffi.lib().pqv_index_list_rows(self._h)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def inverted_lists(self):
+        off, rows = self.list_offsets, self.list_rows
+        return [rows[int(off[i]):int(off[i + 1])] for i in range(self.n_clusters)]
+
+    def close(self):
+        if self._h:
+            _ffi.lib().pqv_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------
+class IndexBuilder:
+    """src/ivf/parquet.rs:23-103.  `source` is a Corpus or a [n, dim] array (the in-memory
+    form of the embedding column); defaults n_clusters=None -> ceil(sqrt(n)), max_iters=20,
+    seed=42 (:32-39)."""
+
+    def __init__(self, source, embedding_column=None, device=0):
+        self._source = source
+        self._embedding_column = embedding_column
+        self._device = device
+        self._n_clusters = None
+        self._max_iters = 20
+        self._seed = 42
+        self._workers = 0
+
+    def n_clusters(self, n_clusters):
+        self._n_clusters = n_clusters
+        return self
+
+    def max_iters(self, max_iters):
+        self._max_iters = max_iters
+        return self
+
+    def seed(self, seed):
+        self._seed = seed
+        return self
+
+    def workers(self, workers):
+        """The available_parallelism() to reproduce; 0 = this host's CPU count."""
+        self._workers = workers
+        return self
+
+    def _config(self):
+        # build_config, src/ivf/parquet.rs:88-102
+        if self._max_iters == 0:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "max_iters must be > 0")
+        if self._n_clusters is not None and self._n_clusters == 0:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "n_clusters must be > 0")
+        if self._embedding_column is not None and not str(self._embedding_column).strip():
+            raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding column name cannot be empty")
+        return (self._n_clusters or 0), self._max_iters, self._seed, self._workers
+
+    def build(self):
+        nc, mi, seed, workers = self._config()
+        h = vp()
+        if isinstance(self._source, Corpus):
+            _check(_ffi.lib().pqv_index_build(self._source._h, nc, mi, seed, workers, C.byref(h)))
+        else:
+            data = np.asarray(self._source)
+            if data.ndim == 2:
+                dim = data.shape[1]
+                flat = _f32(data).reshape(-1)
+            else:  # (flat data, dim) is not representable here; require 2-D
+                raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding data length must be a multiple of dimension")
+            _check(_ffi.lib().pqv_index_build_host(self._device, flat.ctypes.data_as(f32p), flat.size,
+                                                   dim, nc, mi, seed, workers, C.byref(h)))
+        return Index(h)
+
+
+# ---------------------------------------------------------------------------------------
+@dataclass
+class SearchResult:
+    """src/ivf/search.rs:41-45"""
+    row_idx: int
+    distance: float
+
+
+class Searcher:
+    """An index bound to a resident corpus on that corpus' GPU."""
+
+    def __init__(self, index, corpus, flags=_ffi.PQV_LAYOUT_IVF_ORDERED):
+        h = vp()
+        _check(_ffi.lib().pqv_searcher_create(index._h, corpus._h, flags, C.byref(h)))
+        self._h = h
+        self._corpus = corpus
+        self.dim = index.dim
+        self.n_clusters = index.n_clusters
+
+    def probe(self, query, nprobe):
+        q = _f32(query).reshape(-1)
+        out = np.zeros(max(1, min(nprobe, self.n_clusters)), dtype=np.uint32)
+        n = C.c_uint32(0)
+        _check(_ffi.lib().pqv_probe(self._h, q.ctypes.data_as(f32p), q.size, nprobe,
+                                    out.ctypes.data_as(u32p), C.byref(n)))
+        return out[:n.value].copy()
+
+    def candidate_rows(self, query, nprobe):
+        q = _f32(query).reshape(-1)
+        rows = u32p()
+        n = C.c_uint64(0)
+        _check(_ffi.lib().pqv_candidate_rows(self._h, q.ctypes.data_as(f32p), q.size, nprobe,
+                                             C.byref(rows), C.byref(n)))
+        try:
+            return (np.ctypeslib.as_array(rows, shape=(n.value,)).copy() if n.value
+                    else np.zeros(0, dtype=np.uint32))
+        finally:
+            _ffi.lib().pqv_rows_free(rows)
+
+    def topk(self, queries, k, nprobe, max_candidates=0, metric=_ffi.PQV_L2SQ_REF4, sqrt_out=True):
+        """Batched topk(); returns (row_idx [nq,k] u32, dist [nq,k] f32, n_found [nq], n_candidates [nq])."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, qlen = q.shape
+        rows = np.full((nq, max(k, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        nf = np.zeros(nq, dtype=np.uint32)
+        nc = np.zeros(nq, dtype=np.uint64)
+        _check(_ffi.lib().pqv_topk(self._h, q.ctypes.data_as(f32p), nq, qlen, k, nprobe, max_candidates,
+                                   metric, 1 if sqrt_out else 0, rows.ctypes.data_as(u32p),
+                                   dist.ctypes.data_as(f32p), nf.ctypes.data_as(u32p),
+                                   nc.ctypes.data_as(u64p)))
+        return rows, dist, nf, nc
+
+    def topk_device(self, d_queries, nq, k, nprobe, d_row_idx, d_dist, d_n_found=0, d_n_candidates=0,
+                    max_candidates=0, metric=_ffi.PQV_L2SQ_REF4, sqrt_out=True, stream=0):
+        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on `stream`."""
+        _check(_ffi.lib().pqv_topk_device(self._h, vp(d_queries), nq, k, nprobe, max_candidates, metric,
+                                          1 if sqrt_out else 0, vp(d_row_idx), vp(d_dist),
+                                          vp(d_n_found or None), vp(d_n_candidates or None),
+                                          vp(stream or None)))
+
+    def counters(self):
+        c = _ffi.Counters()
+        _check(_ffi.lib().pqv_counters(self._h, C.byref(c)))
+        return {"queries": c.queries, "candidate_rows": c.candidate_rows,
+                "embeddings_fetched": c.embeddings_fetched, "kernel_launches": c.kernel_launches}
+
+    def set_timing(self, enabled):
+        _check(_ffi.lib().pqv_set_timing(self._h, 1 if enabled else 0))
+
+    def timing_read(self):
+        rr, tot, n = C.c_double(0), C.c_double(0), C.c_uint32(0)
+        _check(_ffi.lib().pqv_timing_read(self._h, C.byref(rr), C.byref(tot), C.byref(n)))
+        return rr.value, tot.value, n.value
+
+    def close(self):
+        if self._h:
+            _ffi.lib().pqv_searcher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TopkBuilder:
+    """src/ivf/search.rs:49-81: k and nprobe must be set and > 0."""
+
+    def __init__(self, searcher, query):
+        self._searcher = searcher
+        self._query = query
+        self._k = None
+        self._nprobe = None
+
+    def k(self, k):
+        if k == 0:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "k must be > 0")
+        self._k = k
+        return self
+
+    def nprobe(self, nprobe):
+        if nprobe == 0:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "nprobe must be > 0")
+        self._nprobe = nprobe
+        return self
+
+    def search(self):
+        if self._k is None:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "k must be set")
+        if self._nprobe is None:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "nprobe must be set")
+        rows, dist, nf, _ = self._searcher.topk(_f32(self._query).reshape(1, -1), self._k, self._nprobe)
+        return [SearchResult(int(rows[0, i]), float(dist[0, i])) for i in range(int(nf[0]))]
+
+
+# ---------------------------------------------------------------------------------------
+def rerank_batch(query, cand, k, state=None, ids=None, valid=None, metric=_ffi.PQV_L2SQ_SEQ, device=0):
+    """update_topk_heap for one RecordBatch (src/df_vector/exec.rs:457-484).
+
+    state = (rows u32[<=k], d2 f32[<=k]) from the previous batch or None; returns the new state."""
+    q = _f32(query).reshape(-1)
+    cand = _f32(cand)
+    m, dim = cand.shape if cand.ndim == 2 else (0, q.size)
+    io_rows = np.zeros(max(k, 1), dtype=np.uint32)
+    io_d2 = np.zeros(max(k, 1), dtype=np.float32)
+    cnt = C.c_uint32(0)
+    if state is not None:
+        r, d = state
+        cnt.value = len(r)
+        io_rows[:len(r)] = r
+        io_d2[:len(r)] = d
+    ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+    valid_a = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+    _check(_ffi.lib().pqv_rerank(device, q.ctypes.data_as(f32p), cand.ctypes.data_as(f32p),
+                                 None if ids_a is None else ids_a.ctypes.data_as(u32p),
+                                 None if valid_a is None else valid_a.ctypes.data_as(u8p),
+                                 m, dim, k, metric, io_rows.ctypes.data_as(u32p),
+                                 io_d2.ctypes.data_as(f32p), C.byref(cnt)))
+    return io_rows[:cnt.value].copy(), io_d2[:cnt.value].copy()
+
+
+def merge_topk(dist, rows, counts):
+    """Merge per-shard lists [n_lists, nq, k] -> (dist [nq,k], rows [nq,k], list [nq,k], count [nq])."""
+    dist = _f32(dist)
+    rows = np.ascontiguousarray(rows, dtype=np.uint32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n_lists, nq, k = dist.shape
+    od = np.empty((nq, k), dtype=np.float32)
+    orow = np.empty((nq, k), dtype=np.uint32)
+    ol = np.empty((nq, k), dtype=np.uint32)
+    oc = np.empty(nq, dtype=np.uint32)
+    _check(_ffi.lib().pqv_merge_topk(dist.ctypes.data_as(f32p), rows.ctypes.data_as(u32p),
+                                     counts.ctypes.data_as(u32p), n_lists, nq, k,
+                                     od.ctypes.data_as(f32p), orow.ctypes.data_as(u32p),
+                                     ol.ctypes.data_as(u32p), oc.ctypes.data_as(u32p)))
+    return od, orow, ol, oc

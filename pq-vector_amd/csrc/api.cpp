@@ -1,0 +1,1146 @@
+// api.cpp -- the C ABI of include/pqv.h: host orchestration of the gfx950 kernels.
+//
+// Host logic mirrored here (reference paths):
+//   build_ivf_index / k_means / sample_embeddings   src/ivf/index.rs:152-214,222-242,323-457
+//   IvfIndex::{to_bytes,from_bytes,candidate_rows}    src/ivf/index.rs:57-128
+//   topk()                                            src/ivf/search.rs:83-142
+// There is no CPU compute fallback: distances, argmins and top-k selection only ever run
+// in the HIP kernels of kernels.hip; the host draws the seeded choices, walks the two
+// order-sensitive f32 scalar scans of k-means++ (index.rs:370-383) and moves bytes.
+#include "../../include/pqv.h"
+
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "rng.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(_e == hipErrorOutOfMemory ? PQV_ERR_OOM : PQV_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+int use_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PQV_ERR_NO_DEVICE,
+                    "no HIP device available: libpqv_hip has no CPU fallback (gfx950 required)");
+    if (device < 0 || device >= count)
+        return fail(PQV_ERR_NO_DEVICE, "device index " + std::to_string(device) +
+                                           " out of range (" + std::to_string(count) + " devices)");
+    HIP_TRY(hipSetDevice(device));
+    return PQV_OK;
+}
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    // grow-only
+    hipError_t ensure(size_t n) { return (n <= bytes && p) ? hipSuccess : alloc(n + n / 4); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipHostMalloc(&p, n ? n : 16, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+uint32_t host_workers() {
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? static_cast<uint32_t>(n) : 1u;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------
+struct pqv_index {
+    uint32_t dim = 0;
+    uint32_t n_clusters = 0;
+    std::vector<float> centroids;     // [n_clusters * dim]
+    std::vector<uint64_t> list_off;   // [n_clusters + 1]
+    std::vector<uint32_t> list_rows;  // concatenated inverted lists
+};
+
+struct pqv_corpus {
+    int device = 0;
+    uint32_t dim = 0;
+    uint64_t n = 0;
+    uint64_t capacity = 0;
+    float *d_rows = nullptr;  // [capacity, dim]
+    bool owned = true;
+    hipStream_t stream = nullptr;
+    ~pqv_corpus() {
+        if (d_rows && owned) (void)hipFree(d_rows);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct pqv_searcher {
+    int device = 0;
+    uint32_t dim = 0, n_clusters = 0;
+    uint64_t n = 0;
+    uint64_t max_list_len = 0;
+    pqv_corpus *corpus = nullptr;          // borrowed
+    std::vector<uint64_t> h_list_off;      // host copy for candidate_rows
+    std::vector<uint32_t> h_list_rows;
+    DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf;
+    const float *d_mat = nullptr;          // row storage the re-rank reads
+    const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout)
+    const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout)
+    hipStream_t stream = nullptr;
+    // scratch (guarded by mu)
+    mutable std::mutex mu;
+    mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound;
+    mutable pqv_counters_t counters{};
+    // timing
+    mutable bool timing = false;
+    mutable std::vector<hipEvent_t> ev;    // triples: probe-start, rerank-start, rerank-stop, end
+    ~pqv_searcher() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------
+extern "C" const char *pqv_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int pqv_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count < 0 ? 0 : count;
+}
+
+extern "C" int pqv_abi_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------------
+// corpus
+// ---------------------------------------------------------------------------------------
+extern "C" int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t dim,
+                                 pqv_corpus **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");  // mod.rs:59
+    if (capacity_rows > 0xFFFFFFFFull)
+        return fail(PQV_ERR_UNSUPPORTED, "row ids are u32: at most 4294967295 rows per corpus");
+    if (int rc = use_device(device)) return rc;
+    pqv_corpus *c = new (std::nothrow) pqv_corpus();
+    if (!c) return fail(PQV_ERR_OOM, "host allocation failed");
+    c->device = device;
+    c->dim = dim;
+    c->capacity = capacity_rows;
+    const size_t bytes = std::max<size_t>(16, static_cast<size_t>(capacity_rows) * dim * sizeof(float));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_rows), bytes);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PQV_ERR_OOM, std::string("hipMalloc(corpus): ") + hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PQV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return PQV_OK;
+}
+
+extern "C" int pqv_corpus_append(pqv_corpus *c, const float *rows, uint64_t n_rows) {
+    if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    if (!c->owned) return fail(PQV_ERR_INVALID, "cannot append to a borrowed device buffer");
+    if (n_rows == 0) return PQV_OK;
+    if (!rows) return fail(PQV_ERR_INVALID, "rows must not be NULL");
+    if (c->n + n_rows > c->capacity) return fail(PQV_ERR_INVALID, "corpus capacity exceeded");
+    if (int rc = use_device(c->device)) return rc;
+    HIP_TRY(hipMemcpy(c->d_rows + c->n * c->dim, rows, static_cast<size_t>(n_rows) * c->dim * sizeof(float),
+                      hipMemcpyHostToDevice));
+    c->n += n_rows;
+    return PQV_OK;
+}
+
+extern "C" int pqv_corpus_append_f64(pqv_corpus *c, const double *rows, uint64_t n_rows) {
+    if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    if (!c->owned) return fail(PQV_ERR_INVALID, "cannot append to a borrowed device buffer");
+    if (n_rows == 0) return PQV_OK;
+    if (!rows) return fail(PQV_ERR_INVALID, "rows must not be NULL");
+    if (c->n + n_rows > c->capacity) return fail(PQV_ERR_INVALID, "corpus capacity exceeded");
+    if (int rc = use_device(c->device)) return rc;
+    const uint64_t count = n_rows * c->dim;
+    DevBuf stage;
+    HIP_TRY(stage.alloc(count * sizeof(double)));
+    HIP_TRY(hipMemcpy(stage.p, rows, count * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(pqv::launch_narrow_f64(stage.as<double>(), count, c->d_rows + c->n * c->dim, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n += n_rows;
+    return PQV_OK;
+}
+
+extern "C" int pqv_corpus_upload(int device, const float *rows, uint64_t n, uint32_t dim,
+                                 pqv_corpus **out) {
+    if (int rc = pqv_corpus_create(device, n, dim, out)) return rc;
+    if (int rc = pqv_corpus_append(*out, rows, n)) {
+        delete *out;
+        *out = nullptr;
+        return rc;
+    }
+    return PQV_OK;
+}
+
+extern "C" int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,
+                                      pqv_corpus **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (n > 0xFFFFFFFFull)
+        return fail(PQV_ERR_UNSUPPORTED, "row ids are u32: at most 4294967295 rows per corpus");
+    if (n && !d_rows) return fail(PQV_ERR_INVALID, "d_rows must not be NULL");
+    if (int rc = use_device(device)) return rc;
+    pqv_corpus *c = new (std::nothrow) pqv_corpus();
+    if (!c) return fail(PQV_ERR_OOM, "host allocation failed");
+    c->device = device; c->dim = dim; c->n = n; c->capacity = n;
+    c->d_rows = const_cast<float *>(static_cast<const float *>(d_rows));
+    c->owned = false;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PQV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return PQV_OK;
+}
+
+extern "C" uint64_t pqv_corpus_rows(const pqv_corpus *c) { return c ? c->n : 0; }
+extern "C" uint32_t pqv_corpus_dim(const pqv_corpus *c) { return c ? c->dim : 0; }
+extern "C" int pqv_corpus_device(const pqv_corpus *c) { return c ? c->device : -1; }
+
+extern "C" int pqv_corpus_fetch_rows(const pqv_corpus *c, const uint32_t *rows, uint64_t m,
+                                     float *out) {
+    if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    if (m == 0) return PQV_OK;
+    if (!rows || !out) return fail(PQV_ERR_INVALID, "rows/out must not be NULL");
+    if (!c->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
+    for (uint64_t i = 0; i < m; ++i)
+        if (rows[i] >= c->n) return fail(PQV_ERR_INVALID, "row id out of range");
+    if (int rc = use_device(c->device)) return rc;
+    DevBuf d_idx, d_out;
+    HIP_TRY(d_idx.alloc(m * sizeof(uint32_t)));
+    HIP_TRY(d_out.alloc(m * c->dim * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_idx.p, rows, m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(pqv::launch_gather_rows(c->d_rows, d_idx.as<uint32_t>(), nullptr, m, c->dim,
+                                    d_out.as<float>(), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, d_out.p, m * c->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return PQV_OK;
+}
+
+extern "C" void pqv_corpus_free(pqv_corpus *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------
+// index blob + accessors (src/ivf/index.rs:65-128)
+// ---------------------------------------------------------------------------------------
+namespace {
+inline uint32_t rd_u32(const uint8_t *p) {
+    return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) |
+           (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24);
+}
+inline void wr_u32(uint8_t *p, uint32_t v) {
+    p[0] = static_cast<uint8_t>(v); p[1] = static_cast<uint8_t>(v >> 8);
+    p[2] = static_cast<uint8_t>(v >> 16); p[3] = static_cast<uint8_t>(v >> 24);
+}
+}  // namespace
+
+extern "C" int pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (!bytes || len < 8) return fail(PQV_ERR_FORMAT, "IVF index buffer too small");  // index.rs:89
+    const uint32_t dim = rd_u32(bytes), k = rd_u32(bytes + 4);
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");     // mod.rs:59
+    if (k == 0) return fail(PQV_ERR_INVALID, "Cluster count must be > 0");             // index.rs:24
+    size_t off = 8;
+    const uint64_t clen = static_cast<uint64_t>(k) * dim;
+    if ((len - off) / 4 < clen) return fail(PQV_ERR_FORMAT, "IVF index buffer truncated (centroids)");
+    pqv_index *idx = new (std::nothrow) pqv_index();
+    if (!idx) return fail(PQV_ERR_OOM, "host allocation failed");
+    idx->dim = dim; idx->n_clusters = k;
+    idx->centroids.resize(clen);
+    for (uint64_t i = 0; i < clen; ++i, off += 4) {
+        const uint32_t bits = rd_u32(bytes + off);
+        std::memcpy(&idx->centroids[i], &bits, 4);
+    }
+    idx->list_off.assign(static_cast<size_t>(k) + 1, 0);
+    size_t scan = off;
+    for (uint32_t c = 0; c < k; ++c) {
+        if (len - scan < 4) { delete idx; return fail(PQV_ERR_FORMAT, "IVF index buffer truncated (list length)"); }
+        const uint32_t ll = rd_u32(bytes + scan);
+        scan += 4;
+        if ((len - scan) / 4 < ll) { delete idx; return fail(PQV_ERR_FORMAT, "IVF index buffer truncated (list rows)"); }
+        scan += static_cast<size_t>(ll) * 4;
+        idx->list_off[c + 1] = idx->list_off[c] + ll;
+    }
+    idx->list_rows.resize(idx->list_off[k]);
+    for (uint32_t c = 0; c < k; ++c) {
+        const uint32_t ll = rd_u32(bytes + off);
+        off += 4;
+        uint32_t *dst = idx->list_rows.data() + idx->list_off[c];
+        for (uint32_t i = 0; i < ll; ++i, off += 4) dst[i] = rd_u32(bytes + off);
+    }
+    *out = idx;
+    return PQV_OK;
+}
+
+extern "C" int pqv_index_to_bytes(const pqv_index *idx, uint8_t **buf, size_t *len) {
+    if (!idx || !buf || !len) return fail(PQV_ERR_INVALID, "index/buf/len must not be NULL");
+    const uint64_t k = idx->n_clusters;
+    const size_t sz = 8 + idx->centroids.size() * 4 + static_cast<size_t>(k) * 4 + idx->list_rows.size() * 4;
+    uint8_t *b = static_cast<uint8_t *>(std::malloc(sz));
+    if (!b) return fail(PQV_ERR_OOM, "host allocation failed");
+    size_t off = 0;
+    wr_u32(b, idx->dim); wr_u32(b + 4, idx->n_clusters); off = 8;
+    for (float v : idx->centroids) {
+        uint32_t bits;
+        std::memcpy(&bits, &v, 4);
+        wr_u32(b + off, bits);
+        off += 4;
+    }
+    for (uint64_t c = 0; c < k; ++c) {
+        const uint64_t s = idx->list_off[c], e = idx->list_off[c + 1];
+        wr_u32(b + off, static_cast<uint32_t>(e - s));
+        off += 4;
+        for (uint64_t i = s; i < e; ++i, off += 4) wr_u32(b + off, idx->list_rows[i]);
+    }
+    *buf = b;
+    *len = sz;
+    return PQV_OK;
+}
+
+extern "C" void pqv_bytes_free(uint8_t *buf) { std::free(buf); }
+
+extern "C" int pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const float *centroids,
+                                    const uint64_t *list_off, const uint32_t *list_rows,
+                                    pqv_index **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (n_clusters == 0) return fail(PQV_ERR_INVALID, "Cluster count must be > 0");
+    if (!centroids || !list_off) return fail(PQV_ERR_INVALID, "centroids/list_off must not be NULL");
+    for (uint32_t c = 0; c < n_clusters; ++c)
+        if (list_off[c + 1] < list_off[c]) return fail(PQV_ERR_INVALID, "list_off must be non-decreasing");
+    if (list_off[0] != 0) return fail(PQV_ERR_INVALID, "list_off[0] must be 0");
+    const uint64_t total = list_off[n_clusters];
+    if (total && !list_rows) return fail(PQV_ERR_INVALID, "list_rows must not be NULL");
+    pqv_index *idx = new (std::nothrow) pqv_index();
+    if (!idx) return fail(PQV_ERR_OOM, "host allocation failed");
+    idx->dim = dim; idx->n_clusters = n_clusters;
+    idx->centroids.assign(centroids, centroids + static_cast<uint64_t>(n_clusters) * dim);
+    idx->list_off.assign(list_off, list_off + n_clusters + 1);
+    idx->list_rows.assign(list_rows, list_rows + total);
+    *out = idx;
+    return PQV_OK;
+}
+
+extern "C" uint32_t pqv_index_dim(const pqv_index *i) { return i ? i->dim : 0; }
+extern "C" uint32_t pqv_index_n_clusters(const pqv_index *i) { return i ? i->n_clusters : 0; }
+extern "C" uint64_t pqv_index_n_rows(const pqv_index *i) { return i ? i->list_rows.size() : 0; }
+extern "C" const float *pqv_index_centroids(const pqv_index *i) { return i ? i->centroids.data() : nullptr; }
+extern "C" const uint64_t *pqv_index_list_offsets(const pqv_index *i) { return i ? i->list_off.data() : nullptr; }
+extern "C" const uint32_t *pqv_index_list_rows(const pqv_index *i) { return i ? i->list_rows.data() : nullptr; }
+extern "C" void pqv_index_free(pqv_index *i) { delete i; }
+
+// ---------------------------------------------------------------------------------------
+// k-means on the device (src/ivf/index.rs:323-457)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+// Stable counting sort of rows by cluster == the reference's "ascending row ids per
+// cluster" (index.rs:193-206).
+void lists_from_assignment(const uint32_t *cluster_of, uint64_t n, uint32_t k,
+                           std::vector<uint64_t> &off, std::vector<uint32_t> &rows) {
+    off.assign(static_cast<size_t>(k) + 1, 0);
+    for (uint64_t r = 0; r < n; ++r) off[cluster_of[r] + 1]++;
+    for (uint32_t c = 0; c < k; ++c) off[c + 1] += off[c];
+    rows.resize(n);
+    std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+    for (uint64_t r = 0; r < n; ++r) rows[cur[cluster_of[r]]++] = static_cast<uint32_t>(r);
+}
+
+// d_data [n, dim] resident; writes d_centroids [k, dim] (device) and optionally the final
+// assignment (host).
+int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uint32_t max_iters,
+                  uint64_t seed, uint32_t workers, hipStream_t stream, float *d_centroids,
+                  std::vector<uint32_t> *assign_out, uint32_t *iters_run) {
+    using namespace pqv;
+    if (workers == 0) workers = host_workers();
+    StdRng rng = StdRng::seed_from_u64(seed);                                          // :327
+    HIP_TRY(hipMemsetAsync(d_centroids, 0, static_cast<size_t>(k) * dim * sizeof(float), stream)); // :330
+
+    // k-means++ subset (:332-338)
+    uint64_t init_n = std::max<uint64_t>(std::min<uint64_t>(n, 50000), k);
+    DevBuf d_init_own, d_idx;
+    const float *d_init = d_data;
+    std::vector<uint64_t> init_indices;
+    if (init_n != n) {
+        init_indices = index_sample(rng, n, init_n);
+        HIP_TRY(d_idx.alloc(init_n * sizeof(uint64_t)));
+        HIP_TRY(d_init_own.alloc(init_n * dim * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_idx.p, init_indices.data(), init_n * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_gather_rows(d_data, nullptr, d_idx.as<uint64_t>(), init_n, dim,
+                                   d_init_own.as<float>(), stream));
+        d_init = d_init_own.as<float>();
+    }
+    const uint64_t first_choice = rng.range_usize(0, init_n);                          // :340
+    HIP_TRY(hipMemcpyAsync(d_centroids, d_init + first_choice * dim, dim * sizeof(float),
+                           hipMemcpyDeviceToDevice, stream));                          // :342
+
+    // min_distances (:344-352), then one streaming pass per round (:354-369)
+    DevBuf d_min;
+    HIP_TRY(d_min.alloc(init_n * sizeof(float)));
+    {
+        std::vector<float> inf(init_n, INFINITY);
+        HIP_TRY(hipMemcpyAsync(d_min.p, inf.data(), init_n * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    PinnedBuf h_min;
+    HIP_TRY(h_min.ensure(init_n * sizeof(float)));
+    StreamArgs sa{};
+    sa.mat = d_init; sa.row_of = nullptr; sa.list_off = nullptr; sa.probe = nullptr; sa.cand_base = nullptr;
+    sa.single_begin = 0; sa.single_end = init_n;
+    sa.nq = 1; sa.nprobe = 1; sa.dim = dim; sa.k = 1;
+    sa.rows_per_block = 256;
+    sa.blocks_per_list = static_cast<uint32_t>((init_n + 255) / 256);
+    sa.max_pos = ~0ull; sa.metric = PQV_L2SQ_REF4;
+    sa.out_f32 = d_min.as<float>();
+
+    // chunking of the partial sums (:259-265,:305-306)
+    const uint64_t w = std::max<uint64_t>(1, std::min<uint64_t>(workers, init_n));
+    const uint64_t chunk = (init_n + w - 1) / w;
+
+    sa.queries = d_centroids;  // distances to centroid 0
+    HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+    for (uint32_t i = 1; i < k; ++i) {
+        if (i > 1) {  // round 1 would re-measure centroid 0: min-update is the identity
+            sa.queries = d_centroids + static_cast<uint64_t>(i - 1) * dim;
+            HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+        }
+        HIP_TRY(hipMemcpyAsync(h_min.p, d_min.p, init_n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const float *md = h_min.as<float>();
+        // total = sum over worker chunks of the chunk's sequential f32 sum (:356-370)
+        float total = 0.0f;
+        for (uint64_t s = 0; s < init_n; s += chunk) {
+            const uint64_t e = std::min(init_n, s + chunk);
+            float local = 0.0f;
+            for (uint64_t t = s; t < e; ++t) local = local + md[t];
+            total = total + local;
+        }
+        uint64_t pick = ~0ull;
+        if (total > 0.0f) {
+            const float threshold = rng.unit_f32() * total;                            // :373
+            float cumsum = 0.0f;
+            for (uint64_t slot = 0; slot < init_n; ++slot) {                           // :375-383
+                cumsum = cumsum + md[slot];
+                if (cumsum >= threshold) { pick = slot; break; }
+            }
+        } else {
+            pick = rng.range_usize(0, init_n);                                         // :385
+        }
+        if (pick != ~0ull)  // otherwise centroid i keeps its zero fill, as in the reference
+            HIP_TRY(hipMemcpyAsync(d_centroids + static_cast<uint64_t>(i) * dim, d_init + pick * dim,
+                                   dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    d_min.release(); d_init_own.release(); d_idx.release();
+
+    // Lloyd iterations (:392-454)
+    DevBuf d_assign_a, d_assign_b, d_counts, d_list_rows, d_list_off;
+    HIP_TRY(d_assign_a.alloc(n * sizeof(uint32_t)));
+    HIP_TRY(d_assign_b.alloc(n * sizeof(uint32_t)));
+    HIP_TRY(d_counts.alloc((static_cast<size_t>(k) + 1) * sizeof(unsigned long long)));
+    HIP_TRY(d_list_rows.alloc(n * sizeof(uint32_t)));
+    HIP_TRY(d_list_off.alloc((static_cast<size_t>(k) + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(d_assign_a.p, 0, n * sizeof(uint32_t), stream));            // :392
+    uint32_t *d_prev = d_assign_a.as<uint32_t>(), *d_cur = d_assign_b.as<uint32_t>();
+    std::vector<uint32_t> h_assign(n, 0);
+    std::vector<unsigned long long> h_counts(static_cast<size_t>(k) + 1);
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> rows;
+    uint32_t iters = 0;
+    for (uint32_t iter = 0; iter < max_iters; ++iter) {
+        HIP_TRY(hipMemsetAsync(d_counts.p, 0, (static_cast<size_t>(k) + 1) * sizeof(unsigned long long), stream));
+        unsigned long long *d_changed = d_counts.as<unsigned long long>() + k;
+        HIP_TRY(launch_assign(d_data, n, dim, d_centroids, k, d_cur, d_prev, d_changed, nullptr, stream));
+        HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts.p, h_counts.size() * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_assign.data(), d_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        iters++;
+        std::swap(d_prev, d_cur);
+        if (h_counts[k] == 0) break;                                                   // :432
+        lists_from_assignment(h_assign.data(), n, k, off, rows);
+        HIP_TRY(hipMemcpyAsync(d_list_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_list_rows.p, rows.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_lloyd_update(d_data, dim, d_list_rows.as<uint32_t>(), d_list_off.as<uint64_t>(),
+                                    k, d_centroids, stream));                          // :436-453
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (iters_run) *iters_run = iters;
+    if (assign_out) *assign_out = std::move(h_assign);
+    return PQV_OK;
+}
+
+int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
+                     uint64_t seed, uint32_t workers, pqv_index **out) {
+    using namespace pqv;
+    const uint64_t n = corpus->n;
+    const uint32_t dim = corpus->dim;
+    if (max_iters == 0) return fail(PQV_ERR_INVALID, "max_iters must be > 0");         // parquet.rs:90
+    if (n == 0) return fail(PQV_ERR_INVALID, "Cannot build IVF index with zero vectors"); // index.rs:158
+    uint64_t k = n_clusters;
+    if (k == 0) k = static_cast<uint64_t>(std::ceil(std::sqrt(static_cast<double>(n)))); // :164
+    if (k > n) return fail(PQV_ERR_INVALID, "n_clusters cannot exceed number of vectors"); // :169
+    if (k > 0xFFFFFFFFull) return fail(PQV_ERR_INVALID, "Cluster count must fit in u32");
+    if (!corpus->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
+    if (int rc = use_device(corpus->device)) return rc;
+    hipStream_t stream = corpus->stream;
+
+    uint64_t sample_size = std::max<uint64_t>(n / 20, 1);                              // :172
+    sample_size = std::min<uint64_t>(sample_size, 100000);                             // :173
+    sample_size = std::min<uint64_t>(std::max<uint64_t>(sample_size, k), n);           // :174
+
+    DevBuf d_centroids, d_sample, d_idx;
+    HIP_TRY(d_centroids.alloc(k * dim * sizeof(float)));
+    const float *d_train = corpus->d_rows;
+    if (sample_size != n) {                                                            // :182-187
+        StdRng rng = StdRng::seed_from_u64(seed);                                      // :231
+        std::vector<uint64_t> idx = index_sample(rng, n, sample_size);                 // :232
+        HIP_TRY(d_idx.alloc(sample_size * sizeof(uint64_t)));
+        HIP_TRY(d_sample.alloc(sample_size * dim * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_idx.p, idx.data(), sample_size * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_gather_rows(corpus->d_rows, nullptr, d_idx.as<uint64_t>(), sample_size, dim,
+                                   d_sample.as<float>(), stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        d_train = d_sample.as<float>();
+    }
+    if (int rc = kmeans_device(d_train, sample_size, dim, static_cast<uint32_t>(k), max_iters, seed,
+                               workers, stream, d_centroids.as<float>(), nullptr, nullptr))
+        return rc;
+    d_sample.release(); d_idx.release();
+
+    // final assignment of every row (:189-206)
+    DevBuf d_cluster;
+    HIP_TRY(d_cluster.alloc(n * sizeof(uint32_t)));
+    HIP_TRY(launch_assign(corpus->d_rows, n, dim, d_centroids.as<float>(), static_cast<uint32_t>(k),
+                          d_cluster.as<uint32_t>(), nullptr, nullptr, nullptr, stream));
+    std::vector<uint32_t> cluster_of(n);
+    pqv_index *idx = new (std::nothrow) pqv_index();
+    if (!idx) return fail(PQV_ERR_OOM, "host allocation failed");
+    idx->dim = dim; idx->n_clusters = static_cast<uint32_t>(k);
+    idx->centroids.resize(k * dim);
+    hipError_t e = hipMemcpyAsync(cluster_of.data(), d_cluster.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(idx->centroids.data(), d_centroids.p, k * dim * sizeof(float), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(PQV_ERR_HIP, std::string("final assignment: ") + hipGetErrorString(e));
+    }
+    lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows);
+    *out = idx;
+    return PQV_OK;
+}
+
+}  // namespace
+
+extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
+                               uint64_t seed, uint32_t workers, pqv_index **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (!corpus) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    return build_index_impl(corpus, n_clusters, max_iters, seed, workers, out);
+}
+
+extern "C" int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
+                                    uint32_t n_clusters, uint32_t max_iters, uint64_t seed,
+                                    uint32_t workers, pqv_index **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");     // mod.rs:59
+    if (data_len % dim != 0)
+        return fail(PQV_ERR_INVALID, "Embedding data length must be a multiple of dimension"); // mod.rs:86
+    if (max_iters == 0) return fail(PQV_ERR_INVALID, "max_iters must be > 0");
+    const uint64_t n = data_len / dim;
+    if (n == 0) return fail(PQV_ERR_INVALID, "Cannot build IVF index with zero vectors");
+    pqv_corpus *c = nullptr;
+    if (int rc = pqv_corpus_upload(device, data, n, dim, &c)) return rc;
+    const int rc = build_index_impl(c, n_clusters, max_iters, seed, workers, out);
+    pqv_corpus_free(c);
+    return rc;
+}
+
+extern "C" int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_iters, uint64_t seed,
+                          uint32_t workers, float *centroids, uint32_t *assignments,
+                          uint32_t *iters_run) {
+    if (!sample || !centroids) return fail(PQV_ERR_INVALID, "sample/centroids must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "Cluster count must be > 0");
+    if (sample->n == 0 || k > sample->n) return fail(PQV_ERR_INVALID, "n_clusters cannot exceed number of vectors");
+    if (!sample->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
+    if (int rc = use_device(sample->device)) return rc;
+    DevBuf d_centroids;
+    HIP_TRY(d_centroids.alloc(static_cast<size_t>(k) * sample->dim * sizeof(float)));
+    std::vector<uint32_t> assign;
+    if (int rc = kmeans_device(sample->d_rows, sample->n, sample->dim, k, max_iters, seed, workers,
+                               sample->stream, d_centroids.as<float>(), &assign, iters_run))
+        return rc;
+    HIP_TRY(hipMemcpy(centroids, d_centroids.p, static_cast<size_t>(k) * sample->dim * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    if (assignments) std::memcpy(assignments, assign.data(), assign.size() * sizeof(uint32_t));
+    return PQV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// searcher
+// ---------------------------------------------------------------------------------------
+extern "C" int pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
+                                   pqv_searcher **out) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    if (!index || !corpus) return fail(PQV_ERR_INVALID, "index/corpus must not be NULL");
+    if (index->dim != corpus->dim)
+        return fail(PQV_ERR_INVALID, "index dimension " + std::to_string(index->dim) +
+                                         " does not match corpus dimension " + std::to_string(corpus->dim));
+    for (uint32_t r : index->list_rows)
+        if (r >= corpus->n) return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
+    if (!corpus->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
+    if (int rc = use_device(corpus->device)) return rc;
+    pqv_searcher *s = new (std::nothrow) pqv_searcher();
+    if (!s) return fail(PQV_ERR_OOM, "host allocation failed");
+    s->device = corpus->device; s->dim = index->dim; s->n_clusters = index->n_clusters;
+    s->n = index->list_rows.size(); s->corpus = corpus;
+    s->h_list_off = index->list_off; s->h_list_rows = index->list_rows;
+    for (uint32_t c = 0; c < index->n_clusters; ++c)
+        s->max_list_len = std::max<uint64_t>(s->max_list_len, index->list_off[c + 1] - index->list_off[c]);
+    auto cleanup = [&](int code, const std::string &msg) { delete s; return fail(code, msg); };
+#define S_TRY(expr)                                                                       \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return cleanup(_e == hipErrorOutOfMemory ? PQV_ERR_OOM : PQV_ERR_HIP,         \
+                           std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+    S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
+    S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
+    S_TRY(s->d_ids.alloc(std::max<size_t>(1, index->list_rows.size()) * sizeof(uint32_t)));
+    S_TRY(hipMemcpyAsync(s->d_centroids.p, index->centroids.data(), index->centroids.size() * sizeof(float),
+                         hipMemcpyHostToDevice, s->stream));
+    S_TRY(hipMemcpyAsync(s->d_list_off.p, index->list_off.data(), index->list_off.size() * sizeof(uint64_t),
+                         hipMemcpyHostToDevice, s->stream));
+    if (!index->list_rows.empty())
+        S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice, s->stream));
+    if (flags & PQV_LAYOUT_ROW_ORDER) {
+        s->d_mat = corpus->d_rows;
+        s->d_row_of = s->d_ids.as<uint32_t>();
+        s->d_final_ids = nullptr;
+    } else {
+        S_TRY(s->d_mat_ivf.alloc(std::max<size_t>(1, s->n) * s->dim * sizeof(float)));
+        S_TRY(pqv::launch_gather_rows(corpus->d_rows, s->d_ids.as<uint32_t>(), nullptr, s->n, s->dim,
+                                      s->d_mat_ivf.as<float>(), s->stream));
+        s->d_mat = s->d_mat_ivf.as<float>();
+        s->d_row_of = nullptr;
+        s->d_final_ids = s->d_ids.as<uint32_t>();
+    }
+    S_TRY(hipStreamSynchronize(s->stream));
+    if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
+        (void)hipFree(corpus->d_rows);
+        corpus->d_rows = nullptr;
+    }
+#undef S_TRY
+    *out = s;
+    return PQV_OK;
+}
+
+extern "C" void pqv_searcher_free(pqv_searcher *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+
+namespace {
+
+struct TopkPlan {
+    uint32_t np;            // effective nprobe
+    uint32_t probe_bpl;     // blocks over the centroid matrix
+    uint32_t rr_rows_per_block, rr_bpl;
+    uint32_t n_part_probe, n_part_rr;
+};
+
+TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe) {
+    TopkPlan p{};
+    p.np = std::min<uint32_t>(nprobe, s->n_clusters);
+    // probe pass: every block scans 256 centroids (64 per wave)
+    p.probe_bpl = (s->n_clusters + 255) / 256;
+    p.n_part_probe = p.probe_bpl * pqv::waves_per_block();
+    // re-rank: enough blocks to fill 256 CUs several times over, few enough partial lists
+    const uint64_t max_len = std::max<uint64_t>(1, s->max_list_len);
+    const uint64_t max_bpl = (max_len + 255) / 256;
+    const uint64_t pairs = std::max<uint64_t>(1, static_cast<uint64_t>(nq) * p.np);
+    uint64_t bpl = (8192 + pairs - 1) / pairs;
+    bpl = std::max<uint64_t>(1, std::min<uint64_t>(bpl, max_bpl));
+    uint64_t rpb = (max_len + bpl - 1) / bpl;
+    rpb = (rpb + 255) / 256 * 256;
+    p.rr_rows_per_block = static_cast<uint32_t>(rpb);
+    p.rr_bpl = static_cast<uint32_t>((max_len + rpb - 1) / rpb);
+    p.n_part_rr = p.np * p.rr_bpl * pqv::waves_per_block();
+    return p;
+}
+
+// Enqueue probe -> probe-merge -> re-rank -> final merge for one batch on `stream`.
+int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uint32_t k,
+                 uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                 uint32_t *d_row_idx, float *d_dist, uint32_t *d_n_found, uint64_t *d_n_cand,
+                 hipStream_t stream) {
+    using namespace pqv;
+    const TopkPlan p = plan_topk(s, nq, nprobe);
+    const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
+
+    HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
+    HIP_TRY(s->s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
+    HIP_TRY(s->s_probe.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
+    HIP_TRY(s->s_cand_base.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint64_t)));
+    HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(nq) * sizeof(uint64_t)));
+    HIP_TRY(s->s_part_keys.ensure(static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint64_t)));
+    HIP_TRY(s->s_part_vals.ensure(static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint32_t)));
+
+    const bool timing = s->timing;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (timing) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventCreate(&e2)); HIP_TRY(hipEventCreate(&e3));
+        s->ev.push_back(e0); s->ev.push_back(e1); s->ev.push_back(e2); s->ev.push_back(e3);
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+
+    // 1. centroid probe: the re-rank kernel over the centroid matrix, k = nprobe
+    StreamArgs pa{};
+    pa.mat = s->d_centroids.as<float>(); pa.row_of = nullptr; pa.list_off = nullptr;
+    pa.probe = nullptr; pa.cand_base = nullptr;
+    pa.single_begin = 0; pa.single_end = s->n_clusters;
+    pa.queries = d_queries; pa.nq = nq; pa.nprobe = 1; pa.dim = s->dim; pa.k = p.np;
+    pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl;
+    pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;   // find_closest_centroids always uses index.rs:461
+    pa.part_keys = s->s_probe_keys.as<uint64_t>(); pa.part_vals = s->s_probe_vals.as<uint32_t>();
+    HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
+
+    MergeArgs pm{};
+    pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals;
+    pm.nq = nq; pm.n_part = p.n_part_probe; pm.k_part = p.np; pm.k = p.np;
+    pm.list_off = s->d_list_off.as<uint64_t>();
+    pm.probe = s->s_probe.as<uint32_t>(); pm.cand_base = s->s_cand_base.as<uint64_t>();
+    pm.n_cand = d_n_cand ? d_n_cand : s->s_ncand.as<uint64_t>();
+    pm.max_pos = max_pos;
+    HIP_TRY(launch_merge_probe(pm, stream));
+
+    // 2. candidate re-rank + per-wave top-k
+    StreamArgs ra{};
+    ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
+    ra.probe = s->s_probe.as<uint32_t>(); ra.cand_base = s->s_cand_base.as<uint64_t>();
+    ra.queries = d_queries; ra.nq = nq; ra.nprobe = p.np; ra.dim = s->dim; ra.k = k;
+    ra.rows_per_block = p.rr_rows_per_block; ra.blocks_per_list = p.rr_bpl;
+    ra.max_pos = max_pos; ra.metric = metric;
+    ra.part_keys = s->s_part_keys.as<uint64_t>(); ra.part_vals = s->s_part_vals.as<uint32_t>();
+    if (timing) HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
+    if (timing) HIP_TRY(hipEventRecord(e2, stream));
+
+    // 3. fold the per-wave lists
+    MergeArgs fm{};
+    fm.part_keys = ra.part_keys; fm.part_vals = ra.part_vals;
+    fm.nq = nq; fm.n_part = p.n_part_rr; fm.k_part = k; fm.k = k;
+    fm.ids = s->d_final_ids; fm.row_idx = d_row_idx; fm.dist = d_dist; fm.n_found = d_n_found;
+    fm.sqrt_out = sqrt_out;
+    HIP_TRY(launch_merge_final(fm, stream));
+    if (timing) HIP_TRY(hipEventRecord(e3, stream));
+    s->counters.kernel_launches += 4;
+    return PQV_OK;
+}
+
+int validate_topk(const pqv_searcher *s, uint32_t k, uint32_t nprobe, int metric) {
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");                         // search.rs:67
+    if (nprobe == 0) return fail(PQV_ERR_INVALID, "nprobe must be > 0");               // search.rs:72
+    if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (std::min<uint32_t>(nprobe, s->n_clusters) > 1024)
+        return fail(PQV_ERR_UNSUPPORTED, "nprobe > 1024 is not supported");
+    return PQV_OK;
+}
+
+}  // namespace
+
+extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
+                               uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                               void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
+                               void *hip_stream) {
+    if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
+    if (nq == 0) return PQV_OK;
+    if (!d_queries || !d_row_idx || !d_dist) return fail(PQV_ERR_INVALID, "device pointers must not be NULL");
+    if (int rc = use_device(s->device)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, k, nprobe, max_candidates,
+                                metric, sqrt_out, static_cast<uint32_t *>(d_row_idx),
+                                static_cast<float *>(d_dist), static_cast<uint32_t *>(d_n_found),
+                                static_cast<uint64_t *>(d_n_candidates), stream);
+    if (rc == PQV_OK) s->counters.queries += nq;
+    return rc;
+}
+
+extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq, uint32_t query_len,
+                        uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                        uint32_t *row_idx, float *dist, uint32_t *n_found, uint64_t *n_candidates) {
+    if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
+    if (query_len != s->dim)                                                           // search.rs:91-98
+        return fail(PQV_ERR_INVALID, "Query dimension mismatch: expected " + std::to_string(s->dim) +
+                                         ", got " + std::to_string(query_len));
+    if (nq == 0) return PQV_OK;
+    if (!queries || !row_idx || !dist) return fail(PQV_ERR_INVALID, "queries/row_idx/dist must not be NULL");
+    if (int rc = use_device(s->device)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
+    const TopkPlan p1 = plan_topk(s, 1, nprobe);
+    const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k * 12 + 1;
+    uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / per_query)));
+    HIP_TRY(s->s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));
+    HIP_TRY(s->s_rows.ensure(static_cast<size_t>(batch) * k * sizeof(uint32_t)));
+    HIP_TRY(s->s_dist.ensure(static_cast<size_t>(batch) * k * sizeof(float)));
+    HIP_TRY(s->s_nfound.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
+    HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(batch) * sizeof(uint64_t)));
+    std::vector<uint64_t> h_ncand(batch);
+    for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
+        const uint32_t b = std::min<uint32_t>(batch, nq - q0);
+        HIP_TRY(hipMemcpyAsync(s->s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
+                               static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        if (int rc = enqueue_topk(s, s->s_queries.as<float>(), b, k, nprobe, max_candidates, metric, sqrt_out,
+                                  s->s_rows.as<uint32_t>(), s->s_dist.as<float>(), s->s_nfound.as<uint32_t>(),
+                                  nullptr, s->stream))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, s->s_rows.p,
+                               static_cast<size_t>(b) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, s->s_dist.p,
+                               static_cast<size_t>(b) * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        if (n_found)
+            HIP_TRY(hipMemcpyAsync(n_found + q0, s->s_nfound.p, static_cast<size_t>(b) * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(h_ncand.data(), s->s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        for (uint32_t i = 0; i < b; ++i) {
+            s->counters.candidate_rows += h_ncand[i];
+            s->counters.embeddings_fetched +=
+                max_candidates ? std::min<uint64_t>(h_ncand[i], max_candidates) : h_ncand[i];
+            if (n_candidates) n_candidates[q0 + i] = h_ncand[i];
+        }
+        s->counters.queries += b;
+    }
+    return PQV_OK;
+}
+
+extern "C" int pqv_probe(const pqv_searcher *s, const float *query, uint32_t query_len, uint32_t nprobe,
+                         uint32_t *clusters_out, uint32_t *n_out) {
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    if (nprobe == 0) return fail(PQV_ERR_INVALID, "nprobe must be > 0");
+    if (query_len != s->dim)
+        return fail(PQV_ERR_INVALID, "Query dimension mismatch: expected " + std::to_string(s->dim) +
+                                         ", got " + std::to_string(query_len));
+    if (!query || !clusters_out) return fail(PQV_ERR_INVALID, "query/clusters_out must not be NULL");
+    const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
+    if (np > 1024) return fail(PQV_ERR_UNSUPPORTED, "nprobe > 1024 is not supported");
+    if (int rc = use_device(s->device)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    using namespace pqv;
+    const TopkPlan p = plan_topk(s, 1, nprobe);
+    HIP_TRY(s->s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
+    HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint64_t)));
+    HIP_TRY(s->s_probe_vals.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint32_t)));
+    HIP_TRY(s->s_probe.ensure(static_cast<size_t>(np) * sizeof(uint32_t)));
+    HIP_TRY(s->s_cand_base.ensure(static_cast<size_t>(np) * sizeof(uint64_t)));
+    HIP_TRY(s->s_ncand.ensure(sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(s->s_queries.p, query, static_cast<size_t>(s->dim) * sizeof(float),
+                           hipMemcpyHostToDevice, s->stream));
+    StreamArgs pa{};
+    pa.mat = s->d_centroids.as<float>(); pa.single_begin = 0; pa.single_end = s->n_clusters;
+    pa.queries = s->s_queries.as<float>(); pa.nq = 1; pa.nprobe = 1; pa.dim = s->dim; pa.k = np;
+    pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl; pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;
+    pa.part_keys = s->s_probe_keys.as<uint64_t>(); pa.part_vals = s->s_probe_vals.as<uint32_t>();
+    HIP_TRY(launch_stream(pa, STREAM_TOPK, s->stream));
+    MergeArgs pm{};
+    pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals; pm.nq = 1; pm.n_part = p.n_part_probe;
+    pm.k_part = np; pm.k = np; pm.list_off = s->d_list_off.as<uint64_t>();
+    pm.probe = s->s_probe.as<uint32_t>(); pm.cand_base = s->s_cand_base.as<uint64_t>();
+    pm.n_cand = s->s_ncand.as<uint64_t>(); pm.max_pos = ~0ull;
+    HIP_TRY(launch_merge_probe(pm, s->stream));
+    HIP_TRY(hipMemcpyAsync(clusters_out, s->s_probe.p, static_cast<size_t>(np) * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (n_out) *n_out = np;
+    s->counters.kernel_launches += 2;
+    return PQV_OK;
+}
+
+extern "C" int pqv_candidate_rows(const pqv_searcher *s, const float *query, uint32_t query_len,
+                                  uint32_t nprobe, uint32_t **rows, uint64_t *n_rows) {
+    if (!rows || !n_rows) return fail(PQV_ERR_INVALID, "rows/n_rows must not be NULL");
+    *rows = nullptr; *n_rows = 0;
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
+    std::vector<uint32_t> clusters(std::max<uint32_t>(np, 1));
+    uint32_t got = 0;
+    if (int rc = pqv_probe(s, query, query_len, nprobe, clusters.data(), &got)) return rc;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < got; ++i) total += s->h_list_off[clusters[i] + 1] - s->h_list_off[clusters[i]];
+    uint32_t *buf = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(1, total) * sizeof(uint32_t)));
+    if (!buf) return fail(PQV_ERR_OOM, "host allocation failed");
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < got; ++i) {  // probe-rank major, ascending ids inside (index.rs:59-62)
+        const uint64_t b = s->h_list_off[clusters[i]], e = s->h_list_off[clusters[i] + 1];
+        std::memcpy(buf + o, s->h_list_rows.data() + b, (e - b) * sizeof(uint32_t));
+        o += e - b;
+    }
+    *rows = buf; *n_rows = total;
+    s->counters.candidate_rows += total;
+    return PQV_OK;
+}
+
+extern "C" void pqv_rows_free(uint32_t *rows) { std::free(rows); }
+
+extern "C" int pqv_counters(const pqv_searcher *s, pqv_counters_t *out) {
+    if (!s || !out) return fail(PQV_ERR_INVALID, "searcher/out must not be NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    *out = s->counters;
+    return PQV_OK;
+}
+
+extern "C" int pqv_set_timing(pqv_searcher *s, int enabled) {
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->timing = enabled != 0;
+    return PQV_OK;
+}
+
+extern "C" int pqv_timing_read(const pqv_searcher *s, double *rerank_ms, double *total_ms,
+                               uint32_t *n_calls) {
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    if (int rc = use_device(s->device)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    double rr = 0.0, tot = 0.0;
+    uint32_t calls = 0;
+    for (size_t i = 0; i + 3 < s->ev.size(); i += 4) {
+        HIP_TRY(hipEventSynchronize(s->ev[i + 3]));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, s->ev[i + 1], s->ev[i + 2]));
+        HIP_TRY(hipEventElapsedTime(&b, s->ev[i], s->ev[i + 3]));
+        rr += a; tot += b; calls++;
+    }
+    for (auto e : s->ev) (void)hipEventDestroy(e);
+    s->ev.clear();
+    if (rerank_ms) *rerank_ms = rr;
+    if (total_ms) *total_ms = tot;
+    if (n_calls) *n_calls = calls;
+    return PQV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side merge of per-shard lists (multi-file / multi-GPU)
+// ---------------------------------------------------------------------------------------
+extern "C" int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *counts,
+                              uint32_t n_lists, uint32_t nq, uint32_t k, float *out_dist,
+                              uint32_t *out_rows, uint32_t *out_list, uint32_t *out_count) {
+    if (!dist || !rows || !counts || !out_dist || !out_rows)
+        return fail(PQV_ERR_INVALID, "merge arrays must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");
+    struct Item { float d; uint32_t list, pos, row; };
+    std::vector<Item> items;
+    for (uint32_t q = 0; q < nq; ++q) {
+        items.clear();
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            const uint32_t cnt = std::min<uint32_t>(counts[static_cast<uint64_t>(l) * nq + q], k);
+            const uint64_t base = (static_cast<uint64_t>(l) * nq + q) * k;
+            for (uint32_t i = 0; i < cnt; ++i) items.push_back({dist[base + i], l, i, rows[base + i]});
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+            if (a.d < b.d) return true;
+            if (b.d < a.d) return false;
+            if (a.list != b.list) return a.list < b.list;
+            return a.pos < b.pos;
+        });
+        const uint32_t take = static_cast<uint32_t>(std::min<size_t>(k, items.size()));
+        for (uint32_t i = 0; i < k; ++i) {
+            const uint64_t o = static_cast<uint64_t>(q) * k + i;
+            if (i < take) {
+                out_dist[o] = items[i].d; out_rows[o] = items[i].row;
+                if (out_list) out_list[o] = items[i].list;
+            } else {
+                out_dist[o] = INFINITY; out_rows[o] = 0xFFFFFFFFu;
+                if (out_list) out_list[o] = 0xFFFFFFFFu;
+            }
+        }
+        if (out_count) out_count[q] = take;
+    }
+    return PQV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// batch-granular re-rank (update_topk_heap, src/df_vector/exec.rs:457-484)
+// ---------------------------------------------------------------------------------------
+extern "C" int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
+                          const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+                          uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+    using namespace pqv;
+    if (!query || !io_rows || !io_d2 || !io_count) return fail(PQV_ERR_INVALID, "query/io arrays must not be NULL");
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (k == 0) return PQV_OK;  // heap.len() < 0 is never true and peek() is None: nothing is kept
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
+    if (*io_count > k) return fail(PQV_ERR_INVALID, "io_count exceeds k");
+    if (m == 0) return PQV_OK;
+    if (!cand) return fail(PQV_ERR_INVALID, "cand must not be NULL");
+    if (m > 0x7FFFFFFFull) return fail(PQV_ERR_UNSUPPORTED, "batch larger than 2^31 rows");
+    if (int rc = use_device(device)) return rc;
+
+    // compact away null / wrong-length rows (exec.rs:496-498,526-528), keep arrival order
+    std::vector<uint32_t> keep;
+    const float *src = cand;
+    std::vector<float> packed;
+    uint64_t mv = m;
+    if (valid) {
+        keep.reserve(m);
+        for (uint64_t i = 0; i < m; ++i) if (valid[i]) keep.push_back(static_cast<uint32_t>(i));
+        mv = keep.size();
+        if (mv == 0) return PQV_OK;
+        if (mv != m) {
+            packed.resize(mv * dim);
+            for (uint64_t i = 0; i < mv; ++i)
+                std::memcpy(&packed[i * dim], cand + static_cast<uint64_t>(keep[i]) * dim, dim * sizeof(float));
+            src = packed.data();
+        }
+    }
+    hipStream_t stream = nullptr;  // legacy default stream: this entry is synchronous
+    DevBuf d_cand, d_q, d_keys, d_vals, d_rows, d_dist, d_nf;
+    const uint32_t old = *io_count;
+    const uint32_t bpl = static_cast<uint32_t>((mv + 255) / 256);
+    const uint32_t n_part = bpl * waves_per_block() + 1;  // +1: the running state
+    HIP_TRY(d_cand.alloc(mv * dim * sizeof(float)));
+    HIP_TRY(d_q.alloc(dim * sizeof(float)));
+    HIP_TRY(d_keys.alloc(static_cast<size_t>(n_part) * k * sizeof(uint64_t)));
+    HIP_TRY(d_vals.alloc(static_cast<size_t>(n_part) * k * sizeof(uint32_t)));
+    HIP_TRY(d_rows.alloc(k * sizeof(uint32_t)));
+    HIP_TRY(d_dist.alloc(k * sizeof(float)));
+    HIP_TRY(d_nf.alloc(sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d_cand.p, src, mv * dim * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_q.p, query, dim * sizeof(float), hipMemcpyHostToDevice));
+    // running state as the first partial list: positions 0..old-1 (earlier arrivals win ties);
+    // vals carry a tag bit so the payload can be told from a batch position afterwards
+    std::vector<uint64_t> hk(k, KEY_EMPTY);
+    std::vector<uint32_t> hv(k, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < old; ++i) {
+        uint32_t bits;
+        std::memcpy(&bits, &io_d2[i], 4);
+        hk[i] = (static_cast<uint64_t>(bits) << 32) | i;
+        hv[i] = 0x80000000u | i;
+    }
+    HIP_TRY(hipMemcpy(d_keys.p, hk.data(), k * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_vals.p, hv.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    // batch candidates take positions k, k+1, ... via a cand_base entry
+    DevBuf d_base, d_probe0, d_off;
+    const uint64_t h_base = k, h_off[2] = {0, mv};
+    const uint32_t h_probe0 = 0;
+    HIP_TRY(d_base.alloc(sizeof(uint64_t))); HIP_TRY(d_probe0.alloc(sizeof(uint32_t))); HIP_TRY(d_off.alloc(2 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice));
+    StreamArgs ra{};
+    ra.mat = d_cand.as<float>(); ra.row_of = nullptr; ra.list_off = d_off.as<uint64_t>();
+    ra.probe = d_probe0.as<uint32_t>(); ra.cand_base = d_base.as<uint64_t>();
+    ra.queries = d_q.as<float>(); ra.nq = 1; ra.nprobe = 1; ra.dim = dim; ra.k = k;
+    ra.rows_per_block = 256; ra.blocks_per_list = bpl; ra.max_pos = ~0ull; ra.metric = metric;
+    ra.part_keys = d_keys.as<uint64_t>() + k; ra.part_vals = d_vals.as<uint32_t>() + k;
+    HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
+    MergeArgs fm{};
+    fm.part_keys = d_keys.as<uint64_t>(); fm.part_vals = d_vals.as<uint32_t>();
+    fm.nq = 1; fm.n_part = n_part; fm.k_part = k; fm.k = k; fm.ids = nullptr;
+    fm.row_idx = d_rows.as<uint32_t>(); fm.dist = d_dist.as<float>(); fm.n_found = d_nf.as<uint32_t>();
+    fm.sqrt_out = 0;
+    HIP_TRY(launch_merge_final(fm, stream));
+    std::vector<uint32_t> r(k);
+    std::vector<float> d(k);
+    uint32_t nf = 0;
+    HIP_TRY(hipMemcpy(r.data(), d_rows.p, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d.data(), d_dist.p, k * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&nf, d_nf.p, sizeof nf, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> new_rows(nf);
+    for (uint32_t i = 0; i < nf; ++i) {
+        if (r[i] & 0x80000000u) {
+            new_rows[i] = io_rows[r[i] & 0x7FFFFFFFu];
+        } else {
+            const uint32_t bi = valid && mv != m ? keep[r[i]] : r[i];
+            new_rows[i] = ids ? ids[bi] : bi;
+        }
+    }
+    for (uint32_t i = 0; i < nf; ++i) { io_rows[i] = new_rows[i]; io_d2[i] = d[i]; }
+    *io_count = nf;
+    return PQV_OK;
+}

@@ -1,0 +1,88 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal; the public
+// boundary is include/pqv.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pqv {
+
+// Sentinel key: sorts after every real (d2, position) key.
+constexpr uint64_t KEY_EMPTY = ~0ull;
+
+// What a streaming distance pass does with each row's exact d2.
+enum StreamMode : int {
+    STREAM_TOPK   = 0,  // fold into per-wave top-k lists
+    STREAM_DIST   = 1,  // out_f32[pos] = d2
+    STREAM_MINUPD = 2,  // out_f32[pos] = min(out_f32[pos], d2)   (k-means++ round)
+};
+
+struct StreamArgs {
+    // row storage [*, dim] f32; a list position p maps to storage row (row_of ? row_of[p] : p)
+    const float    *mat;
+    const uint32_t *row_of;
+    // inverted-list offsets in list positions; probe == nullptr => a single list
+    // [single_begin, single_end) is scanned for every query
+    const uint64_t *list_off;
+    const uint32_t *probe;       // [nq, nprobe] cluster ids in probe-rank order
+    const uint64_t *cand_base;   // [nq, nprobe] candidate position of each probed list's first row
+    uint64_t        single_begin, single_end;
+    const float    *queries;     // [nq, dim]
+    uint32_t        nq, nprobe, dim, k;
+    uint32_t        rows_per_block;   // multiple of 256
+    uint32_t        blocks_per_list;  // gridDim.x
+    uint64_t        max_pos;          // candidates at position >= max_pos are ignored
+    int             metric;           // pqv_metric
+    // TOPK outputs: [nq][nprobe*blocks_per_list*4][k]
+    uint64_t       *part_keys;
+    uint32_t       *part_vals;
+    // DIST / MINUPD output, indexed by candidate position (single-list mode)
+    float          *out_f32;
+};
+
+// Streaming exact-order squared-L2 pass (the re-rank kernel).  Returns hipError_t.
+hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s);
+
+struct MergeArgs {
+    const uint64_t *part_keys;   // [nq][n_part][k_part]
+    const uint32_t *part_vals;
+    uint32_t        nq, n_part, k_part, k;
+    // final mode outputs
+    const uint32_t *ids;         // storage row -> file row id (nullptr => identity)
+    uint32_t       *row_idx;     // [nq, k]
+    float          *dist;        // [nq, k]
+    uint32_t       *n_found;     // [nq] or nullptr
+    int             sqrt_out;
+    // probe mode outputs (k == nprobe)
+    const uint64_t *list_off;
+    uint32_t       *probe;       // [nq, k]
+    uint64_t       *cand_base;   // [nq, k]
+    uint64_t       *n_cand;      // [nq] or nullptr
+    uint64_t        max_pos;     // cap applied to n_cand
+};
+hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s);
+hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
+
+// out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
+hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
+                              uint64_t m, uint32_t dim, float *out, hipStream_t s);
+// f64 -> f32 narrowing of a staged column chunk
+hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipStream_t s);
+
+// Lloyd / final assignment: cluster[r] = argmin_j d2(row r, centroid j), strict '<' in
+// ascending j.  prev (optional) -> *changed += (prev[r] != cluster[r]); sizes (optional,
+// zeroed by the caller) += histogram.
+hipError_t launch_assign(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
+                         uint32_t k, uint32_t *cluster, const uint32_t *prev,
+                         unsigned long long *changed, unsigned long long *sizes,
+                         hipStream_t s);
+
+// Lloyd update in reference order: centroid[c][j] = (sum over the cluster's rows in
+// ascending row order of x[r][j]) / size, empty clusters stay 0.
+hipError_t launch_lloyd_update(const float *rows, uint32_t dim, const uint32_t *list_rows,
+                               const uint64_t *list_off, uint32_t k, float *centroids,
+                               hipStream_t s);
+
+// number of per-wave partial lists per (query, probed list)
+inline uint32_t waves_per_block() { return 4; }
+
+}  // namespace pqv

@@ -1,0 +1,598 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the pq-vector hot path.
+//
+// Everything here computes the reference's squared-L2 in the reference's exact f32
+// summation order (no FMA contraction: built with -ffp-contract=off), so distances are
+// bit-identical to the CPU path and every argmin / top-k decision is too.
+//
+//   stream_kernel   the candidate re-rank (src/ivf/search.rs:112-127, exec.rs:457-484),
+//                   the centroid probe (src/ivf/index.rs:130-149) and the k-means++
+//                   min-distance rounds (index.rs:344-369): HBM-streaming, coalesced 16 B
+//                   per lane, per-row serial chains re-created through an LDS transpose.
+//   merge_kernel    folds the per-wave top-k lists of one query (heap semantics of
+//                   search.rs:119-126 == k smallest by (d2, candidate position)).
+//   assign_kernel   Lloyd assign + final assignment (index.rs:395-424, :189-201,:244-257):
+//                   VALU-bound, lane-per-row with the centroid tile in SGPRs.
+//   lloyd_update    index.rs:436-453 with the reference's ascending-row f32 add order.
+//   gather_rows     sample_embeddings (index.rs:234-239) and the IVF-order re-layout.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace pqv {
+
+// ------------------------------------------------------------------------------------
+// small wave64 helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    uint32_t lo = readlane_u32((uint32_t)v, l), hi = readlane_u32((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64);
+    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// Compiler-level ordering point between a wave's LDS writes and its own cross-lane LDS
+// reads.  LDS executes one wave's DS instructions in issue order, so no s_barrier is
+// needed for data that never leaves the wave.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------
+// Wave-distributed sorted top-k list: element e lives in slot e/64, lane e%64; ascending.
+// Keys are (f32 bits of d2 << 32) | candidate position: unique, and ordered exactly like
+// the reference's heap admission rule (strict '<' keeps the earlier candidate on ties).
+// ------------------------------------------------------------------------------------
+template <int S>
+struct WaveTopk {
+    uint64_t key[S];
+    uint32_t val[S];
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < S; ++s) { key[s] = KEY_EMPTY; val[s] = 0xFFFFFFFFu; }
+    }
+    // key of element k-1 (the admission threshold); k is wave-uniform
+    __device__ __forceinline__ uint64_t kth(uint32_t k) const {
+        const uint32_t e = k - 1;
+        uint64_t r = KEY_EMPTY;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if ((int)(e >> 6) == s) r = readlane_u64(key[s], (int)(e & 63));
+        return r;
+    }
+    // insert (x, xv), wave-uniform, dropping the largest element
+    __device__ __forceinline__ void insert(uint64_t x, uint32_t xv, int lane) {
+        int p = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) p += __popcll(__ballot(key[s] < x));
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            uint64_t up = shfl_up1_u64(key[s]);
+            uint32_t upv = (uint32_t)__shfl_up((int)val[s], 1, 64);
+            if (s > 0) {
+                const uint64_t pk = readlane_u64(key[s - 1], 63);
+                const uint32_t pv = readlane_u32(val[s - 1], 63);
+                if (lane == 0) { up = pk; upv = pv; }
+            }
+            const int e = s * 64 + lane;
+            if (e > p) { key[s] = up; val[s] = upv; }
+            else if (e == p) { key[s] = x; val[s] = xv; }
+        }
+    }
+    // offer one candidate per lane (mykey == KEY_EMPTY for lanes with none)
+    __device__ __forceinline__ void offer(uint64_t mykey, uint32_t myval, uint32_t k, int lane) {
+        uint64_t thr = kth(k);
+        unsigned long long m = __ballot(mykey < thr);
+        while (m) {
+            const int L = __builtin_ctzll(m);
+            const uint64_t x = readlane_u64(mykey, L);
+            const uint32_t xv = readlane_u32(myval, L);
+            insert(x, xv, lane);
+            thr = kth(k);
+            m &= m - 1;
+            m &= __ballot(mykey < thr);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// 16-byte row loads.  ALIGNED: dim % 4 == 0 so every row starts 16-B aligned.
+// ------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__device__ __forceinline__ float4 load4(const float *p) {
+    if constexpr (ALIGNED) {
+        return *reinterpret_cast<const float4 *>(p);
+    } else {
+        float4 v;
+        v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+        return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// stream_kernel
+//
+// grid = (blocks_per_list, nprobe | 1, nq); block = 256 threads = 4 independent waves.
+// A wave owns a contiguous run of rows of one inverted list and walks it in 64-row tiles.
+// For a tile and a chunk of CG float4 groups of the dimension:
+//   1. every load instruction reads 64 x 16 B, fully coalesced (CG = 64: one 1 KiB row
+//      segment; CG = 32: two 512 B segments), NB instructions in flight;
+//   2. each lane turns its float4 into the reference's per-group partial
+//      t = ((d0^2 + d1^2) + d2^2) + d3^2  (PQV_L2SQ_REF4) or four squares (PQV_L2SQ_SEQ)
+//      and parks it in a [group][row] LDS tile (XOR-swizzled: conflict-free both ways);
+//   3. lane r then replays row r's serial chain  sum += t_g  in ascending g -- the one
+//      part of the reference arithmetic that cannot be re-associated.
+// LDS traffic is 1/4 of the streamed bytes (REF4), VALU ~12 ops per 16 B: the kernel is
+// bound by the HBM/L2 stream.
+// ------------------------------------------------------------------------------------
+template <int CG, int S, int MODE, bool SEQ, bool ALIGNED>
+__global__ __launch_bounds__(256) void stream_kernel(const StreamArgs a) {
+    constexpr int RPI = 64 / CG;        // rows per load instruction
+    constexpr int NI = CG;              // load instructions per 64-row tile
+    constexpr int EPL = SEQ ? 4 : 1;    // LDS values per lane item
+    constexpr int LROWS = CG * EPL;     // chain length per chunk
+    constexpr int NB = 8;               // loads in flight per lane
+    static_assert(NI % NB == 0, "NI must be a multiple of NB");
+
+    // [chain element e][row r] tile per wave, XOR-swizzled (column r ^ (e & 63)) so that
+    // both the group-major writes and the row-major chain reads are bank-conflict-free
+    // without padding: CG = 64 uses exactly 64 KiB per block.
+    __shared__ float lds_all[4 * LROWS * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float *lds = lds_all + wave * (LROWS * 64);
+#define LDS_AT(e, r) lds[(e) * 64 + ((r) ^ ((e) & 63))]
+
+    const uint32_t q = blockIdx.z, j = blockIdx.y;
+    uint64_t lbeg, lend, cbase;
+    if (a.probe) {
+        const uint32_t c = a.probe[(uint64_t)q * a.nprobe + j];
+        lbeg = a.list_off[c];
+        lend = a.list_off[c + 1];
+        cbase = a.cand_base[(uint64_t)q * a.nprobe + j];
+    } else {
+        lbeg = a.single_begin;
+        lend = a.single_end;
+        cbase = 0;
+    }
+    const uint64_t len = lend - lbeg;
+    const uint64_t wrows = a.rows_per_block / 4;
+    const uint64_t r0 = (uint64_t)blockIdx.x * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows;
+    if (r1 > len) r1 = len;
+
+    const uint32_t dim = a.dim;
+    const uint32_t G = dim >> 2;
+    const uint32_t tail = dim & 3u;
+    const float *qv = a.queries + (uint64_t)q * dim;
+    const int g_in = lane % CG;      // my float4 group inside a chunk
+    const int row_in = lane / CG;    // my row inside a load instruction
+
+    WaveTopk<S> tk;
+    if constexpr (MODE == STREAM_TOPK) tk.init();
+
+    for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+        const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+        // storage row of tile row `lane` (clamped so every address is in range)
+        const uint32_t lrow = (uint32_t)lane < nvalid ? (uint32_t)lane : nvalid - 1;
+        const uint64_t lpos = lbeg + t0 + lrow;
+        const uint32_t my_srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+
+        float sum = 0.0f;
+        for (uint32_t c0 = 0; c0 < G; c0 += CG) {
+            const uint32_t ng = (G - c0 < (uint32_t)CG) ? (G - c0) : (uint32_t)CG;
+            const bool gvalid = (uint32_t)g_in < ng;
+            const uint32_t goff = (c0 + (gvalid ? g_in : 0)) * 4;
+            const float4 qq = load4<ALIGNED>(qv + goff);
+
+#pragma unroll 1
+            for (int ib = 0; ib < NI; ib += NB) {
+                float4 x[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    uint32_t rr = (uint32_t)((ib + u) * RPI + row_in);
+                    if (rr >= nvalid) rr = nvalid - 1;
+                    const uint32_t srow = (uint32_t)__shfl((int)my_srow, (int)rr, 64);
+                    x[u] = load4<ALIGNED>(a.mat + (uint64_t)srow * dim + goff);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int rr = (ib + u) * RPI + row_in;
+                    const float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y;
+                    const float d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
+                    if constexpr (SEQ) {
+                        if (gvalid) {
+                            LDS_AT(g_in * 4 + 0, rr) = d0 * d0;
+                            LDS_AT(g_in * 4 + 1, rr) = d1 * d1;
+                            LDS_AT(g_in * 4 + 2, rr) = d2 * d2;
+                            LDS_AT(g_in * 4 + 3, rr) = d3 * d3;
+                        }
+                    } else {
+                        float t = d0 * d0 + d1 * d1;
+                        t = t + d2 * d2;
+                        t = t + d3 * d3;
+                        if (gvalid) LDS_AT(g_in, rr) = t;
+                    }
+                }
+            }
+            wave_lds_fence();
+            const uint32_t nchain = ng * EPL;
+            uint32_t e = 0;
+            for (; e + 8 <= nchain; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = LDS_AT(e + u, lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; e < nchain; ++e) sum = sum + LDS_AT(e, lane);
+            wave_lds_fence();
+        }
+        if (tail) {  // scalar tail of squared_l2_distance (index.rs:474-478)
+            const float *xr = a.mat + (uint64_t)my_srow * dim + (uint64_t)G * 4;
+            const float *qt = qv + (uint64_t)G * 4;
+            for (uint32_t e = 0; e < tail; ++e) {
+                const float d = qt[e] - xr[e];
+                sum = sum + d * d;
+            }
+        }
+
+        const uint64_t pos = cbase + t0 + (uint64_t)lane;
+        const bool valid = (uint32_t)lane < nvalid && pos < a.max_pos;
+        if constexpr (MODE == STREAM_TOPK) {
+            const uint64_t mykey =
+                valid ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos)
+                      : KEY_EMPTY;
+            tk.offer(mykey, my_srow, a.k, lane);
+        } else if constexpr (MODE == STREAM_MINUPD) {
+            if (valid) {
+                const float old = a.out_f32[pos];
+                if (sum < old) a.out_f32[pos] = sum;   // index.rs:363-365
+            }
+        } else {
+            if (valid) a.out_f32[pos] = sum;
+        }
+    }
+
+    if constexpr (MODE == STREAM_TOPK) {
+        const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+        const uint32_t pi = (j * a.blocks_per_list + blockIdx.x) * 4 + wave;
+        const uint64_t base = ((uint64_t)q * n_part + pi) * a.k;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t e = s * 64 + lane;
+            if (e < a.k) {
+                a.part_keys[base + e] = tk.key[s];
+                a.part_vals[base + e] = tk.val[s];
+            }
+        }
+    }
+}
+
+#undef LDS_AT
+
+template <int CG, int S, int MODE, bool SEQ, bool ALIGNED>
+static hipError_t launch_stream_t(const StreamArgs &a, hipStream_t s) {
+    dim3 grid(a.blocks_per_list, a.probe ? a.nprobe : 1, a.nq);
+    hipLaunchKernelGGL((stream_kernel<CG, S, MODE, SEQ, ALIGNED>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int S>
+static hipError_t launch_stream_topk_s(const StreamArgs &a, hipStream_t s) {
+    const bool aligned = (a.dim % 4) == 0;
+    const uint32_t G = a.dim / 4;
+    if (a.metric == 1) {
+        return aligned ? launch_stream_t<16, S, STREAM_TOPK, true, true>(a, s)
+                       : launch_stream_t<16, S, STREAM_TOPK, true, false>(a, s);
+    }
+    if (!aligned) return launch_stream_t<32, S, STREAM_TOPK, false, false>(a, s);
+    if (G >= 64 && G % 64 == 0) return launch_stream_t<64, S, STREAM_TOPK, false, true>(a, s);
+    return launch_stream_t<32, S, STREAM_TOPK, false, true>(a, s);
+}
+
+hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s) {
+    if (a.nq == 0 || a.blocks_per_list == 0) return hipSuccess;
+    if (mode == STREAM_TOPK) {
+        if (a.k <= 64) return launch_stream_topk_s<1>(a, s);
+        if (a.k <= 256) return launch_stream_topk_s<4>(a, s);
+        if (a.k <= 1024) return launch_stream_topk_s<16>(a, s);
+        return hipErrorInvalidValue;
+    }
+    const bool aligned = (a.dim % 4) == 0;
+    const uint32_t G = a.dim / 4;
+    if (a.metric == 1) {
+        if (mode == STREAM_MINUPD)
+            return aligned ? launch_stream_t<16, 1, STREAM_MINUPD, true, true>(a, s)
+                           : launch_stream_t<16, 1, STREAM_MINUPD, true, false>(a, s);
+        return hipErrorInvalidValue;
+    }
+    if (mode == STREAM_MINUPD) {
+        if (!aligned) return launch_stream_t<32, 1, STREAM_MINUPD, false, false>(a, s);
+        if (G >= 64 && G % 64 == 0) return launch_stream_t<64, 1, STREAM_MINUPD, false, true>(a, s);
+        return launch_stream_t<32, 1, STREAM_MINUPD, false, true>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------
+// merge_kernel: one wave per query folds all partial lists.
+// PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
+// PROBE == true : the k "rows" are centroids; emits the probe order and the candidate
+//                 position base of each probed list (index.rs:57-63's concatenation).
+// ------------------------------------------------------------------------------------
+template <int S, bool PROBE>
+__global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    WaveTopk<S> tk;
+    tk.init();
+    const uint64_t total = (uint64_t)a.n_part * a.k_part;
+    const uint64_t *pk = a.part_keys + (uint64_t)q * total;
+    const uint32_t *pv = a.part_vals + (uint64_t)q * total;
+    for (uint64_t i = 0; i < total; i += 64) {
+        const uint64_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        uint32_t val = 0xFFFFFFFFu;
+        if (idx < total) { key = pk[idx]; val = pv[idx]; }
+        tk.offer(key, val, a.k, lane);
+    }
+    if constexpr (!PROBE) {
+        uint32_t found = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t e = s * 64 + lane;
+            const bool have = e < a.k && tk.key[s] != KEY_EMPTY;
+            found += (uint32_t)__popcll(__ballot(have));
+            if (e < a.k) {
+                uint32_t row = 0xFFFFFFFFu;
+                float d = INFINITY;
+                if (have) {
+                    const float d2 = __uint_as_float((uint32_t)(tk.key[s] >> 32));
+                    row = a.ids ? a.ids[tk.val[s]] : tk.val[s];
+                    d = a.sqrt_out ? __fsqrt_rn(d2) : d2;
+                }
+                a.row_idx[(uint64_t)q * a.k + e] = row;
+                a.dist[(uint64_t)q * a.k + e] = d;
+            }
+        }
+        if (a.n_found && lane == 0) a.n_found[q] = found;
+    } else {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t e = s * 64 + lane;
+            const bool have = e < a.k && tk.key[s] != KEY_EMPTY;
+            const uint32_t c = have ? tk.val[s] : 0;
+            const uint64_t len = have ? (a.list_off[c + 1] - a.list_off[c]) : 0;
+            // inclusive wave scan of len
+            uint64_t incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64);
+                const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+                const uint64_t o = ((uint64_t)hi << 32) | lo;
+                if (lane >= off) incl += o;
+            }
+            if (e < a.k) {
+                a.probe[(uint64_t)q * a.k + e] = c;
+                a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
+            }
+            carry += readlane_u64(incl, 63);
+        }
+        if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
+    }
+}
+
+template <bool PROBE>
+static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    dim3 grid(a.nq), block(64);
+    if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
+    else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
+    else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s) { return launch_merge_t<false>(a, s); }
+hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s) { return launch_merge_t<true>(a, s); }
+
+// ------------------------------------------------------------------------------------
+// gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
+// ------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
+                                                         const uint32_t *__restrict__ idx32,
+                                                         const uint64_t *__restrict__ idx64,
+                                                         uint64_t m, uint32_t dim,
+                                                         float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = wave; i < m; i += nwaves) {
+        const uint64_t r = idx64 ? idx64[i] : (uint64_t)idx32[i];
+        const float *s = src + r * dim;
+        float *d = out + i * dim;
+        if constexpr (ALIGNED) {
+            const uint32_t G = dim >> 2;
+            for (uint32_t g = lane; g < G; g += 64)
+                reinterpret_cast<float4 *>(d)[g] = reinterpret_cast<const float4 *>(s)[g];
+        } else {
+            for (uint32_t e = lane; e < dim; e += 64) d[e] = s[e];
+        }
+    }
+}
+
+hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
+                              uint64_t m, uint32_t dim, float *out, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    uint64_t blocks = (m + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, s, src,
+                           idx32, idx64, m, dim, out);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, s, src,
+                           idx32, idx64, m, dim, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void narrow_f64_kernel(const double *__restrict__ src,
+                                                        uint64_t count, float *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        out[i] = (float)src[i];   // `as f32`: round to nearest even (parquet.rs:253)
+}
+hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(narrow_f64_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, src, count, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// assign_kernel: lane-per-row, CT running sums per lane, centroid chunk wave-uniform (the
+// compiler keeps it in SGPRs via scalar loads), 128 B of the lane's own row per step.
+// Each (row, centroid) chain is summed in ascending group order exactly as
+// squared_l2_distance does; the argmin uses strict '<' in ascending centroid order.
+// ------------------------------------------------------------------------------------
+template <int CT, bool ALIGNED>
+__global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ rows, uint64_t n,
+                                                    uint32_t dim,
+                                                    const float *__restrict__ cent, uint32_t k,
+                                                    uint32_t *__restrict__ cluster,
+                                                    const uint32_t *__restrict__ prev,
+                                                    unsigned long long *__restrict__ changed,
+                                                    unsigned long long *__restrict__ sizes) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r < n;
+    const float *x = rows + (valid ? r : (n - 1)) * dim;
+    const uint32_t G = dim >> 2, tail = dim & 3u;
+    float best = INFINITY;
+    uint32_t bestc = 0;
+
+    for (uint32_t c0 = 0; c0 < k; c0 += CT) {
+        float sum[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) sum[c] = 0.0f;
+
+        uint32_t g0 = 0;
+        for (; g0 + 8 <= G; g0 += 8) {
+            float4 xv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) xv[g] = load4<ALIGNED>(x + (g0 + g) * 4);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
+                const float *cp = cent + (uint64_t)cc * dim + g0 * 4;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 cv = load4<ALIGNED>(cp + g * 4);
+                    const float d0 = xv[g].x - cv.x, d1 = xv[g].y - cv.y;
+                    const float d2 = xv[g].z - cv.z, d3 = xv[g].w - cv.w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    sum[c] = sum[c] + t;
+                }
+            }
+        }
+        for (; g0 < G; ++g0) {
+            const float4 xg = load4<ALIGNED>(x + g0 * 4);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
+                const float4 cv = load4<ALIGNED>(cent + (uint64_t)cc * dim + g0 * 4);
+                const float d0 = xg.x - cv.x, d1 = xg.y - cv.y;
+                const float d2 = xg.z - cv.z, d3 = xg.w - cv.w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum[c] = sum[c] + t;
+            }
+        }
+        for (uint32_t e = 0; e < tail; ++e) {
+            const float xe = x[G * 4 + e];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
+                const float d = xe - cent[(uint64_t)cc * dim + G * 4 + e];
+                sum[c] = sum[c] + d * d;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (c0 + c < k && sum[c] < best) { best = sum[c]; bestc = c0 + c; }
+        }
+    }
+
+    if (valid) {
+        cluster[r] = bestc;
+        if (sizes) atomicAdd(&sizes[bestc], 1ull);
+        if (prev && changed && prev[r] != bestc) atomicAdd(changed, 1ull);
+    }
+}
+
+hipError_t launch_assign(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
+                         uint32_t k, uint32_t *cluster, const uint32_t *prev,
+                         unsigned long long *changed, unsigned long long *sizes, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL((assign_kernel<32, true>), dim3((uint32_t)blocks), dim3(256), 0, s, rows,
+                           n, dim, centroids, k, cluster, prev, changed, sizes);
+    else
+        hipLaunchKernelGGL((assign_kernel<32, false>), dim3((uint32_t)blocks), dim3(256), 0, s, rows,
+                           n, dim, centroids, k, cluster, prev, changed, sizes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// lloyd_update: thread (c, j) adds x[r][j] over cluster c's rows in ascending r -- the
+// same per-element add order as the reference's single-threaded loop (index.rs:438-444)
+// -- then divides by the size (index.rs:446-453); empty clusters stay all-zero.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lloyd_update_kernel(const float *__restrict__ rows,
+                                                          uint32_t dim,
+                                                          const uint32_t *__restrict__ list_rows,
+                                                          const uint64_t *__restrict__ list_off,
+                                                          float *__restrict__ centroids) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t jj = blockIdx.y * 256 + threadIdx.x;
+    if (jj >= dim) return;
+    const uint64_t b = list_off[c], e = list_off[c + 1];
+    float acc = 0.0f;
+    uint64_t i = b;
+    for (; i + 4 <= e; i += 4) {
+        const float v0 = rows[(uint64_t)list_rows[i] * dim + jj];
+        const float v1 = rows[(uint64_t)list_rows[i + 1] * dim + jj];
+        const float v2 = rows[(uint64_t)list_rows[i + 2] * dim + jj];
+        const float v3 = rows[(uint64_t)list_rows[i + 3] * dim + jj];
+        acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+    }
+    for (; i < e; ++i) acc = acc + rows[(uint64_t)list_rows[i] * dim + jj];
+    if (e > b) acc = __fdiv_rn(acc, (float)(e - b));
+    centroids[(uint64_t)c * dim + jj] = acc;
+}
+
+hipError_t launch_lloyd_update(const float *rows, uint32_t dim, const uint32_t *list_rows,
+                               const uint64_t *list_off, uint32_t k, float *centroids,
+                               hipStream_t s) {
+    if (k == 0) return hipSuccess;
+    dim3 grid(k, (dim + 255) / 256);
+    hipLaunchKernelGGL(lloyd_update_kernel, grid, dim3(256), 0, s, rows, dim, list_rows, list_off,
+                       centroids);
+    return hipGetLastError();
+}
+
+}  // namespace pqv

@@ -1,0 +1,276 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact row ids, inverted lists, centroids and distances
+(integer/byte work and f32 in the reference's summation order alike)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _assert_topk_equal(got, want, k):
+    """Row ids must match position by position, except inside groups of exactly equal
+    distances, where the reference's order depends on BinaryHeap history (SURVEY App. B
+    item 5): there the id sets must match."""
+    rows, dist, nf = got
+    orows, odist, onf = want
+    assert (nf == onf).all()
+    for q in range(rows.shape[0]):
+        m = int(nf[q])
+        assert (_bits(dist[q, :m]) == _bits(odist[q, :m])).all(), f"query {q}: distances differ"
+        i = 0
+        while i < m:
+            j = i
+            while j + 1 < m and _bits(odist[q, j + 1:j + 2])[0] == _bits(odist[q, i:i + 1])[0]:
+                j += 1
+            assert sorted(rows[q, i:j + 1].tolist()) == sorted(orows[q, i:j + 1].tolist()), \
+                f"query {q}: ids differ in positions {i}..{j}"
+            i = j + 1
+        assert (rows[q, m:] == 0xFFFFFFFF).all()
+
+
+def _random_index(oracle, rng, n, dim, kc, workers=1):
+    data = rng.random((n, dim), dtype=np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=workers, max_iters=5)
+    return data, oidx
+
+
+# ---------------------------------------------------------------------------------------
+# reference known answers through the GPU path
+# ---------------------------------------------------------------------------------------
+def test_reference_fixture_ids_5_2(pqv, oracle):
+    """src/df_vector/tests.rs:31-39,77-80,99: filter id>=2, k=2 => [5, 2] (exec.rs order)."""
+    vecs = np.array([(0, 0), (1, 0), (0, 2), (5, 5), (2, 2), (0.1, 0.1)], np.float32)
+    corpus = pqv.Corpus.upload(vecs)
+    index = pqv.IndexBuilder(corpus).workers(1).build()
+    assert index.n_clusters == 3
+    s = pqv.Searcher(index, corpus)
+    cand = s.candidate_rows([0, 0], 64)
+    assert len(cand) == 6                      # candidate_rows: 6 (snapshot)
+    fetched = sorted(r for r in cand.tolist() if r >= 2)
+    assert len(fetched) == 4                   # embeddings_fetched: 4 (snapshot)
+    rows, d2 = pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched)
+    assert rows.tolist() == [5, 2]
+    assert np.allclose(d2, [0.02, 4.0])
+
+
+def test_reference_fixture_ids_3_4(pqv):
+    """src/df_vector/tests.rs:166-174,212-215,235."""
+    vecs = np.array([(0, 0), (.05, .05), (.2, .2), (1, 1), (1.1, 1.1), (1.4, 1.4)], np.float32)
+    corpus = pqv.Corpus.upload(vecs)
+    index = pqv.IndexBuilder(corpus).workers(1).build()
+    s = pqv.Searcher(index, corpus)
+    cand = s.candidate_rows([0, 0], 64)
+    fetched = sorted(r for r in cand.tolist() if r >= 3)
+    assert len(cand) == 6 and len(fetched) == 3
+    rows, _ = pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched)
+    assert rows.tolist() == [3, 4]
+
+
+def test_reference_l2_known_answer(pqv):
+    """src/ivf/index.rs:488-493: d2([1,2,3],[4,5,6]) == 27 through the re-rank kernel."""
+    rows, d2 = pqv.rerank_batch([1, 2, 3], np.array([[4, 5, 6]], np.float32), 1,
+                                metric=pqv.PQV_L2SQ_REF4)
+    assert rows.tolist() == [0] and d2.tolist() == [27.0]
+
+
+def test_inplace_fixture_dim2(pqv):
+    """src/ivf/parquet.rs:638-659: 3 rows x 2-D build => dim 2."""
+    vecs = np.array([(0, 0), (1, 0), (0, 2)], np.float32)
+    index = pqv.IndexBuilder(vecs, "vec").build()
+    assert index.dim == 2 and index.n_rows == 3
+
+
+# ---------------------------------------------------------------------------------------
+# top-k vs oracle
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,kc,k,nprobe", [
+    (3000, 128, 12, 10, 4),     # C2-shaped, CG=32 single chunk
+    (2000, 768, 10, 10, 3),     # C3-shaped, CG=64 x 3 chunks
+    (1500, 1536, 8, 10, 3),     # C5-shaped
+    (600, 4096, 5, 10, 5),      # C1-shaped (vldb stand-in dims)
+    (2500, 100, 9, 7, 2),       # G=25: partial chunk
+    (2500, 72, 9, 5, 9),        # G=18, nprobe == n_clusters
+    (1200, 30, 6, 10, 3),       # dim % 4 == 2: unaligned rows + scalar tail
+    (1200, 3, 6, 3, 2),         # dim < 4: tail only
+    (900, 1, 4, 2, 4),
+    (5000, 64, 20, 64, 6),      # k = 64: a full wave of slots
+    (5000, 64, 20, 100, 6),     # reference bench K=100: 4 slots per lane
+    (4000, 32, 8, 300, 8),      # 16 slots per lane
+    (300, 16, 4, 10, 64),       # nprobe > n_clusters: clamped
+    (50, 8, 7, 60, 7),          # k > n: fewer than k results
+])
+@pytest.mark.parametrize("layout", ["ivf", "row"])
+def test_topk_matches_oracle(pqv, oracle, n, dim, kc, k, nprobe, layout):
+    rng = np.random.default_rng(n * 31 + dim)
+    data, oidx = _random_index(oracle, rng, n, dim, kc)
+    queries = rng.random((9, dim), dtype=np.float32)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    flags = pqv.PQV_LAYOUT_ROW_ORDER if layout == "row" else pqv.PQV_LAYOUT_IVF_ORDERED
+    s = pqv.Searcher(index, corpus, flags)
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nc == onc).all()
+    _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+    # probe order and candidate rows, integer work: exact
+    for q in range(3):
+        assert (s.probe(queries[q], nprobe) == oidx.find_closest_centroids(queries[q], nprobe)).all()
+        assert (s.candidate_rows(queries[q], nprobe) == oidx.candidate_rows(queries[q], nprobe)).all()
+
+
+def test_topk_ties_integer_vectors(pqv, oracle):
+    """Tie-heavy integer-valued vectors: survivors are the k smallest by (d2, candidate
+    position) -- the heap's strict '<' keeps earlier candidates (search.rs:121-125)."""
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 3, size=(4000, 8)).astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=6, workers=1, max_iters=4)
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+    queries = rng.integers(0, 3, size=(16, 8)).astype(np.float32)
+    for k in (1, 5, 10, 70):
+        rows, dist, nf, _ = s.topk(queries, k, 3)
+        orows, odist, onf, _ = oidx.topk_batch(data, queries, k, 3)
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+
+
+def test_topk_seq_metric_and_cap(pqv, oracle):
+    """PQV_L2SQ_SEQ (exec.rs:529-533 order, no sqrt) and the max_candidates cap
+    (access.rs:214-242: keep the first max_candidates in probe-rank order)."""
+    rng = np.random.default_rng(11)
+    data, oidx = _random_index(oracle, rng, 3000, 96, 10)
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+    queries = rng.random((6, 96), dtype=np.float32)
+    for cap in (0, 500, 37):
+        rows, d2, nf, nc = s.topk(queries, 10, 4, max_candidates=cap, metric=pqv.PQV_L2SQ_SEQ,
+                                  sqrt_out=False)
+        for q in range(len(queries)):
+            cand = oidx.candidate_rows(queries[q], 4)
+            assert nc[q] == len(cand)
+            if cap:
+                cand = cand[:cap]
+            orow, od2 = oracle.topk_df(data, cand, queries[q], 10)
+            m = len(orow)
+            assert nf[q] == m
+            assert (rows[q, :m] == orow).all()
+            assert (_bits(d2[q, :m]) == _bits(od2)).all()
+
+
+def test_rerank_batches_match_update_topk_heap(pqv, oracle):
+    """Folding RecordBatches one at a time (exec.rs:264-267) == one heap over all rows."""
+    rng = np.random.default_rng(3)
+    emb = rng.random((5000, 48), dtype=np.float32)
+    q = rng.random(48, dtype=np.float32)
+    order = rng.permutation(5000).astype(np.uint32)
+    state = None
+    for b in range(0, 5000, 2048):      # BATCH_ROWS = 2048 (benches/query.rs:29)
+        ids = order[b:b + 2048]
+        valid = (rng.random(len(ids)) > 0.1).astype(np.uint8)
+        state = pqv.rerank_batch(q, emb[ids], 10, state=state, ids=ids, valid=valid)
+        if b == 0:
+            kept = [ids[valid == 1]]
+        else:
+            kept.append(ids[valid == 1])
+    orow, od2 = oracle.topk_df(emb, np.concatenate(kept), q, 10)
+    assert (state[0] == orow).all()
+    assert (_bits(state[1]) == _bits(od2)).all()
+
+
+# ---------------------------------------------------------------------------------------
+# index build vs oracle
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,kc,workers", [
+    (6, 2, 0, 1),            # ceil(sqrt(6)) = 3, sample == n, floyd never runs
+    (400, 16, 0, 8),         # default n_clusters = 20; sample_size clamps to k
+    (4000, 128, 16, 8),      # sampled: 200 rows, floyd/inplace branch
+    (4000, 128, 16, 1),
+    (3000, 30, 12, 3),       # unaligned dim
+    (60000, 8, 25, 8),       # sample 3000, init subset == sample
+    (1200, 768, 6, 5),
+])
+def test_index_build_matches_oracle(pqv, oracle, n, dim, kc, workers):
+    rng = np.random.default_rng(n + dim)
+    data = rng.random((n, dim), dtype=np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=workers)
+    corpus = pqv.Corpus.upload(data)
+    b = pqv.IndexBuilder(corpus).workers(workers)
+    if kc:
+        b = b.n_clusters(kc)
+    index = b.build()
+    assert index.n_clusters == oidx.n_clusters
+    assert (_bits(index.centroids) == _bits(oidx.centroids)).all(), "centroids differ"
+    assert (index.list_offsets == oidx.list_off).all()
+    assert (index.list_rows == oidx.list_rows).all()
+    assert index.to_bytes() == oidx.to_bytes()
+
+
+def test_kmeans_matches_oracle_with_subset_sampling(pqv, oracle):
+    """n > 50_000 rows into k_means: the k-means++ subset is drawn by index::sample
+    (index.rs:332-338) and Lloyd runs over all rows."""
+    rng = np.random.default_rng(99)
+    data = rng.random((52000, 4), dtype=np.float32)
+    ocent, oassign, oiters = oracle.kmeans(data, 7, max_iters=6, seed=42, workers=4)
+    corpus = pqv.Corpus.upload(data)
+    import ctypes as C
+    from pq_vector_amd import _ffi
+    cent = np.zeros((7, 4), np.float32)
+    assign = np.zeros(52000, np.uint32)
+    iters = C.c_uint32(0)
+    rc = _ffi.lib().pqv_kmeans(corpus._h, 7, 6, 42, 4, cent.ctypes.data_as(_ffi.f32p),
+                               assign.ctypes.data_as(_ffi.u32p), C.byref(iters))
+    assert rc == 0, _ffi.lib().pqv_last_error()
+    assert iters.value == oiters
+    assert (_bits(cent) == _bits(ocent)).all()
+    assert (assign == oassign.astype(np.uint32)).all()
+
+
+def test_empty_cluster_and_duplicate_rows(pqv, oracle):
+    """Duplicate vectors: k-means++ total reaches 0 -> uniform pick (index.rs:384-389);
+    clusters that end up empty keep all-zero centroids (index.rs:436,446-453)."""
+    data = np.tile(np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.float32), (50, 1))
+    oidx = oracle.build_index(data, n_clusters=5, workers=2)
+    index = pqv.IndexBuilder(data).n_clusters(5).workers(2).build()
+    assert index.to_bytes() == oidx.to_bytes()
+
+
+def test_f64_column_is_narrowed(pqv, oracle):
+    """src/ivf/parquet.rs:246-256: Float64 embeddings are cast to f32 element-wise."""
+    rng = np.random.default_rng(1)
+    d64 = rng.random((700, 24))
+    corpus = pqv.Corpus.upload(d64)
+    got = corpus.fetch_rows(np.arange(700, dtype=np.uint32))
+    assert (_bits(got) == _bits(d64.astype(np.float32))).all()
+
+
+# ---------------------------------------------------------------------------------------
+# validation texts (reference strings)
+# ---------------------------------------------------------------------------------------
+def test_error_texts(pqv):
+    rng = np.random.default_rng(0)
+    data = rng.random((10, 4), dtype=np.float32)
+    with pytest.raises(pqv.PqvError, match="n_clusters cannot exceed number of vectors"):
+        pqv.IndexBuilder(data).n_clusters(11).build()
+    with pytest.raises(pqv.PqvError, match="max_iters must be > 0"):
+        pqv.IndexBuilder(data).max_iters(0).build()
+    with pytest.raises(pqv.PqvError, match="n_clusters must be > 0"):
+        pqv.IndexBuilder(data).n_clusters(0).build()
+    with pytest.raises(pqv.PqvError, match="Cannot build IVF index with zero vectors"):
+        pqv.IndexBuilder(np.zeros((0, 4), np.float32)).build()
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(pqv.IndexBuilder(corpus).n_clusters(2).build(), corpus)
+    with pytest.raises(pqv.PqvError, match="Query dimension mismatch: expected 4, got 3"):
+        s.topk(np.zeros((1, 3), np.float32), 1, 1)
+    with pytest.raises(pqv.PqvError, match="k must be > 0"):
+        pqv.TopkBuilder(s, data[0]).k(0)
+    with pytest.raises(pqv.PqvError, match="nprobe must be > 0"):
+        pqv.TopkBuilder(s, data[0]).nprobe(0)
+    with pytest.raises(pqv.PqvError, match="k must be set"):
+        pqv.TopkBuilder(s, data[0]).nprobe(1).search()
+    with pytest.raises(pqv.PqvError, match="nprobe must be set"):
+        pqv.TopkBuilder(s, data[0]).k(1).search()
+    res = pqv.TopkBuilder(s, data[3]).k(2).nprobe(2).search()
+    assert res[0].row_idx == 3 and res[0].distance == 0.0
