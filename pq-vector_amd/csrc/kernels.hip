@@ -45,6 +45,12 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// IEEE-754 correctly rounded f32 sqrt and divide (search.rs:133, index.rs:450), taken
+// through f64: 53 >= 2*24+2 bits makes the second rounding innocuous, and it does not
+// depend on how the compiler lowers f32 sqrt/div (v_sqrt_f32 / v_rcp_f32 are ~1 ulp).
+__device__ __forceinline__ float sqrt_f32_ieee(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ float div_f32_ieee(float a, float b) { return (float)((double)a / (double)b); }
+
 // ------------------------------------------------------------------------------------
 // Wave-distributed sorted top-k list: element e lives in slot e/64, lane e%64; ascending.
 // Keys are (f32 bits of d2 << 32) | candidate position: unique, and ordered exactly like
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
                 if (have) {
                     const float d2 = __uint_as_float((uint32_t)(tk.key[s] >> 32));
                     row = a.ids ? a.ids[tk.val[s]] : tk.val[s];
-                    d = a.sqrt_out ? __fsqrt_rn(d2) : d2;
+                    d = a.sqrt_out ? sqrt_f32_ieee(d2) : d2;
                 }
                 a.row_idx[(uint64_t)q * a.k + e] = row;
                 a.dist[(uint64_t)q * a.k + e] = d;
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256) void lloyd_update_kernel(const float *__restri
         acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
     }
     for (; i < e; ++i) acc = acc + rows[(uint64_t)list_rows[i] * dim + jj];
-    if (e > b) acc = __fdiv_rn(acc, (float)(e - b));
+    if (e > b) acc = div_f32_ieee(acc, (float)(e - b));
     centroids[(uint64_t)c * dim + jj] = acc;
 }
 
