@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- top-k QPS (k=10) of the MI355X IVF hot path on BASELINE.json's configs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|tiny] [--nq Q]
+
+A "step" is one pass of the hot path (centroid probe -> candidate re-rank -> top-k merge)
+over one batch of Q synthetic queries, with corpus, index and queries already resident in
+HBM.  Default workload = BASELINE.json configs[1] (C2): 1 M x 128 uniform f32, n_clusters
+100, k 10, nprobe 8.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is cut into N
+contiguous row ranges, one shard + its own IVF index per GPU (the reference's per-file
+index, src/df_vector/index_exec.rs:85-164); every rank searches the whole query batch on
+its shard and the per-shard top-k lists are exchanged with one RCCL all-gather per step
+and merged by (distance, shard, position).  Total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` and
+`cpu_baseline` objects.  torch is plumbing here: device tensors, streams, RCCL.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (rows, dim, n_clusters, nprobe, default queries per step)
+    "c2": (1_000_000, 128, 100, 8, 1024),
+    "c3": (10_000_000, 768, 1024, 32, 1024),
+    "c1": (1024, 4096, 0, 5, 64),          # vldb stand-in: n_clusters = ceil(sqrt(n)) = 32
+    "tiny": (20_000, 64, 16, 4, 64),       # plumbing check
+}
+K = 10
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--nq", type=int, default=0, help="queries per step (default per workload)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pq_vector_amd as pqv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available() or pqv.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: pq_vector_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
+    nq = args.nq or nq_default
+    lo = rank * n_total // world
+    hi = (rank + 1) * n_total // world
+    n_shard = hi - lo
+
+    # ---- synthetic data: the reference's bench recipe (benches/bench_util.rs:12-64) ------
+    # i.i.d. uniform [0,1) f32 with 24-bit resolution, corpus seed 1234, query seed 7.
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    corpus_t = torch.empty((n_shard, dim), dtype=torch.float32, device=dev)
+    step_rows = max(1, (1 << 28) // (dim * 4))
+    for s in range(0, n_shard, step_rows):
+        e = min(n_shard, s + step_rows)
+        u = torch.randint(0, 1 << 24, (e - s, dim), generator=g, device=dev, dtype=torch.int32)
+        corpus_t[s:e] = u.to(torch.float32) * (1.0 / (1 << 24))
+        del u
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(7)
+    queries_t = (torch.randint(0, 1 << 24, (nq, dim), generator=gq, device=dev, dtype=torch.int32)
+                 .to(torch.float32) * (1.0 / (1 << 24)))
+    torch.cuda.synchronize()
+
+    # ---- index build on the GPU (max_iters 20, seed 42: src/ivf/parquet.rs:37-38) --------
+    corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n_shard, dim, device=local_rank,
+                                        keepalive=corpus_t)
+    workers = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    index = pqv.IndexBuilder(corpus).n_clusters(n_clusters).max_iters(20).seed(42).workers(workers).build() \
+        if n_clusters else pqv.IndexBuilder(corpus).max_iters(20).seed(42).workers(workers).build()
+    build_s = time.perf_counter() - t0
+    flags = pqv.PQV_LAYOUT_ROW_ORDER if args.layout == "row" else pqv.PQV_LAYOUT_IVF_ORDERED
+    t0 = time.perf_counter()
+    searcher = pqv.Searcher(index, corpus, flags)
+    layout_s = time.perf_counter() - t0
+    if rank == 0:
+        log(f"[bench] shard rows={n_shard} dim={dim} n_clusters={index.n_clusters} build={build_s:.3f}s "
+            f"relayout={layout_s:.3f}s")
+
+    # ---- device outputs -------------------------------------------------------------------
+    rows_t = torch.empty((nq, K), dtype=torch.int32, device=dev)
+    dist_t = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    nf_t = torch.empty((nq,), dtype=torch.int32, device=dev)
+    nc_t = torch.empty((nq,), dtype=torch.int64, device=dev)
+    if world > 1:
+        gath_d = torch.empty((world, nq, K), dtype=torch.float32, device=dev)
+        gath_r = torch.empty((world, nq, K), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        # hot path on this rank's shard; asynchronous on torch's current stream
+        searcher.topk_device(queries_t.data_ptr(), nq, K, nprobe, rows_t.data_ptr(), dist_t.data_ptr(),
+                             nf_t.data_ptr(), nc_t.data_ptr(), stream=stream)
+        if world == 1:
+            return dist_t, rows_t
+        # exchange: one all-gather of k x {dist, global row} per query, then a stable merge
+        # keyed (dist, shard, position) -- shard-major concatenation + stable sort.
+        grow = rows_t.to(torch.int64) + lo
+        dist.all_gather_into_tensor(gath_d, dist_t)
+        dist.all_gather_into_tensor(gath_r, grow)
+        d = gath_d.permute(1, 0, 2).reshape(nq, world * K)
+        r = gath_r.permute(1, 0, 2).reshape(nq, world * K)
+        order = torch.sort(d, dim=1, stable=True).indices[:, :K]
+        return torch.gather(d, 1, order), torch.gather(r, 1, order)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    searcher.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_d, out_r = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    searcher.set_timing(False)
+    rerank_ms, total_ms, ncalls = searcher.timing_read()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # ---- algorithmic bytes of the dominant (re-rank) kernel --------------------------------
+    ncand = nc_t.cpu().numpy().astype(np.int64)
+    cand_rows = int(ncand.sum())
+    algo_bytes = cand_rows * (4 * dim + 4)          # embedding row + its u32 id
+    rr_ms = rerank_ms / max(1, ncalls)
+    achieved = algo_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("nq") == nq and tj.get("n_gpus", 1) == world:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "topk_queries_per_s_k10",
+        "value": nq * args.steps / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_total}x{dim} uniform f32, n_clusters {index.n_clusters}"
+                               f"{' per shard' if world > 1 else ''}, k {K}, nprobe {nprobe}, "
+                               f"{nq} queries/step, layout {args.layout}",
+                   "rows": n_total, "dim": dim, "n_clusters": int(index.n_clusters), "k": K,
+                   "nprobe": nprobe, "queries_per_step": nq, "shards": world},
+        "index_build_vectors_per_s": n_shard / build_s,
+        "index_build_s": build_s,
+        "candidates_per_query": cand_rows / nq,
+        "roofline": {"bound": "hbm", "kernel": "stream_kernel (candidate re-rank + per-wave top-k)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algo_bytes_per_launch": algo_bytes, "kernel_ms": rr_ms,
+                     "hot_path_ms_per_step": total_ms / max(1, ncalls)},
+    }
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled, one thread -----------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq):
+    """Times the CPU oracle (a port of src/ivf/search.rs:83-142, compiled -O3 -march=native
+    -ffp-contract=off on THIS host) on a bounded sample of the same queries, one thread as
+    the reference's query loop is (search.rs:115), and checks the GPU results against it."""
+    from oracle_binding import Oracle, build_oracle
+    build_oracle("native")
+    o = Oracle(native=True)
+    host = corpus_t.cpu().numpy()
+    qs = queries_t.cpu().numpy()
+    oidx = o.index_from_bytes(index.to_bytes())
+    grows = rows_t.cpu().numpy().view(np.uint32)
+    gdist = dist_t.cpu().numpy()
+    done, spent = 0, 0.0
+    ids_ok, dist_ok = True, True
+    chunk = 4
+    while done < nq and spent < args.cpu_seconds:
+        b = min(chunk, nq - done)
+        t0 = time.perf_counter()
+        orows, odist, onf, _ = oidx.topk_batch(host, qs[done:done + b], K, nprobe)
+        spent += time.perf_counter() - t0
+        ids_ok &= bool((orows == grows[done:done + b]).all())
+        dist_ok &= bool((odist.view(np.uint32) == gdist[done:done + b].view(np.uint32)).all())
+        done += b
+        chunk = min(64, chunk * 2)
+    return {"value": done / spent, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} of the step's {nq} queries, in-memory corpus, oracle -O3 -march=native "
+                      f"-ffp-contract=off, {spent:.1f} s",
+            "host_cpus": os.cpu_count(),
+            "parity": {"queries_checked": done, "row_idx_identical": ids_ok, "dist_bit_identical": dist_ok}}
+
+
+if __name__ == "__main__":
+    main()
