@@ -79,8 +79,8 @@ def main():
 
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
     nq = args.nq or nq_default
-    lo = rank * n_total // world
-    hi = (rank + 1) * n_total // world
+    from pq_vector_amd.sharding import ShardExchange, shard_range
+    lo, hi = shard_range(rank, world, n_total)
     n_shard = hi - lo
 
     # ---- synthetic data: the reference's bench recipe (benches/bench_util.rs:12-64) ------
@@ -121,9 +121,7 @@ def main():
     dist_t = torch.empty((nq, K), dtype=torch.float32, device=dev)
     nf_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     nc_t = torch.empty((nq,), dtype=torch.int64, device=dev)
-    if world > 1:
-        gath_d = torch.empty((world, nq, K), dtype=torch.float32, device=dev)
-        gath_r = torch.empty((world, nq, K), dtype=torch.int64, device=dev)
+    xchg = ShardExchange(world, nq, K, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -133,14 +131,8 @@ def main():
         if world == 1:
             return dist_t, rows_t
         # exchange: one all-gather of k x {dist, global row} per query, then a stable merge
-        # keyed (dist, shard, position) -- shard-major concatenation + stable sort.
-        grow = rows_t.to(torch.int64) + lo
-        dist.all_gather_into_tensor(gath_d, dist_t)
-        dist.all_gather_into_tensor(gath_r, grow)
-        d = gath_d.permute(1, 0, 2).reshape(nq, world * K)
-        r = gath_r.permute(1, 0, 2).reshape(nq, world * K)
-        order = torch.sort(d, dim=1, stable=True).indices[:, :K]
-        return torch.gather(d, 1, order), torch.gather(r, 1, order)
+        # keyed (dist, shard, position) -- pq_vector_amd/sharding.py
+        return xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, lo)
 
     def barrier():
         if world > 1:

@@ -296,3 +296,42 @@ def test_error_texts(pqv):
         pqv.TopkBuilder(s, data[0]).k(1).search()
     res = pqv.TopkBuilder(s, data[3]).k(2).nprobe(2).search()
     assert res[0].row_idx == 3 and res[0].distance == 0.0
+
+
+# ---------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/*.npz, generated by tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------
+import glob as _glob
+import os as _os
+
+_GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLDEN, "*.npz"))),
+                         ids=lambda p: _os.path.basename(p))
+def test_gpu_reproduces_golden(pqv, oracle, path):
+    g = np.load(path)
+    data, queries = g["data"], g["queries"]
+    k, nprobe = int(g["k"]), int(g["nprobe"])
+    ties = "ties" in _os.path.basename(path)
+    corpus = pqv.Corpus.upload(data)
+    for w in g["workers_list"].tolist():
+        b = pqv.IndexBuilder(corpus).max_iters(int(g["max_iters"])).seed(int(g["seed"])).workers(w)
+        if int(g["n_clusters"]):
+            b = b.n_clusters(int(g["n_clusters"]))
+        index = b.build()
+        assert index.to_bytes() == g[f"w{w}_blob"].tobytes(), "index blob differs from the golden blob"
+        s = pqv.Searcher(index, corpus)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == g[f"w{w}_n_candidates"]).all()
+        for q in range(len(queries)):
+            assert (s.probe(queries[q], nprobe) == g[f"w{w}_probe"][q]).all()
+        want = (g[f"w{w}_topk_rows"], g[f"w{w}_topk_dist_bits"].view(np.float32), g[f"w{w}_n_found"])
+        if ties:
+            oidx = oracle.index_from_bytes(g[f"w{w}_blob"].tobytes())
+            cands = [set(oidx.candidate_rows(q, nprobe).tolist()) for q in queries]
+            ok = lambda q, row, d: row in cands[q] and \
+                np.float32(np.sqrt(oracle.l2_ref4(queries[q], data[row]))) == d
+            _assert_topk_equal((rows, dist, nf), want, k, boundary_ok=ok)
+        else:
+            _assert_topk_equal((rows, dist, nf), want, k)
