@@ -139,7 +139,8 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound;
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr;
+    int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
     mutable pqv_counters_t counters{};
     // timing
     mutable bool timing = false;
@@ -679,6 +680,10 @@ extern "C" int pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, u
             return cleanup(_e == hipErrorOutOfMemory ? PQV_ERR_OOM : PQV_ERR_HIP,         \
                            std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
+    if (const char *m = std::getenv("PQV_RERANK_MODE")) {   // A/B switch for benchmarking
+        if (!std::strcmp(m, "stream")) s->rerank_mode = 1;
+        else if (!std::strcmp(m, "tile")) s->rerank_mode = 2;
+    }
     S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
     S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
@@ -725,9 +730,11 @@ struct TopkPlan {
     uint32_t probe_bpl;     // blocks over the centroid matrix
     uint32_t rr_rows_per_block, rr_bpl;
     uint32_t n_part_probe, n_part_rr;
+    bool tile;              // batched cluster-major tiles instead of one stream per (query, list)
+    uint32_t max_groups;
 };
 
-TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe) {
+TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
     TopkPlan p{};
     p.np = std::min<uint32_t>(nprobe, s->n_clusters);
     // probe pass: every block scans 256 centroids (64 per wave)
@@ -737,6 +744,23 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe) {
     const uint64_t max_len = std::max<uint64_t>(1, s->max_list_len);
     const uint64_t max_bpl = (max_len + 255) / 256;
     const uint64_t pairs = std::max<uint64_t>(1, static_cast<uint64_t>(nq) * p.np);
+    // Tile path: worth it once several queries share a cluster (each streamed row is then
+    // reused by up to TILE_QB queries).  One top-k slot per lane => k <= 64; REF4 order only.
+    p.tile = metric == PQV_L2SQ_REF4 && k <= 64 && pairs >= 4ull * s->n_clusters;
+    if (s->rerank_mode == 1) p.tile = false;
+    if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 64;
+    if (p.tile) {
+        const uint64_t est_groups = std::max<uint64_t>(1, pairs / pqv::TILE_QB);
+        uint64_t bpl = (4096 + est_groups - 1) / est_groups;
+        bpl = std::max<uint64_t>(1, std::min<uint64_t>(bpl, max_bpl));
+        uint64_t rpb = (max_len + bpl - 1) / bpl;
+        rpb = (rpb + 255) / 256 * 256;
+        p.rr_rows_per_block = static_cast<uint32_t>(rpb);
+        p.rr_bpl = static_cast<uint32_t>((max_len + rpb - 1) / rpb);
+        p.n_part_rr = p.np * p.rr_bpl * pqv::waves_per_block();
+        p.max_groups = static_cast<uint32_t>(pairs / pqv::TILE_QB + std::min<uint64_t>(s->n_clusters, pairs));
+        return p;
+    }
     uint64_t bpl = (8192 + pairs - 1) / pairs;
     bpl = std::max<uint64_t>(1, std::min<uint64_t>(bpl, max_bpl));
     uint64_t rpb = (max_len + bpl - 1) / bpl;
@@ -753,7 +777,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                  uint32_t *d_row_idx, float *d_dist, uint32_t *d_n_found, uint64_t *d_n_cand,
                  hipStream_t stream) {
     using namespace pqv;
-    const TopkPlan p = plan_topk(s, nq, nprobe);
+    const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
 
     HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
@@ -794,6 +818,35 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     HIP_TRY(launch_merge_probe(pm, stream));
 
     // 2. candidate re-rank + per-wave top-k
+    if (p.tile) {
+        const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
+        // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1]
+        HIP_TRY(s->s_pair_u32.ensure((4ull * kc + 3) * sizeof(uint32_t)));
+        HIP_TRY(s->s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
+        HIP_TRY(s->s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
+        uint32_t *u = s->s_pair_u32.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(u, 0, 2ull * kc * sizeof(uint32_t), stream));
+        HIP_TRY(s->s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(s->s_gthr.p, 0xFF, static_cast<size_t>(nq) * sizeof(unsigned long long), stream));
+        PairSortArgs ps{};
+        ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc;
+        ps.hist = u; ps.cursor = u + kc; ps.pair_off = u + 2ull * kc; ps.group_off = u + 3ull * kc + 1;
+        ps.n_groups = u + 4ull * kc + 2;
+        ps.pairs = s->s_pairs.as<uint32_t>(); ps.groups = s->s_groups.as<uint4>();
+        HIP_TRY(launch_pair_sort(ps, stream));
+        TileArgs ta{};
+        ta.mat = s->d_mat; ta.row_of = s->d_row_of; ta.list_off = s->d_list_off.as<uint64_t>();
+        ta.queries = d_queries; ta.cand_base = s->s_cand_base.as<uint64_t>();
+        ta.pairs = ps.pairs; ta.groups = ps.groups; ta.n_groups = ps.n_groups; ta.max_groups = p.max_groups;
+        ta.nq = nq; ta.nprobe = p.np; ta.dim = s->dim; ta.k = k;
+        ta.rows_per_block = p.rr_rows_per_block; ta.blocks_per_list = p.rr_bpl; ta.max_pos = max_pos;
+        ta.gthr = s->s_gthr.as<unsigned long long>();
+        ta.part_keys = s->s_part_keys.as<uint64_t>(); ta.part_vals = s->s_part_vals.as<uint32_t>();
+        if (timing) HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(launch_tile_rerank(ta, stream));
+        if (timing) HIP_TRY(hipEventRecord(e2, stream));
+        s->counters.kernel_launches += 3;
+    }
     StreamArgs ra{};
     ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
     ra.probe = s->s_probe.as<uint32_t>(); ra.cand_base = s->s_cand_base.as<uint64_t>();
@@ -801,9 +854,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     ra.rows_per_block = p.rr_rows_per_block; ra.blocks_per_list = p.rr_bpl;
     ra.max_pos = max_pos; ra.metric = metric;
     ra.part_keys = s->s_part_keys.as<uint64_t>(); ra.part_vals = s->s_part_vals.as<uint32_t>();
-    if (timing) HIP_TRY(hipEventRecord(e1, stream));
-    HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
-    if (timing) HIP_TRY(hipEventRecord(e2, stream));
+    if (!p.tile) {
+        if (timing) HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
+        if (timing) HIP_TRY(hipEventRecord(e2, stream));
+    }
 
     // 3. fold the per-wave lists
     MergeArgs fm{};
@@ -860,7 +915,7 @@ extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
-    const TopkPlan p1 = plan_topk(s, 1, nprobe);
+    const TopkPlan p1 = plan_topk(s, 1, nprobe, k, metric);
     const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k * 12 + 1;
     uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / per_query)));
     HIP_TRY(s->s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));

@@ -62,6 +62,46 @@ struct MergeArgs {
 hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s);
 hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 
+// ---- batched re-rank: cluster-major tiles ------------------------------------------------
+// The (query, probe-rank) pairs of a batch are bucketed by cluster; a "group" is up to
+// TILE_QB pairs of one cluster.  tile_rerank streams each row tile of that cluster ONCE for
+// the whole group (queries as wave-uniform scalar operands), instead of once per query.
+constexpr int TILE_QB = 16;
+
+struct PairSortArgs {
+    const uint32_t *probe;     // [nq * nprobe] cluster of pair p = q*nprobe + j
+    uint32_t        n_pairs, n_clusters;
+    uint32_t       *hist;      // [n_clusters]      (zeroed by the caller)
+    uint32_t       *cursor;    // [n_clusters]      (zeroed by the caller)
+    uint32_t       *pair_off;  // [n_clusters + 1]
+    uint32_t       *group_off; // [n_clusters + 1]
+    uint32_t       *pairs;     // [n_pairs] pair ids bucketed by cluster
+    uint4          *groups;    // [max_groups] {cluster, first slot, count, 0}
+    uint32_t       *n_groups;  // [1]
+};
+// hist -> scan -> scatter; three tiny launches
+hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
+
+struct TileArgs {
+    const float    *mat;
+    const uint32_t *row_of;
+    const uint64_t *list_off;
+    const float    *queries;
+    const uint64_t *cand_base;   // [nq * nprobe]
+    const uint32_t *pairs;
+    const uint4    *groups;
+    const uint32_t *n_groups;
+    uint32_t        max_groups;  // gridDim.y
+    uint32_t        nq, nprobe, dim, k;
+    uint32_t        rows_per_block, blocks_per_list;
+    uint64_t        max_pos;
+    unsigned long long *gthr;    // [nq] per-query global admission threshold, preset to KEY_EMPTY
+    uint64_t       *part_keys;   // same layout as StreamArgs: [nq][nprobe*blocks_per_list*4][k]
+    uint32_t       *part_vals;
+};
+// PQV_L2SQ_REF4 only, k <= 64
+hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
+
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
                               uint64_t m, uint32_t dim, float *out, hipStream_t s);

@@ -123,6 +123,30 @@ __device__ __forceinline__ float4 load4(const float *p) {
     }
 }
 
+// Wave-uniform 16-byte operand (a query / centroid chunk shared by all 64 lanes): read
+// through the constant address space so the backend always selects scalar loads
+// (s_load_dwordx4..x16 into SGPRs, consumed as free scalar VALU operands).  Without this the
+// compiler falls back to per-lane vector loads as soon as the kernel also contains atomics
+// or stores it cannot prove disjoint from the operand matrix.
+typedef const __attribute__((address_space(4))) float cfloat_as4;
+template <bool ALIGNED>
+__device__ __forceinline__ float4 load4_uniform(const float *p) {
+    cfloat_as4 *c = (cfloat_as4 *)(uintptr_t)p;
+    if constexpr (ALIGNED) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) f32x4_t cf32x4_as4;
+        const f32x4_t v = *(cf32x4_as4 *)c;
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        float4 v;
+        v.x = c[0]; v.y = c[1]; v.z = c[2]; v.w = c[3];
+        return v;
+    }
+}
+__device__ __forceinline__ float load1_uniform(const float *p) {
+    return *(cfloat_as4 *)(uintptr_t)p;
+}
+
 // ------------------------------------------------------------------------------------
 // stream_kernel
 //
@@ -412,6 +436,336 @@ hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s) { return launch
 hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s) { return launch_merge_t<true>(a, s); }
 
 // ------------------------------------------------------------------------------------
+// pair bucketing for the batched re-rank: counting sort of (query, probe-rank) pairs by
+// cluster + the group table.  Order inside a bucket is arbitrary (atomics) and does not
+// matter: every pair writes its partial lists to slots fixed by (q, j, chunk, wave).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_hist_kernel(const PairSortArgs a) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p < a.n_pairs) atomicAdd(&a.hist[a.probe[p]], 1u);
+}
+
+__global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
+    // single block: exclusive scans of hist and of ceil(hist / TILE_QB)
+    __shared__ uint32_t s_pair[1024], s_grp[1024];
+    __shared__ uint32_t carry_pair, carry_grp;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { carry_pair = 0; carry_grp = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
+        const uint32_t c = base + tid;
+        const uint32_t h = c < a.n_clusters ? a.hist[c] : 0;
+        const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
+        s_pair[tid] = h; s_grp[tid] = g;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint32_t vp = 0, vg = 0;
+            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; }
+            __syncthreads();
+            s_pair[tid] += vp; s_grp[tid] += vg;
+            __syncthreads();
+        }
+        if (c < a.n_clusters) {
+            a.pair_off[c] = carry_pair + s_pair[tid] - h;
+            a.group_off[c] = carry_grp + s_grp[tid] - g;
+        }
+        __syncthreads();
+        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.pair_off[a.n_clusters] = carry_pair;
+        a.group_off[a.n_clusters] = carry_grp;
+        *a.n_groups = carry_grp;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_pairs) return;
+    const uint32_t c = a.probe[p];
+    const uint32_t i = atomicAdd(&a.cursor[c], 1u);
+    const uint32_t slot = a.pair_off[c] + i;
+    a.pairs[slot] = p;
+    if (i % TILE_QB == 0) {
+        const uint32_t h = a.hist[c];
+        const uint32_t cnt = (h - i < (uint32_t)TILE_QB) ? (h - i) : (uint32_t)TILE_QB;
+        a.groups[a.group_off[c] + i / TILE_QB] = make_uint4(c, slot, cnt, 0u);
+    }
+}
+
+hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s) {
+    if (a.n_pairs == 0) return hipSuccess;
+    const uint32_t blocks = (a.n_pairs + 255) / 256;
+    hipLaunchKernelGGL(pair_hist_kernel, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(pair_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// tile_rerank_kernel: the batched candidate re-rank.
+//
+// grid = (blocks_per_list, max_groups); block = 4 independent waves.  A block takes one
+// group (<= QB queries that all probe cluster c) and one row chunk of c's inverted list;
+// each wave walks its rows lane-per-row in 64-row tiles.  Per tile the lane's row is
+// loaded 128 B at a time (a full cache line per lane) and every query of the group is
+// applied to it from SGPRs (wave-uniform scalar loads) -- each streamed row is used QB
+// times, with zero LDS traffic.  Every (row, query) chain is the reference's serial
+//   sum += ((d0^2 + d1^2) + d2^2) + d3^2   in ascending group order (index.rs:461-480).
+// Top-k: one wave-distributed sorted list per query of the group (registers); the first
+// tile seeds it with a 64-lane bitonic sort, later tiles insert past the k-th key.
+// ------------------------------------------------------------------------------------
+// 64-lane bitonic sort of (key, val), ascending
+__device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)key, j, 64);
+            const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64);
+            const uint32_t pv = (uint32_t)__shfl_xor((int)val, j, 64);
+            const uint64_t pk = ((uint64_t)phi << 32) | plo;
+            const bool up = (lane & k2) == 0;
+            const bool lower = (lane & j) == 0;
+            const bool take_min = lower == up;
+            const bool sw = take_min ? (pk < key) : (pk > key);
+            if (sw) { key = pk; val = pv; }
+        }
+    }
+}
+
+// Per-wave state of the tile kernel in dynamic LDS.  The top-k lists are touched only when
+// a candidate beats the admission threshold, which becomes rare once the per-query global
+// threshold has tightened:
+//   keys[wave][QB][k] u64 | kth[wave][QB] u64 | vals[wave][QB][k] u32 | sums[wave][QB][64] f32
+extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+
+// Fold this tile's candidates of one query into the wave's LDS-resident list.
+__device__ __forceinline__ void tile_fold(uint64_t *lkeys, uint32_t *lvals, uint64_t *lkth,
+                                          unsigned long long *gthr, uint64_t gseen,
+                                          uint64_t local_kth, uint64_t mykey, uint32_t myval,
+                                          uint32_t k, int lane) {
+    WaveTopk<1> tk;
+    tk.key[0] = (uint32_t)lane < k ? lkeys[lane] : KEY_EMPTY;
+    tk.val[0] = (uint32_t)lane < k ? lvals[lane] : 0xFFFFFFFFu;
+    if (readlane_u64(tk.key[0], 0) == KEY_EMPTY) {
+        // empty list: sort the whole tile once instead of up to 64 single inserts
+        uint64_t key = mykey < gseen ? mykey : KEY_EMPTY;
+        uint32_t val = myval;
+        bitonic_sort64(key, val, lane);
+        tk.key[0] = key; tk.val[0] = val;
+    } else {
+        uint64_t thr = local_kth < gseen ? local_kth : gseen;
+        unsigned long long m = __ballot(mykey < thr);
+        while (m) {
+            const int L = __builtin_ctzll(m);
+            const uint64_t x = readlane_u64(mykey, L);
+            const uint32_t xv = readlane_u32(myval, L);
+            tk.insert(x, xv, lane);
+            const uint64_t nk = tk.kth(k);
+            thr = nk < thr ? nk : thr;
+            m &= m - 1;
+            m &= __ballot(mykey < thr);
+        }
+    }
+    if ((uint32_t)lane < k) { lkeys[lane] = tk.key[0]; lvals[lane] = tk.val[0]; }
+    const uint64_t nk = tk.kth(k);
+    if (lane == 0) {
+        *lkth = nk;
+        // any wave's k-th key bounds the final k-th key from above: publish it
+        if (nk < gseen) atomicMin(gthr, (unsigned long long)nk);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// tile_rerank_kernel: the batched candidate re-rank.
+//
+// grid = (blocks_per_list, max_groups); block = 4 independent waves.  A block takes one
+// group (<= QB queries that all probe cluster c) and one row chunk of c's inverted list;
+// each wave walks its rows lane-per-row in 64-row tiles.  Per tile the lane's row is
+// loaded 128 B at a time (a full cache line per lane) and every query of the group is
+// applied to it from SGPRs (wave-uniform scalar loads) -- each streamed row is used QB
+// times, with zero LDS traffic in the distance loop.  Every (row, query) chain is the
+// reference's serial  sum += ((d0^2 + d1^2) + d2^2) + d3^2  in ascending group order
+// (index.rs:461-480).
+//
+// Top-k: a candidate is admitted iff its key beats min(this wave's k-th key, the query's
+// GLOBAL threshold).  The global threshold is the minimum over all waves of their k-th
+// keys (device-scope atomic min): each is an upper bound of the final k-th key, so nothing
+// that belongs to the final top-k is ever rejected, and the merged result is independent
+// of timing.  It collapses the work of the ~nprobe*blocks*4 independent lists per query to
+// roughly one list's worth of inserts.  Per-query state is held lane-parallel (lane q of
+// a wave holds query q's row index / candidate base / thresholds) and the epilogue is a
+// rolled loop over the group's queries reading the tile's sums back from LDS, so the
+// fold code exists once.
+// ------------------------------------------------------------------------------------
+template <int QB, bool ALIGNED>
+__global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
+    const uint32_t gi = blockIdx.y;
+    if (gi >= *a.n_groups) return;
+    const uint4 grp = a.groups[gi];
+    const uint32_t c = grp.x, p0 = grp.y, cnt = grp.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t k = a.k;
+
+    uint64_t *all_keys = reinterpret_cast<uint64_t *>(tile_lds);
+    uint64_t *all_kth = all_keys + 4u * QB * k;
+    uint32_t *all_vals = reinterpret_cast<uint32_t *>(all_kth + 4u * QB);
+    float *all_sums = reinterpret_cast<float *>(all_vals + 4u * QB * k);
+    uint64_t *lkeys = all_keys + (uint32_t)wave * QB * k;
+    uint64_t *lkth = all_kth + (uint32_t)wave * QB;
+    uint32_t *lvals = all_vals + (uint32_t)wave * QB * k;
+    float *lsums = all_sums + (uint32_t)wave * QB * 64;
+    for (uint32_t i = lane; i < QB * k; i += 64) { lkeys[i] = KEY_EMPTY; lvals[i] = 0xFFFFFFFFu; }
+    if (lane < QB) lkth[lane] = KEY_EMPTY;
+    wave_lds_fence();
+
+    const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
+    const uint64_t len = lend - lbeg;
+    const uint64_t wrows = a.rows_per_block / 4;
+    const uint64_t r0 = (uint64_t)blockIdx.x * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows;
+    if (r1 > len) r1 = len;
+
+    const uint32_t dim = a.dim;
+    const uint32_t G = dim >> 2, tail = dim & 3u;
+
+    // lane-parallel per-query state: lane q (< QB) owns query q of the group
+    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
+    const uint32_t my_pair = a.pairs[my_slot];
+    const uint32_t my_qrow = my_pair / a.nprobe;
+    const uint64_t my_cbase = a.cand_base[my_pair];
+
+    for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+        const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+        const uint32_t lrow = (uint32_t)lane < nvalid ? (uint32_t)lane : nvalid - 1;
+        const uint64_t lpos = lbeg + t0 + lrow;
+        const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+        const float *x = a.mat + (uint64_t)srow * dim;
+        // this tile's view of the global thresholds (relaxed device-scope load; a stale
+        // value is only a looser bound).  Issued now, consumed after the distance loop.
+        const uint64_t my_gthr =
+            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        float sum[QB];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) sum[qq] = 0.0f;
+
+        uint32_t g0 = 0;
+        for (; g0 + 8 <= G; g0 += 8) {
+            float4 xv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) xv[g] = load4<ALIGNED>(x + (g0 + g) * 4);
+            // Software pipeline over the group's queries.  Scalar (SMEM) loads return out
+            // of order, so the only usable wait is lgkmcnt(0); the order per query is
+            //   wait(current chunk) -> issue next chunk's loads -> math on current chunk
+            // which keeps exactly one 128-B chunk in flight behind ~190 cycles of VALU and
+            // bounds the live scalar state to two chunks (64 SGPRs).  sched_barrier pins it.
+            float4 qc[8];
+            {
+                const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, 0) * dim + g0 * 4;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) qc[g] = load4_uniform<ALIGNED>(qp + g * 4);
+            }
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                float4 qn[8];
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): current chunk has landed
+                if (qq + 1 < QB) {
+                    const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, qq + 1) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qn[g] = load4_uniform<ALIGNED>(qp + g * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = qc[g].x - xv[g].x, d1 = qc[g].y - xv[g].y;
+                    const float d2 = qc[g].z - xv[g].z, d3 = qc[g].w - xv[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    sum[qq] = sum[qq] + t;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (qq + 1 < QB) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qc[g] = qn[g];
+                }
+            }
+        }
+        for (; g0 < G; ++g0) {
+            const float4 xg = load4<ALIGNED>(x + g0 * 4);
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                const float4 qv = load4_uniform<ALIGNED>(a.queries + (uint64_t)readlane_u32(my_qrow, qq) * dim + g0 * 4);
+                const float d0 = qv.x - xg.x, d1 = qv.y - xg.y;
+                const float d2 = qv.z - xg.z, d3 = qv.w - xg.w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum[qq] = sum[qq] + t;
+            }
+        }
+        for (uint32_t e = 0; e < tail; ++e) {
+            const float xe = x[G * 4 + e];
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                const float d = load1_uniform(a.queries + (uint64_t)readlane_u32(my_qrow, qq) * dim + G * 4 + e) - xe;
+                sum[qq] = sum[qq] + d * d;
+            }
+        }
+
+        // ---- top-k epilogue: rolled over the group's queries --------------------------
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) lsums[qq * 64 + lane] = sum[qq];
+        wave_lds_fence();
+        const uint64_t my_lkth = lkth[(uint32_t)lane < (uint32_t)QB ? lane : 0];
+        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
+        const uint64_t posl = t0 + (uint64_t)lane;
+#pragma unroll 1
+        for (uint32_t qq = 0; qq < cnt; ++qq) {
+            const uint64_t thr = readlane_u64(my_thr, (int)qq);
+            const uint64_t pos = readlane_u64(my_cbase, (int)qq) + posl;
+            const bool valid = (uint32_t)lane < nvalid && pos < a.max_pos;
+            const float sv = lsums[qq * 64 + lane];
+            const uint64_t mykey =
+                valid ? (((uint64_t)__float_as_uint(sv) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
+            if (__ballot(mykey < thr) != 0ull) {
+                tile_fold(lkeys + qq * k, lvals + qq * k, lkth + qq,
+                          a.gthr + readlane_u32(my_qrow, (int)qq), readlane_u64(my_gthr, (int)qq),
+                          readlane_u64(my_lkth, (int)qq), mykey, srow, k, lane);
+            }
+        }
+        wave_lds_fence();
+    }
+
+    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+#pragma unroll 1
+    for (uint32_t qq = 0; qq < cnt; ++qq) {
+        const uint32_t pr = readlane_u32(my_pair, (int)qq);
+        const uint32_t q = pr / a.nprobe, j = pr % a.nprobe;
+        const uint32_t pi = (j * a.blocks_per_list + blockIdx.x) * 4 + wave;
+        const uint64_t base = ((uint64_t)q * n_part + pi) * k;
+        if ((uint32_t)lane < k) {
+            a.part_keys[base + lane] = lkeys[qq * k + lane];
+            a.part_vals[base + lane] = lvals[qq * k + lane];
+        }
+    }
+}
+
+hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
+    if (a.max_groups == 0 || a.blocks_per_list == 0) return hipSuccess;
+    if (a.k > 64) return hipErrorInvalidValue;   // one slot per lane; larger k uses stream_kernel
+    dim3 grid(a.blocks_per_list, a.max_groups), block(256);
+    const size_t lds = 4ull * TILE_QB * a.k * 12 + 4ull * TILE_QB * 8 + 4ull * TILE_QB * 64 * 4;
+    if ((a.dim % 4) == 0) hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, false>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
 // ------------------------------------------------------------------------------------
 template <bool ALIGNED>
@@ -502,7 +856,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 const float *cp = cent + (uint64_t)cc * dim + g0 * 4;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const float4 cv = load4<ALIGNED>(cp + g * 4);
+                    const float4 cv = load4_uniform<ALIGNED>(cp + g * 4);
                     const float d0 = xv[g].x - cv.x, d1 = xv[g].y - cv.y;
                     const float d2 = xv[g].z - cv.z, d3 = xv[g].w - cv.w;
                     float t = d0 * d0 + d1 * d1;
@@ -517,7 +871,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
-                const float4 cv = load4<ALIGNED>(cent + (uint64_t)cc * dim + g0 * 4);
+                const float4 cv = load4_uniform<ALIGNED>(cent + (uint64_t)cc * dim + g0 * 4);
                 const float d0 = xg.x - cv.x, d1 = xg.y - cv.y;
                 const float d2 = xg.z - cv.z, d3 = xg.w - cv.w;
                 float t = d0 * d0 + d1 * d1;
@@ -531,7 +885,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
-                const float d = xe - cent[(uint64_t)cc * dim + G * 4 + e];
+                const float d = xe - load1_uniform(cent + (uint64_t)cc * dim + G * 4 + e);
                 sum[c] = sum[c] + d * d;
             }
         }

@@ -335,3 +335,45 @@ def test_gpu_reproduces_golden(pqv, oracle, path):
             _assert_topk_equal((rows, dist, nf), want, k, boundary_ok=ok)
         else:
             _assert_topk_equal((rows, dist, nf), want, k)
+
+
+# ---------------------------------------------------------------------------------------
+# batched cluster-major tile path (tile_rerank_kernel) vs the streaming path vs the oracle
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,kc,k,nprobe,nq", [
+    (6000, 128, 10, 10, 4, 70),      # C2-shaped: ~28 queries per cluster, partial groups
+    (3000, 768, 6, 10, 3, 40),       # C3-shaped rows (3 KB)
+    (4000, 100, 8, 7, 8, 33),        # G = 25: 3 full 128-B steps + 1 remainder group
+    (2500, 30, 5, 10, 2, 50),        # unaligned rows + scalar tail
+    (1500, 3, 4, 3, 4, 20),          # tail only
+    (5000, 64, 7, 64, 3, 45),        # k = 64
+    (300, 16, 3, 10, 3, 300),        # many queries, tiny lists (< 64 rows per wave)
+])
+@pytest.mark.parametrize("layout", ["ivf", "row"])
+def test_tile_path_matches_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, nprobe, nq, layout):
+    rng = np.random.default_rng(n + 7 * dim + nq)
+    data, oidx = _random_index(oracle, rng, n, dim, kc)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    flags = pqv.PQV_LAYOUT_ROW_ORDER if layout == "row" else pqv.PQV_LAYOUT_IVF_ORDERED
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    results = {}
+    for mode in ("tile", "stream"):
+        monkeypatch.setenv("PQV_RERANK_MODE", mode)
+        s = pqv.Searcher(index, corpus, flags)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all()
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+        results[mode] = (rows, dist)
+    assert (results["tile"][0] == results["stream"][0]).all()
+    assert (_bits(results["tile"][1]) == _bits(results["stream"][1])).all()
+    # the cap applies to the tile path too
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    s = pqv.Searcher(index, corpus, flags)
+    rows, d2, nf, nc = s.topk(queries[:5], k, nprobe, max_candidates=97, sqrt_out=False)
+    for q in range(5):
+        cand = oidx.candidate_rows(queries[q], nprobe)[:97]
+        d = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
+        order = np.lexsort((np.arange(len(cand)), d.view(np.uint32)))[:k]
+        assert (rows[q, :len(order)] == cand[order]).all() and nf[q] == len(order)
