@@ -10,6 +10,7 @@
 #include "../../include/pqv.h"
 
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -90,6 +91,17 @@ struct PinnedBuf {
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
+
+// PQV_VERBOSE=1: phase timings of the build on stderr
+bool verbose() {
+    static const bool v = [] { const char *e = std::getenv("PQV_VERBOSE"); return e && *e && *e != '0'; }();
+    return v;
+}
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
 
 uint32_t host_workers() {
     long n = sysconf(_SC_NPROCESSORS_ONLN);
@@ -469,6 +481,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     const uint64_t w = std::max<uint64_t>(1, std::min<uint64_t>(workers, init_n));
     const uint64_t chunk = (init_n + w - 1) / w;
 
+    const double t_pp0 = now_s();
     sa.queries = d_centroids;  // distances to centroid 0
     HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
     for (uint32_t i = 1; i < k; ++i) {
@@ -503,6 +516,10 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
                                    dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
     }
     d_min.release(); d_init_own.release(); d_idx.release();
+    HIP_TRY(hipStreamSynchronize(stream));
+    const double t_pp1 = now_s();
+    if (verbose()) std::fprintf(stderr, "[pqv] k-means++: %u rounds over %llu rows in %.3f s\n", k,
+                                (unsigned long long)init_n, t_pp1 - t_pp0);
 
     // Lloyd iterations (:392-454)
     DevBuf d_assign_a, d_assign_b, d_counts, d_list_rows, d_list_off;
@@ -536,6 +553,8 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
                                     k, d_centroids, stream));                          // :436-453
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (verbose()) std::fprintf(stderr, "[pqv] Lloyd: %u iterations over %llu rows in %.3f s\n", iters,
+                                (unsigned long long)n, now_s() - t_pp1);
     if (iters_run) *iters_run = iters;
     if (assign_out) *assign_out = std::move(h_assign);
     return PQV_OK;
@@ -580,6 +599,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     d_sample.release(); d_idx.release();
 
     // final assignment of every row (:189-206)
+    const double t_fa0 = now_s();
     DevBuf d_cluster;
     HIP_TRY(d_cluster.alloc(n * sizeof(uint32_t)));
     HIP_TRY(launch_assign(corpus->d_rows, n, dim, d_centroids.as<float>(), static_cast<uint32_t>(k),
@@ -597,7 +617,10 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         delete idx;
         return fail(PQV_ERR_HIP, std::string("final assignment: ") + hipGetErrorString(e));
     }
+    const double t_fa1 = now_s();
     lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows);
+    if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
+                                (unsigned long long)n, t_fa1 - t_fa0, now_s() - t_fa1);
     *out = idx;
     return PQV_OK;
 }
