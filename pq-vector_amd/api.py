@@ -199,9 +199,9 @@ class Index:
 
 # ---------------------------------------------------------------------------------------
 class IndexBuilder:
-    """src/ivf/parquet.rs:23-103.  `source` is a Corpus or a [n, dim] array (the in-memory
-    form of the embedding column); defaults n_clusters=None -> ceil(sqrt(n)), max_iters=20,
-    seed=42 (:32-39)."""
+    """src/ivf/parquet.rs:23-103.  `source` is a Parquet path (with `embedding_column`, as in the
+    reference), a Corpus or a [n, dim] array (the in-memory form of the embedding column);
+    defaults n_clusters=None -> ceil(sqrt(n)), max_iters=20, seed=42 (:32-39)."""
 
     def __init__(self, source, embedding_column=None, device=0):
         self._source = source
@@ -239,20 +239,57 @@ class IndexBuilder:
             raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding column name cannot be empty")
         return (self._n_clusters or 0), self._max_iters, self._seed, self._workers
 
-    def build(self):
+    def _is_path(self):
+        import os
+        return isinstance(self._source, (str, bytes, os.PathLike))
+
+    def _require_column(self):
+        if not self._is_path():
+            raise PqvError(_ffi.PQV_ERR_INVALID, "build_inplace/build_new need a Parquet path as source")
+        if self._embedding_column is None or not str(self._embedding_column).strip():
+            raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding column name cannot be empty")   # mod.rs:25
+
+    def _build_on(self, corpus):
         nc, mi, seed, workers = self._config()
         h = vp()
+        _check(_ffi.lib().pqv_index_build(corpus._h, nc, mi, seed, workers, C.byref(h)))
+        return Index(h)
+
+    def _load_parquet(self):
+        from . import parquet_io
+        self._config()                       # build_config() runs first (parquet.rs:58,72)
+        self._require_column()
+        return parquet_io.load_embedding_column(self._source, self._embedding_column, self._device)
+
+    def build_inplace(self):
+        """Build and append the index to the source file (src/ivf/parquet.rs:57-69)."""
+        from . import parquet_io
+        index = self._build_on(self._load_parquet())
+        parquet_io.append_index_inplace(self._source, index, self._embedding_column)
+        return index
+
+    def build_new(self, output):
+        """Build and write a new file that carries the index (src/ivf/parquet.rs:71-86)."""
+        from . import parquet_io
+        index = self._build_on(self._load_parquet())
+        parquet_io.write_parquet_with_index(self._source, output, index, self._embedding_column)
+        return index
+
+    def build(self):
+        """In-memory form: returns the Index without touching any file."""
+        nc, mi, seed, workers = self._config()
+        if self._is_path():
+            return self._build_on(self._load_parquet())
         if isinstance(self._source, Corpus):
-            _check(_ffi.lib().pqv_index_build(self._source._h, nc, mi, seed, workers, C.byref(h)))
-        else:
-            data = np.asarray(self._source)
-            if data.ndim == 2:
-                dim = data.shape[1]
-                flat = _f32(data).reshape(-1)
-            else:  # (flat data, dim) is not representable here; require 2-D
-                raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding data length must be a multiple of dimension")
-            _check(_ffi.lib().pqv_index_build_host(self._device, flat.ctypes.data_as(f32p), flat.size,
-                                                   dim, nc, mi, seed, workers, C.byref(h)))
+            return self._build_on(self._source)
+        data = np.asarray(self._source)
+        if data.ndim != 2:
+            raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding data length must be a multiple of dimension")
+        dim = data.shape[1]
+        flat = _f32(data).reshape(-1)
+        h = vp()
+        _check(_ffi.lib().pqv_index_build_host(self._device, flat.ctypes.data_as(f32p), flat.size,
+                                               dim, nc, mi, seed, workers, C.byref(h)))
         return Index(h)
 
 
@@ -345,11 +382,38 @@ class Searcher:
             pass
 
 
-class TopkBuilder:
-    """src/ivf/search.rs:49-81: k and nprobe must be set and > 0."""
+_PATH_SEARCHERS = {}
 
-    def __init__(self, searcher, query):
-        self._searcher = searcher
+
+def searcher_for_parquet(path, device=0):
+    """Index + embedding column of an indexed Parquet file, resident on `device`.  Cached per
+    (path, size, mtime): the reference re-opens the file, re-parses the blob and re-reads the
+    candidate rows on every query (src/ivf/search.rs:89,102-110); here they stay in HBM."""
+    import os
+    from . import parquet_io
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_size, st.st_mtime_ns, device)
+    hit = _PATH_SEARCHERS.get(key)
+    if hit is None:
+        index, column = parquet_io.read_index_from_parquet(path)
+        corpus = parquet_io.load_embedding_column(path, column, device)
+        hit = Searcher(index, corpus, _ffi.PQV_LAYOUT_IVF_ORDERED | _ffi.PQV_RELEASE_ROW_ORDER)
+        _PATH_SEARCHERS.clear()          # one resident file at a time by default
+        _PATH_SEARCHERS[key] = hit
+    return hit
+
+
+class TopkBuilder:
+    """src/ivf/search.rs:49-81: k and nprobe must be set and > 0.  `source` is an indexed
+    Parquet path (as in the reference) or an existing Searcher."""
+
+    def __init__(self, source, query, device=0):
+        import os
+        if isinstance(source, (str, bytes, os.PathLike)):
+            self._path, self._searcher = source, None
+        else:
+            self._path, self._searcher = None, source
+        self._device = device
         self._query = query
         self._k = None
         self._nprobe = None
@@ -371,6 +435,8 @@ class TopkBuilder:
             raise PqvError(_ffi.PQV_ERR_INVALID, "k must be set")
         if self._nprobe is None:
             raise PqvError(_ffi.PQV_ERR_INVALID, "nprobe must be set")
+        if self._searcher is None:
+            self._searcher = searcher_for_parquet(self._path, self._device)
         rows, dist, nf, _ = self._searcher.topk(_f32(self._query).reshape(1, -1), self._k, self._nprobe)
         return [SearchResult(int(rows[0, i]), float(dist[0, i])) for i in range(int(nf[0]))]
 

@@ -1,0 +1,381 @@
+"""Parquet side of the hot path (SURVEY.md 8f N1 + N2): stream the embedding column into HBM,
+embed / read the IVF index blob in the file the way pq-vector does, so files written here are
+readable by the reference and vice versa.
+
+  N1  load_embedding_column    read_parquet_with_embeddings   src/ivf/parquet.rs:216-305
+  N2  append_index_inplace     append_index_inplace           src/ivf/parquet.rs:542-611
+      write_parquet_with_index write_parquet_with_index       src/ivf/parquet.rs:316-377
+      read_index_from_parquet  read_index_from_parquet        src/ivf/parquet.rs:191-208
+      has_pq_vector_index      has_pq_vector_index            src/ivf/parquet.rs:187-189
+
+On-disk format:
+    [PAR1][row groups ...][old Thrift footer, now dead bytes]
+    ["PQ_VECTOR1"][u64 LE blob_len][blob (IvfIndex::to_bytes)]        <- pq_vector_index_offset
+    [Thrift FileMetaData + KV pq_vector_index_offset / pq_vector_embedding_column][u32 len]["PAR1"]
+
+The footer is rewritten with a small generic Thrift-compact re-serialiser: every top-level
+FileMetaData field is copied byte for byte except key_value_metadata (field 5), so the schema,
+row groups, column orders and created_by survive untouched whatever writer produced the file.
+This is host I/O glue (pyarrow + bytes); no distance arithmetic happens here.
+"""
+import os
+import struct
+
+import numpy as np
+
+from . import _ffi
+from .api import Corpus, Index, PqvError
+
+MAGIC = b"PQ_VECTOR1"                                   # src/ivf/parquet.rs:106
+OFFSET_KEY = "pq_vector_index_offset"                   # :109
+COLUMN_KEY = "pq_vector_embedding_column"               # :112
+FOOTER_SIZE = 8
+
+
+def _err(msg):
+    return PqvError(_ffi.PQV_ERR_INVALID, msg)
+
+
+# ---------------------------------------------------------------------------------------
+# Thrift compact protocol: just enough to splice FileMetaData.key_value_metadata
+# ---------------------------------------------------------------------------------------
+T_STOP, T_TRUE, T_FALSE, T_BYTE, T_I16, T_I32, T_I64, T_DOUBLE, T_BINARY, T_LIST, T_SET, T_MAP, \
+    T_STRUCT, T_UUID = range(14)
+
+
+def _varint(buf, pos):
+    shift = val = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        val |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return val, pos
+        shift += 7
+
+
+def _put_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _zigzag_decode(v):
+    return (v >> 1) ^ -(v & 1)
+
+
+def _zigzag_encode(v):
+    return (v << 1) ^ (v >> 63)
+
+
+def _skip(buf, pos, ttype):
+    """Return the position just past one value of `ttype` starting at pos."""
+    if ttype in (T_TRUE, T_FALSE):
+        return pos
+    if ttype == T_BYTE:
+        return pos + 1
+    if ttype in (T_I16, T_I32, T_I64):
+        return _varint(buf, pos)[1]
+    if ttype == T_DOUBLE:
+        return pos + 8
+    if ttype == T_UUID:
+        return pos + 16
+    if ttype == T_BINARY:
+        n, pos = _varint(buf, pos)
+        return pos + n
+    if ttype in (T_LIST, T_SET):
+        h = buf[pos]
+        pos += 1
+        n, et = h >> 4, h & 0x0F
+        if n == 15:
+            n, pos = _varint(buf, pos)
+        for _ in range(n):
+            pos = pos + 1 if et in (T_TRUE, T_FALSE) else _skip(buf, pos, et)
+        return pos
+    if ttype == T_MAP:
+        n, pos = _varint(buf, pos)
+        if n:
+            kv = buf[pos]
+            pos += 1
+            for _ in range(n):
+                pos = _skip(buf, pos, kv >> 4)
+                pos = _skip(buf, pos, kv & 0x0F)
+        return pos
+    if ttype == T_STRUCT:
+        while True:
+            h = buf[pos]
+            pos += 1
+            if h == T_STOP:
+                return pos
+            if not h >> 4:
+                pos = _varint(buf, pos)[1]
+            pos = _skip(buf, pos, h & 0x0F)
+    raise _err(f"unsupported Thrift type {ttype} in parquet footer")
+
+
+def _struct_fields(buf):
+    """Top-level fields of a struct: [(field_id, type, raw value bytes)]."""
+    fields, pos, last = [], 0, 0
+    while True:
+        h = buf[pos]
+        pos += 1
+        if h == T_STOP:
+            return fields
+        delta, ttype = h >> 4, h & 0x0F
+        if delta:
+            fid = last + delta
+        else:
+            z, pos = _varint(buf, pos)
+            fid = _zigzag_decode(z)
+        end = _skip(buf, pos, ttype)
+        fields.append((fid, ttype, bytes(buf[pos:end])))
+        pos, last = end, fid
+
+
+def _emit_struct(fields):
+    out, last = bytearray(), 0
+    for fid, ttype, raw in sorted(fields, key=lambda f: f[0]):
+        delta = fid - last
+        if 0 < delta <= 15:
+            out.append((delta << 4) | ttype)
+        else:
+            out.append(ttype)
+            out += _put_varint(_zigzag_encode(fid))
+        out += raw
+        last = fid
+    out.append(T_STOP)
+    return bytes(out)
+
+
+def _decode_kv_list(raw):
+    h = raw[0]
+    pos = 1
+    n = h >> 4
+    if n == 15:
+        n, pos = _varint(raw, pos)
+    out = []
+    for _ in range(n):
+        end = _skip(raw, pos, T_STRUCT)
+        key = val = None
+        for fid, ttype, v in _struct_fields(raw[pos:end]):
+            if ttype == T_BINARY:
+                ln, p = _varint(v, 0)
+                s = bytes(v[p:p + ln])
+                if fid == 1:
+                    key = s
+                elif fid == 2:
+                    val = s
+        out.append((key, val))
+        pos = end
+    return out
+
+
+def _encode_kv_list(kvs):
+    out = bytearray()
+    n = len(kvs)
+    if n < 15:
+        out.append((n << 4) | T_STRUCT)
+    else:
+        out.append(0xF0 | T_STRUCT)
+        out += _put_varint(n)
+    for key, val in kvs:
+        fields = [(1, T_BINARY, _put_varint(len(key)) + key)]
+        if val is not None:
+            fields.append((2, T_BINARY, _put_varint(len(val)) + val))
+        out += _emit_struct(fields)
+    return bytes(out)
+
+
+def _read_footer(path):
+    size = os.path.getsize(path)
+    if size < FOOTER_SIZE:
+        raise _err("Parquet file too small to contain a footer")               # parquet.rs:549
+    with open(path, "rb") as f:
+        f.seek(size - FOOTER_SIZE)
+        tail = f.read(FOOTER_SIZE)
+        if tail[4:] == b"PARE":
+            raise _err("Encrypted parquet footers are not supported for in-place indexing")  # :557
+        if tail[4:] != b"PAR1":
+            raise _err("Invalid Parquet file: corrupt footer")
+        meta_len = struct.unpack("<I", tail[:4])[0]
+        if meta_len + FOOTER_SIZE > size:
+            raise _err("Parquet footer length exceeds file size")              # :562
+        f.seek(size - FOOTER_SIZE - meta_len)
+        meta = f.read(meta_len)
+    return size, meta
+
+
+def _footer_kv(meta):
+    for fid, ttype, raw in _struct_fields(meta):
+        if fid == 5 and ttype == T_LIST:
+            return _decode_kv_list(raw)
+    return []
+
+
+# ---------------------------------------------------------------------------------------
+# N2: index blob in the file
+# ---------------------------------------------------------------------------------------
+def read_index_metadata(path):
+    """(offset, embedding_column) from the footer KV, or None (parse_index_metadata :120-143)."""
+    _, meta = _read_footer(path)
+    kv = dict((k, v) for k, v in _footer_kv(meta) if k is not None)
+    off, col = kv.get(OFFSET_KEY.encode()), kv.get(COLUMN_KEY.encode())
+    if off is None or col is None:
+        return None
+    col = col.decode()
+    if not col.strip():
+        raise _err("Embedding column name cannot be empty")
+    return int(off.decode()), col
+
+
+def has_pq_vector_index(path):
+    return read_index_metadata(path) is not None
+
+
+def read_index_payload(payload):
+    """read_index_from_payload (src/ivf/parquet.rs:151-174)."""
+    header = len(MAGIC) + 8
+    if len(payload) < header:
+        raise _err("pq-vector index payload is truncated")
+    if payload[:len(MAGIC)] != MAGIC:
+        raise _err("Invalid pq-vector index magic")
+    n = struct.unpack("<Q", payload[len(MAGIC):header])[0]
+    if len(payload) < header + n:
+        raise _err("pq-vector index bytes are truncated")
+    return Index.from_bytes(payload[header:header + n])
+
+
+def read_index_from_parquet(path):
+    meta = read_index_metadata(path)
+    if meta is None:
+        raise _err("Missing pq-vector index metadata in parquet footer")       # :197
+    offset, column = meta
+    with open(path, "rb") as f:
+        f.seek(offset)
+        payload = f.read()                                                     # read_to_end :204
+    try:
+        return read_index_payload(payload), column
+    except PqvError as e:
+        raise PqvError(e.code, f"Failed to decode pq-vector index payload at offset {offset}: {e.message}")
+
+
+def append_index_inplace(path, index, embedding_column):
+    """Overwrite the 8-byte tail with MAGIC | len | blob, then a new footer whose KV carries the
+    offset and the column name; the old Thrift footer stays in the body as dead bytes and
+    stale pq_vector_* entries are replaced (src/ivf/parquet.rs:542-611)."""
+    size, meta = _read_footer(path)
+    index_offset = size - FOOTER_SIZE                                          # :565-566
+    fields = _struct_fields(meta)
+    kvs = []
+    for fid, ttype, raw in fields:
+        if fid == 5 and ttype == T_LIST:
+            kvs = _decode_kv_list(raw)
+    kvs = [(k, v) for k, v in kvs if k not in (OFFSET_KEY.encode(), COLUMN_KEY.encode())]  # :573-575
+    kvs.append((OFFSET_KEY.encode(), str(index_offset).encode()))
+    kvs.append((COLUMN_KEY.encode(), embedding_column.encode()))
+    fields = [f for f in fields if f[0] != 5] + [(5, T_LIST, _encode_kv_list(kvs))]
+    new_meta = _emit_struct(fields)
+    blob = index.to_bytes()
+    with open(path, "r+b") as f:
+        f.seek(index_offset)
+        f.write(MAGIC)
+        f.write(struct.pack("<Q", len(blob)))
+        f.write(blob)
+        f.write(new_meta)
+        f.write(struct.pack("<I", len(new_meta)))
+        f.write(b"PAR1")
+        f.truncate()
+    return index_offset
+
+
+def write_parquet_with_index(source, output, index, embedding_column):
+    """build_new (src/ivf/parquet.rs:316-377): a copy of `source` whose embedding column is
+    stored one vector per data page (page limit dim*4 bytes, no dictionary, chunk-level
+    statistics) so single rows can be fetched by page index, followed by the index blob.
+    The blob sits after the copy's footer exactly as in the in-place layout (standard readers
+    ignore it either way)."""
+    import pyarrow.parquet as pq
+    src = pq.ParquetFile(source)
+    names = src.schema_arrow.names
+    other = [n for n in names if n != embedding_column]
+    rg_rows = src.metadata.row_group(0).num_rows if src.metadata.num_row_groups else 1 << 20
+    compression = "NONE"
+    if src.metadata.num_row_groups and src.metadata.row_group(0).num_columns:
+        c = src.metadata.row_group(0).column(0).compression
+        compression = "NONE" if c == "UNCOMPRESSED" else c
+    writer = pq.ParquetWriter(output, src.schema_arrow, data_page_size=max(1, index.dim * 4),
+                              use_dictionary=other, write_statistics=True, write_page_index=True,
+                              compression=compression)
+    try:
+        for i in range(src.metadata.num_row_groups):
+            writer.write_table(src.read_row_group(i), row_group_size=rg_rows)
+    finally:
+        writer.close()
+    return append_index_inplace(output, index, embedding_column)
+
+
+# ---------------------------------------------------------------------------------------
+# N1: embedding column -> HBM
+# ---------------------------------------------------------------------------------------
+def _column_chunks(path, column, batch_rows=1 << 16):
+    """Yields validated [rows, dim] float arrays (f32 or f64) of the column, batch by batch,
+    with the reference's checks and messages (src/ivf/parquet.rs:231-280)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    pf = pq.ParquetFile(path)
+    if column not in pf.schema_arrow.names:
+        raise _err(f"Column '{column}' not found")
+    typ = pf.schema_arrow.field(column).type
+    if not (pa.types.is_list(typ) or pa.types.is_large_list(typ) or pa.types.is_fixed_size_list(typ)):
+        raise _err("Embedding column is not a list array")
+    if not (pa.types.is_float32(typ.value_type) or pa.types.is_float64(typ.value_type)):
+        raise _err("Embedding values are not float32/float64")
+    dim = None
+    for batch in pf.iter_batches(batch_size=batch_rows, columns=[column]):
+        arr = batch.column(0)
+        if arr.null_count > 0:
+            raise _err("Embedding column contains null rows")
+        n = len(arr)
+        if n == 0:
+            continue
+        flat = arr.flatten()                      # honours the slice offsets
+        if flat.null_count > 0:
+            raise _err("Embedding values contain nulls")
+        if pa.types.is_fixed_size_list(typ):
+            lens = np.full(n, typ.list_size, dtype=np.int64)
+        else:
+            off = arr.offsets.to_numpy()
+            lens = np.diff(off)
+        if (lens == 0).any():
+            raise _err("Embedding row has zero length")
+        if dim is None:
+            dim = int(lens[0])
+        if (lens != dim).any():
+            raise _err("Embedding vectors have inconsistent dimensions")
+        vals = flat.to_numpy(zero_copy_only=False)
+        yield vals.reshape(n, dim)
+    if dim is None:
+        raise _err("Embedding column has no rows")
+
+
+def load_embedding_column(path, column, device=0):
+    """Stream the column row-group-sized batch by batch into one resident [n, dim] f32 matrix
+    (Float64 values are narrowed on the device, parquet.rs:246-256).  Nothing larger than one
+    batch is ever materialised on the host, unlike the reference's Vec<f32> of the whole
+    column (:226)."""
+    import pyarrow.parquet as pq
+    n_rows = pq.ParquetFile(path).metadata.num_rows
+    corpus = None
+    for chunk in _column_chunks(path, column):
+        if corpus is None:
+            corpus = Corpus.create(n_rows, chunk.shape[1], device)
+        corpus.append(chunk)
+    if corpus is None:
+        raise _err("Embedding column has no rows")
+    return corpus

@@ -377,3 +377,61 @@ def test_tile_path_matches_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, nprob
         d = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
         order = np.lexsort((np.arange(len(cand)), d.view(np.uint32)))[:k]
         assert (rows[q, :len(order)] == cand[order]).all() and nf[q] == len(order)
+
+
+# ---------------------------------------------------------------------------------------
+# reference API on real Parquet files
+# ---------------------------------------------------------------------------------------
+def test_parquet_build_inplace_and_topk(pqv, oracle, tmp_path):
+    """README quick-start flow of the reference: IndexBuilder::new(path, col).build_inplace(),
+    then TopkBuilder::new(path, &query).k(..)?.nprobe(..)?.search() -- checked against the
+    oracle run on the same column values (f64 column: narrowed like parquet.rs:246-256)."""
+    import os
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(21)
+    n, dim = 3000, 48
+    vecs64 = rng.random((n, dim))
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)),
+                  "embedding": pa.array(vecs64.tolist(), type=pa.list_(pa.field("item", pa.float64())))})
+    path = str(tmp_path / "data.parquet")
+    pq.write_table(t, path, row_group_size=1024)
+    size0 = os.path.getsize(path)
+    index = pqv.IndexBuilder(path, "embedding").n_clusters(12).workers(4).build_inplace()
+    assert os.path.getsize(path) > size0 and pqv.has_pq_vector_index(path)
+    data = vecs64.astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=12, workers=4)
+    assert index.to_bytes() == oidx.to_bytes()
+    stored, col = pqv.read_index_from_parquet(path)
+    assert col == "embedding" and stored.to_bytes() == oidx.to_bytes()
+    assert pq.read_table(path).num_rows == n                       # still a valid Parquet file
+
+    q = rng.random(dim, dtype=np.float32)
+    hits = pqv.TopkBuilder(path, q).k(10).nprobe(4).search()
+    orows, odist, _ = oidx.topk(data, q, 10, 4)
+    assert [h.row_idx for h in hits] == orows.tolist()
+    assert [np.float32(h.distance) for h in hits] == odist.tolist()
+    # second query reuses the resident searcher
+    hits2 = pqv.TopkBuilder(path, data[17]).k(3).nprobe(12).search()
+    assert hits2[0].row_idx == 17 and hits2[0].distance == 0.0
+
+
+def test_parquet_build_new_reference_fixture(pqv, tmp_path):
+    """src/df_vector/tests.rs:16-104 data through build_new: 6 rows x 2-D, default clusters."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    vecs = [(0, 0), (1, 0), (0, 2), (5, 5), (2, 2), (0.1, 0.1)]
+    t = pa.table({"id": pa.array(range(6), type=pa.int32()),
+                  "vec": pa.array([list(v) for v in vecs], type=pa.list_(pa.field("item", pa.float32())))})
+    src, out = str(tmp_path / "source.parquet"), str(tmp_path / "indexed.parquet")
+    pq.write_table(t, src)
+    pqv.IndexBuilder(src, "vec").build_new(out)
+    assert pqv.has_pq_vector_index(out) and not pqv.has_pq_vector_index(src)
+    index, col = pqv.read_index_from_parquet(out)
+    assert col == "vec" and index.dim == 2 and index.n_clusters == 3
+    hits = pqv.TopkBuilder(out, [0.0, 0.0]).k(2).nprobe(64).search()
+    assert [h.row_idx for h in hits] == [0, 5]
+    with pytest.raises(pqv.PqvError, match="Embedding column name cannot be empty"):
+        pqv.IndexBuilder(src, " ").build_inplace()
+    with pytest.raises(pqv.PqvError, match="Column 'nope' not found"):
+        pqv.IndexBuilder(src, "nope").build_inplace()
