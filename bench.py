@@ -47,6 +47,12 @@ def log(*a):
 
 
 def main():
+    # Libraries (RCCL prints a version banner) may write to fd 1; the contract is ONE JSON line
+    # on stdout.  Point fd 1 at stderr for the run and keep the real stdout for the result.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -56,6 +62,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the shard exchange even with one rank (path check)")
+    ap.add_argument("--single", type=int, default=0,
+                    help="also time this many single-query calls (latency mode) and report them")
     args = ap.parse_args()
 
     import torch
@@ -73,8 +83,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: pq_vector_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
@@ -121,21 +133,21 @@ def main():
     dist_t = torch.empty((nq, K), dtype=torch.float32, device=dev)
     nf_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     nc_t = torch.empty((nq,), dtype=torch.int64, device=dev)
-    xchg = ShardExchange(world, nq, K, dev)
+    xchg = ShardExchange(world, nq, K, dev, always_collective=args.force_dist)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         # hot path on this rank's shard; asynchronous on torch's current stream
         searcher.topk_device(queries_t.data_ptr(), nq, K, nprobe, rows_t.data_ptr(), dist_t.data_ptr(),
                              nf_t.data_ptr(), nc_t.data_ptr(), stream=stream)
-        if world == 1:
+        if not use_dist:
             return dist_t, rows_t
         # exchange: one all-gather of k x {dist, global row} per query, then a stable merge
         # keyed (dist, shard, position) -- pq_vector_amd/sharding.py
         return xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, lo)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +164,7 @@ def main():
     rerank_ms, total_ms, ncalls = searcher.timing_read()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -217,12 +229,35 @@ def main():
                                       "the no-FMA ceiling is half the 157.3 TF vector peak"}},
     }
 
+    if use_dist and rank == 0:
+        # the merged answer of the exchange must equal this rank's own when there is one shard
+        if world == 1:
+            result["exchange_check"] = bool(torch.equal(out_d, dist_t)
+                                            and torch.equal(out_r, (rows_t.to(torch.int64) & 0xFFFFFFFF) + lo))
+
+    # ---- optional latency mode: one query per call through the same device API ------------
+    if args.single and rank == 0:
+        lat = []
+        for i in range(min(args.single, nq) + 5):
+            q1 = queries_t[i % nq:i % nq + 1]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            searcher.topk_device(q1.data_ptr(), 1, K, nprobe, rows_t.data_ptr(), dist_t.data_ptr(),
+                                 nf_t.data_ptr(), nc_t.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        lat = np.array(lat[5:]) * 1e6
+        result["single_query"] = {"calls": int(lat.size), "p50_us": float(np.percentile(lat, 50)),
+                                  "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()),
+                                  "qps": float(1e6 / lat.mean()),
+                                  "note": "one query per call, host-synchronised after each (4 kernel launches)"}
     # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled, one thread -----------
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq)
     if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 

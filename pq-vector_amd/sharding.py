@@ -33,8 +33,9 @@ def merge_gathered(gath_dist, gath_rows, k):
 class ShardExchange:
     """Pre-allocated all-gather buffers for a fixed (nq, k); one collective per tensor."""
 
-    def __init__(self, world, nq, k, device):
+    def __init__(self, world, nq, k, device, always_collective=False):
         self.world, self.nq, self.k = world, nq, k
+        self.always_collective = always_collective
         self.gath_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
         self.gath_r = torch.empty((world, nq, k), dtype=torch.int64, device=device)
 
@@ -42,7 +43,7 @@ class ShardExchange:
         """local_dist [nq,k] f32, local_rows_i64 [nq,k] shard-local ids (-1 / 0xFFFFFFFF = empty)."""
         empty = (local_rows_i64 < 0) | (local_rows_i64 == 0xFFFFFFFF)
         grow = torch.where(empty, torch.full_like(local_rows_i64, -1), local_rows_i64 + row_base)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return local_dist, grow
         # rank-major concatenation along dim 0: the layout both RCCL and gloo accept
         dist.all_gather_into_tensor(self.gath_d.view(self.world * self.nq, self.k), local_dist.contiguous())
