@@ -152,6 +152,13 @@ void pqv_rows_free(uint32_t *rows);
  *   metric       PQV_L2SQ_REF4 (TopkBuilder) or PQV_L2SQ_SEQ (VectorTopKExec)
  *   sqrt_out     nonzero => dist = sqrt(d2) as TopkBuilder returns (:133); 0 => d2
  *   row_idx/dist host [nq*k]; entries past n_found[q] are 0xFFFFFFFF / +inf
+ * Ties: when two of a query's k results (or the k-th and the runner-up) have EQUAL output
+ * distance, which rows survive and in what order is an artefact of Rust's BinaryHeap sift
+ * history (search.rs:113-140).  pqv_topk detects that on the device and replays exactly those
+ * queries through the same heap mechanics on the host (distances still computed on the GPU),
+ * so its results equal the reference's in every non-NaN case.  pqv_topk_device never leaves
+ * the GPU: it returns the k smallest by (d2, candidate position), identical to the reference
+ * whenever no such tie exists.
  *   n_found      host [nq] (may be NULL)
  *   n_candidates host [nq] (may be NULL): sum of the probed lists' lengths, before the cap */
 int pqv_topk(const pqv_searcher *searcher, const float *queries, uint32_t nq,
@@ -193,6 +200,7 @@ typedef struct pqv_counters_t {
     uint64_t candidate_rows;     /* sum over queries of probed list lengths              */
     uint64_t embeddings_fetched; /* rows whose distance was computed (after the cap)     */
     uint64_t kernel_launches;    /* device kernels enqueued                              */
+    uint64_t exact_replays;      /* pqv_topk queries replayed through the exact heap     */
 } pqv_counters_t;
 int pqv_counters(const pqv_searcher *searcher, pqv_counters_t *out);
 

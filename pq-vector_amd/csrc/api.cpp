@@ -151,7 +151,8 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr;
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr, s_tie,
+        s_replay;
     int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
     mutable pqv_counters_t counters{};
     // timing
@@ -795,10 +796,12 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
 }
 
 // Enqueue probe -> probe-merge -> re-rank -> final merge for one batch on `stream`.
+// `k` is the list length the kernels work with; the first k_out entries are written out.
+// With k == k_out + 1 the merge can also flag queries whose output distances tie (d_tie).
 int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uint32_t k,
-                 uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                 uint32_t k_out, uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                  uint32_t *d_row_idx, float *d_dist, uint32_t *d_n_found, uint64_t *d_n_cand,
-                 hipStream_t stream) {
+                 uint32_t *d_tie, hipStream_t stream) {
     using namespace pqv;
     const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
@@ -888,7 +891,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.part_keys = ra.part_keys; fm.part_vals = ra.part_vals;
     fm.nq = nq; fm.n_part = p.n_part_rr; fm.k_part = k; fm.k = k;
     fm.ids = s->d_final_ids; fm.row_idx = d_row_idx; fm.dist = d_dist; fm.n_found = d_n_found;
-    fm.sqrt_out = sqrt_out;
+    fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
     s->counters.kernel_launches += 4;
@@ -908,6 +911,106 @@ int validate_topk(const pqv_searcher *s, uint32_t k, uint32_t nprobe, int metric
 
 }  // namespace
 
+namespace {
+
+// ---- exact replay of the reference's heap for one query ----------------------------------
+// std::collections::BinaryHeap<HeapItem> as src/ivf/search.rs:113-127 / exec.rs:264,474-481
+// drive it (max-heap on distance; Ord = partial_cmp().unwrap_or(Equal)), restated from the
+// published std source: push = append + sift_up (stops on <=), pop = swap_remove(0) +
+// sift_down_to_bottom (right child on ties) + sift_up.  Only used for queries whose output
+// distances tie, where survivors and order depend on this exact mechanics.
+struct HeapEnt { float d; uint32_t row; };
+
+inline bool ent_le(const HeapEnt &a, const HeapEnt &b) { return !(a.d > b.d); }
+
+inline void heap_sift_up(std::vector<HeapEnt> &h, size_t start, size_t pos) {
+    const HeapEnt e = h[pos];
+    while (pos > start) {
+        const size_t parent = (pos - 1) / 2;
+        if (ent_le(e, h[parent])) break;
+        h[pos] = h[parent];
+        pos = parent;
+    }
+    h[pos] = e;
+}
+
+inline void heap_push(std::vector<HeapEnt> &h, HeapEnt e) {
+    h.push_back(e);
+    heap_sift_up(h, 0, h.size() - 1);
+}
+
+inline void heap_pop(std::vector<HeapEnt> &h) {
+    HeapEnt item = h.back();
+    h.pop_back();
+    if (h.empty()) return;
+    std::swap(item, h[0]);
+    const size_t end = h.size();
+    size_t pos = 0;
+    const HeapEnt e = h[0];
+    size_t child = 1;
+    while (end >= 2 && child <= end - 2) {
+        if (ent_le(h[child], h[child + 1])) child += 1;
+        h[pos] = h[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (child == end - 1) { h[pos] = h[child]; pos = child; }
+    h[pos] = e;
+    heap_sift_up(h, 0, pos);
+}
+
+// Recompute one query's candidate distances on the device (STREAM_DIST), then replay them
+// through the heap in candidate order.  qi indexes the current sub-batch's probe scratch.
+int replay_query_exact(const pqv_searcher *s, const float *d_query, uint32_t qi, uint32_t np, uint32_t k,
+                       uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
+                       uint32_t *n_found) {
+    using namespace pqv;
+    std::vector<uint32_t> clusters(np);
+    HIP_TRY(hipMemcpyAsync(clusters.data(), s->s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
+                           np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    uint64_t total = 0;
+    for (uint32_t c : clusters) total += s->h_list_off[c + 1] - s->h_list_off[c];
+    const uint64_t use = max_candidates ? std::min<uint64_t>(total, max_candidates) : total;
+    std::vector<float> d(std::max<uint64_t>(1, total));
+    if (total) {
+        HIP_TRY(s->s_replay.ensure(total * sizeof(float)));
+        StreamArgs ra{};
+        ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
+        ra.probe = s->s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np;
+        ra.cand_base = s->s_cand_base.as<uint64_t>() + static_cast<size_t>(qi) * np;
+        ra.queries = d_query; ra.nq = 1; ra.nprobe = np; ra.dim = s->dim; ra.k = 1;
+        ra.rows_per_block = 1024;
+        ra.blocks_per_list = static_cast<uint32_t>((std::max<uint64_t>(1, s->max_list_len) + 1023) / 1024);
+        ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = s->s_replay.as<float>();
+        HIP_TRY(launch_stream(ra, STREAM_DIST, s->stream));
+        HIP_TRY(hipMemcpyAsync(d.data(), s->s_replay.p, total * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    std::vector<HeapEnt> heap;
+    heap.reserve(static_cast<size_t>(k) + 1);
+    uint64_t pos = 0;
+    for (uint32_t c : clusters) {                                        // candidate_rows order
+        const uint64_t b = s->h_list_off[c], e = s->h_list_off[c + 1];
+        for (uint64_t i = b; i < e && pos < use; ++i, ++pos) {
+            const HeapEnt ent{d[pos], s->h_list_rows[i]};
+            if (heap.size() < k) heap_push(heap, ent);                   // search.rs:119-120
+            else if (ent.d < heap[0].d) { heap_pop(heap); heap_push(heap, ent); }   // :121-125
+        }
+    }
+    if (sqrt_out) for (auto &h : heap) h.d = std::sqrt(h.d);             // :133 (IEEE sqrtf)
+    std::stable_sort(heap.begin(), heap.end(), [](const HeapEnt &a, const HeapEnt &b) { return a.d < b.d; });
+    for (uint32_t i = 0; i < k; ++i) {
+        if (i < heap.size()) { row_idx[i] = heap[i].row; dist[i] = heap[i].d; }
+        else { row_idx[i] = 0xFFFFFFFFu; dist[i] = INFINITY; }
+    }
+    if (n_found) *n_found = static_cast<uint32_t>(heap.size());
+    s->counters.kernel_launches += 1;
+    return PQV_OK;
+}
+
+}  // namespace
+
 extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
                                uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                                void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
@@ -918,10 +1021,10 @@ extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uin
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
-    const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, k, nprobe, max_candidates,
+    const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, k, k, nprobe, max_candidates,
                                 metric, sqrt_out, static_cast<uint32_t *>(d_row_idx),
                                 static_cast<float *>(d_dist), static_cast<uint32_t *>(d_n_found),
-                                static_cast<uint64_t *>(d_n_candidates), stream);
+                                static_cast<uint64_t *>(d_n_candidates), nullptr, stream);
     if (rc == PQV_OK) s->counters.queries += nq;
     return rc;
 }
@@ -937,31 +1040,38 @@ extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq
     if (!queries || !row_idx || !dist) return fail(PQV_ERR_INVALID, "queries/row_idx/dist must not be NULL");
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
+    // One extra merged entry (the runner-up) lets the merge kernel see ties at the k-th
+    // distance; queries it flags are replayed through the exact heap (replay_query_exact).
+    const uint32_t k_int = k < 1024 ? k + 1 : k;
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
-    const TopkPlan p1 = plan_topk(s, 1, nprobe, k, metric);
-    const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k * 12 + 1;
+    const TopkPlan p1 = plan_topk(s, 1, nprobe, k_int, metric);
+    const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + 1;
     uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / per_query)));
     HIP_TRY(s->s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));
     HIP_TRY(s->s_rows.ensure(static_cast<size_t>(batch) * k * sizeof(uint32_t)));
     HIP_TRY(s->s_dist.ensure(static_cast<size_t>(batch) * k * sizeof(float)));
     HIP_TRY(s->s_nfound.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
     HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(batch) * sizeof(uint64_t)));
+    HIP_TRY(s->s_tie.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
     std::vector<uint64_t> h_ncand(batch);
+    std::vector<uint32_t> h_tie(batch), h_nf(batch);
+    const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
     for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
         const uint32_t b = std::min<uint32_t>(batch, nq - q0);
         HIP_TRY(hipMemcpyAsync(s->s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
                                static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
-        if (int rc = enqueue_topk(s, s->s_queries.as<float>(), b, k, nprobe, max_candidates, metric, sqrt_out,
-                                  s->s_rows.as<uint32_t>(), s->s_dist.as<float>(), s->s_nfound.as<uint32_t>(),
-                                  nullptr, s->stream))
+        if (int rc = enqueue_topk(s, s->s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
+                                  sqrt_out, s->s_rows.as<uint32_t>(), s->s_dist.as<float>(),
+                                  s->s_nfound.as<uint32_t>(), nullptr, s->s_tie.as<uint32_t>(), s->stream))
             return rc;
         HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, s->s_rows.p,
                                static_cast<size_t>(b) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, s->s_dist.p,
                                static_cast<size_t>(b) * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-        if (n_found)
-            HIP_TRY(hipMemcpyAsync(n_found + q0, s->s_nfound.p, static_cast<size_t>(b) * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(h_nf.data(), s->s_nfound.p, static_cast<size_t>(b) * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(h_tie.data(), s->s_tie.p, static_cast<size_t>(b) * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(h_ncand.data(), s->s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -970,6 +1080,16 @@ extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq
             s->counters.embeddings_fetched +=
                 max_candidates ? std::min<uint64_t>(h_ncand[i], max_candidates) : h_ncand[i];
             if (n_candidates) n_candidates[q0 + i] = h_ncand[i];
+            if (h_tie[i]) {
+                // tied output distances: survivors / order follow Rust's heap mechanics exactly
+                if (int rc = replay_query_exact(s, s->s_queries.as<float>() + static_cast<size_t>(i) * s->dim, i, np,
+                                                k, max_candidates, metric, sqrt_out,
+                                                row_idx + static_cast<uint64_t>(q0 + i) * k,
+                                                dist + static_cast<uint64_t>(q0 + i) * k, &h_nf[i]))
+                    return rc;
+                s->counters.exact_replays++;
+            }
+            if (n_found) n_found[q0 + i] = h_nf[i];
         }
         s->counters.queries += b;
     }

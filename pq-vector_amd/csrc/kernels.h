@@ -52,6 +52,10 @@ struct MergeArgs {
     float          *dist;        // [nq, k]
     uint32_t       *n_found;     // [nq] or nullptr
     int             sqrt_out;
+    uint32_t        k_out;       // results written per query (<= k); 0 => k
+    uint32_t       *tie_flag;    // [nq] or nullptr: 1 iff two of the first k_out+1 merged entries
+                                 // (k_out entries + the runner-up) have equal OUTPUT distance --
+                                 // then the reference's order/survivors depend on heap history
     // probe mode outputs (k == nprobe)
     const uint64_t *list_off;
     uint32_t       *probe;       // [nq, k]

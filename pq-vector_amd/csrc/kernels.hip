@@ -343,6 +343,9 @@ hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s) {
         if (mode == STREAM_MINUPD)
             return aligned ? launch_stream_t<16, 1, STREAM_MINUPD, true, true>(a, s)
                            : launch_stream_t<16, 1, STREAM_MINUPD, true, false>(a, s);
+        if (mode == STREAM_DIST)
+            return aligned ? launch_stream_t<16, 1, STREAM_DIST, true, true>(a, s)
+                           : launch_stream_t<16, 1, STREAM_DIST, true, false>(a, s);
         return hipErrorInvalidValue;
     }
     if (mode == STREAM_MINUPD) {
@@ -350,6 +353,9 @@ hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s) {
         if (G >= 64 && G % 64 == 0) return launch_stream_t<64, 1, STREAM_MINUPD, false, true>(a, s);
         return launch_stream_t<32, 1, STREAM_MINUPD, false, true>(a, s);
     }
+    if (mode == STREAM_DIST)
+        return aligned ? launch_stream_t<32, 1, STREAM_DIST, false, true>(a, s)
+                       : launch_stream_t<32, 1, STREAM_DIST, false, false>(a, s);
     return hipErrorInvalidValue;
 }
 
@@ -376,25 +382,49 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
         tk.offer(key, val, a.k, lane);
     }
     if constexpr (!PROBE) {
+        const uint32_t k_out = a.k_out ? a.k_out : a.k;
         uint32_t found = 0;
+        bool tie = false;
+        float outd[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool have = tk.key[s] != KEY_EMPTY;
+            const float d2 = __uint_as_float((uint32_t)(tk.key[s] >> 32));
+            outd[s] = have ? (a.sqrt_out ? sqrt_f32_ieee(d2) : d2) : INFINITY;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t e = s * 64 + lane;
             const bool have = e < a.k && tk.key[s] != KEY_EMPTY;
-            found += (uint32_t)__popcll(__ballot(have));
-            if (e < a.k) {
+            found += (uint32_t)__popcll(__ballot(have && e < k_out));
+            // neighbour e+1 (next lane, or lane 0 of the next slot)
+            float nd = __shfl_down(outd[s], 1, 64);
+            uint64_t nkey = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(tk.key[s] >> 32), 1, 64) << 32) |
+                            (uint32_t)__shfl_down((int)(uint32_t)tk.key[s], 1, 64);
+            if (lane == 63) {
+                if (s + 1 < S) {
+                    nd = __builtin_bit_cast(float, readlane_u32(__builtin_bit_cast(uint32_t, outd[s + 1 < S ? s + 1 : s]), 0));
+                    nkey = readlane_u64(tk.key[s + 1 < S ? s + 1 : s], 0);
+                } else {
+                    nkey = KEY_EMPTY;
+                }
+            }
+            // pairs (e, e+1) with e < k_out and e+1 < k (the runner-up is entry k_out)
+            if (have && e < k_out && e + 1 < a.k && nkey != KEY_EMPTY && nd == outd[s]) tie = true;
+            if (e < k_out) {
                 uint32_t row = 0xFFFFFFFFu;
                 float d = INFINITY;
                 if (have) {
-                    const float d2 = __uint_as_float((uint32_t)(tk.key[s] >> 32));
                     row = a.ids ? a.ids[tk.val[s]] : tk.val[s];
-                    d = a.sqrt_out ? sqrt_f32_ieee(d2) : d2;
+                    d = outd[s];
                 }
-                a.row_idx[(uint64_t)q * a.k + e] = row;
-                a.dist[(uint64_t)q * a.k + e] = d;
+                a.row_idx[(uint64_t)q * k_out + e] = row;
+                a.dist[(uint64_t)q * k_out + e] = d;
             }
         }
         if (a.n_found && lane == 0) a.n_found[q] = found;
+        const bool any_tie = __ballot(tie) != 0ull;
+        if (a.tie_flag && lane == 0) a.tie_flag[q] = any_tie ? 1u : 0u;
     } else {
         uint64_t carry = 0;
 #pragma unroll

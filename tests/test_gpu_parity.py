@@ -132,31 +132,47 @@ def test_topk_matches_oracle(pqv, oracle, n, dim, kc, k, nprobe, layout):
 
 
 def test_topk_ties_integer_vectors(pqv, oracle):
-    """Tie-heavy integer-valued vectors.  Every candidate strictly closer than the k-th
-    distance survives in both; the distance multiset is identical; among candidates tied
-    AT the k-th distance the GPU keeps the earliest in candidate order, while Rust's heap
-    keeps a history-dependent subset (the oracle emulates it) -- see _assert_topk_equal."""
+    """Tie-heavy integer-valued vectors.  With tied output distances, which rows survive and in
+    what order is an artefact of Rust's BinaryHeap sift history (the oracle emulates it).
+    pqv_topk flags such queries on the device and replays them through the same heap mechanics:
+    its answer must equal the oracle's position by position, ties included."""
     rng = np.random.default_rng(5)
     data = rng.integers(0, 3, size=(4000, 8)).astype(np.float32)
     oidx = oracle.build_index(data, n_clusters=6, workers=1, max_iters=4)
     corpus = pqv.Corpus.upload(data)
-    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
-    queries = rng.integers(0, 3, size=(16, 8)).astype(np.float32)
-    cands = [set(oidx.candidate_rows(q, 3).tolist()) for q in queries]
+    queries = rng.integers(0, 3, size=(80, 8)).astype(np.float32)
+    for mode in ("stream", "tile"):
+        import os
+        os.environ["PQV_RERANK_MODE"] = mode
+        try:
+            s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+        finally:
+            del os.environ["PQV_RERANK_MODE"]
+        for k in (1, 5, 10, 63, 64, 70):
+            for cap in (0, 900):
+                rows, dist, nf, _ = s.topk(queries, k, 3, max_candidates=cap)
+                if cap:
+                    for q in range(len(queries)):
+                        cand = oidx.candidate_rows(queries[q], 3)[:cap]
+                        orow, od2 = oracle_topk_ref4(oracle, data, cand, queries[q], k)
+                        assert (rows[q, :len(orow)] == orow).all() and nf[q] == len(orow)
+                        assert (_bits(dist[q, :len(orow)]) == _bits(od2)).all()
+                else:
+                    orows, odist, onf, _ = oidx.topk_batch(data, queries, k, 3)
+                    assert (nf == onf).all()
+                    assert (rows == orows).all(), f"mode {mode} k {k}: ids differ from the reference heap order"
+                    assert (_bits(dist) == _bits(odist)).all()
+        assert s.counters()["exact_replays"] > 0
 
-    def tied_candidate(q, row, d):
-        return row in cands[q] and np.float32(np.sqrt(oracle.l2_ref4(queries[q], data[row]))) == d
 
-    for k in (1, 5, 10, 70):
-        rows, dist, nf, _ = s.topk(queries, k, 3)
-        orows, odist, onf, _ = oidx.topk_batch(data, queries, k, 3)
-        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k, boundary_ok=tied_candidate)
-        # GPU rule: k smallest by (d2, candidate position)
-        for q in range(len(queries)):
-            cand = oidx.candidate_rows(queries[q], 3)
-            d2 = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
-            order = np.lexsort((np.arange(len(cand)), d2.view(np.uint32)))[:k]
-            assert (rows[q, :len(order)] == cand[order]).all()
+def oracle_topk_ref4(oracle, data, cand, query, k):
+    """search.rs:112-141 over an explicit candidate list (cap applied), REF4 order, sqrt, via a
+    one-cluster oracle index whose single list is `cand` in that order."""
+    sub = np.ascontiguousarray(data[cand])
+    idx = oracle.index_from_parts(data.shape[1], np.zeros((1, data.shape[1]), np.float32),
+                                  [np.arange(len(cand), dtype=np.uint32)])
+    rows, dist, _ = idx.topk(sub, query, k, 1)
+    return cand[rows], dist
 
 
 def test_topk_seq_metric_and_cap(pqv, oracle):
@@ -327,12 +343,9 @@ def test_gpu_reproduces_golden(pqv, oracle, path):
         for q in range(len(queries)):
             assert (s.probe(queries[q], nprobe) == g[f"w{w}_probe"][q]).all()
         want = (g[f"w{w}_topk_rows"], g[f"w{w}_topk_dist_bits"].view(np.float32), g[f"w{w}_n_found"])
-        if ties:
-            oidx = oracle.index_from_bytes(g[f"w{w}_blob"].tobytes())
-            cands = [set(oidx.candidate_rows(q, nprobe).tolist()) for q in queries]
-            ok = lambda q, row, d: row in cands[q] and \
-                np.float32(np.sqrt(oracle.l2_ref4(queries[q], data[row]))) == d
-            _assert_topk_equal((rows, dist, nf), want, k, boundary_ok=ok)
+        if ties:      # exact replay: identical to the reference's heap order, ties included
+            assert (nf == want[2]).all() and (rows == want[0]).all()
+            assert (_bits(dist) == _bits(want[1])).all()
         else:
             _assert_topk_equal((rows, dist, nf), want, k)
 
