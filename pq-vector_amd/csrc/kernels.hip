@@ -679,77 +679,109 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
         const uint64_t my_gthr =
             __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-        float sum[QB];
-#pragma unroll
-        for (int qq = 0; qq < QB; ++qq) sum[qq] = 0.0f;
-
+        // Distance loop.  The running sums of the group's queries live in LDS
+        // (lsums[query][lane]); per 128-B step of the lane's row, a ROLLED loop over exactly
+        // the group's `cnt` queries applies each query chunk (wave-uniform, SGPRs) and does a
+        // read-modify-write of that query's sum.  No padded work for partial groups, a small
+        // loop body, few VGPRs => enough resident waves to hide the scalar-load latency.
         uint32_t g0 = 0;
         for (; g0 + 8 <= G; g0 += 8) {
             float4 xv[8];
 #pragma unroll
             for (int g = 0; g < 8; ++g) xv[g] = load4<ALIGNED>(x + (g0 + g) * 4);
-            // Software pipeline over the group's queries.  Scalar (SMEM) loads return out
-            // of order, so the only usable wait is lgkmcnt(0); the order per query is
-            //   wait(current chunk) -> issue next chunk's loads -> math on current chunk
-            // which keeps exactly one 128-B chunk in flight behind ~190 cycles of VALU and
-            // bounds the live scalar state to two chunks (64 SGPRs).  sched_barrier pins it.
-            float4 qc[8];
+            // Scalar (SMEM) loads return out of order, so the only usable wait is
+            // lgkmcnt(0).  Software pipeline, two chunk register sets ping-ponging:
+            //   wait(chunk of query q) -> issue loads of query q+1 -> math on query q
+            // keeps one 128-B chunk in flight behind ~200 cycles of VALU; sched_barrier
+            // pins that order (otherwise hipcc issues every load right before its use).
+            float4 qa[8], qb[8];
             {
                 const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, 0) * dim + g0 * 4;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) qc[g] = load4_uniform<ALIGNED>(qp + g * 4);
+                for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(qp + g * 4);
             }
+            uint32_t qq = 0;
+#pragma unroll 1
+            for (; qq + 2 <= cnt; qq += 2) {
+                float acc0 = g0 ? lsums[qq * 64 + lane] : 0.0f;
+                float acc1 = g0 ? lsums[(qq + 1) * 64 + lane] : 0.0f;
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): qa (and the sums) landed
+                {
+                    const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, (int)qq + 1) * dim + g0 * 4;
 #pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                float4 qn[8];
-                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): current chunk has landed
-                if (qq + 1 < QB) {
-                    const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, qq + 1) * dim + g0 * 4;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) qn[g] = load4_uniform<ALIGNED>(qp + g * 4);
+                    for (int g = 0; g < 8; ++g) qb[g] = load4_uniform<ALIGNED>(qp + g * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const float d0 = qc[g].x - xv[g].x, d1 = qc[g].y - xv[g].y;
-                    const float d2 = qc[g].z - xv[g].z, d3 = qc[g].w - xv[g].w;
+                    const float d0 = qa[g].x - xv[g].x, d1 = qa[g].y - xv[g].y;
+                    const float d2 = qa[g].z - xv[g].z, d3 = qa[g].w - xv[g].w;
                     float t = d0 * d0 + d1 * d1;
                     t = t + d2 * d2;
                     t = t + d3 * d3;
-                    sum[qq] = sum[qq] + t;
+                    acc0 = acc0 + t;
+                }
+                lsums[qq * 64 + lane] = acc0;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // qb landed
+                {
+                    const uint32_t nq2 = qq + 2 < cnt ? qq + 2 : cnt - 1;
+                    const float *qp = a.queries + (uint64_t)readlane_u32(my_qrow, (int)nq2) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(qp + g * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (qq + 1 < QB) {
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) qc[g] = qn[g];
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = qb[g].x - xv[g].x, d1 = qb[g].y - xv[g].y;
+                    const float d2 = qb[g].z - xv[g].z, d3 = qb[g].w - xv[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc1 = acc1 + t;
                 }
+                lsums[(qq + 1) * 64 + lane] = acc1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (qq < cnt) {   // odd count: qa holds the last query's chunk
+                float acc = g0 ? lsums[qq * 64 + lane] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = qa[g].x - xv[g].x, d1 = qa[g].y - xv[g].y;
+                    const float d2 = qa[g].z - xv[g].z, d3 = qa[g].w - xv[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc = acc + t;
+                }
+                lsums[qq * 64 + lane] = acc;
             }
         }
         for (; g0 < G; ++g0) {
             const float4 xg = load4<ALIGNED>(x + g0 * 4);
-#pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                const float4 qv = load4_uniform<ALIGNED>(a.queries + (uint64_t)readlane_u32(my_qrow, qq) * dim + g0 * 4);
+#pragma unroll 1
+            for (uint32_t qq = 0; qq < cnt; ++qq) {
+                const float4 qv = load4_uniform<ALIGNED>(a.queries + (uint64_t)readlane_u32(my_qrow, (int)qq) * dim + g0 * 4);
                 const float d0 = qv.x - xg.x, d1 = qv.y - xg.y;
                 const float d2 = qv.z - xg.z, d3 = qv.w - xg.w;
                 float t = d0 * d0 + d1 * d1;
                 t = t + d2 * d2;
                 t = t + d3 * d3;
-                sum[qq] = sum[qq] + t;
+                const float acc = g0 ? lsums[qq * 64 + lane] : 0.0f;
+                lsums[qq * 64 + lane] = acc + t;
             }
         }
         for (uint32_t e = 0; e < tail; ++e) {
             const float xe = x[G * 4 + e];
-#pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                const float d = load1_uniform(a.queries + (uint64_t)readlane_u32(my_qrow, qq) * dim + G * 4 + e) - xe;
-                sum[qq] = sum[qq] + d * d;
+#pragma unroll 1
+            for (uint32_t qq = 0; qq < cnt; ++qq) {
+                const float d = load1_uniform(a.queries + (uint64_t)readlane_u32(my_qrow, (int)qq) * dim + G * 4 + e) - xe;
+                const float acc = (G || e) ? lsums[qq * 64 + lane] : 0.0f;
+                lsums[qq * 64 + lane] = acc + d * d;
             }
         }
 
         // ---- top-k epilogue: rolled over the group's queries --------------------------
-#pragma unroll
-        for (int qq = 0; qq < QB; ++qq) lsums[qq * 64 + lane] = sum[qq];
         wave_lds_fence();
         const uint64_t my_lkth = lkth[(uint32_t)lane < (uint32_t)QB ? lane : 0];
         const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
