@@ -882,12 +882,13 @@ hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipS
 }
 
 // ------------------------------------------------------------------------------------
-// assign_kernel: lane-per-row, CT running sums per lane, centroid chunk wave-uniform (the
-// compiler keeps it in SGPRs via scalar loads: plain loads from a __restrict__ const pointer
-// with a uniform index -- measured faster here than the explicit constant-address-space form
-// the tile kernel needs), 128 B of the lane's own row per step.
-// Each (row, centroid) chain is summed in ascending group order exactly as
-// squared_l2_distance does; the argmin uses strict '<' in ascending centroid order.
+// assign_kernel: Lloyd assign + final assignment (index.rs:395-424, :189-201, :244-257).
+// Same skeleton as the tile re-rank: lane-per-row, 128 B of the lane's own row per step, a
+// tile of CT centroids applied to it as wave-uniform scalar operands through the rolled,
+// software-pipelined loop (two chunk register sets ping-ponging behind lgkmcnt(0) waits),
+// running sums in LDS (lsums[centroid][lane]).  Every (row, centroid) chain is summed in
+// ascending group order exactly as squared_l2_distance does; the argmin uses strict '<' in
+// ascending centroid order.  Exact-order f32 VALU-bound.
 // ------------------------------------------------------------------------------------
 template <int CT, bool ALIGNED>
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ rows, uint64_t n,
@@ -897,6 +898,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                                                     const uint32_t *__restrict__ prev,
                                                     unsigned long long *__restrict__ changed,
                                                     unsigned long long *__restrict__ sizes) {
+    __shared__ float lsums_all[4 * CT * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *lsums = lsums_all + wave * (CT * 64);
+
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = r < n;
     const float *x = rows + (valid ? r : (n - 1)) * dim;
@@ -905,58 +911,105 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
     uint32_t bestc = 0;
 
     for (uint32_t c0 = 0; c0 < k; c0 += CT) {
-        float sum[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) sum[c] = 0.0f;
-
+        const uint32_t cnt = (k - c0 < (uint32_t)CT) ? (k - c0) : (uint32_t)CT;
         uint32_t g0 = 0;
         for (; g0 + 8 <= G; g0 += 8) {
             float4 xv[8];
 #pragma unroll
             for (int g = 0; g < 8; ++g) xv[g] = load4<ALIGNED>(x + (g0 + g) * 4);
+            float4 qa[8], qb[8];
+            {
+                const float *cp = cent + (uint64_t)c0 * dim + g0 * 4;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
-                const float *cp = cent + (uint64_t)cc * dim + g0 * 4;
+                for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(cp + g * 4);
+            }
+            uint32_t cc = 0;
+#pragma unroll 1
+            for (; cc + 2 <= cnt; cc += 2) {
+                float acc0 = g0 ? lsums[cc * 64 + lane] : 0.0f;
+                float acc1 = g0 ? lsums[(cc + 1) * 64 + lane] : 0.0f;
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+                {
+                    const float *cp = cent + (uint64_t)(c0 + cc + 1) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qb[g] = load4_uniform<ALIGNED>(cp + g * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const float4 cv = load4<ALIGNED>(cp + g * 4);
-                    const float d0 = xv[g].x - cv.x, d1 = xv[g].y - cv.y;
-                    const float d2 = xv[g].z - cv.z, d3 = xv[g].w - cv.w;
+                    const float d0 = xv[g].x - qa[g].x, d1 = xv[g].y - qa[g].y;
+                    const float d2 = xv[g].z - qa[g].z, d3 = xv[g].w - qa[g].w;
                     float t = d0 * d0 + d1 * d1;
                     t = t + d2 * d2;
                     t = t + d3 * d3;
-                    sum[c] = sum[c] + t;
+                    acc0 = acc0 + t;
                 }
+                lsums[cc * 64 + lane] = acc0;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                {
+                    const uint32_t nc2 = cc + 2 < cnt ? cc + 2 : cnt - 1;
+                    const float *cp = cent + (uint64_t)(c0 + nc2) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(cp + g * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = xv[g].x - qb[g].x, d1 = xv[g].y - qb[g].y;
+                    const float d2 = xv[g].z - qb[g].z, d3 = xv[g].w - qb[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc1 = acc1 + t;
+                }
+                lsums[(cc + 1) * 64 + lane] = acc1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cc < cnt) {
+                float acc = g0 ? lsums[cc * 64 + lane] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = xv[g].x - qa[g].x, d1 = xv[g].y - qa[g].y;
+                    const float d2 = xv[g].z - qa[g].z, d3 = xv[g].w - qa[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc = acc + t;
+                }
+                lsums[cc * 64 + lane] = acc;
             }
         }
         for (; g0 < G; ++g0) {
             const float4 xg = load4<ALIGNED>(x + g0 * 4);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
-                const float4 cv = load4<ALIGNED>(cent + (uint64_t)cc * dim + g0 * 4);
+#pragma unroll 1
+            for (uint32_t cc = 0; cc < cnt; ++cc) {
+                const float4 cv = load4_uniform<ALIGNED>(cent + (uint64_t)(c0 + cc) * dim + g0 * 4);
                 const float d0 = xg.x - cv.x, d1 = xg.y - cv.y;
                 const float d2 = xg.z - cv.z, d3 = xg.w - cv.w;
                 float t = d0 * d0 + d1 * d1;
                 t = t + d2 * d2;
                 t = t + d3 * d3;
-                sum[c] = sum[c] + t;
+                const float acc = g0 ? lsums[cc * 64 + lane] : 0.0f;
+                lsums[cc * 64 + lane] = acc + t;
             }
         }
         for (uint32_t e = 0; e < tail; ++e) {
             const float xe = x[G * 4 + e];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const uint32_t cc = (c0 + c < k) ? (c0 + c) : (k - 1);
-                const float d = xe - cent[(uint64_t)cc * dim + G * 4 + e];
-                sum[c] = sum[c] + d * d;
+#pragma unroll 1
+            for (uint32_t cc = 0; cc < cnt; ++cc) {
+                const float d = xe - load1_uniform(cent + (uint64_t)(c0 + cc) * dim + G * 4 + e);
+                const float acc = (G || e) ? lsums[cc * 64 + lane] : 0.0f;
+                lsums[cc * 64 + lane] = acc + d * d;
             }
         }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            if (c0 + c < k && sum[c] < best) { best = sum[c]; bestc = c0 + c; }
+        wave_lds_fence();
+#pragma unroll 1
+        for (uint32_t cc = 0; cc < cnt; ++cc) {
+            const float v = lsums[cc * 64 + lane];
+            if (v < best) { best = v; bestc = c0 + cc; }   // strict '<': lowest centroid wins ties
         }
+        wave_lds_fence();
     }
 
     if (valid) {
