@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the shard exchange even with one rank (path check)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo lets several ranks share one GPU (path check only; the real run uses RCCL)")
     ap.add_argument("--single", type=int, default=0,
                     help="also time this many single-query calls (latency mode) and report them")
     args = ap.parse_args()
@@ -81,13 +83,18 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available() or pqv.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: pq_vector_amd has no CPU fallback")
+    if args.backend == "gloo":          # test hook: ranks may share a device
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
     nq = args.nq or nq_default
