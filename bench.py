@@ -8,6 +8,9 @@ over one batch of Q synthetic queries, with corpus, index and queries already re
 HBM.  Default workload = BASELINE.json configs[1] (C2): 1 M x 128 uniform f32, n_clusters
 100, k 10, nprobe 8.
 
+`--workload c4` is the sharded 100 M x 768 configuration: every rank holds one 12.5 M-row shard
+(weak scaling; at N = 8 the job searches the whole 100 M corpus).
+
 N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is cut into N
 contiguous row ranges, one shard + its own IVF index per GPU (the reference's per-file
 index, src/df_vector/index_exec.rs:85-164); every rank searches the whole query batch on
@@ -35,6 +38,7 @@ WORKLOADS = {
     # name: (rows, dim, n_clusters, nprobe, default queries per step)
     "c2": (1_000_000, 128, 100, 8, 1024),
     "c3": (10_000_000, 768, 1024, 32, 1024),
+    "c4": (12_500_000, 768, 1024, 32, 1024),   # PER-RANK shard of the 100M x 768 corpus (weak scaling)
     "c1": (1024, 4096, 0, 5, 64),          # vldb stand-in: n_clusters = ceil(sqrt(n)) = 32
     "tiny": (20_000, 64, 16, 4, 64),       # plumbing check
 }
@@ -99,7 +103,12 @@ def main():
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
     nq = args.nq or nq_default
     from pq_vector_amd.sharding import ShardExchange, shard_range
-    lo, hi = shard_range(rank, world, n_total)
+    weak = args.workload == "c4"           # per-rank shard size fixed: N ranks hold N x rows
+    if weak:
+        lo, hi = rank * n_total, (rank + 1) * n_total
+        n_total = n_total * world
+    else:
+        lo, hi = shard_range(rank, world, n_total)
     n_shard = hi - lo
 
     # ---- synthetic data: the reference's bench recipe (benches/bench_util.rs:12-64) ------
@@ -207,7 +216,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if weak else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",

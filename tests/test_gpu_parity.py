@@ -448,3 +448,55 @@ def test_parquet_build_new_reference_fixture(pqv, tmp_path):
         pqv.IndexBuilder(src, " ").build_inplace()
     with pytest.raises(pqv.PqvError, match="Column 'nope' not found"):
         pqv.IndexBuilder(src, "nope").build_inplace()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs[1] at FULL size (1 M x 128, n_clusters 100, nprobe 8, k 10):
+# size-independent properties + an oracle spot check
+# ---------------------------------------------------------------------------------------
+def test_full_size_c2_properties(pqv, oracle, monkeypatch):
+    n, dim, kc, k, nprobe, nq = 1_000_000, 128, 100, 10, 8, 512
+    rng = np.random.default_rng(1234)
+    data = (rng.integers(0, 1 << 24, size=(n, dim), dtype=np.int32).astype(np.float32)
+            * np.float32(1.0 / (1 << 24)))                       # the bench recipe: 24-bit uniform [0,1)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.IndexBuilder(corpus).n_clusters(kc).workers(8).build()
+    # index invariants: every row listed exactly once, lists ascending
+    off, rows = index.list_offsets, index.list_rows
+    assert int(off[-1]) == n and np.array_equal(np.sort(rows), np.arange(n, dtype=np.uint32))
+    for c in range(kc):
+        l = rows[int(off[c]):int(off[c + 1])].astype(np.int64)
+        assert (np.diff(l) > 0).all()
+    # determinism / idempotence: a second build gives the identical blob
+    blob = index.to_bytes()
+    assert pqv.IndexBuilder(corpus).n_clusters(kc).workers(8).build().to_bytes() == blob
+    assert pqv.Index.from_bytes(blob).to_bytes() == blob
+
+    queries = np.ascontiguousarray(data[rng.choice(n, nq, replace=False)])   # self-queries
+    queries[nq // 2:] = rng.random((nq - nq // 2, dim), dtype=np.float32)
+    out = {}
+    for mode in ("tile", "stream"):
+        monkeypatch.setenv("PQV_RERANK_MODE", mode)
+        s = pqv.Searcher(index, corpus)
+        out[mode] = s.topk(queries, k, nprobe)
+    # two independent kernels (lane-per-row SGPR tiles vs coalesced stream + LDS transpose)
+    for a, b in zip(out["tile"], out["stream"]):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b)
+    rows_t, dist_t, nf, nc = out["tile"]
+    assert (nf == k).all()
+    assert (np.diff(dist_t.astype(np.float64), axis=1) >= 0).all()          # sorted ascending
+    # a row queried with itself comes back first at distance 0 (its own cluster is probed first)
+    self_q = queries[:nq // 2]
+    assert (dist_t[:nq // 2, 0] == 0).all()
+    assert (np.abs(data[rows_t[:nq // 2, 0]] - self_q).max(axis=1) == 0).all()
+    # distances are what they claim: recompute in f64 for every returned row
+    for q in range(0, nq, 37):
+        d = np.sqrt(((data[rows_t[q]].astype(np.float64) - queries[q]) ** 2).sum(axis=1))
+        assert np.allclose(d, dist_t[q], rtol=1e-5, atol=1e-6)
+    # oracle spot check on the same index (bit-exact)
+    oidx = oracle.index_from_bytes(blob)
+    sel = np.arange(0, nq, 16)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries[sel], k, nprobe)
+    assert (rows_t[sel] == orows).all() and (_bits(dist_t[sel]) == _bits(odist)).all()
+    assert (nc[sel] == onc).all()
