@@ -47,6 +47,13 @@ typedef enum pqv_metric {
     PQV_L2SQ_SEQ  = 1  /* src/df_vector/exec.rs:529-533: dist += d^2, element by element */
 } pqv_metric;
 
+/* Metrics of pqv_brute_topk (an EXTENSION: the reference has neither cosine distance nor a
+ * batched brute-force path -- SURVEY F5; BASELINE.json configs[4] asks for it).  Scores are a
+ * dense Q.V^T contraction on the f32 matrix cores, so distances agree with an f64 oracle to
+ * ~1e-6 relative (well inside the north star's 1e-4), not bit for bit. */
+#define PQV_COSINE      2   /* 1 - q.v / (|q| |v|); zero-norm vectors get distance 1            */
+#define PQV_L2SQ_MFMA   3   /* |q|^2 + |v|^2 - 2 q.v (norm-expansion form, clamped at 0)        */
+
 /* pqv_searcher_create flags */
 #define PQV_LAYOUT_IVF_ORDERED   0x0u /* copy rows into cluster-contiguous order in HBM (default) */
 #define PQV_LAYOUT_ROW_ORDER     0x1u /* keep file row order; re-rank gathers rows by id          */
@@ -174,6 +181,13 @@ int pqv_topk_device(const pqv_searcher *searcher, const void *d_queries, uint32_
                     uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric,
                     int sqrt_out, void *d_row_idx, void *d_dist, void *d_n_found,
                     void *d_n_candidates, void *hip_stream);
+
+/* Exhaustive top-k of nq queries over EVERY row of the resident column (no index), batched
+ * on the matrix cores: what DataFusion's brute-force `ORDER BY array_distance(..) LIMIT k`
+ * baseline does row by row (benches/query.rs:76-98), for the metrics above.  Results are
+ * ordered ascending by (distance, row id).  Host arrays as in pqv_topk. */
+int pqv_brute_topk(const pqv_corpus *corpus, const float *queries, uint32_t nq, uint32_t query_len,
+                   uint32_t k, int metric, uint32_t *row_idx, float *dist, uint32_t *n_found);
 
 /* update_topk_heap / compute_distance_values (src/df_vector/exec.rs:457-550) for one
  * RecordBatch worth of rows: cand host [m, dim] values buffer, ids[m] the payload to return

@@ -17,11 +17,11 @@ behind libpqv_hip.so; importing this package without the built library fails lou
 from .api import (Corpus, Index, IndexBuilder, PqvError, Searcher, SearchResult, TopkBuilder,
                   device_count, merge_topk, rerank_batch, searcher_for_parquet)
 from .parquet_io import has_pq_vector_index, read_index_from_parquet
-from ._ffi import (PQV_L2SQ_REF4, PQV_L2SQ_SEQ, PQV_LAYOUT_IVF_ORDERED, PQV_LAYOUT_ROW_ORDER,
+from ._ffi import (PQV_L2SQ_REF4, PQV_L2SQ_SEQ, PQV_COSINE, PQV_L2SQ_MFMA, PQV_LAYOUT_IVF_ORDERED, PQV_LAYOUT_ROW_ORDER,
                    PQV_RELEASE_ROW_ORDER, LIB_PATH)
 
 __all__ = ["Corpus", "Index", "IndexBuilder", "PqvError", "Searcher", "SearchResult",
-           "TopkBuilder", "device_count", "merge_topk", "rerank_batch", "searcher_for_parquet",
+           "TopkBuilder", "device_count", "merge_topk", "rerank_batch", "searcher_for_parquet", "PQV_COSINE", "PQV_L2SQ_MFMA",
            "has_pq_vector_index", "read_index_from_parquet", "PQV_L2SQ_REF4",
            "PQV_L2SQ_SEQ", "PQV_LAYOUT_IVF_ORDERED", "PQV_LAYOUT_ROW_ORDER",
            "PQV_RELEASE_ROW_ORDER", "LIB_PATH"]

@@ -26,6 +26,8 @@ PQV_ERR_FORMAT = -6
 
 PQV_L2SQ_REF4 = 0
 PQV_L2SQ_SEQ = 1
+PQV_COSINE = 2
+PQV_L2SQ_MFMA = 3
 
 PQV_LAYOUT_IVF_ORDERED = 0x0
 PQV_LAYOUT_ROW_ORDER = 0x1
@@ -77,6 +79,7 @@ SIGNATURES = {
                            C.c_int, C.c_int, u32p, f32p, u32p, u64p]),
     "pqv_topk_device": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
                                   C.c_int, vp, vp, vp, vp, vp]),
+    "pqv_brute_topk": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, f32p, u32p]),
     "pqv_rerank": (C.c_int, [C.c_int, f32p, f32p, u32p, u8p, C.c_uint64, C.c_uint32, C.c_uint32,
                              C.c_int, u32p, f32p, u32p]),
     "pqv_merge_topk": (C.c_int, [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p,

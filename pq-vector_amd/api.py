@@ -100,6 +100,21 @@ class Corpus:
                                                 out.ctypes.data_as(f32p)))
         return out
 
+    def brute_topk(self, queries, k, metric=_ffi.PQV_COSINE):
+        """Exhaustive batched top-k over every resident row on the matrix cores (extension:
+        cosine / norm-expansion L2).  Returns (row_idx [nq,k], dist [nq,k], n_found [nq])."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, qlen = q.shape
+        rows = np.full((nq, max(k, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        dist = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        nf = np.zeros(nq, dtype=np.uint32)
+        _check(_ffi.lib().pqv_brute_topk(self._h, q.ctypes.data_as(f32p), nq, qlen, k, metric,
+                                         rows.ctypes.data_as(u32p), dist.ctypes.data_as(f32p),
+                                         nf.ctypes.data_as(u32p)))
+        return rows, dist, nf
+
     def close(self):
         if self._h:
             _ffi.lib().pqv_corpus_free(self._h)

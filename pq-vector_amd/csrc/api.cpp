@@ -129,6 +129,10 @@ struct pqv_corpus {
     float *d_rows = nullptr;  // [capacity, dim]
     bool owned = true;
     hipStream_t stream = nullptr;
+    // lazily computed per-row auxiliaries of pqv_brute_topk: 1/|v| and |v|^2
+    mutable std::mutex aux_mu;
+    mutable DevBuf aux_rnorm, aux_norm2;
+    mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0;
     ~pqv_corpus() {
         if (d_rows && owned) (void)hipFree(d_rows);
         if (stream) (void)hipStreamDestroy(stream);
@@ -1197,6 +1201,129 @@ extern "C" int pqv_timing_read(const pqv_searcher *s, double *rerank_ms, double 
     if (rerank_ms) *rerank_ms = rr;
     if (total_ms) *total_ms = tot;
     if (n_calls) *n_calls = calls;
+    return PQV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// batched brute force on the matrix cores (BASELINE config 5; extension, see pqv.h)
+// ---------------------------------------------------------------------------------------
+extern "C" int pqv_brute_topk(const pqv_corpus *c, const float *queries, uint32_t nq, uint32_t query_len,
+                              uint32_t k, int metric, uint32_t *row_idx, float *dist, uint32_t *n_found) {
+    using namespace pqv;
+    if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (metric != PQV_COSINE && metric != PQV_L2SQ_MFMA)
+        return fail(PQV_ERR_INVALID, "pqv_brute_topk: metric must be PQV_COSINE or PQV_L2SQ_MFMA");
+    if (query_len != c->dim)
+        return fail(PQV_ERR_INVALID, "Query dimension mismatch: expected " + std::to_string(c->dim) +
+                                         ", got " + std::to_string(query_len));
+    if (nq == 0) return PQV_OK;
+    if (!queries || !row_idx || !dist) return fail(PQV_ERR_INVALID, "queries/row_idx/dist must not be NULL");
+    if (!c->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
+    if (int rc = use_device(c->device)) return rc;
+    hipStream_t stream = c->stream;
+    const uint64_t n = c->n;
+    const uint32_t dim = c->dim;
+    const int mode = metric == PQV_COSINE ? 0 : 1;
+
+    // per-row auxiliary (cached in the corpus, recomputed if rows were appended since)
+    const float *d_row_aux = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->aux_mu);
+        DevBuf &buf = mode == 0 ? c->aux_rnorm : c->aux_norm2;
+        uint64_t &have = mode == 0 ? c->aux_rnorm_rows : c->aux_norm2_rows;
+        if (have != n || !buf.p) {
+            HIP_TRY(buf.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
+            HIP_TRY(launch_row_norms(c->d_rows, n, dim, mode, buf.as<float>(), stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            have = n;
+        }
+        d_row_aux = buf.as<float>();
+    }
+
+    const uint32_t cap = std::max<uint32_t>(16384, 4 * k);
+    const uint32_t qbatch = std::min<uint32_t>(nq, 4096);
+    DevBuf d_q, d_qaux, d_cand, d_cnt, d_cnt_saved, d_thr, d_flag, d_rows_out, d_dist_out, d_nf;
+    HIP_TRY(d_q.alloc(static_cast<size_t>(qbatch) * dim * sizeof(float)));
+    HIP_TRY(d_qaux.alloc(static_cast<size_t>(qbatch) * sizeof(float)));
+    HIP_TRY(d_cand.alloc(static_cast<size_t>(qbatch) * cap * sizeof(unsigned long long)));
+    HIP_TRY(d_cnt.alloc(static_cast<size_t>(qbatch) * sizeof(uint32_t)));
+    HIP_TRY(d_cnt_saved.alloc(static_cast<size_t>(qbatch) * sizeof(uint32_t)));
+    HIP_TRY(d_thr.alloc(static_cast<size_t>(qbatch) * sizeof(unsigned long long)));
+    HIP_TRY(d_flag.alloc(sizeof(uint32_t)));
+    HIP_TRY(d_rows_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(uint32_t)));
+    HIP_TRY(d_dist_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(float)));
+    HIP_TRY(d_nf.alloc(static_cast<size_t>(qbatch) * sizeof(uint32_t)));
+
+    for (uint32_t q0 = 0; q0 < nq; q0 += qbatch) {
+        const uint32_t b = std::min<uint32_t>(qbatch, nq - q0);
+        HIP_TRY(hipMemcpyAsync(d_q.p, queries + static_cast<uint64_t>(q0) * dim, static_cast<size_t>(b) * dim * sizeof(float),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, mode, d_qaux.as<float>(), stream));
+        HIP_TRY(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(b) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(d_thr.p, 0xFF, static_cast<size_t>(b) * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), stream));
+
+        // Progressive thresholds: row ranges grow 8x; after each range the per-query k-th key
+        // becomes the admission threshold of the next, so only ~8k candidates per query
+        // survive each pass.  A range whose survivors overflow a buffer (adversarially ordered
+        // rows) is rolled back and split.
+        std::vector<std::pair<uint64_t, uint64_t>> todo;
+        {
+            std::vector<std::pair<uint64_t, uint64_t>> fwd;
+            uint64_t lo = 0, len = std::min<uint64_t>(n, std::max<uint64_t>(8192, 8ull * k));
+            while (lo < n) {
+                const uint64_t hi = std::min<uint64_t>(n, lo + len);
+                fwd.emplace_back(lo, hi);
+                lo = hi;
+                len *= 8;
+            }
+            todo.assign(fwd.rbegin(), fwd.rend());   // stack: pop_back() yields ascending ranges
+        }
+        while (!todo.empty()) {
+            const auto range = todo.back();
+            todo.pop_back();
+            HIP_TRY(hipMemcpyAsync(d_cnt_saved.p, d_cnt.p, static_cast<size_t>(b) * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, stream));
+            BruteArgs ba{};
+            ba.rows = c->d_rows; ba.queries = d_q.as<float>(); ba.row_aux = d_row_aux; ba.query_aux = d_qaux.as<float>();
+            ba.row_begin = range.first; ba.row_end = range.second; ba.nq = b; ba.dim = dim;
+            ba.metric = mode == 0 ? BRUTE_COSINE : BRUTE_L2SQ;
+            ba.thr = d_thr.as<unsigned long long>(); ba.cand = d_cand.as<unsigned long long>();
+            ba.cand_cnt = d_cnt.as<uint32_t>(); ba.cap = cap;
+            HIP_TRY(launch_brute_mfma(ba, stream));
+            // overflow is checked BEFORE the select pass touches the buffer fronts, so a
+            // rollback only has to restore the counts
+            HIP_TRY(launch_brute_overflow_check(d_cnt.as<uint32_t>(), b, cap, d_flag.as<uint32_t>(), stream));
+            uint32_t flag = 0;
+            HIP_TRY(hipMemcpyAsync(&flag, d_flag.p, sizeof flag, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (flag) {
+                const uint64_t len = range.second - range.first;
+                if (len <= cap / 2)
+                    return fail(PQV_ERR_HIP, "pqv_brute_topk: candidate buffer overflow on a minimal range");
+                HIP_TRY(hipMemcpyAsync(d_cnt.p, d_cnt_saved.p, static_cast<size_t>(b) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), stream));
+                const uint64_t mid = range.first + len / 2;
+                todo.emplace_back(mid, range.second);
+                todo.emplace_back(range.first, mid);
+                continue;
+            }
+            HIP_TRY(launch_brute_select(d_cand.as<unsigned long long>(), d_cnt.as<uint32_t>(), cap, b, k,
+                                        d_thr.as<unsigned long long>(), d_flag.as<uint32_t>(), stream));
+        }
+        HIP_TRY(launch_brute_finish(d_cand.as<unsigned long long>(), d_cnt.as<uint32_t>(), cap, b, k,
+                                    d_rows_out.as<uint32_t>(), d_dist_out.as<float>(), d_nf.as<uint32_t>(), stream));
+        HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, d_rows_out.p, static_cast<size_t>(b) * k * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, d_dist_out.p, static_cast<size_t>(b) * k * sizeof(float),
+                               hipMemcpyDeviceToHost, stream));
+        if (n_found)
+            HIP_TRY(hipMemcpyAsync(n_found + q0, d_nf.p, static_cast<size_t>(b) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     return PQV_OK;
 }
 

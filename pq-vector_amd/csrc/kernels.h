@@ -106,6 +106,43 @@ struct TileArgs {
 // PQV_L2SQ_REF4 only, k <= 64
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
 
+// ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
+// score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:
+//   BRUTE_COSINE : d = 1 - s * rq[i] * rv[j]     (rq, rv = reciprocal L2 norms)
+//   BRUTE_L2SQ   : d = max(0, qn[i] + vn[j] - 2 s)   (norm-expansion form: NOT the reference's
+//                  summation order -- tolerance-level agreement only)
+// Candidates whose key beats the query's current threshold are appended to a per-query buffer.
+enum BruteMetric : int { BRUTE_COSINE = 0, BRUTE_L2SQ = 1 };
+
+struct BruteArgs {
+    const float *rows;        // [n, dim]
+    const float *queries;     // [nq, dim]
+    const float *row_aux;     // [n]  rv (cosine) or vn (l2)
+    const float *query_aux;   // [nq] rq or qn
+    uint64_t     row_begin, row_end;   // row range of this launch
+    uint32_t     nq, dim;
+    int          metric;
+    const unsigned long long *thr;     // [nq] admission threshold (sortable key), KEY_EMPTY = none
+    unsigned long long *cand;          // [nq][cap] appended keys
+    uint32_t    *cand_cnt;             // [nq]
+    uint32_t     cap;
+};
+hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s);
+// per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2
+hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s);
+// fold a query's appended candidates to its k best (kept at the front of the buffer), set
+// thr[q] to its k-th key once k candidates exist, report overflow (count > cap) in *overflow
+hipError_t launch_brute_select(unsigned long long *cand, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
+                               uint32_t k, unsigned long long *thr, uint32_t *overflow, hipStream_t s);
+// *overflow |= 1 if any query's appended count exceeds cap (run BEFORE the select pass, which
+// rewrites the buffer fronts)
+hipError_t launch_brute_overflow_check(const uint32_t *cand_cnt, uint32_t nq, uint32_t cap, uint32_t *overflow,
+                                       hipStream_t s);
+// decode the k best keys of every query: row ids + distances
+hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *cand_cnt, uint32_t cap,
+                               uint32_t nq, uint32_t k, uint32_t *row_idx, float *dist, uint32_t *n_found,
+                               hipStream_t s);
+
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
                               uint64_t m, uint32_t dim, float *out, hipStream_t s);

@@ -828,6 +828,266 @@ hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
+// Batched brute force on the matrix cores (BASELINE config 5: cosine, 1024-query batches).
+//
+// brute_mfma_kernel: block tile 128 queries x 128 rows, 4 waves as 2 x 2, each wave a
+// 64 x 64 sub-tile = 2 x 2 MFMA tiles of v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate:
+// a k-ordered fmaf chain, exact f32 products -- bf16 would miss the 1e-4 tolerance).
+// K is walked in 16-float stages: each thread fetches 2+2 float4 (queries / rows) into
+// registers one stage ahead, the tiles sit in LDS as [row][k] with a 17-dword row stride so
+// the MFMA operand reads (32 rows x same k per half-wave) are bank-conflict-free.
+// Epilogue: distance from the score, a sortable key (distance bits | row id) per (query, row),
+// compared with the query's admission threshold staged in LDS; the rare survivors are
+// appended to the query's candidate buffer with one atomic each.  Nothing of the
+// nq x n score matrix is ever written.
+// ------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t sortable_bits(float d) {
+    const uint32_t b = __float_as_uint(d);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unsortable_bits(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+constexpr int BR_BM = 128, BR_BN = 128, BR_BK = 16, BR_ST = 17;
+
+__global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
+    __shared__ float As[BR_BM * BR_ST];
+    __shared__ float Bs[BR_BN * BR_ST];
+    __shared__ unsigned long long thr_s[BR_BM];
+    __shared__ float qaux_s[BR_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint64_t n0 = a.row_begin + (uint64_t)blockIdx.x * BR_BN;
+    const uint32_t m0 = blockIdx.y * BR_BM;
+    const uint32_t dim = a.dim;
+    const bool al4 = (dim & 3u) == 0;
+
+    // staging: thread -> (row ld_r / ld_r + 64, 4 consecutive k at ld_c)
+    const int ld_r = tid >> 2, ld_c = (tid & 3) * 4;
+    float4 ra[2], rb[2];
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t qi = m0 + ld_r + 64 * h;
+            const uint64_t vj = n0 + ld_r + 64 * h;
+            const uint32_t kk = k0 + ld_c;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (qi < a.nq) {
+                const float *p = a.queries + (uint64_t)qi * dim + kk;
+                if (al4 && kk + 4 <= dim) va = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (kk < dim) va.x = p[0];
+                    if (kk + 1 < dim) va.y = p[1];
+                    if (kk + 2 < dim) va.z = p[2];
+                    if (kk + 3 < dim) va.w = p[3];
+                }
+            }
+            if (vj < a.row_end) {
+                const float *p = a.rows + vj * dim + kk;
+                if (al4 && kk + 4 <= dim) vb = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (kk < dim) vb.x = p[0];
+                    if (kk + 1 < dim) vb.y = p[1];
+                    if (kk + 2 < dim) vb.z = p[2];
+                    if (kk + 3 < dim) vb.w = p[3];
+                }
+            }
+            ra[h] = va; rb[h] = vb;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float *pa = As + (ld_r + 64 * h) * BR_ST + ld_c;
+            float *pb = Bs + (ld_r + 64 * h) * BR_ST + ld_c;
+            pa[0] = ra[h].x; pa[1] = ra[h].y; pa[2] = ra[h].z; pa[3] = ra[h].w;
+            pb[0] = rb[h].x; pb[1] = rb[h].y; pb[2] = rb[h].z; pb[3] = rb[h].w;
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (tid < BR_BM) {
+        const uint32_t qi = m0 + tid;
+        thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
+        qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
+    }
+
+    const uint32_t nk = (dim + BR_BK - 1) / BR_BK;
+    fetch(0);
+    stash();
+    __syncthreads();
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch((kt + 1) * BR_BK);
+#pragma unroll
+        for (int kk = 0; kk < BR_BK; kk += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                av[t] = As[(wm * 64 + t * 32 + l31) * BR_ST + kk + lk];
+                bv[t] = Bs[(wn * 64 + t * 32 + l31) * BR_ST + kk + lk];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            stash();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint64_t vj = n0 + wn * 64 + j * 32 + l31;
+        const bool jv = vj < a.row_end;
+        const float vaux = jv ? a.row_aux[vj] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const uint32_t qi = m0 + ml;
+                const float sc = acc[i][j][r];
+                float d;
+                if (a.metric == BRUTE_COSINE) d = 1.0f - sc * qaux_s[ml] * vaux;
+                else { d = qaux_s[ml] + vaux - 2.0f * sc; d = d < 0.0f ? 0.0f : d; }
+                const unsigned long long key =
+                    ((unsigned long long)sortable_bits(d) << 32) | (unsigned long long)(uint32_t)vj;
+                if (jv && qi < a.nq && key < thr_s[ml]) {
+                    const uint32_t slot = atomicAdd(&a.cand_cnt[qi], 1u);
+                    if (slot < a.cap) a.cand[(uint64_t)qi * a.cap + slot] = key;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
+    if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
+    const uint64_t nb = (a.row_end - a.row_begin + BR_BN - 1) / BR_BN;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((uint32_t)nb, (a.nq + BR_BM - 1) / BR_BM);
+    hipLaunchKernelGGL(brute_mfma_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// one wave per row; f32 partial sums, wave-reduced
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ rows, uint64_t n,
+                                                       uint32_t dim, int mode, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        float acc = 0.0f;
+        for (uint32_t e = lane; e < dim; e += 64) acc = fmaf(p[e], p[e], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out[r] = mode == 0 ? (acc > 0.0f ? 1.0f / sqrtf(acc) : 0.0f) : acc;
+    }
+}
+hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, n, dim, mode, out);
+    return hipGetLastError();
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void brute_select_kernel(unsigned long long *cand, uint32_t *cand_cnt,
+                                                         uint32_t cap, uint32_t k,
+                                                         unsigned long long *thr, uint32_t *overflow) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t cnt = cand_cnt[q];
+    if (cnt > cap) { if (lane == 0) atomicOr(overflow, 1u); return; }
+    unsigned long long *c = cand + (uint64_t)q * cap;
+    WaveTopk<S> tk;
+    tk.init();
+    for (uint32_t i = 0; i < cnt; i += 64) {
+        const uint64_t key = (i + lane < cnt) ? c[i + lane] : KEY_EMPTY;
+        tk.offer(key, 0u, k, lane);
+    }
+    uint32_t kept = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        const bool have = e < k && tk.key[s] != KEY_EMPTY;
+        kept += (uint32_t)__popcll(__ballot(have));
+        if (e < k) c[e] = tk.key[s];
+    }
+    if (lane == 0) {
+        cand_cnt[q] = kept;
+        thr[q] = kept >= k ? tk.kth(k) : KEY_EMPTY;
+    }
+}
+__global__ __launch_bounds__(256) void brute_overflow_kernel(const uint32_t *cand_cnt, uint32_t nq,
+                                                            uint32_t cap, uint32_t *overflow) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nq && cand_cnt[q] > cap) atomicOr(overflow, 1u);
+}
+hipError_t launch_brute_overflow_check(const uint32_t *cand_cnt, uint32_t nq, uint32_t cap, uint32_t *overflow,
+                                       hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(brute_overflow_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, cand_cnt, nq, cap, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_brute_select(unsigned long long *cand, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
+                               uint32_t k, unsigned long long *thr, uint32_t *overflow, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(brute_select_kernel<1>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else if (k <= 256) hipLaunchKernelGGL(brute_select_kernel<4>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else if (k <= 1024) hipLaunchKernelGGL(brute_select_kernel<16>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void brute_finish_kernel(const unsigned long long *cand, const uint32_t *cand_cnt,
+                                                          uint32_t cap, uint32_t nq, uint32_t k,
+                                                          uint32_t *row_idx, float *dist, uint32_t *n_found) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)nq * k) return;
+    const uint32_t q = (uint32_t)(i / k), e = (uint32_t)(i % k);
+    const uint32_t cnt = cand_cnt[q] < k ? cand_cnt[q] : k;
+    if (e < cnt) {
+        const unsigned long long key = cand[(uint64_t)q * cap + e];
+        row_idx[i] = (uint32_t)key;
+        dist[i] = unsortable_bits((uint32_t)(key >> 32));
+    } else {
+        row_idx[i] = 0xFFFFFFFFu;
+        dist[i] = INFINITY;
+    }
+    if (e == 0 && n_found) n_found[q] = cnt;
+}
+hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *cand_cnt, uint32_t cap,
+                               uint32_t nq, uint32_t k, uint32_t *row_idx, float *dist, uint32_t *n_found,
+                               hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)nq * k;
+    hipLaunchKernelGGL(brute_finish_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, cand,
+                       cand_cnt, cap, nq, k, row_idx, dist, n_found);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
 // ------------------------------------------------------------------------------------
 template <bool ALIGNED>

@@ -500,3 +500,68 @@ def test_full_size_c2_properties(pqv, oracle, monkeypatch):
     orows, odist, onf, onc = oidx.topk_batch(data, queries[sel], k, nprobe)
     assert (rows_t[sel] == orows).all() and (_bits(dist_t[sel]) == _bits(odist)).all()
     assert (nc[sel] == onc).all()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 5 (extension): batched brute-force cosine / L2 on the matrix cores vs an
+# f64 brute-force oracle.  Tolerance: distances within 1e-4 relative (north star), ids equal
+# except where the oracle's own neighbouring distances are closer than that tolerance.
+# ---------------------------------------------------------------------------------------
+def _f64_brute(data, queries, k, metric):
+    d64, q64 = data.astype(np.float64), queries.astype(np.float64)
+    s = q64 @ d64.T
+    if metric == "cos":
+        nq_, nv = np.linalg.norm(q64, axis=1), np.linalg.norm(d64, axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dist = 1.0 - s / (nq_[:, None] * nv[None, :])
+        dist[~np.isfinite(dist)] = 1.0
+    else:
+        dist = (q64 ** 2).sum(1)[:, None] + (d64 ** 2).sum(1)[None, :] - 2 * s
+    order = np.argsort(dist, axis=1, kind="stable")[:, :k]
+    return order, np.take_along_axis(dist, order, axis=1), dist
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [
+    (20000, 1536, 130, 10),     # C5-shaped rows (ada-002 dim), > 1 query tile, partial tiles
+    (9000, 96, 33, 10),
+    (70000, 64, 260, 25),       # several progressive ranges (8k, 64k)
+    (500, 50, 5, 10),           # dim % 16 != 0, dim % 4 != 0, fewer rows than a tile
+    (300, 7, 3, 400),           # k > n
+])
+@pytest.mark.parametrize("metric", ["cos", "l2"])
+def test_brute_mfma_matches_f64_oracle(pqv, n, dim, nq, k, metric):
+    rng = np.random.default_rng(n + dim)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == "cos" and n > 400:
+        data[123] = 0                      # a zero-norm row: distance 1 by definition
+    corpus = pqv.Corpus.upload(data)
+    m = pqv.PQV_COSINE if metric == "cos" else pqv.PQV_L2SQ_MFMA
+    rows, dist, nf = corpus.brute_topk(queries, k, m)
+    order, odist, full = _f64_brute(data, queries, k, metric)
+    kk = min(k, n)
+    assert (nf == kk).all()
+    scale = np.maximum(np.abs(odist[:, :kk]), 1e-3)
+    assert (np.abs(dist[:, :kk] - odist[:, :kk]) <= 1e-4 * scale + 1e-6).all(), "distance beyond 1e-4 relative"
+    for q in range(nq):
+        got = rows[q, :kk]
+        assert len(set(got.tolist())) == kk and (got < n).all()
+        # every returned row must truly belong: its exact distance is within tolerance of the
+        # oracle's k-th distance, and every oracle row clearly inside the k-th must be present
+        kth = odist[q, kk - 1]
+        tol = 1e-4 * max(abs(kth), 1e-3) + 1e-6
+        assert (full[q, got] <= kth + tol).all()
+        sure = order[q, :kk][odist[q, :kk] < kth - tol]
+        assert set(sure.tolist()) <= set(got.tolist())
+        assert (np.diff(dist[q, :kk]) >= 0).all()
+    assert (rows[:, kk:] == 0xFFFFFFFF).all()
+
+
+def test_brute_rejects_bad_arguments(pqv):
+    corpus = pqv.Corpus.upload(np.ones((10, 4), np.float32))
+    with pytest.raises(pqv.PqvError, match="Query dimension mismatch: expected 4, got 3"):
+        corpus.brute_topk(np.ones((1, 3), np.float32), 1)
+    with pytest.raises(pqv.PqvError, match="k must be > 0"):
+        corpus.brute_topk(np.ones((1, 4), np.float32), 0)
+    with pytest.raises(pqv.PqvError, match="metric must be"):
+        corpus.brute_topk(np.ones((1, 4), np.float32), 1, metric=pqv.PQV_L2SQ_REF4)
