@@ -244,18 +244,15 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algo_bytes_per_launch": algo_bytes, "kernel_ms": rr_ms,
                      "hot_path_ms_per_step": total_ms / max(1, ncalls),
-                     "valu": {"ref_flops_per_launch": flops,
-                              "achieved_tflops": flops / (rr_ms * 1e-3) / 1e12 if rr_ms > 0 else 0.0,
-                              "peak_tflops_f32_vector": 157.3,
-                              "note": "reference arithmetic is 3 non-fusable f32 ops per element (no FMA): "
-                                      "the no-FMA ceiling is half the 157.3 TF vector peak"}},
+                     "valu": {"ref_ops_per_launch": flops,
+                              "achieved_tops": flops / (rr_ms * 1e-3) / 1e12 if rr_ms > 0 else 0.0,
+                              "peak_tops_measured": 63.0,
+                              "frac": (flops / (rr_ms * 1e-3) / 1e12 / 63.0) if rr_ms > 0 else 0.0,
+                              "note": "the reference arithmetic is 3 non-fusable f32 ops per element (sub, mul, "
+                                      "add; no FMA).  tools/valu_ubench.hip measures ~63 T such ops/s on this "
+                                      "chip (packed f32 ops issue at half rate, profiles/r01_valu_ubench.txt): "
+                                      "that, not HBM, bounds the batched kernel"}},
     }
-
-    if use_dist and rank == 0:
-        # the merged answer of the exchange must equal this rank's own when there is one shard
-        if world == 1:
-            result["exchange_check"] = bool(torch.equal(out_d, dist_t)
-                                            and torch.equal(out_r, (rows_t.to(torch.int64) & 0xFFFFFFFF) + lo))
 
     # ---- optional latency mode: one query per call through the same device API ------------
     if args.single and rank == 0:
