@@ -779,10 +779,13 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 64;
     if (p.tile) {
         const uint64_t est_groups = std::max<uint64_t>(1, pairs / pqv::TILE_QB);
-        uint64_t bpl = (4096 + est_groups - 1) / est_groups;
-        bpl = std::max<uint64_t>(1, std::min<uint64_t>(bpl, max_bpl));
-        uint64_t rpb = (max_len + bpl - 1) / bpl;
-        rpb = (rpb + 255) / 256 * 256;
+        // Rows per block: long enough to amortise a block's setup and top-k warm-up, short
+        // enough that imbalanced lists do not leave a tail (measured optimum ~1.5 k on C2/C3);
+        // shrink only when that would leave the GPU with too few blocks.
+        static const uint64_t tile_rows = [] { const char *e = std::getenv("PQV_TILE_ROWS"); return e ? std::strtoull(e, nullptr, 10) : 1536ull; }();
+        uint64_t rpb = std::min<uint64_t>(tile_rows, (max_len + 255) / 256 * 256);
+        while (rpb > 256 && est_groups * ((max_len + rpb - 1) / rpb) < 2048) rpb -= 256;
+        (void)max_bpl;
         p.rr_rows_per_block = static_cast<uint32_t>(rpb);
         p.rr_bpl = static_cast<uint32_t>((max_len + rpb - 1) / rpb);
         p.n_part_rr = p.np * p.rr_bpl * pqv::waves_per_block();
