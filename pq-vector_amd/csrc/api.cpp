@@ -43,6 +43,20 @@ int fail(int code, const std::string &msg) {
                         std::string(#expr) + ": " + hipGetErrorString(_e));              \
     } while (0)
 
+// No C++ exception may cross the C ABI: every entry point runs its body through guard().
+template <class F>
+int guard(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(PQV_ERR_OOM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(PQV_ERR_INVALID, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(PQV_ERR_INVALID, "internal error");
+    }
+}
+
 int use_device(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -158,12 +172,17 @@ struct pqv_searcher {
         s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr, s_tie,
         s_replay;
     int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
+    // the scratch above is reused by every call: a call on another stream first waits for the
+    // previous call's kernels (event recorded at the end of each enqueue)
+    mutable hipEvent_t scratch_done = nullptr;
+    mutable hipStream_t scratch_stream = nullptr;
     mutable pqv_counters_t counters{};
     // timing
     mutable bool timing = false;
     mutable std::vector<hipEvent_t> ev;    // triples: probe-start, rerank-start, rerank-stop, end
     ~pqv_searcher() {
         for (auto e : ev) (void)hipEventDestroy(e);
+        if (scratch_done) (void)hipEventDestroy(scratch_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -184,7 +203,7 @@ extern "C" int pqv_abi_version(void) { return 100; }
 // ---------------------------------------------------------------------------------------
 // corpus
 // ---------------------------------------------------------------------------------------
-extern "C" int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t dim,
+static int pqv_corpus_create_impl(int device, uint64_t capacity_rows, uint32_t dim,
                                  pqv_corpus **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
@@ -211,8 +230,12 @@ extern "C" int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t di
     *out = c;
     return PQV_OK;
 }
+extern "C" int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t dim,
+                                 pqv_corpus **out) {
+    return guard([&] { return pqv_corpus_create_impl(device, capacity_rows, dim, out); });
+}
 
-extern "C" int pqv_corpus_append(pqv_corpus *c, const float *rows, uint64_t n_rows) {
+static int pqv_corpus_append_impl(pqv_corpus *c, const float *rows, uint64_t n_rows) {
     if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
     if (!c->owned) return fail(PQV_ERR_INVALID, "cannot append to a borrowed device buffer");
     if (n_rows == 0) return PQV_OK;
@@ -224,8 +247,11 @@ extern "C" int pqv_corpus_append(pqv_corpus *c, const float *rows, uint64_t n_ro
     c->n += n_rows;
     return PQV_OK;
 }
+extern "C" int pqv_corpus_append(pqv_corpus *c, const float *rows, uint64_t n_rows) {
+    return guard([&] { return pqv_corpus_append_impl(c, rows, n_rows); });
+}
 
-extern "C" int pqv_corpus_append_f64(pqv_corpus *c, const double *rows, uint64_t n_rows) {
+static int pqv_corpus_append_f64_impl(pqv_corpus *c, const double *rows, uint64_t n_rows) {
     if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
     if (!c->owned) return fail(PQV_ERR_INVALID, "cannot append to a borrowed device buffer");
     if (n_rows == 0) return PQV_OK;
@@ -241,8 +267,11 @@ extern "C" int pqv_corpus_append_f64(pqv_corpus *c, const double *rows, uint64_t
     c->n += n_rows;
     return PQV_OK;
 }
+extern "C" int pqv_corpus_append_f64(pqv_corpus *c, const double *rows, uint64_t n_rows) {
+    return guard([&] { return pqv_corpus_append_f64_impl(c, rows, n_rows); });
+}
 
-extern "C" int pqv_corpus_upload(int device, const float *rows, uint64_t n, uint32_t dim,
+static int pqv_corpus_upload_impl(int device, const float *rows, uint64_t n, uint32_t dim,
                                  pqv_corpus **out) {
     if (int rc = pqv_corpus_create(device, n, dim, out)) return rc;
     if (int rc = pqv_corpus_append(*out, rows, n)) {
@@ -252,8 +281,12 @@ extern "C" int pqv_corpus_upload(int device, const float *rows, uint64_t n, uint
     }
     return PQV_OK;
 }
+extern "C" int pqv_corpus_upload(int device, const float *rows, uint64_t n, uint32_t dim,
+                                 pqv_corpus **out) {
+    return guard([&] { return pqv_corpus_upload_impl(device, rows, n, dim, out); });
+}
 
-extern "C" int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,
+static int pqv_corpus_from_device_impl(int device, const void *d_rows, uint64_t n, uint32_t dim,
                                       pqv_corpus **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
@@ -275,12 +308,16 @@ extern "C" int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n
     *out = c;
     return PQV_OK;
 }
+extern "C" int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,
+                                      pqv_corpus **out) {
+    return guard([&] { return pqv_corpus_from_device_impl(device, d_rows, n, dim, out); });
+}
 
 extern "C" uint64_t pqv_corpus_rows(const pqv_corpus *c) { return c ? c->n : 0; }
 extern "C" uint32_t pqv_corpus_dim(const pqv_corpus *c) { return c ? c->dim : 0; }
 extern "C" int pqv_corpus_device(const pqv_corpus *c) { return c ? c->device : -1; }
 
-extern "C" int pqv_corpus_fetch_rows(const pqv_corpus *c, const uint32_t *rows, uint64_t m,
+static int pqv_corpus_fetch_rows_impl(const pqv_corpus *c, const uint32_t *rows, uint64_t m,
                                      float *out) {
     if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
     if (m == 0) return PQV_OK;
@@ -298,6 +335,10 @@ extern "C" int pqv_corpus_fetch_rows(const pqv_corpus *c, const uint32_t *rows, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, d_out.p, m * c->dim * sizeof(float), hipMemcpyDeviceToHost));
     return PQV_OK;
+}
+extern "C" int pqv_corpus_fetch_rows(const pqv_corpus *c, const uint32_t *rows, uint64_t m,
+                                     float *out) {
+    return guard([&] { return pqv_corpus_fetch_rows_impl(c, rows, m, out); });
 }
 
 extern "C" void pqv_corpus_free(pqv_corpus *c) {
@@ -320,7 +361,7 @@ inline void wr_u32(uint8_t *p, uint32_t v) {
 }
 }  // namespace
 
-extern "C" int pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index **out) {
+static int pqv_index_from_bytes_impl(const uint8_t *bytes, size_t len, pqv_index **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
     if (!bytes || len < 8) return fail(PQV_ERR_FORMAT, "IVF index buffer too small");  // index.rs:89
@@ -358,8 +399,11 @@ extern "C" int pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index 
     *out = idx;
     return PQV_OK;
 }
+extern "C" int pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index **out) {
+    return guard([&] { return pqv_index_from_bytes_impl(bytes, len, out); });
+}
 
-extern "C" int pqv_index_to_bytes(const pqv_index *idx, uint8_t **buf, size_t *len) {
+static int pqv_index_to_bytes_impl(const pqv_index *idx, uint8_t **buf, size_t *len) {
     if (!idx || !buf || !len) return fail(PQV_ERR_INVALID, "index/buf/len must not be NULL");
     const uint64_t k = idx->n_clusters;
     const size_t sz = 8 + idx->centroids.size() * 4 + static_cast<size_t>(k) * 4 + idx->list_rows.size() * 4;
@@ -383,10 +427,13 @@ extern "C" int pqv_index_to_bytes(const pqv_index *idx, uint8_t **buf, size_t *l
     *len = sz;
     return PQV_OK;
 }
+extern "C" int pqv_index_to_bytes(const pqv_index *idx, uint8_t **buf, size_t *len) {
+    return guard([&] { return pqv_index_to_bytes_impl(idx, buf, len); });
+}
 
 extern "C" void pqv_bytes_free(uint8_t *buf) { std::free(buf); }
 
-extern "C" int pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const float *centroids,
+static int pqv_index_from_parts_impl(uint32_t dim, uint32_t n_clusters, const float *centroids,
                                     const uint64_t *list_off, const uint32_t *list_rows,
                                     pqv_index **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
@@ -407,6 +454,11 @@ extern "C" int pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const flo
     idx->list_rows.assign(list_rows, list_rows + total);
     *out = idx;
     return PQV_OK;
+}
+extern "C" int pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const float *centroids,
+                                    const uint64_t *list_off, const uint32_t *list_rows,
+                                    pqv_index **out) {
+    return guard([&] { return pqv_index_from_parts_impl(dim, n_clusters, centroids, list_off, list_rows, out); });
 }
 
 extern "C" uint32_t pqv_index_dim(const pqv_index *i) { return i ? i->dim : 0; }
@@ -632,15 +684,19 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
 
 }  // namespace
 
-extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
+static int pqv_index_build_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
                                uint64_t seed, uint32_t workers, pqv_index **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
     if (!corpus) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
     return build_index_impl(corpus, n_clusters, max_iters, seed, workers, out);
 }
+extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
+                               uint64_t seed, uint32_t workers, pqv_index **out) {
+    return guard([&] { return pqv_index_build_impl(corpus, n_clusters, max_iters, seed, workers, out); });
+}
 
-extern "C" int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
+static int pqv_index_build_host_impl(int device, const float *data, uint64_t data_len, uint32_t dim,
                                     uint32_t n_clusters, uint32_t max_iters, uint64_t seed,
                                     uint32_t workers, pqv_index **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
@@ -657,8 +713,13 @@ extern "C" int pqv_index_build_host(int device, const float *data, uint64_t data
     pqv_corpus_free(c);
     return rc;
 }
+extern "C" int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
+                                    uint32_t n_clusters, uint32_t max_iters, uint64_t seed,
+                                    uint32_t workers, pqv_index **out) {
+    return guard([&] { return pqv_index_build_host_impl(device, data, data_len, dim, n_clusters, max_iters, seed, workers, out); });
+}
 
-extern "C" int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_iters, uint64_t seed,
+static int pqv_kmeans_impl(const pqv_corpus *sample, uint32_t k, uint32_t max_iters, uint64_t seed,
                           uint32_t workers, float *centroids, uint32_t *assignments,
                           uint32_t *iters_run) {
     if (!sample || !centroids) return fail(PQV_ERR_INVALID, "sample/centroids must not be NULL");
@@ -677,11 +738,16 @@ extern "C" int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_ite
     if (assignments) std::memcpy(assignments, assign.data(), assign.size() * sizeof(uint32_t));
     return PQV_OK;
 }
+extern "C" int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_iters, uint64_t seed,
+                          uint32_t workers, float *centroids, uint32_t *assignments,
+                          uint32_t *iters_run) {
+    return guard([&] { return pqv_kmeans_impl(sample, k, max_iters, seed, workers, centroids, assignments, iters_run); });
+}
 
 // ---------------------------------------------------------------------------------------
 // searcher
 // ---------------------------------------------------------------------------------------
-extern "C" int pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
+static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
                                    pqv_searcher **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
@@ -743,6 +809,10 @@ extern "C" int pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, u
 #undef S_TRY
     *out = s;
     return PQV_OK;
+}
+extern "C" int pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
+                                   pqv_searcher **out) {
+    return guard([&] { return pqv_searcher_create_impl(index, corpus, flags, out); });
 }
 
 extern "C" void pqv_searcher_free(pqv_searcher *s) {
@@ -812,6 +882,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     using namespace pqv;
     const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
+    if (!s->scratch_done) HIP_TRY(hipEventCreateWithFlags(&s->scratch_done, hipEventDisableTiming));
+    if (s->scratch_stream && s->scratch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->scratch_done, 0));
 
     HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
     HIP_TRY(s->s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
@@ -901,6 +973,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
+    HIP_TRY(hipEventRecord(s->scratch_done, stream));
+    s->scratch_stream = stream;
     s->counters.kernel_launches += 4;
     return PQV_OK;
 }
@@ -1018,7 +1092,7 @@ int replay_query_exact(const pqv_searcher *s, const float *d_query, uint32_t qi,
 
 }  // namespace
 
-extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
+static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
                                uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                                void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
                                void *hip_stream) {
@@ -1035,8 +1109,14 @@ extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uin
     if (rc == PQV_OK) s->counters.queries += nq;
     return rc;
 }
+extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
+                               uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                               void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
+                               void *hip_stream) {
+    return guard([&] { return pqv_topk_device_impl(s, d_queries, nq, k, nprobe, max_candidates, metric, sqrt_out, d_row_idx, d_dist, d_n_found, d_n_candidates, hip_stream); });
+}
 
-extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq, uint32_t query_len,
+static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t nq, uint32_t query_len,
                         uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                         uint32_t *row_idx, float *dist, uint32_t *n_found, uint64_t *n_candidates) {
     if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
@@ -1102,8 +1182,13 @@ extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq
     }
     return PQV_OK;
 }
+extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq, uint32_t query_len,
+                        uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                        uint32_t *row_idx, float *dist, uint32_t *n_found, uint64_t *n_candidates) {
+    return guard([&] { return pqv_topk_impl(s, queries, nq, query_len, k, nprobe, max_candidates, metric, sqrt_out, row_idx, dist, n_found, n_candidates); });
+}
 
-extern "C" int pqv_probe(const pqv_searcher *s, const float *query, uint32_t query_len, uint32_t nprobe,
+static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t query_len, uint32_t nprobe,
                          uint32_t *clusters_out, uint32_t *n_out) {
     if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
     if (nprobe == 0) return fail(PQV_ERR_INVALID, "nprobe must be > 0");
@@ -1144,8 +1229,12 @@ extern "C" int pqv_probe(const pqv_searcher *s, const float *query, uint32_t que
     s->counters.kernel_launches += 2;
     return PQV_OK;
 }
+extern "C" int pqv_probe(const pqv_searcher *s, const float *query, uint32_t query_len, uint32_t nprobe,
+                         uint32_t *clusters_out, uint32_t *n_out) {
+    return guard([&] { return pqv_probe_impl(s, query, query_len, nprobe, clusters_out, n_out); });
+}
 
-extern "C" int pqv_candidate_rows(const pqv_searcher *s, const float *query, uint32_t query_len,
+static int pqv_candidate_rows_impl(const pqv_searcher *s, const float *query, uint32_t query_len,
                                   uint32_t nprobe, uint32_t **rows, uint64_t *n_rows) {
     if (!rows || !n_rows) return fail(PQV_ERR_INVALID, "rows/n_rows must not be NULL");
     *rows = nullptr; *n_rows = 0;
@@ -1168,24 +1257,34 @@ extern "C" int pqv_candidate_rows(const pqv_searcher *s, const float *query, uin
     s->counters.candidate_rows += total;
     return PQV_OK;
 }
+extern "C" int pqv_candidate_rows(const pqv_searcher *s, const float *query, uint32_t query_len,
+                                  uint32_t nprobe, uint32_t **rows, uint64_t *n_rows) {
+    return guard([&] { return pqv_candidate_rows_impl(s, query, query_len, nprobe, rows, n_rows); });
+}
 
 extern "C" void pqv_rows_free(uint32_t *rows) { std::free(rows); }
 
-extern "C" int pqv_counters(const pqv_searcher *s, pqv_counters_t *out) {
+static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     if (!s || !out) return fail(PQV_ERR_INVALID, "searcher/out must not be NULL");
     std::lock_guard<std::mutex> lock(s->mu);
     *out = s->counters;
     return PQV_OK;
 }
+extern "C" int pqv_counters(const pqv_searcher *s, pqv_counters_t *out) {
+    return guard([&] { return pqv_counters_impl(s, out); });
+}
 
-extern "C" int pqv_set_timing(pqv_searcher *s, int enabled) {
+static int pqv_set_timing_impl(pqv_searcher *s, int enabled) {
     if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
     std::lock_guard<std::mutex> lock(s->mu);
     s->timing = enabled != 0;
     return PQV_OK;
 }
+extern "C" int pqv_set_timing(pqv_searcher *s, int enabled) {
+    return guard([&] { return pqv_set_timing_impl(s, enabled); });
+}
 
-extern "C" int pqv_timing_read(const pqv_searcher *s, double *rerank_ms, double *total_ms,
+static int pqv_timing_read_impl(const pqv_searcher *s, double *rerank_ms, double *total_ms,
                                uint32_t *n_calls) {
     if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
     if (int rc = use_device(s->device)) return rc;
@@ -1206,11 +1305,15 @@ extern "C" int pqv_timing_read(const pqv_searcher *s, double *rerank_ms, double 
     if (n_calls) *n_calls = calls;
     return PQV_OK;
 }
+extern "C" int pqv_timing_read(const pqv_searcher *s, double *rerank_ms, double *total_ms,
+                               uint32_t *n_calls) {
+    return guard([&] { return pqv_timing_read_impl(s, rerank_ms, total_ms, n_calls); });
+}
 
 // ---------------------------------------------------------------------------------------
 // batched brute force on the matrix cores (BASELINE config 5; extension, see pqv.h)
 // ---------------------------------------------------------------------------------------
-extern "C" int pqv_brute_topk(const pqv_corpus *c, const float *queries, uint32_t nq, uint32_t query_len,
+static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32_t nq, uint32_t query_len,
                               uint32_t k, int metric, uint32_t *row_idx, float *dist, uint32_t *n_found) {
     using namespace pqv;
     if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
@@ -1329,11 +1432,15 @@ extern "C" int pqv_brute_topk(const pqv_corpus *c, const float *queries, uint32_
     }
     return PQV_OK;
 }
+extern "C" int pqv_brute_topk(const pqv_corpus *c, const float *queries, uint32_t nq, uint32_t query_len,
+                              uint32_t k, int metric, uint32_t *row_idx, float *dist, uint32_t *n_found) {
+    return guard([&] { return pqv_brute_topk_impl(c, queries, nq, query_len, k, metric, row_idx, dist, n_found); });
+}
 
 // ---------------------------------------------------------------------------------------
 // host-side merge of per-shard lists (multi-file / multi-GPU)
 // ---------------------------------------------------------------------------------------
-extern "C" int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *counts,
+static int pqv_merge_topk_impl(const float *dist, const uint32_t *rows, const uint32_t *counts,
                               uint32_t n_lists, uint32_t nq, uint32_t k, float *out_dist,
                               uint32_t *out_rows, uint32_t *out_list, uint32_t *out_count) {
     if (!dist || !rows || !counts || !out_dist || !out_rows)
@@ -1369,11 +1476,16 @@ extern "C" int pqv_merge_topk(const float *dist, const uint32_t *rows, const uin
     }
     return PQV_OK;
 }
+extern "C" int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *counts,
+                              uint32_t n_lists, uint32_t nq, uint32_t k, float *out_dist,
+                              uint32_t *out_rows, uint32_t *out_list, uint32_t *out_count) {
+    return guard([&] { return pqv_merge_topk_impl(dist, rows, counts, n_lists, nq, k, out_dist, out_rows, out_list, out_count); });
+}
 
 // ---------------------------------------------------------------------------------------
 // batch-granular re-rank (update_topk_heap, src/df_vector/exec.rs:457-484)
 // ---------------------------------------------------------------------------------------
-extern "C" int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
+static int pqv_rerank_impl(int device, const float *query, const float *cand, const uint32_t *ids,
                           const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
                           uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
     using namespace pqv;
@@ -1471,4 +1583,9 @@ extern "C" int pqv_rerank(int device, const float *query, const float *cand, con
     for (uint32_t i = 0; i < nf; ++i) { io_rows[i] = new_rows[i]; io_d2[i] = d[i]; }
     *io_count = nf;
     return PQV_OK;
+}
+extern "C" int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
+                          const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+                          uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+    return guard([&] { return pqv_rerank_impl(device, query, cand, ids, valid, m, dim, k, metric, io_rows, io_d2, io_count); });
 }
