@@ -843,10 +843,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     const uint64_t max_bpl = (max_len + 255) / 256;
     const uint64_t pairs = std::max<uint64_t>(1, static_cast<uint64_t>(nq) * p.np);
     // Tile path: worth it once several queries share a cluster (each streamed row is then
-    // reused by up to TILE_QB queries).  One top-k slot per lane => k <= 64; REF4 order only.
-    p.tile = metric == PQV_L2SQ_REF4 && k <= 64 && pairs >= 4ull * s->n_clusters;
+    // reused by up to TILE_QB queries).  k <= 256; REF4 order only.
+    p.tile = metric == PQV_L2SQ_REF4 && k <= 256 && pairs >= 4ull * s->n_clusters;
     if (s->rerank_mode == 1) p.tile = false;
-    if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 64;
+    if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 256;
     if (p.tile) {
         const uint64_t est_groups = std::max<uint64_t>(1, pairs / pqv::TILE_QB);
         // Rows per block: long enough to amortise a block's setup and top-k warm-up, short

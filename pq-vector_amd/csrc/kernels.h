@@ -103,7 +103,8 @@ struct TileArgs {
     uint64_t       *part_keys;   // same layout as StreamArgs: [nq][nprobe*blocks_per_list*4][k]
     uint32_t       *part_vals;
 };
-// PQV_L2SQ_REF4 only, k <= 64
+// PQV_L2SQ_REF4 only, k <= 256.  Every (query, list, chunk, wave) slot of the partial-list buffer is
+// initialised by the wave that owns it (also for chunks past a short list's end).
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------

@@ -565,20 +565,22 @@ __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int
     }
 }
 
-// Per-wave state of the tile kernel in dynamic LDS.  The top-k lists are touched only when
-// a candidate beats the admission threshold, which becomes rare once the per-query global
-// threshold has tightened:
-//   keys[wave][QB][k] u64 | kth[wave][QB] u64 | vals[wave][QB][k] u32 | sums[wave][QB][64] f32
-extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
-
-// Fold this tile's candidates of one query into the wave's LDS-resident list.
-__device__ __forceinline__ void tile_fold(uint64_t *lkeys, uint32_t *lvals, uint64_t *lkth,
-                                          unsigned long long *gthr, uint64_t gseen,
-                                          uint64_t local_kth, uint64_t mykey, uint32_t myval,
-                                          uint32_t k, int lane) {
-    WaveTopk<1> tk;
-    tk.key[0] = (uint32_t)lane < k ? lkeys[lane] : KEY_EMPTY;
-    tk.val[0] = (uint32_t)lane < k ? lvals[lane] : 0xFFFFFFFFu;
+// Fold this tile's candidates of one query into the wave's list, which lives in its final
+// global slot (part_keys/part_vals[base .. base+k)): the list is touched only when a
+// candidate beats the admission threshold, which is rare once the per-query global threshold
+// has tightened, so it costs neither registers nor LDS in the distance loop.
+// Returns the list's new k-th key.
+template <int S>
+__device__ __forceinline__ uint64_t tile_fold(uint64_t *gkeys, uint32_t *gvals, unsigned long long *gthr,
+                                              uint64_t gseen, uint64_t local_kth, uint64_t mykey,
+                                              uint32_t myval, uint32_t k, int lane) {
+    WaveTopk<S> tk;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        tk.key[s] = e < k ? gkeys[e] : KEY_EMPTY;
+        tk.val[s] = e < k ? gvals[e] : 0xFFFFFFFFu;
+    }
     if (readlane_u64(tk.key[0], 0) == KEY_EMPTY) {
         // empty list: sort the whole tile once instead of up to 64 single inserts
         uint64_t key = mykey < gseen ? mykey : KEY_EMPTY;
@@ -599,13 +601,15 @@ __device__ __forceinline__ void tile_fold(uint64_t *lkeys, uint32_t *lvals, uint
             m &= __ballot(mykey < thr);
         }
     }
-    if ((uint32_t)lane < k) { lkeys[lane] = tk.key[0]; lvals[lane] = tk.val[0]; }
-    const uint64_t nk = tk.kth(k);
-    if (lane == 0) {
-        *lkth = nk;
-        // any wave's k-th key bounds the final k-th key from above: publish it
-        if (nk < gseen) atomicMin(gthr, (unsigned long long)nk);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        if (e < k) { gkeys[e] = tk.key[s]; gvals[e] = tk.val[s]; }
     }
+    const uint64_t nk = tk.kth(k);
+    // any wave's k-th key bounds the final k-th key from above: publish it
+    if (lane == 0 && nk < gseen) atomicMin(gthr, (unsigned long long)nk);
+    return nk;
 }
 
 // ------------------------------------------------------------------------------------
@@ -615,22 +619,21 @@ __device__ __forceinline__ void tile_fold(uint64_t *lkeys, uint32_t *lvals, uint
 // group (<= QB queries that all probe cluster c) and one row chunk of c's inverted list;
 // each wave walks its rows lane-per-row in 64-row tiles.  Per tile the lane's row is
 // loaded 128 B at a time (a full cache line per lane) and every query of the group is
-// applied to it from SGPRs (wave-uniform scalar loads) -- each streamed row is used QB
-// times, with zero LDS traffic in the distance loop.  Every (row, query) chain is the
-// reference's serial  sum += ((d0^2 + d1^2) + d2^2) + d3^2  in ascending group order
-// (index.rs:461-480).
+// applied to it from SGPRs (wave-uniform scalar loads) -- each streamed row is used up to QB
+// times.  Every (row, query) chain is the reference's serial
+//   sum += ((d0^2 + d1^2) + d2^2) + d3^2   in ascending group order (index.rs:461-480).
 //
 // Top-k: a candidate is admitted iff its key beats min(this wave's k-th key, the query's
 // GLOBAL threshold).  The global threshold is the minimum over all waves of their k-th
 // keys (device-scope atomic min): each is an upper bound of the final k-th key, so nothing
 // that belongs to the final top-k is ever rejected, and the merged result is independent
 // of timing.  It collapses the work of the ~nprobe*blocks*4 independent lists per query to
-// roughly one list's worth of inserts.  Per-query state is held lane-parallel (lane q of
-// a wave holds query q's row index / candidate base / thresholds) and the epilogue is a
-// rolled loop over the group's queries reading the tile's sums back from LDS, so the
-// fold code exists once.
+// roughly one list's worth of inserts.  Per-query state is held lane-parallel (lane q of a
+// wave holds query q's row index / candidate base / thresholds / local k-th key) and the
+// epilogue is a rolled loop over the group's queries reading the tile's sums back from LDS,
+// so the fold code exists once.  LDS holds only the running sums (QB x 64 floats per wave).
 // ------------------------------------------------------------------------------------
-template <int QB, bool ALIGNED>
+template <int QB, int S, bool ALIGNED>
 __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint32_t gi = blockIdx.y;
     if (gi >= *a.n_groups) return;
@@ -640,17 +643,8 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t k = a.k;
 
-    uint64_t *all_keys = reinterpret_cast<uint64_t *>(tile_lds);
-    uint64_t *all_kth = all_keys + 4u * QB * k;
-    uint32_t *all_vals = reinterpret_cast<uint32_t *>(all_kth + 4u * QB);
-    float *all_sums = reinterpret_cast<float *>(all_vals + 4u * QB * k);
-    uint64_t *lkeys = all_keys + (uint32_t)wave * QB * k;
-    uint64_t *lkth = all_kth + (uint32_t)wave * QB;
-    uint32_t *lvals = all_vals + (uint32_t)wave * QB * k;
-    float *lsums = all_sums + (uint32_t)wave * QB * 64;
-    for (uint32_t i = lane; i < QB * k; i += 64) { lkeys[i] = KEY_EMPTY; lvals[i] = 0xFFFFFFFFu; }
-    if (lane < QB) lkth[lane] = KEY_EMPTY;
-    wave_lds_fence();
+    __shared__ float lsums_all[4 * QB * 64];
+    float *lsums = lsums_all + wave * (QB * 64);
 
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
@@ -667,6 +661,18 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint32_t my_pair = a.pairs[my_slot];
     const uint32_t my_qrow = my_pair / a.nprobe;
     const uint64_t my_cbase = a.cand_base[my_pair];
+    uint64_t my_lkth = KEY_EMPTY;          // k-th key of this wave's list of query `lane`
+    // this wave's list of query `lane`: slot (q, j, chunk, wave) of the partial-list buffer
+    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+    const uint64_t my_base =
+        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + blockIdx.x) * 4 + wave) * k;
+
+    // lists start empty
+#pragma unroll 1
+    for (uint32_t qq = 0; qq < cnt; ++qq) {
+        const uint64_t base = readlane_u64(my_base, (int)qq);
+        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
+    }
 
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
         // (lsums[query][lane]); per 128-B step of the lane's row, a ROLLED loop over exactly
         // the group's `cnt` queries applies each query chunk (wave-uniform, SGPRs) and does a
         // read-modify-write of that query's sum.  No padded work for partial groups, a small
-        // loop body, few VGPRs => enough resident waves to hide the scalar-load latency.
+        // loop body, few VGPRs => enough resident waves to hide the load latencies.
         uint32_t g0 = 0;
         for (; g0 + 8 <= G; g0 += 8) {
             float4 xv[8];
@@ -783,7 +789,6 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
 
         // ---- top-k epilogue: rolled over the group's queries --------------------------
         wave_lds_fence();
-        const uint64_t my_lkth = lkth[(uint32_t)lane < (uint32_t)QB ? lane : 0];
         const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
         const uint64_t posl = t0 + (uint64_t)lane;
 #pragma unroll 1
@@ -795,36 +800,31 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
             const uint64_t mykey =
                 valid ? (((uint64_t)__float_as_uint(sv) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
             if (__ballot(mykey < thr) != 0ull) {
-                tile_fold(lkeys + qq * k, lvals + qq * k, lkth + qq,
-                          a.gthr + readlane_u32(my_qrow, (int)qq), readlane_u64(my_gthr, (int)qq),
-                          readlane_u64(my_lkth, (int)qq), mykey, srow, k, lane);
+                const uint64_t base = readlane_u64(my_base, (int)qq);
+                const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
+                                                 a.gthr + readlane_u32(my_qrow, (int)qq),
+                                                 readlane_u64(my_gthr, (int)qq), readlane_u64(my_lkth, (int)qq),
+                                                 mykey, srow, k, lane);
+                if ((uint32_t)lane == qq) my_lkth = nk;
             }
         }
         wave_lds_fence();
     }
+}
 
-    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
-#pragma unroll 1
-    for (uint32_t qq = 0; qq < cnt; ++qq) {
-        const uint32_t pr = readlane_u32(my_pair, (int)qq);
-        const uint32_t q = pr / a.nprobe, j = pr % a.nprobe;
-        const uint32_t pi = (j * a.blocks_per_list + blockIdx.x) * 4 + wave;
-        const uint64_t base = ((uint64_t)q * n_part + pi) * k;
-        if ((uint32_t)lane < k) {
-            a.part_keys[base + lane] = lkeys[qq * k + lane];
-            a.part_vals[base + lane] = lvals[qq * k + lane];
-        }
-    }
+template <int S>
+static hipError_t launch_tile_s(const TileArgs &a, hipStream_t s) {
+    dim3 grid(a.blocks_per_list, a.max_groups), block(256);
+    if ((a.dim % 4) == 0) hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, S, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, S, false>), grid, block, 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
     if (a.max_groups == 0 || a.blocks_per_list == 0) return hipSuccess;
-    if (a.k > 64) return hipErrorInvalidValue;   // one slot per lane; larger k uses stream_kernel
-    dim3 grid(a.blocks_per_list, a.max_groups), block(256);
-    const size_t lds = 4ull * TILE_QB * a.k * 12 + 4ull * TILE_QB * 8 + 4ull * TILE_QB * 64 * 4;
-    if ((a.dim % 4) == 0) hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, false>), grid, block, lds, s, a);
-    return hipGetLastError();
+    if (a.k <= 64) return launch_tile_s<1>(a, s);
+    if (a.k <= 256) return launch_tile_s<4>(a, s);
+    return hipErrorInvalidValue;   // larger k uses stream_kernel
 }
 
 // ------------------------------------------------------------------------------------

@@ -360,6 +360,8 @@ def test_gpu_reproduces_golden(pqv, oracle, path):
     (2500, 30, 5, 10, 2, 50),        # unaligned rows + scalar tail
     (1500, 3, 4, 3, 4, 20),          # tail only
     (5000, 64, 7, 64, 3, 45),        # k = 64
+    (6000, 32, 6, 100, 3, 40),       # reference bench K = 100: 4 list slots per lane
+    (3000, 16, 4, 255, 4, 30),       # k + 1 = 256: the widest list the tile path takes
     (300, 16, 3, 10, 3, 300),        # many queries, tiny lists (< 64 rows per wave)
 ])
 @pytest.mark.parametrize("layout", ["ivf", "row"])
