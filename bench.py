@@ -41,6 +41,7 @@ WORKLOADS = {
     "c4": (12_500_000, 768, 1024, 32, 1024),   # PER-RANK shard of the 100M x 768 corpus (weak scaling)
     "c5": (10_000_000, 1536, 0, 0, 1024),      # brute-force cosine on the matrix cores (no index)
     "c5s": (1_000_000, 1536, 0, 0, 1024),      # same, 1 M rows (quick check)
+    "refbench": (1_000_000, 1024, 0, 16, 1024),  # the reference's benches/query.rs:27-31 shape; use --k 100
     "c1": (1024, 4096, 0, 5, 64),          # vldb stand-in: n_clusters = ceil(sqrt(n)) = 32
     "tiny": (20_000, 64, 16, 4, 64),       # plumbing check
 }
@@ -65,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--nq", type=int, default=0, help="queries per step (default per workload)")
+    ap.add_argument("--k", type=int, default=10, help="neighbours per query (BASELINE metric: 10)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
@@ -75,6 +77,8 @@ def main():
     ap.add_argument("--single", type=int, default=0,
                     help="also time this many single-query calls (latency mode) and report them")
     args = ap.parse_args()
+    global K
+    K = args.k
 
     import torch
     import torch.distributed as dist
@@ -214,7 +218,7 @@ def main():
 
     flops = 3 * dim * cand_rows                       # sub, mul, add per element
     result = {
-        "metric": "topk_queries_per_s_k10",
+        "metric": f"topk_queries_per_s_k{K}",
         "value": nq * args.steps / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
@@ -345,15 +349,31 @@ def cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq):
     grows = rows_t.cpu().numpy().view(np.uint32)
     gdist = dist_t.cpu().numpy()
     done, spent = 0, 0.0
-    ids_ok, dist_ok = True, True
+    ids_ok, dist_ok, ids_tie_ok, tie_groups = True, True, True, 0
     chunk = 4
     while done < nq and spent < args.cpu_seconds:
         b = min(chunk, nq - done)
         t0 = time.perf_counter()
         orows, odist, onf, _ = oidx.topk_batch(host, qs[done:done + b], K, nprobe)
         spent += time.perf_counter() - t0
-        ids_ok &= bool((orows == grows[done:done + b]).all())
+        g = grows[done:done + b]
+        ids_ok &= bool((orows == g).all())
         dist_ok &= bool((odist.view(np.uint32) == gdist[done:done + b].view(np.uint32)).all())
+        # pqv_topk_device orders equal output distances by (d2, position); Rust orders them by heap
+        # history (the host API pqv_topk replays that exactly).  Inside a group of equal distance the
+        # id SETS must still agree.
+        for i in range(b):
+            if (orows[i] == g[i]).all():
+                continue
+            j = 0
+            while j < K:
+                e = j
+                while e + 1 < K and odist[i, e + 1] == odist[i, j]:
+                    e += 1
+                if e > j:
+                    tie_groups += 1
+                ids_tie_ok &= sorted(orows[i, j:e + 1].tolist()) == sorted(g[i, j:e + 1].tolist())
+                j = e + 1
         done += b
         chunk = min(64, chunk * 2)
     return {"value": done / spent, "unit": "queries/s", "cores": 1, "kind": "port",
@@ -361,7 +381,9 @@ def cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq):
             "sample": f"first {done} of the step's {nq} queries, in-memory corpus, oracle -O3 -march=native "
                       f"-ffp-contract=off, {spent:.1f} s",
             "host_cpus": os.cpu_count(),
-            "parity": {"queries_checked": done, "row_idx_identical": ids_ok, "dist_bit_identical": dist_ok}}
+            "parity": {"queries_checked": done, "row_idx_identical": ids_ok, "dist_bit_identical": dist_ok,
+                       "row_idx_identical_up_to_order_inside_equal_distance_groups": ids_tie_ok,
+                       "equal_distance_groups_seen": tie_groups}}
 
 
 if __name__ == "__main__":
