@@ -204,8 +204,11 @@ def main():
     mode = os.environ.get("PQV_RERANK_MODE", "auto")
     pairs_per_cluster = nq * nprobe / max(1, int(index.n_clusters))
     tile = mode == "tile" or (mode != "stream" and pairs_per_cluster >= 4)
-    kernel = ("tile_rerank_kernel (batched cluster-major re-rank, 16 queries per streamed row tile)"
-              if tile else "stream_kernel (one candidate stream per (query, probed list))")
+    screened = tile and os.environ.get("PQV_TILE_FILTER", "1") != "0"
+    kernel = ("tile_rerank_kernel seed window + tile_filter_kernel (batched cluster-major re-rank, 16 queries per "
+              "streamed row tile, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened
+              else "tile_rerank_kernel (batched cluster-major re-rank, 16 queries per streamed row tile)" if tile
+              else "stream_kernel (one candidate stream per (query, probed list))")
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}_{'tile' if tile else 'stream'}.json")
     if os.path.exists(tpath):
@@ -257,6 +260,8 @@ def main():
                                       "chip (packed f32 ops issue at half rate, profiles/r01_valu_ubench.txt): "
                                       "that, not HBM, bounds the batched kernel"}},
     }
+
+    result["counters"] = searcher.counters()
 
     # ---- optional latency mode: one query per call through the same device API ------------
     if args.single and rank == 0:

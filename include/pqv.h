@@ -215,6 +215,8 @@ typedef struct pqv_counters_t {
     uint64_t embeddings_fetched; /* rows whose distance was computed (after the cap)     */
     uint64_t kernel_launches;    /* device kernels enqueued                              */
     uint64_t exact_replays;      /* pqv_topk queries replayed through the exact heap     */
+    uint64_t screened_pairs;     /* (row, query) pairs put through the MFMA lower-bound   */
+    uint64_t screen_survivors;   /* ... of which were evaluated exactly                   */
 } pqv_counters_t;
 int pqv_counters(const pqv_searcher *searcher, pqv_counters_t *out);
 

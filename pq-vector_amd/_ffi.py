@@ -37,7 +37,8 @@ PQV_RELEASE_ROW_ORDER = 0x2
 class Counters(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("candidate_rows", C.c_uint64),
                 ("embeddings_fetched", C.c_uint64), ("kernel_launches", C.c_uint64),
-                ("exact_replays", C.c_uint64)]
+                ("exact_replays", C.c_uint64), ("screened_pairs", C.c_uint64),
+                ("screen_survivors", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/pqv.h declares

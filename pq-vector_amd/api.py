@@ -376,7 +376,8 @@ class Searcher:
         _check(_ffi.lib().pqv_counters(self._h, C.byref(c)))
         return {"queries": c.queries, "candidate_rows": c.candidate_rows,
                 "embeddings_fetched": c.embeddings_fetched, "kernel_launches": c.kernel_launches,
-                "exact_replays": c.exact_replays}
+                "exact_replays": c.exact_replays, "screened_pairs": c.screened_pairs,
+                "screen_survivors": c.screen_survivors}
 
     def set_timing(self, enabled):
         _check(_ffi.lib().pqv_set_timing(self._h, 1 if enabled else 0))

@@ -161,7 +161,7 @@ struct pqv_searcher {
     pqv_corpus *corpus = nullptr;          // borrowed
     std::vector<uint64_t> h_list_off;      // host copy for candidate_rows
     std::vector<uint32_t> h_list_rows;
-    DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf;
+    DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats, d_row_norm2;   // |x|^2 per storage row (MFMA screen)
     const float *d_mat = nullptr;          // row storage the re-rank reads
     const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout)
     const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout)
@@ -170,7 +170,8 @@ struct pqv_searcher {
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
         s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr, s_tie,
-        s_replay;
+        s_replay, s_qnorm;
+    int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
     // the scratch above is reused by every call: a call on another stream first waits for the
     // previous call's kernels (event recorded at the end of each enqueue)
@@ -801,6 +802,15 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         s->d_row_of = nullptr;
         s->d_final_ids = s->d_ids.as<uint32_t>();
     }
+    if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m && *m != '0') ? 1 : 0;
+    S_TRY(s->d_stats.alloc(2 * sizeof(unsigned long long)));
+    S_TRY(hipMemsetAsync(s->d_stats.p, 0, 2 * sizeof(unsigned long long), s->stream));
+    // squared norms of the storage rows, for the MFMA screen of the batched re-rank
+    {
+        const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
+        S_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, n_storage) * sizeof(float)));
+        S_TRY(pqv::launch_row_norms(s->d_mat, n_storage, s->dim, 1, s->d_row_norm2.as<float>(), s->stream));
+    }
     S_TRY(hipStreamSynchronize(s->stream));
     if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
         (void)hipFree(corpus->d_rows);
@@ -830,6 +840,8 @@ struct TopkPlan {
     uint32_t n_part_probe, n_part_rr;
     bool tile;              // batched cluster-major tiles instead of one stream per (query, list)
     uint32_t max_groups;
+    bool filter;            // tile path: exact seed window + MFMA-screened remainder
+    uint32_t seed_rows, filter_bpl;
 };
 
 TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
@@ -857,7 +869,34 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         while (rpb > 256 && est_groups * ((max_len + rpb - 1) / rpb) < 2048) rpb -= 256;
         (void)max_bpl;
         p.rr_rows_per_block = static_cast<uint32_t>(rpb);
-        p.rr_bpl = static_cast<uint32_t>((max_len + rpb - 1) / rpb);
+        // MFMA screen: the first seed_rows rows of every probed list are evaluated exactly (that
+        // seeds the per-query thresholds), the rest goes through the screened kernel
+        p.seed_rows = 256;
+        p.filter = s->tile_filter && max_len > 4ull * p.seed_rows;
+        // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
+        // multiple of 8 the blocks of ALL query groups for one row chunk share an XCD (and its L2)
+        // and are dispatched together: a chunk is then fetched from HBM once, not once per group.
+        auto chunks_x8 = [&](uint64_t rows, uint64_t &rows_per_block) {
+            uint64_t b = (rows + rows_per_block - 1) / rows_per_block;
+            b = (b + 7) / 8 * 8;
+            rows_per_block = ((rows + b - 1) / b + 255) / 256 * 256;
+            return static_cast<uint32_t>((rows + rows_per_block - 1) / rows_per_block + 7) / 8 * 8;
+        };
+        // (measured: it UNBALANCES the XCDs, because high chunk indices exist only for long lists:
+        //  C3 33 -> 60 ms.  Kept behind PQV_XCD_ALIGN=1 for experiments; off by default.)
+        static const bool xcd_align = [] { const char *e = std::getenv("PQV_XCD_ALIGN"); return e && *e == '1'; }();
+        if (p.filter) {
+            uint64_t r = rpb;
+            p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
+                                     : static_cast<uint32_t>((max_len - p.seed_rows + rpb - 1) / rpb);
+            p.rr_rows_per_block = static_cast<uint32_t>(r);
+            p.rr_bpl = 1 + p.filter_bpl;
+        } else {
+            uint64_t r = rpb;
+            p.filter_bpl = 0;
+            p.rr_bpl = xcd_align ? chunks_x8(max_len, r) : static_cast<uint32_t>((max_len + rpb - 1) / rpb);
+            p.rr_rows_per_block = static_cast<uint32_t>(r);
+        }
         p.n_part_rr = p.np * p.rr_bpl * pqv::waves_per_block();
         p.max_groups = static_cast<uint32_t>(pairs / pqv::TILE_QB + std::min<uint64_t>(s->n_clusters, pairs));
         return p;
@@ -947,8 +986,28 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.rows_per_block = p.rr_rows_per_block; ta.blocks_per_list = p.rr_bpl; ta.max_pos = max_pos;
         ta.gthr = s->s_gthr.as<unsigned long long>();
         ta.part_keys = s->s_part_keys.as<uint64_t>(); ta.part_vals = s->s_part_vals.as<uint32_t>();
+        ta.row_norm2 = s->d_row_norm2.as<float>();
+        ta.stats = s->d_stats.as<unsigned long long>();
+        static const int xcd_swz = [] { const char *e = std::getenv("PQV_XCD_SWIZZLE"); return (e && *e == '1') ? 1 : 0; }();   // measured: no gain on C2, -30 % on C3
+        ta.xcd_swizzle = xcd_swz;
+        if (p.filter) {
+            HIP_TRY(s->s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
+            HIP_TRY(launch_row_norms(d_queries, nq, s->dim, 1, s->s_qnorm.as<float>(), stream));
+            ta.query_norm2 = s->s_qnorm.as<float>();
+        }
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(launch_tile_rerank(ta, stream));
+        if (p.filter) {
+            TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
+            seed.row_offset = 0; seed.chunk_offset = 0; seed.grid_x = 1; seed.rows_per_block = p.seed_rows;
+            HIP_TRY(launch_tile_rerank(seed, stream));
+            HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.rr_bpl, 0, k, ta.gthr, stream));
+            ta.row_offset = p.seed_rows; ta.chunk_offset = 1; ta.grid_x = p.filter_bpl;
+            HIP_TRY(launch_tile_filter(ta, stream));
+            s->counters.kernel_launches += 2;
+        } else {
+            ta.row_offset = 0; ta.chunk_offset = 0; ta.grid_x = p.rr_bpl;
+            HIP_TRY(launch_tile_rerank(ta, stream));
+        }
         if (timing) HIP_TRY(hipEventRecord(e2, stream));
         s->counters.kernel_launches += 3;
     }
@@ -1266,8 +1325,13 @@ extern "C" void pqv_rows_free(uint32_t *rows) { std::free(rows); }
 
 static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     if (!s || !out) return fail(PQV_ERR_INVALID, "searcher/out must not be NULL");
+    if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(hipMemcpy(st, s->d_stats.p, sizeof st, hipMemcpyDeviceToHost));   // synchronises the device
     *out = s->counters;
+    out->screened_pairs = st[0];
+    out->screen_survivors = st[1];
     return PQV_OK;
 }
 extern "C" int pqv_counters(const pqv_searcher *s, pqv_counters_t *out) {

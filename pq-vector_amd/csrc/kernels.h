@@ -100,12 +100,31 @@ struct TileArgs {
     uint32_t        rows_per_block, blocks_per_list;
     uint64_t        max_pos;
     unsigned long long *gthr;    // [nq] per-query global admission threshold, preset to KEY_EMPTY
+    // row window of this launch inside every list: rows [row_offset, row_offset + gridDim.x *
+    // rows_per_block); its blocks use partial-list chunk slots chunk_offset + blockIdx.x
+    uint64_t        row_offset;
+    uint32_t        chunk_offset;
+    uint32_t        grid_x;      // gridDim.x of this launch (blocks_per_list is the slot stride)
+    // MFMA filter only: squared norms of the storage rows / of the queries
+    const float    *row_norm2;   // indexed like mat rows
+    const float    *query_norm2; // [nq]
+    int             xcd_swizzle; // 1: XCD-aware workgroup remap (speed only)
+    unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
     uint64_t       *part_keys;   // same layout as StreamArgs: [nq][nprobe*blocks_per_list*4][k]
     uint32_t       *part_vals;
 };
 // PQV_L2SQ_REF4 only, k <= 256.  Every (query, list, chunk, wave) slot of the partial-list buffer is
 // initialised by the wave that owns it (also for chunks past a short list's end).
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
+// Same contract, but every (row, query) pair is first screened with an MFMA lower bound of its
+// distance; only pairs that could still beat the query's admission threshold are evaluated in
+// the reference's exact order.  Needs thresholds seeded by a prior launch_tile_rerank window.
+hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s);
+// After the exact seed window: gthr[q] = min(gthr[q], k-th smallest key over ALL of q's seed lists)
+// (chunk slot `chunk` of every probed list) -- the k-th of the union, far tighter than the min of
+// the per-wave k-th keys the fold publishes.
+hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t blocks_per_list,
+                                 uint32_t chunk, uint32_t k, unsigned long long *gthr, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:

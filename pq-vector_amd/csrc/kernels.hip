@@ -546,6 +546,20 @@ hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s) {
 // Top-k: one wave-distributed sorted list per query of the group (registers); the first
 // tile seeds it with a 64-lane bitonic sort, later tiles insert past the k-th key.
 // ------------------------------------------------------------------------------------
+// XCD-aware workgroup remap (bijective form).  Hardware places workgroup L on XCD L % 8; giving
+// XCD i the i-th CONTIGUOUS slice of the (chunk-fastest) block space puts the blocks of
+// consecutive query groups -- the groups of one cluster -- on one XCD, so a row chunk fetched
+// for one group is an L2 hit for the next.  Placement only affects speed, never results.
+__device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by, int enable) {
+    if (!enable) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const uint32_t nwg = gridDim.x * gridDim.y;
+    const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = L & 7u;
+    const uint32_t V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bx = V % gridDim.x;
+    by = V / gridDim.x;
+}
+
 // 64-lane bitonic sort of (key, val), ascending
 __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int lane) {
 #pragma unroll
@@ -635,7 +649,8 @@ __device__ __forceinline__ uint64_t tile_fold(uint64_t *gkeys, uint32_t *gvals, 
 // ------------------------------------------------------------------------------------
 template <int QB, int S, bool ALIGNED>
 __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
-    const uint32_t gi = blockIdx.y;
+    uint32_t bx, gi;
+    xcd_remap(bx, gi, a.xcd_swizzle);
     if (gi >= *a.n_groups) return;
     const uint4 grp = a.groups[gi];
     const uint32_t c = grp.x, p0 = grp.y, cnt = grp.z;
@@ -649,9 +664,10 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
     const uint64_t wrows = a.rows_per_block / 4;
-    const uint64_t r0 = (uint64_t)blockIdx.x * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
+    if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
     const uint32_t G = dim >> 2, tail = dim & 3u;
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     // this wave's list of query `lane`: slot (q, j, chunk, wave) of the partial-list buffer
     const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
     const uint64_t my_base =
-        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + blockIdx.x) * 4 + wave) * k;
+        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + a.chunk_offset + bx) * 4 + wave) * k;
 
     // lists start empty
 #pragma unroll 1
@@ -812,16 +828,344 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// tile_filter_kernel: the batched re-rank with an MFMA lower-bound screen.
+//
+// Same work decomposition as tile_rerank_kernel (group of <= 16 queries x row chunk of one
+// list; a wave walks 64-row tiles).  Per tile the 16 x 64 score block s = q.x is computed on
+// the matrix cores (v_mfma_f32_16x16x4_f32: four 16 x 16 tiles, exact f32 products), then
+//     d~ = |q|^2 + |x|^2 - 2 s,     lb = d~ - c (2 (|q|^2 + |x|^2) + |d~|),  c = (dim + 16) 2^-22
+// lb is a rigorous lower bound of the reference's d2: both d2 (index.rs:461-480 order) and d~
+// approximate the real sum within first-order bounds (dim/4 + 5) u D and (dim + 4) u (|q| + |x|)^2,
+// u = 2^-24, and c carries a 4x safety factor.  A pair is skipped iff lb > the query's
+// threshold distance -- then its exact key cannot beat the threshold key.  Survivors (a
+// fraction of a percent once thresholds are seeded) are queued per wave and evaluated 64 at a
+// time, lane-per-pair, in the reference's exact summation order, then folded exactly like in
+// tile_rerank_kernel.  Results are therefore identical to the unscreened kernel.
+// The k-order of the MFMA contraction is permuted (lane kk owns 4 consecutive dims of each
+// 16-dim step) so that every operand fetch is one 16-byte load; the bound is order-free.
+// ------------------------------------------------------------------------------------
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+
+template <int S, bool ALIGNED, bool PREFETCH>
+__global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
+    static_assert(TILE_QB == 16, "the 16x16x4 MFMA tile fixes the group size");
+    constexpr int PEND = 1024 + 64;        // pending (query, row) pairs per wave: a whole tile fits
+    uint32_t bx, gi;
+    xcd_remap(bx, gi, a.xcd_swizzle);
+    if (gi >= *a.n_groups) return;
+    const uint4 grp = a.groups[gi];
+    const uint32_t c = grp.x, p0 = grp.y, cnt = grp.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t k = a.k;
+
+    __shared__ uint32_t pend_all[4 * PEND];     // (query slot << 28) | row-in-list offset from r0
+    uint32_t *pend = pend_all + wave * PEND;
+
+    const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
+    const uint64_t len = lend - lbeg;
+    const uint64_t wrows = a.rows_per_block / 4;
+    uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows;
+    if (r1 > len) r1 = len;
+    if (r0 > len) r0 = len;
+
+    const uint32_t dim = a.dim;
+    const uint32_t G = dim >> 2, tail = dim & 3u;
+    const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+
+    // lane-parallel per-query state: lane q (< 16) owns query q of the group
+    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
+    const uint32_t my_pair = a.pairs[my_slot];
+    const uint32_t my_qrow = my_pair / a.nprobe;
+    const uint64_t my_cbase = a.cand_base[my_pair];
+    const float my_qn = a.query_norm2[my_qrow];
+    uint64_t my_lkth = KEY_EMPTY;
+    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+    const uint64_t my_base =
+        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + a.chunk_offset + bx) * 4 + wave) * k;
+#pragma unroll 1
+    for (uint32_t qq = 0; qq < cnt; ++qq) {
+        const uint64_t base = readlane_u64(my_base, (int)qq);
+        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
+    }
+
+    // MFMA operand roles of this lane: query / row index inside a 16-tile, and its k slice
+    const int l15 = lane & 15, kk = lane >> 4;
+    const float *qrow_ptr = a.queries + (uint64_t)__shfl((int)my_qrow, l15, 64) * dim;
+    float qn4[4];      // |q|^2 of the 4 queries whose scores this lane receives: i = kk*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qn4[r] = __shfl(my_qn, kk * 4 + r, 64);
+
+    uint32_t npend = 0;
+    uint32_t n_exact = 0;
+
+    // exact evaluation of queued pairs [start, start + count), count <= 64, lane-per-pair in the
+    // reference's summation order, then one fold per query of the group
+    auto eval = [&](uint32_t start, uint32_t count) {
+        wave_lds_fence();
+        const bool have = (uint32_t)lane < count;
+        const uint32_t pe = pend[start + (have ? lane : 0)];
+        const uint32_t qs = pe >> 28;                       // query slot in the group
+        const uint64_t roff = r0 + (pe & 0x0FFFFFFFu);       // row offset in the list
+        const uint64_t lpos = lbeg + roff;
+        const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+        const float *x = a.mat + (uint64_t)srow * dim;
+        const float *q = a.queries + (uint64_t)__shfl((int)my_qrow, (int)qs, 64) * dim;
+        float sum = 0.0f;
+        uint32_t g = 0;
+        for (; g + 2 <= G; g += 2) {       // 4 loads in flight per lane, then the ordered chain
+            float4 xv[2], qv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { xv[u] = load4<ALIGNED>(x + (g + u) * 4); qv[u] = load4<ALIGNED>(q + (g + u) * 4); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y;
+                const float d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum = sum + t;
+            }
+        }
+        for (; g < G; ++g) {
+            const float4 xv = load4<ALIGNED>(x + g * 4), qv = load4<ALIGNED>(q + g * 4);
+            const float d0 = qv.x - xv.x, d1 = qv.y - xv.y, d2 = qv.z - xv.z, d3 = qv.w - xv.w;
+            float t = d0 * d0 + d1 * d1;
+            t = t + d2 * d2;
+            t = t + d3 * d3;
+            sum = sum + t;
+        }
+        for (uint32_t e = 0; e < tail; ++e) {
+            const float d = q[G * 4 + e] - x[G * 4 + e];
+            sum = sum + d * d;
+        }
+        const uint64_t my_gthr =
+            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
+#pragma unroll 1
+        for (uint32_t qq = 0; qq < cnt; ++qq) {
+            const uint64_t pos = readlane_u64(my_cbase, (int)qq) + roff;
+            const bool mine = have && qs == qq && pos < a.max_pos;
+            const uint64_t mykey =
+                mine ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
+            const uint64_t thr = readlane_u64(my_thr, (int)qq);
+            if (__ballot(mykey < thr) != 0ull) {
+                const uint64_t base = readlane_u64(my_base, (int)qq);
+                const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
+                                                 a.gthr + readlane_u32(my_qrow, (int)qq),
+                                                 readlane_u64(my_gthr, (int)qq), readlane_u64(my_lkth, (int)qq),
+                                                 mykey, srow, k, lane);
+                if ((uint32_t)lane == qq) my_lkth = nk;
+            }
+        }
+    };
+    // evaluate tail batches until fewer than `keep_below` entries remain
+    auto drain = [&](uint32_t keep_below) {
+        while (npend >= keep_below && npend > 0) {
+            const uint32_t take = npend < 64 ? npend : 64;
+            eval(npend - take, take);
+            n_exact += take;
+            npend -= take;
+        }
+        wave_lds_fence();
+    };
+
+    const bool fast_k = ALIGNED && (dim & 15u) == 0;       // wave-uniform
+    for (uint64_t t0 = r0;; t0 += 64) {
+        const bool last = t0 >= r1;
+        if (!last) {
+            const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+            // rows of the four 16-row tiles this lane feeds (B operand) / receives (C columns)
+            const float *xrow[4];
+            float xn[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint32_t rr = (uint32_t)(16 * t + l15);
+                if (rr >= nvalid) rr = nvalid - 1;
+                const uint64_t lpos = lbeg + t0 + rr;
+                const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+                xrow[t] = a.mat + (uint64_t)srow * dim;
+                xn[t] = a.row_norm2[srow];
+            }
+            // thresholds of this tile (a stale value is only a looser bound)
+            const uint64_t my_gthr =
+                __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
+            // threshold DISTANCE (upper 32 bits of the key) of the lane's 4 queries; KEY_EMPTY
+            // gives the NaN pattern 0xFFFFFFFF, which compares false below: "cannot skip"
+            const float my_thr_d = __uint_as_float((uint32_t)(my_thr >> 32));
+            float thr4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) thr4[r] = __shfl(my_thr_d, kk * 4 + r, 64);
+
+            f32x4_acc acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+
+            if (fast_k) {
+                if constexpr (PREFETCH) {
+                    // long rows (many K steps per tile): operands of step k0 + 16 are fetched
+                    // behind the 16 MFMAs of step k0 (costs ~20 VGPRs = one wave of occupancy)
+                    float4 qc = load4<true>(qrow_ptr + 4 * kk), qnx;
+                    float4 xc[4], xnx[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xc[t] = load4<true>(xrow[t] + 4 * kk);
+                    for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+                        const bool more = k0 + 16 < dim;
+                        if (more) {
+                            qnx = load4<true>(qrow_ptr + k0 + 16 + 4 * kk);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) xnx[t] = load4<true>(xrow[t] + k0 + 16 + 4 * kk);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, xc[t].x, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, xc[t].y, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, xc[t].z, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, xc[t].w, acc[t], 0, 0, 0);
+                        }
+                        if (more) {
+                            qc = qnx;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) xc[t] = xnx[t];
+                        }
+                    }
+                } else {
+                    // short rows: no explicit prefetch, the registers are worth more as occupancy
+                    for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+                        const float4 qc = load4<true>(qrow_ptr + k0 + 4 * kk);
+                        float4 xc[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) xc[t] = load4<true>(xrow[t] + k0 + 4 * kk);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, xc[t].x, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, xc[t].y, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, xc[t].z, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, xc[t].w, acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+                    const uint32_t kb = k0 + 4 * kk;      // this lane's 4 dims of the step
+                    float qf[4] = {0.f, 0.f, 0.f, 0.f}, xf[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xf[t][e] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (kb + e < dim) {
+                            qf[e] = qrow_ptr[kb + e];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) xf[t][e] = xrow[t][kb + e];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[e], xf[t][e], acc[t], 0, 0, 0);
+                }
+            }
+
+            // screen: C/D layout col j = lane & 15 (row 16 t + j of the tile), row i = kk * 4 + r (query)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool jvalid = (uint32_t)(16 * t + l15) < nvalid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t qi = (uint32_t)(kk * 4 + r);
+                    const float nn = qn4[r] + xn[t];
+                    const float dt = nn - 2.0f * acc[t][r];
+                    const float lb = dt - cmargin * (2.0f * nn + fabsf(dt));
+                    const bool skip = lb > thr4[r];            // false when the threshold is EMPTY (NaN)
+                    const bool keep = jvalid && qi < cnt && !skip;
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (keep) pend[npend + before] = (qi << 28) | (uint32_t)(t0 - r0 + 16 * t + l15);
+                        npend += (uint32_t)__popcll(m);
+                    }
+                }
+            }
+        }
+        // evaluate full batches (everything at the end), keep a partial batch queued otherwise
+        drain(last ? 1u : 64u);
+        if (last) break;
+    }
+    if (a.stats && lane == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)(r1 - r0) * cnt);
+        atomicAdd(&a.stats[1], (unsigned long long)n_exact);
+    }
+}
+
 template <int S>
 static hipError_t launch_tile_s(const TileArgs &a, hipStream_t s) {
-    dim3 grid(a.blocks_per_list, a.max_groups), block(256);
+    dim3 grid(a.grid_x, a.max_groups), block(256);
     if ((a.dim % 4) == 0) hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, S, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((tile_rerank_kernel<TILE_QB, S, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
+// gthr[q] = min(gthr[q], k-th smallest key over the seed lists of q)
+template <int S>
+__global__ __launch_bounds__(64) void seed_threshold_kernel(const uint64_t *part_keys, uint32_t nprobe,
+                                                           uint32_t blocks_per_list, uint32_t chunk, uint32_t k,
+                                                           unsigned long long *gthr) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n_part = nprobe * blocks_per_list * 4;
+    WaveTopk<S> tk;
+    tk.init();
+    const uint32_t total = nprobe * 4 * k;      // entries of q's seed lists
+    for (uint32_t i = 0; i < total; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        if (idx < total) {
+            const uint32_t list = idx / k, e = idx % k;          // list = j * 4 + wave
+            const uint32_t j = list >> 2, w = list & 3;
+            key = part_keys[((uint64_t)q * n_part + (j * blocks_per_list + chunk) * 4 + w) * k + e];
+        }
+        tk.offer(key, 0u, k, lane);
+    }
+    const uint64_t kth = tk.kth(k);
+    if (lane == 0 && kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
+}
+hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t blocks_per_list,
+                                 uint32_t chunk, uint32_t k, unsigned long long *gthr, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(seed_threshold_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, blocks_per_list, chunk, k, gthr);
+    else if (k <= 256) hipLaunchKernelGGL(seed_threshold_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, blocks_per_list, chunk, k, gthr);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int S>
+static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
+    dim3 grid(a.grid_x, a.max_groups), block(256);
+    if ((a.dim % 4) == 0) {
+        if (a.dim > 256) hipLaunchKernelGGL((tile_filter_kernel<S, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((tile_filter_kernel<S, true, false>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((tile_filter_kernel<S, false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s) {
+    if (a.max_groups == 0 || a.grid_x == 0) return hipSuccess;
+    if (a.k <= 64) return launch_filter_s<1>(a, s);
+    if (a.k <= 256) return launch_filter_s<4>(a, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
-    if (a.max_groups == 0 || a.blocks_per_list == 0) return hipSuccess;
+    if (a.max_groups == 0 || a.grid_x == 0) return hipSuccess;
     if (a.k <= 64) return launch_tile_s<1>(a, s);
     if (a.k <= 256) return launch_tile_s<4>(a, s);
     return hipErrorInvalidValue;   // larger k uses stream_kernel
