@@ -567,3 +567,34 @@ def test_brute_rejects_bad_arguments(pqv):
         corpus.brute_topk(np.ones((1, 4), np.float32), 0)
     with pytest.raises(pqv.PqvError, match="metric must be"):
         corpus.brute_topk(np.ones((1, 4), np.float32), 1, metric=pqv.PQV_L2SQ_REF4)
+
+
+def test_mfma_screen_under_cancellation(pqv, oracle, monkeypatch):
+    """Rows = large common offset + tiny noise: |q|^2 + |x|^2 - 2 q.x cancels catastrophically,
+    the screen's margin dwarfs every distance, so (nearly) all pairs must survive it and be
+    evaluated exactly -- results stay bit-identical to the oracle; also exercises the per-wave
+    pending queue at its worst-case fill.  A second corpus mixes magnitudes over 6 decades."""
+    rng = np.random.default_rng(77)
+    n, dim, kc, k, nprobe, nq = 12000, 64, 6, 10, 3, 96
+    for variant in ("offset", "decades"):
+        if variant == "offset":
+            data = (100.0 + 0.01 * rng.random((n, dim))).astype(np.float32)
+            queries = (100.0 + 0.01 * rng.random((nq, dim))).astype(np.float32)
+        else:
+            scale = (10.0 ** rng.integers(-3, 4, size=(n, 1))).astype(np.float32)
+            data = (rng.standard_normal((n, dim)).astype(np.float32) * scale)
+            queries = rng.standard_normal((nq, dim)).astype(np.float32) * np.float32(10.0)
+        oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=5)
+        corpus = pqv.Corpus.upload(data)
+        monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+        monkeypatch.setenv("PQV_TILE_FILTER", "1")
+        s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (rows == orows).all(), variant
+        assert (_bits(dist) == _bits(odist)).all(), variant
+        c = s.counters()
+        assert c["screened_pairs"] > 0
+        if variant == "offset":
+            assert c["screen_survivors"] > 0.9 * c["screened_pairs"]   # the bound cannot prune here
