@@ -802,7 +802,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         s->d_row_of = nullptr;
         s->d_final_ids = s->d_ids.as<uint32_t>();
     }
-    if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m && *m != '0') ? 1 : 0;
+    if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m == '2') ? 2 : (*m && *m != '0') ? 1 : 0;
     S_TRY(s->d_stats.alloc(2 * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, 2 * sizeof(unsigned long long), s->stream));
     // squared norms of the storage rows, for the MFMA screen of the batched re-rank
@@ -872,7 +872,12 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // MFMA screen: the first seed_rows rows of every probed list are evaluated exactly (that
         // seeds the per-query thresholds), the rest goes through the screened kernel
         p.seed_rows = 256;
-        p.filter = s->tile_filter && max_len > 4ull * p.seed_rows;
+        // The MFMA screen pays when the 16-query tiles are mostly full and lists are long compared
+        // with the exact seed window; otherwise (measured on the reference bench shape: 16 pairs per
+        // cluster, 1000-row lists, 130 k vs 103 k QPS) the exact kernel alone is faster.
+        const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
+        p.filter = s->tile_filter && k <= 32 && pairs >= 24ull * s->n_clusters && mean_len >= 16ull * p.seed_rows;
+        if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
         // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
         // multiple of 8 the blocks of ALL query groups for one row chunk share an XCD (and its L2)
         // and are dispatched together: a chunk is then fetched from HBM once, not once per group.

@@ -374,17 +374,20 @@ def test_tile_path_matches_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, nprob
     flags = pqv.PQV_LAYOUT_ROW_ORDER if layout == "row" else pqv.PQV_LAYOUT_IVF_ORDERED
     orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
     results = {}
-    for mode in ("tile", "stream"):
-        monkeypatch.setenv("PQV_RERANK_MODE", mode)
+    for mode in ("tile", "screen", "stream"):
+        monkeypatch.setenv("PQV_RERANK_MODE", "tile" if mode == "screen" else mode)
+        monkeypatch.setenv("PQV_TILE_FILTER", "2" if mode == "screen" else "0")   # 2 = force the MFMA screen
         s = pqv.Searcher(index, corpus, flags)
         rows, dist, nf, nc = s.topk(queries, k, nprobe)
         assert (nc == onc).all()
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
         results[mode] = (rows, dist)
-    assert (results["tile"][0] == results["stream"][0]).all()
-    assert (_bits(results["tile"][1]) == _bits(results["stream"][1])).all()
-    # the cap applies to the tile path too
+    for m in ("tile", "screen"):
+        assert (results[m][0] == results["stream"][0]).all()
+        assert (_bits(results[m][1]) == _bits(results["stream"][1])).all()
+    # the cap applies to the tile path too (screened form)
     monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
     s = pqv.Searcher(index, corpus, flags)
     rows, d2, nf, nc = s.topk(queries[:5], k, nprobe, max_candidates=97, sqrt_out=False)
     for q in range(5):
@@ -477,14 +480,17 @@ def test_full_size_c2_properties(pqv, oracle, monkeypatch):
     queries = np.ascontiguousarray(data[rng.choice(n, nq, replace=False)])   # self-queries
     queries[nq // 2:] = rng.random((nq - nq // 2, dim), dtype=np.float32)
     out = {}
-    for mode in ("tile", "stream"):
-        monkeypatch.setenv("PQV_RERANK_MODE", mode)
+    for mode in ("tile", "screen", "stream"):
+        monkeypatch.setenv("PQV_RERANK_MODE", "tile" if mode == "screen" else mode)
+        monkeypatch.setenv("PQV_TILE_FILTER", "2" if mode == "screen" else "0")
         s = pqv.Searcher(index, corpus)
         out[mode] = s.topk(queries, k, nprobe)
-    # two independent kernels (lane-per-row SGPR tiles vs coalesced stream + LDS transpose)
-    for a, b in zip(out["tile"], out["stream"]):
-        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
-                              b.view(np.uint32) if b.dtype == np.float32 else b)
+    # three independent paths (lane-per-row SGPR tiles, the same behind the MFMA screen, and the
+    # coalesced stream + LDS transpose) must agree bit for bit
+    for m in ("tile", "screen"):
+        for a, b in zip(out[m], out["stream"]):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                  b.view(np.uint32) if b.dtype == np.float32 else b)
     rows_t, dist_t, nf, nc = out["tile"]
     assert (nf == k).all()
     assert (np.diff(dist_t.astype(np.float64), axis=1) >= 0).all()          # sorted ascending
@@ -587,7 +593,7 @@ def test_mfma_screen_under_cancellation(pqv, oracle, monkeypatch):
         oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=5)
         corpus = pqv.Corpus.upload(data)
         monkeypatch.setenv("PQV_RERANK_MODE", "tile")
-        monkeypatch.setenv("PQV_TILE_FILTER", "1")
+        monkeypatch.setenv("PQV_TILE_FILTER", "2")      # force the screen regardless of the dispatch rule
         s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
         rows, dist, nf, nc = s.topk(queries, k, nprobe)
         orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
