@@ -159,7 +159,12 @@ def main():
     dist_t = torch.empty((nq, K), dtype=torch.float32, device=dev)
     nf_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     nc_t = torch.empty((nq,), dtype=torch.int64, device=dev)
-    xchg = ShardExchange(world, nq, K, dev, always_collective=args.force_dist)
+    if weak:
+        bases = [r * (n_total // world) for r in range(world)]
+    else:
+        bases = [shard_range(r, world, n_total)[0] for r in range(world)]
+    xchg = ShardExchange(world, nq, K, dev, always_collective=args.force_dist,
+                         row_bases=bases if args.backend == "nccl" else None)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -170,6 +175,8 @@ def main():
             return dist_t, rows_t
         # exchange: one all-gather of k x {dist, global row} per query, then a stable merge
         # keyed (dist, shard, position) -- pq_vector_amd/sharding.py
+        if xchg.fast:
+            return xchg.exchange_u32(dist_t, rows_t)
         return xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, lo)
 
     def barrier():
@@ -274,6 +281,12 @@ def main():
                               "valu_view": valu_view}
 
     result["counters"] = searcher.counters()
+    if use_dist and xchg.fast:
+        # the library merge kernel against the torch stable-sort merge of the same gathered lists
+        ref_d, ref_r = xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, lo)
+        ok = torch.tensor([int(torch.equal(ref_d, out_d) and torch.equal(ref_r, out_r))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        result["exchange_check"] = bool(ok.item())
 
     # ---- optional latency mode: one query per call through the same device API ------------
     if args.single and rank == 0:

@@ -207,6 +207,15 @@ int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *coun
                    uint32_t n_lists, uint32_t nq, uint32_t k, float *out_dist,
                    uint32_t *out_rows, uint32_t *out_list, uint32_t *out_count);
 
+/* Device-resident form of the merge for the multi-GPU exchange: d_dist f32 / d_rows u32
+ * [n_lists, nq, k] as delivered by one all-gather of every rank's pqv_topk_device outputs
+ * (empty slots: 0xFFFFFFFF rows), d_row_base i64[n_lists] the first global row of each shard.
+ * Writes d_out_dist f32[nq, k] and d_out_rows i64[nq, k] (global row ids, -1 = none), ordered
+ * by (distance, list, position).  Asynchronous on hip_stream (NULL = the default stream). */
+int pqv_merge_topk_device(int device, const void *d_dist, const void *d_rows, const void *d_row_base,
+                          uint32_t n_lists, uint32_t nq, uint32_t k, void *d_out_dist,
+                          void *d_out_rows, void *hip_stream);
+
 /* Counters mirroring the reference's plan metrics (src/df_vector/index_exec.rs:289-299,
  * src/df_vector/exec.rs:411-427), accumulated per searcher since creation. */
 typedef struct pqv_counters_t {

@@ -85,6 +85,7 @@ SIGNATURES = {
                              C.c_int, u32p, f32p, u32p]),
     "pqv_merge_topk": (C.c_int, [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p,
                                  u32p, u32p]),
+    "pqv_merge_topk_device": (C.c_int, [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "pqv_counters": (C.c_int, [vp, C.POINTER(Counters)]),
     "pqv_set_timing": (C.c_int, [vp, C.c_int]),
     "pqv_timing_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u32p]),

@@ -1551,6 +1551,28 @@ extern "C" int pqv_merge_topk(const float *dist, const uint32_t *rows, const uin
     return guard([&] { return pqv_merge_topk_impl(dist, rows, counts, n_lists, nq, k, out_dist, out_rows, out_list, out_count); });
 }
 
+static int pqv_merge_topk_device_impl(int device, const void *d_dist, const void *d_rows, const void *d_row_base,
+                                      uint32_t n_lists, uint32_t nq, uint32_t k, void *d_out_dist,
+                                      void *d_out_rows, void *hip_stream) {
+    if (!d_dist || !d_rows || !d_row_base || !d_out_dist || !d_out_rows)
+        return fail(PQV_ERR_INVALID, "device pointers must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (n_lists == 0 || nq == 0) return PQV_OK;
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(pqv::launch_shard_merge(static_cast<const float *>(d_dist), static_cast<const uint32_t *>(d_rows),
+                                    static_cast<const long long *>(d_row_base), n_lists, nq, k,
+                                    static_cast<float *>(d_out_dist), static_cast<long long *>(d_out_rows),
+                                    static_cast<hipStream_t>(hip_stream)));
+    return PQV_OK;
+}
+extern "C" int pqv_merge_topk_device(int device, const void *d_dist, const void *d_rows, const void *d_row_base,
+                                     uint32_t n_lists, uint32_t nq, uint32_t k, void *d_out_dist,
+                                     void *d_out_rows, void *hip_stream) {
+    return guard([&] { return pqv_merge_topk_device_impl(device, d_dist, d_rows, d_row_base, n_lists, nq, k,
+                                                         d_out_dist, d_out_rows, hip_stream); });
+}
+
 // ---------------------------------------------------------------------------------------
 // batch-granular re-rank (update_topk_heap, src/df_vector/exec.rs:457-484)
 // ---------------------------------------------------------------------------------------

@@ -163,6 +163,13 @@ hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *c
                                uint32_t nq, uint32_t k, uint32_t *row_idx, float *dist, uint32_t *n_found,
                                hipStream_t s);
 
+// Merge of per-shard top-k lists gathered from all ranks: dist/rows [n_shards, nq, k] (unused
+// slots: +inf / 0xFFFFFFFF), row_base[n_shards] the shards' first global row.  One wave per
+// query; order = ascending (distance, shard, position in the shard's list).
+hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
+                              uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
+                              long long *out_rows, hipStream_t s);
+
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
                               uint64_t m, uint32_t dim, float *out, hipStream_t s);

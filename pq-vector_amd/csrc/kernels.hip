@@ -1432,6 +1432,66 @@ hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *c
 }
 
 // ------------------------------------------------------------------------------------
+// shard_merge_kernel: the exchange step of the sharded search (one list per GPU/file, merged
+// like the reference's single heap over all files, src/df_vector/exec.rs:264-267).
+// ------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict__ dist,
+                                                        const uint32_t *__restrict__ rows,
+                                                        const long long *__restrict__ row_base,
+                                                        uint32_t n_shards, uint32_t nq, uint32_t k,
+                                                        float *__restrict__ out_dist,
+                                                        long long *__restrict__ out_rows) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    WaveTopk<S> tk;
+    tk.init();
+    const uint32_t total = n_shards * k;
+    for (uint32_t i = 0; i < total; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        uint32_t val = 0xFFFFFFFFu;
+        if (idx < total) {
+            const uint32_t sh = idx / k, e = idx % k;
+            const uint64_t src = ((uint64_t)sh * nq + q) * k + e;
+            const uint32_t r = rows[src];
+            if (r != 0xFFFFFFFFu) {
+                key = ((uint64_t)sortable_bits(dist[src]) << 32) | (uint64_t)idx;   // idx = shard * k + position
+                val = idx;
+            }
+        }
+        tk.offer(key, val, k, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        if (e < k) {
+            float d = INFINITY;
+            long long gr = -1;
+            if (tk.key[s] != KEY_EMPTY) {
+                const uint32_t idx = tk.val[s];
+                const uint64_t src = ((uint64_t)(idx / k) * nq + q) * k + (idx % k);
+                d = dist[src];
+                gr = row_base[idx / k] + (long long)rows[src];
+            }
+            out_dist[(uint64_t)q * k + e] = d;
+            out_rows[(uint64_t)q * k + e] = gr;
+        }
+    }
+}
+
+hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
+                              uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
+                              long long *out_rows, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(shard_merge_kernel<1>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
+    else if (k <= 256) hipLaunchKernelGGL(shard_merge_kernel<4>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
+    else if (k <= 1024) hipLaunchKernelGGL(shard_merge_kernel<16>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
 // ------------------------------------------------------------------------------------
 template <bool ALIGNED>

@@ -31,13 +31,41 @@ def merge_gathered(gath_dist, gath_rows, k):
 
 
 class ShardExchange:
-    """Pre-allocated all-gather buffers for a fixed (nq, k); one collective per tensor."""
+    """Pre-allocated all-gather buffers for a fixed (nq, k); one collective per tensor.
 
-    def __init__(self, world, nq, k, device, always_collective=False):
+    On GPUs the merge is one library kernel (pqv_merge_topk_device, ordered by (distance, shard,
+    position)); on CPU tensors (gloo tests) the same order comes from a stable torch sort."""
+
+    def __init__(self, world, nq, k, device, always_collective=False, row_bases=None):
         self.world, self.nq, self.k = world, nq, k
         self.always_collective = always_collective
+        self.device = torch.device(device)
         self.gath_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
         self.gath_r = torch.empty((world, nq, k), dtype=torch.int64, device=device)
+        self.fast = self.device.type == "cuda" and row_bases is not None
+        if self.fast:
+            self.gath_r32 = torch.empty((world, nq, k), dtype=torch.int32, device=device)
+            self.bases = torch.tensor(list(row_bases), dtype=torch.int64, device=device)
+            self.out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
+            self.out_r = torch.empty((nq, k), dtype=torch.int64, device=device)
+
+    def exchange_u32(self, local_dist, local_rows_i32):
+        """GPU fast path: local_rows_i32 [nq,k] is the searcher's raw u32 output viewed as int32
+        (0xFFFFFFFF = empty).  Two all-gathers + one merge kernel on the current stream."""
+        from . import _ffi
+        if self.world == 1 and not self.always_collective:
+            self.gath_d[0].copy_(local_dist)
+            self.gath_r32[0].copy_(local_rows_i32)
+        else:
+            dist.all_gather_into_tensor(self.gath_d.view(self.world * self.nq, self.k), local_dist.contiguous())
+            dist.all_gather_into_tensor(self.gath_r32.view(self.world * self.nq, self.k), local_rows_i32.contiguous())
+        rc = _ffi.lib().pqv_merge_topk_device(
+            self.device.index or 0, _ffi.vp(self.gath_d.data_ptr()), _ffi.vp(self.gath_r32.data_ptr()),
+            _ffi.vp(self.bases.data_ptr()), self.world, self.nq, self.k, _ffi.vp(self.out_d.data_ptr()),
+            _ffi.vp(self.out_r.data_ptr()), _ffi.vp(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(_ffi.lib().pqv_last_error().decode())
+        return self.out_d, self.out_r
 
     def exchange(self, local_dist, local_rows_i64, row_base):
         """local_dist [nq,k] f32, local_rows_i64 [nq,k] shard-local ids (-1 / 0xFFFFFFFF = empty)."""

@@ -604,3 +604,33 @@ def test_mfma_screen_under_cancellation(pqv, oracle, monkeypatch):
         assert c["screened_pairs"] > 0
         if variant == "offset":
             assert c["screen_survivors"] > 0.9 * c["screened_pairs"]   # the bound cannot prune here
+
+
+def test_merge_topk_device_matches_stable_sort(pqv):
+    """pqv_merge_topk_device (the multi-GPU exchange merge) == shard-major stable sort, incl. ties,
+    short lists and row bases beyond 2^32."""
+    import torch
+    from pq_vector_amd import _ffi
+    from pq_vector_amd.sharding import merge_gathered
+    lib = _ffi.lib()
+    torch.manual_seed(5)
+    for (w, nq, k) in [(1, 3, 10), (2, 17, 10), (8, 64, 100), (4, 5, 300), (3, 2, 1)]:
+        d = torch.randint(0, 50, (w, nq, k), device="cuda").float().sort(dim=2).values  # many ties
+        r = torch.randint(0, 1 << 31, (w, nq, k), device="cuda", dtype=torch.int64)
+        short = torch.rand((w, nq, 1), device="cuda") < 0.3          # some lists are short
+        tail = torch.arange(k, device="cuda").view(1, 1, k) >= max(1, k // 2)
+        empty = short & tail
+        d = torch.where(empty, torch.full_like(d, float("inf")), d).contiguous()
+        bases = torch.tensor([i * ((1 << 32) + 12345) for i in range(w)], dtype=torch.int64, device="cuda")
+        grow = torch.where(empty, torch.full_like(r, -1), r + bases.view(w, 1, 1))
+        want_d, want_r = merge_gathered(d, grow, k)
+        r_u32 = torch.where(empty, torch.full_like(r, -1), r).to(torch.int32).contiguous()  # -1 == 0xFFFFFFFF
+        out_d = torch.empty((nq, k), device="cuda")
+        out_r = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        rc = lib.pqv_merge_topk_device(0, _ffi.vp(d.data_ptr()), _ffi.vp(r_u32.data_ptr()),
+                                       _ffi.vp(bases.data_ptr()), w, nq, k, _ffi.vp(out_d.data_ptr()),
+                                       _ffi.vp(out_r.data_ptr()), _ffi.vp(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.pqv_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out_d, want_d), (w, nq, k)
+        assert torch.equal(out_r, want_r), (w, nq, k)
