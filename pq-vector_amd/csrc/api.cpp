@@ -169,9 +169,11 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_gthr, s_tie,
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_gthr, s_tie,
         s_replay, s_qnorm;
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
+    int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
+    uint32_t cand_cap = 2048;              // PQV_CAND_CAP: candidate-buffer entries per query of the wide screened path
     int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
     // the scratch above is reused by every call: a call on another stream first waits for the
     // previous call's kernels (event recorded at the end of each enqueue)
@@ -803,8 +805,10 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         s->d_final_ids = s->d_ids.as<uint32_t>();
     }
     if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m == '2') ? 2 : (*m && *m != '0') ? 1 : 0;
-    S_TRY(s->d_stats.alloc(2 * sizeof(unsigned long long)));
-    S_TRY(hipMemsetAsync(s->d_stats.p, 0, 2 * sizeof(unsigned long long), s->stream));
+    if (const char *m = std::getenv("PQV_FILTER_VARIANT")) s->filter_variant = std::atoi(m);
+    if (const char *m = std::getenv("PQV_CAND_CAP")) s->cand_cap = std::max<uint32_t>(1, static_cast<uint32_t>(std::strtoul(m, nullptr, 10)));
+    S_TRY(s->d_stats.alloc(8 * sizeof(unsigned long long)));
+    S_TRY(hipMemsetAsync(s->d_stats.p, 0, 8 * sizeof(unsigned long long), s->stream));
     // squared norms of the storage rows, for the MFMA screen of the batched re-rank
     {
         const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
@@ -842,6 +846,9 @@ struct TopkPlan {
     uint32_t max_groups;
     bool filter;            // tile path: exact seed window + MFMA-screened remainder
     uint32_t seed_rows, filter_bpl;
+    bool quad;              // filter: wide_filter_kernel (quad_width queries per block)
+    uint32_t filter_rows_per_block, max_quads, quad_width;
+    uint32_t slots_per_pair;   // partial lists per (query, probe rank)
 };
 
 TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
@@ -891,18 +898,26 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         //  C3 33 -> 60 ms.  Kept behind PQV_XCD_ALIGN=1 for experiments; off by default.)
         static const bool xcd_align = [] { const char *e = std::getenv("PQV_XCD_ALIGN"); return e && *e == '1'; }();
         if (p.filter) {
+            // wide kernel: 64 (dim <= 128) or 32 (dim <= 256) queries per block, staged in LDS
+            const int variant = s->filter_variant;
+            p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : s->dim <= 256 ? 32 : 0;
+            p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
             uint64_t r = rpb;
             p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
-                                     : static_cast<uint32_t>((max_len - p.seed_rows + rpb - 1) / rpb);
-            p.rr_rows_per_block = static_cast<uint32_t>(r);
+                                     : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
+            p.filter_rows_per_block = static_cast<uint32_t>(r);
+            p.rr_rows_per_block = static_cast<uint32_t>(rpb);
             p.rr_bpl = 1 + p.filter_bpl;
+            p.slots_per_pair = 4 * (1 + p.filter_bpl);
         } else {
             uint64_t r = rpb;
             p.filter_bpl = 0;
             p.rr_bpl = xcd_align ? chunks_x8(max_len, r) : static_cast<uint32_t>((max_len + rpb - 1) / rpb);
             p.rr_rows_per_block = static_cast<uint32_t>(r);
+            p.slots_per_pair = 4 * p.rr_bpl;
         }
-        p.n_part_rr = p.np * p.rr_bpl * pqv::waves_per_block();
+        p.n_part_rr = p.np * p.slots_per_pair + ((p.filter && p.quad) ? 1 : 0);   // + the candidate buffer's k best
+        p.max_quads = static_cast<uint32_t>(pairs / std::max<uint32_t>(16, p.quad_width) + std::min<uint64_t>(s->n_clusters, pairs));
         p.max_groups = static_cast<uint32_t>(pairs / pqv::TILE_QB + std::min<uint64_t>(s->n_clusters, pairs));
         return p;
     }
@@ -969,8 +984,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     // 2. candidate re-rank + per-wave top-k
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
-        // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1]
-        HIP_TRY(s->s_pair_u32.ensure((4ull * kc + 3) * sizeof(uint32_t)));
+        // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
+        HIP_TRY(s->s_pair_u32.ensure((5ull * kc + 5) * sizeof(uint32_t)));
+        HIP_TRY(s->s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
         HIP_TRY(s->s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
         HIP_TRY(s->s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
         uint32_t *u = s->s_pair_u32.as<uint32_t>();
@@ -981,20 +997,37 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc;
         ps.hist = u; ps.cursor = u + kc; ps.pair_off = u + 2ull * kc; ps.group_off = u + 3ull * kc + 1;
         ps.n_groups = u + 4ull * kc + 2;
-        ps.pairs = s->s_pairs.as<uint32_t>(); ps.groups = s->s_groups.as<uint4>();
+        ps.quad_off = u + 4ull * kc + 3; ps.n_quads = u + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
+        ps.pairs = s->s_pairs.as<uint32_t>(); ps.groups = s->s_groups.as<uint4>(); ps.quads = s->s_quads.as<uint4>();
         HIP_TRY(launch_pair_sort(ps, stream));
         TileArgs ta{};
         ta.mat = s->d_mat; ta.row_of = s->d_row_of; ta.list_off = s->d_list_off.as<uint64_t>();
         ta.queries = d_queries; ta.cand_base = s->s_cand_base.as<uint64_t>();
         ta.pairs = ps.pairs; ta.groups = ps.groups; ta.n_groups = ps.n_groups; ta.max_groups = p.max_groups;
         ta.nq = nq; ta.nprobe = p.np; ta.dim = s->dim; ta.k = k;
+        ta.quads = ps.quads; ta.n_quads = ps.n_quads; ta.max_quads = p.max_quads; ta.quad_width = p.quad_width;
         ta.rows_per_block = p.rr_rows_per_block; ta.blocks_per_list = p.rr_bpl; ta.max_pos = max_pos;
+        ta.slots_per_pair = p.slots_per_pair; ta.slot_base = 0; ta.n_part = p.n_part_rr;
         ta.gthr = s->s_gthr.as<unsigned long long>();
         ta.part_keys = s->s_part_keys.as<uint64_t>(); ta.part_vals = s->s_part_vals.as<uint32_t>();
         ta.row_norm2 = s->d_row_norm2.as<float>();
         ta.stats = s->d_stats.as<unsigned long long>();
         static const int xcd_swz = [] { const char *e = std::getenv("PQV_XCD_SWIZZLE"); return (e && *e == '1') ? 1 : 0; }();   // measured: no gain on C2, -30 % on C3
         ta.xcd_swizzle = xcd_swz;
+        if (p.filter && p.quad) {
+            if (!s->d_mat_blk.p) {
+                // one-off: the blocked MFMA-operand copy of the lists (second copy of the corpus in HBM)
+                std::vector<uint64_t> boff(static_cast<size_t>(kc) + 1, 0);
+                for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
+                HIP_TRY(s->d_blk_off.alloc(boff.size() * sizeof(uint64_t)));
+                HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+                HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
+                HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                          (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+            }
+            ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
+            ta.blk_off = s->d_blk_off.as<uint64_t>();
+        }
         if (p.filter) {
             HIP_TRY(s->s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
             HIP_TRY(launch_row_norms(d_queries, nq, s->dim, 1, s->s_qnorm.as<float>(), stream));
@@ -1003,14 +1036,33 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
         if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
-            seed.row_offset = 0; seed.chunk_offset = 0; seed.grid_x = 1; seed.rows_per_block = p.seed_rows;
+            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.rows_per_block = p.seed_rows;
             HIP_TRY(launch_tile_rerank(seed, stream));
-            HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.rr_bpl, 0, k, ta.gthr, stream));
-            ta.row_offset = p.seed_rows; ta.chunk_offset = 1; ta.grid_x = p.filter_bpl;
-            HIP_TRY(launch_tile_filter(ta, stream));
+            ta.row_offset = p.seed_rows; ta.slot_base = 4; ta.grid_x = p.filter_bpl;
+            ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = p.quad ? 0 : 1;
+            if (p.quad) {
+                const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
+                HIP_TRY(s->s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
+                HIP_TRY(s->s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
+                HIP_TRY(s->s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+                ta.cand_keys = s->s_cand_keys.as<uint64_t>(); ta.cand_vals = s->s_cand_vals.as<uint32_t>();
+                ta.cand_cnt = s->s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap;
+                HIP_TRY(launch_cand_seed(ta.part_keys, ta.part_vals, nq, p.np, p.slots_per_pair, p.n_part_rr, k, ta.gthr,
+                                         ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, stream));
+                HIP_TRY(launch_tile_filter(ta, stream));
+                // the buffer's k best become partial list number np * slots_per_pair of every query
+                const uint64_t extra = static_cast<uint64_t>(p.np) * p.slots_per_pair * k;
+                HIP_TRY(launch_cand_select(ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, nq, k, ta.gthr,
+                                           ta.part_keys + extra, ta.part_vals + extra,
+                                           static_cast<uint64_t>(p.n_part_rr) * k, stream));
+                s->counters.kernel_launches += 1;
+            } else {
+                HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.slots_per_pair, k, ta.gthr, stream));
+                HIP_TRY(launch_tile_filter(ta, stream));
+            }
             s->counters.kernel_launches += 2;
         } else {
-            ta.row_offset = 0; ta.chunk_offset = 0; ta.grid_x = p.rr_bpl;
+            ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.rr_bpl;
             HIP_TRY(launch_tile_rerank(ta, stream));
         }
         if (timing) HIP_TRY(hipEventRecord(e2, stream));
@@ -1332,8 +1384,11 @@ static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     if (!s || !out) return fail(PQV_ERR_INVALID, "searcher/out must not be NULL");
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
-    unsigned long long st[2] = {0, 0};
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(st, s->d_stats.p, sizeof st, hipMemcpyDeviceToHost));   // synchronises the device
+#ifdef PQV_PROFILE_PHASES
+    std::fprintf(stderr, "[pqv phases] waves %llu  total %llu  kloop %llu  screen %llu  drain %llu (s_memtime ticks)\n", st[6], st[2], st[3], st[4], st[5]);
+#endif
     *out = s->counters;
     out->screened_pairs = st[0];
     out->screen_survivors = st[1];

@@ -82,6 +82,11 @@ struct PairSortArgs {
     uint32_t       *pairs;     // [n_pairs] pair ids bucketed by cluster
     uint4          *groups;    // [max_groups] {cluster, first slot, count, 0}
     uint32_t       *n_groups;  // [1]
+    // quads: up to quad_width (32 or 64) pairs of one cluster (the unit of wide_filter_kernel)
+    uint32_t        quad_width;
+    uint32_t       *quad_off;  // [n_clusters + 1]
+    uint4          *quads;     // [max_quads] {cluster, first slot, count, 0}
+    uint32_t       *n_quads;   // [1]
 };
 // hist -> scan -> scatter; three tiny launches
 hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
@@ -96,21 +101,35 @@ struct TileArgs {
     const uint4    *groups;
     const uint32_t *n_groups;
     uint32_t        max_groups;  // gridDim.y
+    const uint4    *quads;       // wide_filter_kernel: gridDim.y = max_quads
+    const uint32_t *n_quads;
+    uint32_t        max_quads, quad_width;
     uint32_t        nq, nprobe, dim, k;
     uint32_t        rows_per_block, blocks_per_list;
     uint64_t        max_pos;
     unsigned long long *gthr;    // [nq] per-query global admission threshold, preset to KEY_EMPTY
     // row window of this launch inside every list: rows [row_offset, row_offset + gridDim.x *
-    // rows_per_block); its blocks use partial-list chunk slots chunk_offset + blockIdx.x
+    // rows_per_block).  Partial-list slots: a (query, probe rank j) pair owns slots_per_pair
+    // lists; block bx of this launch writes slots slot_base + bx * 4 + wave (one list per wave)
     uint64_t        row_offset;
-    uint32_t        chunk_offset;
-    uint32_t        grid_x;      // gridDim.x of this launch (blocks_per_list is the slot stride)
+    uint32_t        slots_per_pair, slot_base;
+    uint32_t        n_part;      // partial lists per query in part_keys (>= nprobe * slots_per_pair)
+    uint32_t        grid_x;      // gridDim.x of this launch
+    int             filter_variant;   // launch_tile_filter: 0 = wide_filter_kernel (2 or 4 query groups per block,
+                                      // queries staged in LDS), 1 = tile_filter_kernel (one group per block)
     // MFMA filter only: squared norms of the storage rows / of the queries
+    const float4   *mat_blk;     // wide_filter_kernel: blocked copy of the IVF-ordered lists (launch_block_rows)
+    const uint64_t *blk_off;     // [n_clusters + 1] first 16-row tile of every list in mat_blk
     const float    *row_norm2;   // indexed like mat rows
     const float    *query_norm2; // [nq]
     int             xcd_swizzle; // 1: XCD-aware workgroup remap (speed only)
+    // wide_filter_kernel: per-query append buffers of exact-verified candidates
+    uint64_t       *cand_keys;   // [nq][cand_cap]
+    uint32_t       *cand_vals;
+    uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
+    uint32_t        cand_cap;
     unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
-    uint64_t       *part_keys;   // same layout as StreamArgs: [nq][nprobe*blocks_per_list*4][k]
+    uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
 };
 // PQV_L2SQ_REF4 only, k <= 256.  Every (query, list, chunk, wave) slot of the partial-list buffer is
@@ -121,10 +140,21 @@ hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
 // the reference's exact order.  Needs thresholds seeded by a prior launch_tile_rerank window.
 hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s);
 // After the exact seed window: gthr[q] = min(gthr[q], k-th smallest key over ALL of q's seed lists)
-// (chunk slot `chunk` of every probed list) -- the k-th of the union, far tighter than the min of
-// the per-wave k-th keys the fold publishes.
-hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t blocks_per_list,
-                                 uint32_t chunk, uint32_t k, unsigned long long *gthr, hipStream_t s);
+// (slots 0..3 of every (query, probe rank) pair) -- the k-th of the union, far tighter than the min
+// of the per-wave k-th keys the fold publishes.
+hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
+                                 uint32_t k, unsigned long long *gthr, hipStream_t s);
+
+// Candidate buffers of the wide screened path (see kernels.hip).  cand_seed: k best of the seed lists
+// (slots 0..3 of every probe rank; cleared) -> buffer front, gthr = their k-th key.  cand_select: fold
+// the appended candidates to the k best (buffer front), tighten gthr; optional copy to out_keys/vals
+// [q * out_stride + e] as one more partial list for the final merge.
+hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
+                            uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
+                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, hipStream_t s);
+hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
+                              uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
+                              uint64_t out_stride, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:
@@ -169,6 +199,11 @@ hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *c
 hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
                               uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
                               long long *out_rows, hipStream_t s);
+
+// MFMA-operand copy of the IVF-ordered lists: 16-row tiles, tile T column ch row j at float4 index
+// (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)
+hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                             uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

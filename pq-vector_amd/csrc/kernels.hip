@@ -477,36 +477,40 @@ __global__ __launch_bounds__(256) void pair_hist_kernel(const PairSortArgs a) {
 
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     // single block: exclusive scans of hist and of ceil(hist / TILE_QB)
-    __shared__ uint32_t s_pair[1024], s_grp[1024];
-    __shared__ uint32_t carry_pair, carry_grp;
+    __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024];
+    __shared__ uint32_t carry_pair, carry_grp, carry_quad;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { carry_pair = 0; carry_grp = 0; }
+    if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
         const uint32_t c = base + tid;
         const uint32_t h = c < a.n_clusters ? a.hist[c] : 0;
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
-        s_pair[tid] = h; s_grp[tid] = g;
+        const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
+        s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t vp = 0, vg = 0;
-            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; }
+            uint32_t vp = 0, vg = 0, vq = 0;
+            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; vq = s_quad[tid - off]; }
             __syncthreads();
-            s_pair[tid] += vp; s_grp[tid] += vg;
+            s_pair[tid] += vp; s_grp[tid] += vg; s_quad[tid] += vq;
             __syncthreads();
         }
         if (c < a.n_clusters) {
             a.pair_off[c] = carry_pair + s_pair[tid] - h;
             a.group_off[c] = carry_grp + s_grp[tid] - g;
+            a.quad_off[c] = carry_quad + s_quad[tid] - qd;
         }
         __syncthreads();
-        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; }
+        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; carry_quad += s_quad[1023]; }
         __syncthreads();
     }
     if (tid == 0) {
         a.pair_off[a.n_clusters] = carry_pair;
         a.group_off[a.n_clusters] = carry_grp;
+        a.quad_off[a.n_clusters] = carry_quad;
         *a.n_groups = carry_grp;
+        *a.n_quads = carry_quad;
     }
 }
 
@@ -521,6 +525,10 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
         const uint32_t h = a.hist[c];
         const uint32_t cnt = (h - i < (uint32_t)TILE_QB) ? (h - i) : (uint32_t)TILE_QB;
         a.groups[a.group_off[c] + i / TILE_QB] = make_uint4(c, slot, cnt, 0u);
+    }
+    if (i % a.quad_width == 0) {
+        const uint32_t h = a.hist[c];
+        a.quads[a.quad_off[c] + i / a.quad_width] = make_uint4(c, slot, h - i < a.quad_width ? h - i : a.quad_width, 0u);
     }
 }
 
@@ -558,6 +566,12 @@ __device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by, int enable
     const uint32_t V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     bx = V % gridDim.x;
     by = V / gridDim.x;
+}
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // 64-lane bitonic sort of (key, val), ascending
@@ -679,9 +693,9 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint64_t my_cbase = a.cand_base[my_pair];
     uint64_t my_lkth = KEY_EMPTY;          // k-th key of this wave's list of query `lane`
     // this wave's list of query `lane`: slot (q, j, chunk, wave) of the partial-list buffer
-    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+    const uint32_t n_part = a.n_part;
     const uint64_t my_base =
-        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + a.chunk_offset + bx) * 4 + wave) * k;
+        ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
 
     // lists start empty
 #pragma unroll 1
@@ -883,9 +897,9 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
     const uint64_t my_cbase = a.cand_base[my_pair];
     const float my_qn = a.query_norm2[my_qrow];
     uint64_t my_lkth = KEY_EMPTY;
-    const uint32_t n_part = a.nprobe * a.blocks_per_list * 4;
+    const uint32_t n_part = a.n_part;
     const uint64_t my_base =
-        ((uint64_t)my_qrow * n_part + ((my_pair % a.nprobe) * a.blocks_per_list + a.chunk_offset + bx) * 4 + wave) * k;
+        ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
 #pragma unroll 1
     for (uint32_t qq = 0; qq < cnt; ++qq) {
         const uint64_t base = readlane_u64(my_base, (int)qq);
@@ -1104,6 +1118,394 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Per-query candidate buffers of the wide screened path: cand_keys/vals [nq][cap], cand_cnt[nq].
+//   cand_seed_kernel   : after the exact seed window -- the k best of q's seed lists (slots 0..3 of
+//                        every probe rank) become the buffer's first entries, gthr[q] their k-th key;
+//                        the seed slots are cleared (their content now lives in the buffer).
+//   cand_select_kernel : folds the appended candidates to the k best (kept at the buffer's front),
+//                        tightens gthr[q]; with out_keys it also writes them as one more partial
+//                        list for the final merge.
+// One wave per query.
+// ------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(64) void cand_seed_kernel(uint64_t *part_keys, uint32_t *part_vals, uint32_t nprobe,
+                                                      uint32_t slots_per_pair, uint32_t n_part, uint32_t k,
+                                                      unsigned long long *gthr, uint64_t *cand_keys,
+                                                      uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    WaveTopk<S> tk;
+    tk.init();
+    const uint32_t total = nprobe * 4 * k;
+    for (uint32_t i = 0; i < total; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        uint32_t val = 0xFFFFFFFFu;
+        if (idx < total) {
+            const uint32_t list = idx / k, e = idx % k;          // list = j * 4 + wave
+            const uint64_t src = ((uint64_t)q * n_part + (list >> 2) * slots_per_pair + (list & 3)) * k + e;
+            key = part_keys[src]; val = part_vals[src];
+            part_keys[src] = KEY_EMPTY; part_vals[src] = 0xFFFFFFFFu;
+        }
+        tk.offer(key, val, k, lane);
+    }
+    uint32_t found = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        const bool have = e < k && tk.key[s] != KEY_EMPTY;
+        if (have) { cand_keys[(uint64_t)q * cap + e] = tk.key[s]; cand_vals[(uint64_t)q * cap + e] = tk.val[s]; }
+        found += (uint32_t)__popcll(__ballot(have));
+    }
+    const uint64_t kth = tk.kth(k);
+    if (lane == 0) {
+        cand_cnt[q] = found;
+        if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void cand_select_kernel(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt,
+                                                        uint32_t cap, uint32_t k, unsigned long long *gthr,
+                                                        uint64_t *out_keys, uint32_t *out_vals, uint64_t out_stride) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    uint32_t n = cand_cnt[q];
+    if (n > cap) n = cap;
+    WaveTopk<S> tk;
+    tk.init();
+    for (uint32_t i = 0; i < n; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        uint32_t val = 0xFFFFFFFFu;
+        if (idx < n) { key = cand_keys[(uint64_t)q * cap + idx]; val = cand_vals[(uint64_t)q * cap + idx]; }
+        tk.offer(key, val, k, lane);
+    }
+    uint32_t found = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        if (e < k) {
+            const bool have = tk.key[s] != KEY_EMPTY;
+            if (have) { cand_keys[(uint64_t)q * cap + e] = tk.key[s]; cand_vals[(uint64_t)q * cap + e] = tk.val[s]; }
+            if (out_keys) { out_keys[(uint64_t)q * out_stride + e] = tk.key[s]; out_vals[(uint64_t)q * out_stride + e] = tk.val[s]; }
+            found += (uint32_t)__popcll(__ballot(have));
+        } else {
+            found += (uint32_t)__popcll(__ballot(false));
+        }
+    }
+    const uint64_t kth = tk.kth(k);
+    if (lane == 0) {
+        cand_cnt[q] = found;
+        if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
+    }
+}
+
+hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
+                            uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
+                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k > cap) return hipErrorInvalidValue;
+    if (k <= 64) hipLaunchKernelGGL(cand_seed_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap);
+    else if (k <= 256) hipLaunchKernelGGL(cand_seed_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
+                              uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
+                              uint64_t out_stride, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(cand_select_kernel<1>, dim3(nq), dim3(64), 0, s, cand_keys, cand_vals, cand_cnt, cap, k, gthr, out_keys, out_vals, out_stride);
+    else if (k <= 256) hipLaunchKernelGGL(cand_select_kernel<4>, dim3(nq), dim3(64), 0, s, cand_keys, cand_vals, cand_cnt, cap, k, gthr, out_keys, out_vals, out_stride);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// wide_filter_kernel<NG, S>: the MFMA-screened re-rank with NG 16-query groups (a "quad" of up
+// to 16 NG queries of one cluster) per block.
+//
+// tile_filter_kernel fetches 5 operand vectors from global memory per 16 MFMAs and re-reads a
+// cluster's rows once per 16-query group (8 flop per byte).  Here the block's queries are staged
+// ONCE in LDS ([16 NG][dim], 16-byte columns XOR-swizzled by the query index so the A-operand
+// ds_read_b128 is bank-conflict free); each wave walks its own rows exactly as before, but every
+// 64-row x 16-dim B operand it loads is contracted against all NG query groups: 4 global loads per
+// 16 NG MFMAs, rows re-read once per 16 NG queries, and -- unlike staging the ROWS in LDS, which
+// was tried first and lost to barrier skew -- the waves never synchronise after the prologue.
+// Screening bound, pending queue (drained after every group's screen, so one tile's worth of
+// capacity still suffices), exact re-evaluation and fold are those of tile_filter_kernel.
+// Per-query state is lane-parallel over all 64 lanes (lane = query index in the quad).
+// Requires dim % 64 == 0 (swizzle closure), 16 NG * dim * 4 bytes of LDS, the IVF-ordered layout
+// (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
+// ------------------------------------------------------------------------------------
+template <int NG, int S>
+__global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
+    static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
+    constexpr int PEND = 1024 + 64;
+    constexpr uint32_t NQ = 16 * NG;
+    const uint32_t bx = blockIdx.x;
+    if (blockIdx.y >= *a.n_quads) return;
+    const uint4 quad = a.quads[blockIdx.y];          // {cluster, first pair slot, pair count <= NQ, 0}
+    const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
+    const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t k = a.k;
+
+    extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
+    __shared__ uint32_t pend_all[4 * PEND];          // (query index << 26) | row offset from the wave's r0
+    uint32_t *pend = pend_all + wave * PEND;
+
+    const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
+    const uint64_t len = lend - lbeg;
+    const uint64_t wrows = a.rows_per_block / 4;
+    uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows;
+    if (r1 > len) r1 = len;
+    if (r0 > len) r0 = len;
+
+    const uint32_t dim = a.dim;
+    const uint32_t G = dim >> 2;                     // 16-byte columns per row (multiple of 4)
+    const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+
+    // lane-parallel per-query state: lane q owns query q of the quad
+    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
+    const uint32_t my_pair = a.pairs[my_slot];
+    const uint32_t my_qrow = my_pair / a.nprobe;
+    const uint64_t my_cbase = a.cand_base[my_pair];
+    const float my_qn = a.query_norm2[my_qrow];
+    uint64_t my_lkth = KEY_EMPTY;
+    const uint32_t n_part = a.n_part;
+    const uint64_t my_base =
+        ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
+#pragma unroll 1
+    for (uint32_t qq = 0; qq < cnt; ++qq) {
+        const uint64_t base = readlane_u64(my_base, (int)qq);
+        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
+    }
+
+    // stage the quad's queries (all 256 threads; queries past cnt alias the last one and are masked later)
+    for (uint32_t idx = threadIdx.x; idx < NQ * G; idx += 256) {
+        const uint32_t q = idx / G, ch = idx - q * G;
+        const uint32_t qrow = a.pairs[p0 + (q < cnt ? q : cnt - 1)] / a.nprobe;
+        qs[q * G + (ch ^ (q & 15u))] = load4<true>(a.queries + (uint64_t)qrow * dim + ch * 4);
+    }
+    __syncthreads();
+
+    const int l15 = lane & 15, kk = lane >> 4;
+    const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;   // the list's 16-row tiles
+    uint32_t npend = 0;
+    uint32_t n_exact = 0;
+#ifdef PQV_PROFILE_PHASES
+    uint64_t ph_k = 0, ph_s = 0, ph_e = 0; const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
+
+    auto eval = [&](uint32_t start, uint32_t count) {
+        wave_lds_fence();
+        const bool have = (uint32_t)lane < count;
+        const uint32_t pe = pend[start + (have ? lane : 0)];
+        const uint32_t qsl = pe >> 26;                        // query index in the quad
+        const uint64_t roff = r0 + (pe & 0x03FFFFFFu);         // row offset in the list
+        const uint64_t lpos = lbeg + roff;
+        const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+        const float *x = a.mat + (uint64_t)srow * dim;
+        const float4 *ql = qs + qsl * G;              // the pair's query, staged (swizzled) in LDS
+        const uint32_t qsw = qsl & 15u;
+        float sum = 0.0f;
+        // 8 row chunks in flight per lane, then the reference's ordered chain over them
+        for (uint32_t g = 0; g < G; g += 8) {
+            float4 xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = load4<true>(x + (g + u) * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 qv = ql[(g + u) ^ qsw];
+                const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
+                const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum = sum + t;
+            }
+        }
+        const uint64_t my_gthr =
+            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
+        const uint64_t pos = shfl_u64(my_cbase, (int)qsl) + roff;
+        const uint64_t mykey_all =
+            (have && pos < a.max_pos) ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
+        // A pair that beats its query's threshold is APPENDED to the query's candidate buffer: one
+        // atomic per lane, all lanes in parallel (a sorted per-wave list would cost one global
+        // read-modify-write round trip per query, serially -- measured: half of the kernel).
+        const bool pass = mykey_all < shfl_u64(my_thr, (int)qsl);
+        bool spill = false;
+        const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qsl, 64);
+        if (pass) {
+            const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
+            if (idx < a.cand_cap) {
+                a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = mykey_all;
+                a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = srow;
+            } else {
+                spill = true;          // buffer full: fall back to this wave's sorted list (slow, exact)
+            }
+        }
+        unsigned long long todo = __ballot(spill);
+        while (todo) {
+            const uint32_t qq = readlane_u32(qsl, __builtin_ctzll(todo));
+            const bool mine = spill && qsl == qq;
+            todo &= ~__ballot(mine);
+            const uint64_t mykey = mine ? mykey_all : KEY_EMPTY;
+            const uint64_t thr = readlane_u64(my_thr, (int)qq);
+            if (__ballot(mykey < thr) != 0ull) {
+                const uint64_t base = readlane_u64(my_base, (int)qq);
+                const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
+                                                 a.gthr + readlane_u32(my_qrow, (int)qq),
+                                                 readlane_u64(my_gthr, (int)qq), readlane_u64(my_lkth, (int)qq),
+                                                 mykey, srow, k, lane);
+                if ((uint32_t)lane == qq) my_lkth = nk;
+            }
+        }
+    };
+    auto drain = [&](uint32_t keep_below) {
+        while (npend >= keep_below && npend > 0) {
+            const uint32_t take = npend < 64 ? npend : 64;
+            eval(npend - take, take);
+            n_exact += take;
+            npend -= take;
+        }
+        wave_lds_fence();
+    };
+
+    const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;   // this lane's float4 inside a 1 KiB operand block
+    for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+        const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+        // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
+        // 16-byte column ch, row j of the tile at float4 index (T * G + ch) * 16 + j -- the 64 lanes
+        // (j = lane & 15, ch = k0 / 4 + lane >> 4) of one load read 1 KiB contiguous.  Tile bases are
+        // wave-uniform (scalar registers); the lane offset is shared by all loads.
+        const float4 *xbase[4];
+        float xn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t rr = (uint32_t)(16 * t + l15);
+            if (rr >= nvalid) rr = nvalid - 1;
+            xn[t] = a.row_norm2[lbeg + t0 + rr];
+            uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
+            if (T > blk_last) T = blk_last;             // tiles past the list's end: masked below
+            xbase[t] = a.mat_blk + T * G * 16;
+        }
+        const uint64_t my_gthr =
+            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
+        // threshold DISTANCE of this lane's query; KEY_EMPTY gives NaN: "cannot skip"
+        const float my_thr_d = __uint_as_float((uint32_t)(my_thr >> 32));
+
+        f32x4_acc acc[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+
+#ifdef PQV_PROFILE_PHASES
+        const uint64_t ph_a = __builtin_amdgcn_s_memtime();
+#endif
+        float4 xc[4], xnx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xc[t] = xbase[t][lane_off];
+        for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+            const bool more = k0 + 16 < dim;
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xnx[t] = xbase[t][(k0 + 16) * 4 + lane_off];   // next 4 columns
+            }
+            const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if ((uint32_t)g < ng) {
+                    const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, xc[t].x, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, xc[t].y, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, xc[t].z, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, xc[t].w, acc[g][t], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xc[t] = xnx[t];
+            }
+        }
+
+        // screen, ROLLED over the groups (one copy of the code and of the drain): C/D layout col
+        // j = lane & 15 (row 16 t + j of the tile), row i = kk * 4 + r (query i of group g).  After the
+        // last tile one extra pass flushes what is still queued.
+#ifdef PQV_PROFILE_PHASES
+        __builtin_amdgcn_s_waitcnt(0); const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a;
+#endif
+        const uint32_t gend = ng + (t0 + 64 >= r1 ? 1u : 0u);
+#pragma unroll 1
+        for (uint32_t g = 0; g < gend; ++g) {
+            if (g < ng) {
+                f32x4_acc cur[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cur[t] = acc[0][t];
+#pragma unroll
+                for (int gg = 1; gg < NG; ++gg)
+                    if (g == (uint32_t)gg) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) cur[t] = acc[gg][t];
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t qi = 16 * g + (uint32_t)(kk * 4 + r);
+                    const float qn = __shfl(my_qn, (int)qi, 64);
+                    const float thr = __shfl(my_thr_d, (int)qi, 64);
+                    const bool qvalid = qi < cnt;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bool jvalid = (uint32_t)(16 * t + l15) < nvalid;
+                        const float nn = qn + xn[t];
+                        const float dt = nn - 2.0f * cur[t][r];
+                        const float lb = dt - cmargin * (2.0f * nn + fabsf(dt));
+                        const bool skip = lb > thr;            // false when the threshold is EMPTY (NaN)
+                        const bool keep = jvalid && qvalid && !skip;
+                        const unsigned long long m = __ballot(keep);
+                        if (m) {
+                            const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (keep) pend[npend + before] = (qi << 26) | (uint32_t)(t0 - r0 + 16 * t + l15);
+                            npend += (uint32_t)__popcll(m);
+                        }
+                    }
+                }
+            }
+#ifdef PQV_PROFILE_PHASES
+            const uint64_t ph_c = __builtin_amdgcn_s_memtime();
+#endif
+            drain(g == ng ? 1u : 64u);
+#ifdef PQV_PROFILE_PHASES
+            ph_e += __builtin_amdgcn_s_memtime() - ph_c;
+#endif
+        }
+#ifdef PQV_PROFILE_PHASES
+        ph_s += __builtin_amdgcn_s_memtime() - ph_b;
+#endif
+    }
+    if (a.stats && lane == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)(r1 - r0) * cnt);
+        atomicAdd(&a.stats[1], (unsigned long long)n_exact);
+#ifdef PQV_PROFILE_PHASES
+        atomicAdd(&a.stats[2], (unsigned long long)(__builtin_amdgcn_s_memtime() - ph_t0));
+        atomicAdd(&a.stats[3], (unsigned long long)ph_k);
+        atomicAdd(&a.stats[4], (unsigned long long)(ph_s - ph_e));
+        atomicAdd(&a.stats[5], (unsigned long long)ph_e);
+        atomicAdd(&a.stats[6], 1ull);
+#endif
+    }
+}
+
 template <int S>
 static hipError_t launch_tile_s(const TileArgs &a, hipStream_t s) {
     dim3 grid(a.grid_x, a.max_groups), block(256);
@@ -1115,11 +1517,11 @@ static hipError_t launch_tile_s(const TileArgs &a, hipStream_t s) {
 // gthr[q] = min(gthr[q], k-th smallest key over the seed lists of q)
 template <int S>
 __global__ __launch_bounds__(64) void seed_threshold_kernel(const uint64_t *part_keys, uint32_t nprobe,
-                                                           uint32_t blocks_per_list, uint32_t chunk, uint32_t k,
+                                                           uint32_t slots_per_pair, uint32_t k,
                                                            unsigned long long *gthr) {
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint32_t n_part = nprobe * blocks_per_list * 4;
+    const uint32_t n_part = nprobe * slots_per_pair;
     WaveTopk<S> tk;
     tk.init();
     const uint32_t total = nprobe * 4 * k;      // entries of q's seed lists
@@ -1129,24 +1531,34 @@ __global__ __launch_bounds__(64) void seed_threshold_kernel(const uint64_t *part
         if (idx < total) {
             const uint32_t list = idx / k, e = idx % k;          // list = j * 4 + wave
             const uint32_t j = list >> 2, w = list & 3;
-            key = part_keys[((uint64_t)q * n_part + (j * blocks_per_list + chunk) * 4 + w) * k + e];
+            key = part_keys[((uint64_t)q * n_part + j * slots_per_pair + w) * k + e];
         }
         tk.offer(key, 0u, k, lane);
     }
     const uint64_t kth = tk.kth(k);
     if (lane == 0 && kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
 }
-hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t blocks_per_list,
-                                 uint32_t chunk, uint32_t k, unsigned long long *gthr, hipStream_t s) {
+hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
+                                 uint32_t k, unsigned long long *gthr, hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(seed_threshold_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, blocks_per_list, chunk, k, gthr);
-    else if (k <= 256) hipLaunchKernelGGL(seed_threshold_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, blocks_per_list, chunk, k, gthr);
+    if (k <= 64) hipLaunchKernelGGL(seed_threshold_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, slots_per_pair, k, gthr);
+    else if (k <= 256) hipLaunchKernelGGL(seed_threshold_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, nprobe, slots_per_pair, k, gthr);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 template <int S>
 static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
+    if (a.filter_variant == 0) {
+        if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
+        const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+        if (a.quad_width == 64 && lds4 <= 32768)
+            hipLaunchKernelGGL((wide_filter_kernel<4, S>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+        else if (a.quad_width == 32 && lds2 <= 32768)
+            hipLaunchKernelGGL((wide_filter_kernel<2, S>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     dim3 grid(a.grid_x, a.max_groups), block(256);
     if ((a.dim % 4) == 0) {
         if (a.dim > 256) hipLaunchKernelGGL((tile_filter_kernel<S, true, true>), grid, block, 0, s, a);
@@ -1488,6 +1900,39 @@ hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const lon
     else if (k <= 256) hipLaunchKernelGGL(shard_merge_kernel<4>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
     else if (k <= 1024) hipLaunchKernelGGL(shard_merge_kernel<16>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// block_rows_kernel: the MFMA-operand copy of the IVF-ordered lists.  Every list is cut into
+// 16-row tiles (the last one zero-padded); tile T stores 16-byte column ch of its row j at float4
+// index (T * G + ch) * 16 + j, so a 16x16x4 MFMA operand fetch (16 rows x 4 columns) is one
+// contiguous 1 KiB read.  grid = (tiles of the longest list, n_clusters).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_rows_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                        const uint64_t *__restrict__ blk_off, uint32_t dim,
+                                                        float4 *__restrict__ out) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 2;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        float4 *dst = out + (blk_off[c] + tl) * G * 16;
+        for (uint32_t e = threadIdx.x; e < G * 16; e += 256) {
+            const uint32_t ch = e >> 4, j = e & 15;
+            const uint64_t p = tl * 16 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < len) v = *reinterpret_cast<const float4 *>(src + (lbeg + p) * dim + ch * 4);
+            dst[e] = v;
+        }
+    }
+}
+hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                             uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(block_rows_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim,
+                       static_cast<float4 *>(out));
     return hipGetLastError();
 }
 

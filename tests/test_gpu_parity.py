@@ -575,6 +575,49 @@ def test_brute_rejects_bad_arguments(pqv):
         corpus.brute_topk(np.ones((1, 4), np.float32), 1, metric=pqv.PQV_L2SQ_REF4)
 
 
+@pytest.mark.parametrize("n,dim,kc,k,nprobe,nq", [
+    (20000, 128, 8, 10, 4, 200),     # wide kernel, 4 query groups per block (64 queries in LDS)
+    (12000, 256, 5, 10, 3, 150),     # wide kernel, 2 query groups per block
+    (16000, 64, 6, 32, 3, 130),      # k = 32: the largest k the screen takes by default
+    (9000, 192, 4, 5, 2, 77),        # dim % 64 == 0 but not a power of two; partial quads
+    (12000, 96, 5, 10, 3, 100),      # dim % 64 != 0: one 16-query group per block (tile_filter_kernel)
+])
+@pytest.mark.parametrize("variant", ["default", "tiny_buffer", "narrow"])
+def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, nprobe, nq, variant):
+    """Long lists so the MFMA screen really runs: the wide kernel (queries staged in LDS, rows from the
+    blocked copy, survivors appended to per-query buffers), the same with a 16-entry buffer (every
+    query overflows into the per-wave sorted lists) and the one-group-per-block kernel must all
+    reproduce the oracle bit for bit."""
+    rng = np.random.default_rng(3 * n + dim + nq)
+    data, oidx = _random_index(oracle, rng, n, dim, kc)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    queries[::7] = data[rng.integers(0, n, size=len(queries[::7]))]      # exact hits: distance 0
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    if variant == "tiny_buffer":
+        monkeypatch.setenv("PQV_CAND_CAP", "16")
+    if variant == "narrow":
+        monkeypatch.setenv("PQV_FILTER_VARIANT", "1")
+    s = pqv.Searcher(index, corpus)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    assert (nc == onc).all()
+    _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+    c = s.counters()
+    assert c["screened_pairs"] > 0 and 0 < c["screen_survivors"] < 0.2 * c["screened_pairs"]
+    # max_candidates cuts inside the screened window
+    cap = 2 * (n // kc) // 3 + 300
+    rows, d2, nf, nc = s.topk(queries[:6], k, nprobe, max_candidates=cap, sqrt_out=False)
+    for q in range(6):
+        cand = oidx.candidate_rows(queries[q], nprobe)[:cap]
+        d = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
+        order = np.lexsort((np.arange(len(cand)), d.view(np.uint32)))[:k]
+        assert nf[q] == len(order)
+        assert (_bits(d2[q, :len(order)]) == _bits(d[order])).all()
+
+
 def test_mfma_screen_under_cancellation(pqv, oracle, monkeypatch):
     """Rows = large common offset + tiny noise: |q|^2 + |x|^2 - 2 q.x cancels catastrophically,
     the screen's margin dwarfs every distance, so (nearly) all pairs must survive it and be
