@@ -807,8 +807,13 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m == '2') ? 2 : (*m && *m != '0') ? 1 : 0;
     if (const char *m = std::getenv("PQV_FILTER_VARIANT")) s->filter_variant = std::atoi(m);
     if (const char *m = std::getenv("PQV_CAND_CAP")) s->cand_cap = std::max<uint32_t>(1, static_cast<uint32_t>(std::strtoul(m, nullptr, 10)));
+#ifdef PQV_PROFILE_PHASES
+    S_TRY(s->d_stats.alloc((8 + 8 * 65536) * sizeof(unsigned long long)));
+    S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 8 * 65536) * sizeof(unsigned long long), s->stream));
+#else
     S_TRY(s->d_stats.alloc(8 * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, 8 * sizeof(unsigned long long), s->stream));
+#endif
     // squared norms of the storage rows, for the MFMA screen of the batched re-rank
     {
         const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
@@ -993,6 +998,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(hipMemsetAsync(u, 0, 2ull * kc * sizeof(uint32_t), stream));
         HIP_TRY(s->s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(s->s_gthr.p, 0xFF, static_cast<size_t>(nq) * sizeof(unsigned long long), stream));
+        // every partial list starts EMPTY (all-ones keys and values)
+        HIP_TRY(hipMemsetAsync(s->s_part_keys.p, 0xFF, static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint64_t), stream));
+        HIP_TRY(hipMemsetAsync(s->s_part_vals.p, 0xFF, static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint32_t), stream));
         PairSortArgs ps{};
         ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc;
         ps.hist = u; ps.cursor = u + kc; ps.pair_off = u + 2ull * kc; ps.group_off = u + 3ull * kc + 1;
@@ -1387,7 +1395,13 @@ static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(st, s->d_stats.p, sizeof st, hipMemcpyDeviceToHost));   // synchronises the device
 #ifdef PQV_PROFILE_PHASES
-    std::fprintf(stderr, "[pqv phases] waves %llu  total %llu  kloop %llu  screen %llu  drain %llu (s_memtime ticks)\n", st[6], st[2], st[3], st[4], st[5]);
+    {
+        std::vector<unsigned long long> rec(8 + 8 * 65536);
+        HIP_TRY(hipMemcpy(rec.data(), s->d_stats.p, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (const char *path = std::getenv("PQV_PHASES_OUT")) {
+            if (FILE *f = std::fopen(path, "wb")) { std::fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f); std::fclose(f); }
+        }
+    }
 #endif
     *out = s->counters;
     out->screened_pairs = st[0];

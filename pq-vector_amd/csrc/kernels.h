@@ -132,8 +132,8 @@ struct TileArgs {
     uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
 };
-// PQV_L2SQ_REF4 only, k <= 256.  Every (query, list, chunk, wave) slot of the partial-list buffer is
-// initialised by the wave that owns it (also for chunks past a short list's end).
+// PQV_L2SQ_REF4 only, k <= 256.  The caller presets the whole partial-list buffer to EMPTY (0xFF bytes:
+// KEY_EMPTY keys, 0xFFFFFFFF values); a wave touches its slots only when a candidate is admitted.
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
 // Same contract, but every (row, query) pair is first screened with an MFMA lower bound of its
 // distance; only pairs that could still beat the query's admission threshold are evaluated in

@@ -17,6 +17,8 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include <math.h>
 
 namespace pqv {
@@ -26,6 +28,20 @@ namespace pqv {
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+// v[lane L] = wave-uniform value s (v_writelane_b32 with an immediate lane; this hipcc has no builtin)
+template <int L>
+__device__ __forceinline__ void writelane_imm(uint32_t &v, uint32_t s) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     uint32_t lo = readlane_u32((uint32_t)v, l), hi = readlane_u32((uint32_t)(v >> 32), l);
@@ -697,12 +713,8 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint64_t my_base =
         ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
 
-    // lists start empty
-#pragma unroll 1
-    for (uint32_t qq = 0; qq < cnt; ++qq) {
-        const uint64_t base = readlane_u64(my_base, (int)qq);
-        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
-    }
+    // (the partial-list buffer was preset to EMPTY by the caller: one memset instead of k-entry stores per
+    //  wave and query)
 
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
@@ -900,11 +912,6 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
     const uint32_t n_part = a.n_part;
     const uint64_t my_base =
         ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
-#pragma unroll 1
-    for (uint32_t qq = 0; qq < cnt; ++qq) {
-        const uint64_t base = readlane_u64(my_base, (int)qq);
-        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
-    }
 
     // MFMA operand roles of this lane: query / row index inside a 16-tile, and its k slice
     const int l15 = lane & 15, kk = lane >> 4;
@@ -1240,10 +1247,13 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
 template <int NG, int S>
-__global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
+__global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 1024 + 64;
     constexpr uint32_t NQ = 16 * NG;
+#ifdef PQV_PROFILE_PHASES
+    const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t bx = blockIdx.x;
     if (blockIdx.y >= *a.n_quads) return;
     const uint4 quad = a.quads[blockIdx.y];          // {cluster, first pair slot, pair count <= NQ, 0}
@@ -1268,6 +1278,8 @@ __global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
     const uint32_t dim = a.dim;
     const uint32_t G = dim >> 2;                     // 16-byte columns per row (multiple of 4)
     const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+    const float inv1c = 1.0f / (1.0f - cmargin);
+    const float alpha = 0.5f * (1.0f - 2.0f * cmargin * inv1c), beta = 0.5f * inv1c;
 
     // lane-parallel per-query state: lane q owns query q of the quad
     const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
@@ -1279,17 +1291,17 @@ __global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
     const uint32_t n_part = a.n_part;
     const uint64_t my_base =
         ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
-#pragma unroll 1
-    for (uint32_t qq = 0; qq < cnt; ++qq) {
-        const uint64_t base = readlane_u64(my_base, (int)qq);
-        for (uint32_t e = lane; e < k; e += 64) { a.part_keys[base + e] = KEY_EMPTY; a.part_vals[base + e] = 0xFFFFFFFFu; }
-    }
 
-    // stage the quad's queries (all 256 threads; queries past cnt alias the last one and are masked later)
-    for (uint32_t idx = threadIdx.x; idx < NQ * G; idx += 256) {
-        const uint32_t q = idx / G, ch = idx - q * G;
-        const uint32_t qrow = a.pairs[p0 + (q < cnt ? q : cnt - 1)] / a.nprobe;
-        qs[q * G + (ch ^ (q & 15u))] = load4<true>(a.queries + (uint64_t)qrow * dim + ch * 4);
+    // stage the quad's queries: 256 / NQ threads per query, 16-byte columns interleaved between them; the
+    // row pointer comes from the lane-parallel state (queries past cnt alias the last one, masked later)
+    {
+        constexpr uint32_t TPQ = 256 / NQ;
+        const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
+        const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
+        float4 *dst = qs + q * G;
+        const uint32_t sw = q & 15u;
+#pragma unroll 8
+        for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
     }
     __syncthreads();
 
@@ -1298,7 +1310,7 @@ __global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
     uint32_t npend = 0;
     uint32_t n_exact = 0;
 #ifdef PQV_PROFILE_PHASES
-    uint64_t ph_k = 0, ph_s = 0, ph_e = 0; const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
+    uint64_t ph_k = 0, ph_s = 0, ph_e = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
     auto eval = [&](uint32_t start, uint32_t count) {
@@ -1410,76 +1422,102 @@ __global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_a = __builtin_amdgcn_s_memtime();
 #endif
-        float4 xc[4], xnx[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xc[t] = xbase[t][lane_off];
-        for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
-            const bool more = k0 + 16 < dim;
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) xnx[t] = xbase[t][(k0 + 16) * 4 + lane_off];   // next 4 columns
-            }
+        // K loop, two 16-dim steps per iteration with ping-pong operand registers: the loads of the
+        // next step are in flight behind the 16 NG MFMAs of the current one.  Full quads (all NG
+        // groups active) run a branch-free body, so the compiler's wait counts stay exact (with the
+        // per-group branches it falls back to vmcnt(0) in front of every MFMA group, which serialises
+        // the prefetch).
+        float4 xa[4], xb[4];
+        auto mma = [&](const float4 (&x)[4], uint32_t k0, auto full) {
             const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if ((uint32_t)g < ng) {
+                if (decltype(full)::value || (uint32_t)g < ng) {
                     const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, xc[t].x, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, xc[t].y, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, xc[t].z, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, xc[t].w, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, x[t].y, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, x[t].z, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, x[t].w, acc[g][t], 0, 0, 0);
                     }
                 }
             }
-            if (more) {
+        };
+        auto kloop = [&](auto full) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xc[t] = xnx[t];
+            for (int t = 0; t < 4; ++t) xa[t] = xbase[t][lane_off];
+            uint32_t k0 = 0;
+            for (; k0 + 32 < dim; k0 += 32) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+                mma(xa, k0, full);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xa[t] = xbase[t][(k0 + 32) * 4 + lane_off];
+                mma(xb, k0 + 16, full);
             }
-        }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+            mma(xa, k0, full);
+            mma(xb, k0 + 16, full);
+        };
+        if (ng == (uint32_t)NG) kloop(std::true_type{});
+        else kloop(std::false_type{});
 
-        // screen, ROLLED over the groups (one copy of the code and of the drain): C/D layout col
-        // j = lane & 15 (row 16 t + j of the tile), row i = kk * 4 + r (query i of group g).  After the
-        // last tile one extra pass flushes what is still queued.
 #ifdef PQV_PROFILE_PHASES
-        __builtin_amdgcn_s_waitcnt(0); const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a;
+        const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a;
 #endif
+        // Screen.  skip  <=>  lb > thr  <=>  d~ > (thr + 2 c nn) / (1 - c)  <=>  s < smin, with
+        //     smin = (nn - (thr + 2 c nn) / (1 - c)) / 2 = (alpha |q|^2 - beta thr) + alpha |x|^2
+        // (d~ = nn - 2 s; for d~ < 0 the bound is negative and never skips either way): one add and one
+        // compare of the raw accumulator per pair.  The roundings of smin (a few u nn) come out of the
+        // 4x safety factor of c (>= 64 u).  Invalid rows / queries get +inf (always skipped), an EMPTY
+        // threshold is NaN (never skipped).  C/D layout: col j = lane & 15 (row 16 t + j of the tile),
+        // row i = kk * 4 + r (query i of group g).
+        // The 64-bit keep-mask of (g, r, t) is parked in lane g*16 + r*4 + t of a register pair
+        // (v_writelane): branch-free, and the accumulators die here -- the expansion of the masks into
+        // queue entries and the exact evaluation below do not have to share registers with them.
+        float bt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
+        const float my_a = (uint32_t)lane < cnt ? alpha * my_qn - beta * my_thr_d : INFINITY;
+        uint32_t mask_lo = 0, mask_hi = 0;
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float ar = __shfl(my_a, 16 * g + kk * 4 + r, 64);
+                static_for<4>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    const unsigned long long m = __ballot(!(acc[g][t][r] < ar + bt[t]));
+                    writelane_imm<g * 16 + r * 4 + t>(mask_lo, (uint32_t)m);
+                    writelane_imm<g * 16 + r * 4 + t>(mask_hi, (uint32_t)(m >> 32));
+                });
+            });
+        });
+        const uint32_t rowbase = (uint32_t)(t0 - r0) + 16u * ((uint32_t)lane & 3u);   // + (source lane & 15)
+        const uint32_t qbase = ((uint32_t)lane >> 2) & 3u;                           // r of this lane's mask
+        // expand group by group (<= 1024 entries each) with the drain in between; after the last tile one
+        // extra pass flushes the queue
         const uint32_t gend = ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t g = 0; g < gend; ++g) {
             if (g < ng) {
-                f32x4_acc cur[4];
+                unsigned long long mm = ((uint32_t)lane >> 4) == g ? (((unsigned long long)mask_hi << 32) | mask_lo) : 0ull;
+                const uint32_t cntl = (uint32_t)__popcll(mm);
+                uint32_t incl = cntl;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) cur[t] = acc[0][t];
-#pragma unroll
-                for (int gg = 1; gg < NG; ++gg)
-                    if (g == (uint32_t)gg) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) cur[t] = acc[gg][t];
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t qi = 16 * g + (uint32_t)(kk * 4 + r);
-                    const float qn = __shfl(my_qn, (int)qi, 64);
-                    const float thr = __shfl(my_thr_d, (int)qi, 64);
-                    const bool qvalid = qi < cnt;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bool jvalid = (uint32_t)(16 * t + l15) < nvalid;
-                        const float nn = qn + xn[t];
-                        const float dt = nn - 2.0f * cur[t][r];
-                        const float lb = dt - cmargin * (2.0f * nn + fabsf(dt));
-                        const bool skip = lb > thr;            // false when the threshold is EMPTY (NaN)
-                        const bool keep = jvalid && qvalid && !skip;
-                        const unsigned long long m = __ballot(keep);
-                        if (m) {
-                            const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                            if (keep) pend[npend + before] = (qi << 26) | (uint32_t)(t0 - r0 + 16 * t + l15);
-                            npend += (uint32_t)__popcll(m);
-                        }
-                    }
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+                    if (lane >= off) incl += v;
                 }
+                uint32_t at = npend + incl - cntl;
+                while (mm) {
+                    const uint32_t L = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    pend[at++] = ((16 * g + 4 * (L >> 4) + qbase) << 26) | (rowbase + (L & 15u));
+                }
+                npend += readlane_u32(incl, 63);
             }
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
@@ -1497,11 +1535,14 @@ __global__ __launch_bounds__(256, 2) void wide_filter_kernel(const TileArgs a) {
         atomicAdd(&a.stats[0], (unsigned long long)(r1 - r0) * cnt);
         atomicAdd(&a.stats[1], (unsigned long long)n_exact);
 #ifdef PQV_PROFILE_PHASES
-        atomicAdd(&a.stats[2], (unsigned long long)(__builtin_amdgcn_s_memtime() - ph_t0));
-        atomicAdd(&a.stats[3], (unsigned long long)ph_k);
-        atomicAdd(&a.stats[4], (unsigned long long)(ph_s - ph_e));
-        atomicAdd(&a.stats[5], (unsigned long long)ph_e);
-        atomicAdd(&a.stats[6], 1ull);
+        {   // per-wave record: [start, prologue, kloop, screen, drain, end, rows, cnt] at stats[8 + 8 * wave id]
+            const unsigned long long wid = atomicAdd(&a.stats[6], 1ull);
+            if (wid < 65536ull) {
+                unsigned long long *rec = a.stats + 8 + 8 * wid;
+                rec[0] = ph_t0; rec[1] = ph_pro; rec[2] = ph_k; rec[3] = ph_s - ph_e; rec[4] = ph_e;
+                rec[5] = __builtin_amdgcn_s_memtime(); rec[6] = (unsigned long long)(r1 - r0); rec[7] = cnt | ((unsigned long long)n_exact << 32);
+            }
+        }
 #endif
     }
 }

@@ -1,0 +1,18 @@
+import numpy as np, sys
+r = np.fromfile(sys.argv[1], dtype=np.uint64)
+n = int(min(r[6], 65536)); rec = r[8:8+8*n].reshape(n, 8).astype(np.int64)
+t0 = rec[:,0].min(); start = rec[:,0]-t0; end = rec[:,5]-t0
+dur = end-start
+print("waves", n, "span", end.max(), "ticks")
+print("mean dur", dur.mean(), "prologue", rec[:,1].mean(), "kloop", rec[:,2].mean(), "screen", rec[:,3].mean(), "drain", rec[:,4].mean(), "other", (dur-rec[:,1]-rec[:,2]-rec[:,3]-rec[:,4]).mean())
+full = (rec[:,7] & 0xffffffff) == 64
+print("full quads: n", full.sum(), "dur", dur[full].mean(), "kloop", rec[full,2].mean(), "rows", rec[full,6].mean(), "evals", (rec[full,7]>>32).mean())
+# concurrency over time
+ev = np.concatenate([np.stack([start, np.ones(n)],1), np.stack([end, -np.ones(n)],1)])
+ev = ev[ev[:,0].argsort()]
+lvl = np.cumsum(ev[:,1]); tt = ev[:,0]
+tot = end.max(); 
+for f in range(10):
+    a, b = tot*f/10, tot*(f+1)/10
+    m = (tt>=a)&(tt<b)
+    print(f"  {f*10:3d}%: avg resident waves {lvl[m].mean() if m.any() else 0:.0f}")
