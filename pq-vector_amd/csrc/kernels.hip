@@ -34,6 +34,17 @@ template <int L>
 __device__ __forceinline__ void writelane_imm(uint32_t &v, uint32_t s) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
 }
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS): row_shr 1/2/4/8 inside each
+// 16-lane row, then row_bcast:15 / row_bcast:31 carry the row totals across rows
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -1266,6 +1277,8 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
     extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
     __shared__ uint32_t pend_all[4 * PEND];          // (query index << 26) | row offset from the wave's r0
     uint32_t *pend = pend_all + wave * PEND;
+    __shared__ __attribute__((aligned(16))) float aq_all[4 * 64];   // per-wave, per-query screen terms
+    float *aq = aq_all + wave * 64;
 
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
@@ -1474,48 +1487,55 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
         // 4x safety factor of c (>= 64 u).  Invalid rows / queries get +inf (always skipped), an EMPTY
         // threshold is NaN (never skipped).  C/D layout: col j = lane & 15 (row 16 t + j of the tile),
         // row i = kk * 4 + r (query i of group g).
-        // The 64-bit keep-mask of (g, r, t) is parked in lane g*16 + r*4 + t of a register pair
-        // (v_writelane): branch-free, and the accumulators die here -- the expansion of the masks into
-        // queue entries and the exact evaluation below do not have to share registers with them.
+        // Every lane collects the keep-bits of ITS 16 NG pairs (g, r, t) in one register per two groups:
+        // bits = 2 bits + keep (v_addc with the compare's carry) -- three VALU ops per pair, no
+        // branches, and the accumulators die here: the expansion of the bits into queue entries and the
+        // exact evaluation below do not have to share registers with them.
         float bt[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
-        const float my_a = (uint32_t)lane < cnt ? alpha * my_qn - beta * my_thr_d : INFINITY;
-        uint32_t mask_lo = 0, mask_hi = 0;
-        static_for<NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            static_for<4>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const float ar = __shfl(my_a, 16 * g + kk * 4 + r, 64);
-                static_for<4>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    const unsigned long long m = __ballot(!(acc[g][t][r] < ar + bt[t]));
-                    writelane_imm<g * 16 + r * 4 + t>(mask_lo, (uint32_t)m);
-                    writelane_imm<g * 16 + r * 4 + t>(mask_hi, (uint32_t)(m >> 32));
-                });
-            });
-        });
-        const uint32_t rowbase = (uint32_t)(t0 - r0) + 16u * ((uint32_t)lane & 3u);   // + (source lane & 15)
-        const uint32_t qbase = ((uint32_t)lane >> 2) & 3u;                           // r of this lane's mask
+        // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
+        // kk for each group as one 16-byte load
+        wave_lds_fence();
+        aq[lane] = (uint32_t)lane < cnt ? alpha * my_qn - beta * my_thr_d : INFINITY;
+        wave_lds_fence();
+        uint32_t bits[(NG + 1) / 2];
+#pragma unroll
+        for (int w = 0; w < (NG + 1) / 2; ++w) bits[w] = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(aq + 16 * g + 4 * kk);
+            const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bool keep = !(acc[g][t][r] < ar[r] + bt[t]);
+                    bits[g >> 1] = bits[g >> 1] + bits[g >> 1] + (keep ? 1u : 0u);
+                }
+            }
+        }
+        // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
+        const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
         // expand group by group (<= 1024 entries each) with the drain in between; after the last tile one
         // extra pass flushes the queue
         const uint32_t gend = ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t g = 0; g < gend; ++g) {
             if (g < ng) {
-                unsigned long long mm = ((uint32_t)lane >> 4) == g ? (((unsigned long long)mask_hi << 32) | mask_lo) : 0ull;
-                const uint32_t cntl = (uint32_t)__popcll(mm);
-                uint32_t incl = cntl;
+                uint32_t w = bits[0];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
-                    if (lane >= off) incl += v;
-                }
+                for (int ww = 1; ww < (NG + 1) / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? bits[ww] : w;
+                uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
+                const uint32_t cntl = (uint32_t)__popc(mm);
+                const uint32_t incl = wave_incl_scan_u32(cntl);
                 uint32_t at = npend + incl - cntl;
+                const uint32_t qb = (16 * g + 4 * (uint32_t)kk) << 26;
                 while (mm) {
-                    const uint32_t L = (uint32_t)__builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    pend[at++] = ((16 * g + 4 * (L >> 4) + qbase) << 26) | (rowbase + (L & 15u));
+                    const uint32_t b = 31u - (uint32_t)__clz(mm);        // highest set bit first
+                    mm &= ~(1u << b);
+                    const uint32_t c = 15u - b;                          // c = 4 r + t
+                    pend[at++] = qb + ((c >> 2) << 26) + rowbase + 16u * (c & 3u);
                 }
                 npend += readlane_u32(incl, 63);
             }
