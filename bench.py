@@ -43,6 +43,9 @@ WORKLOADS = {
     "c5s": (1_000_000, 1536, 0, 0, 1024),      # same, 1 M rows (quick check)
     "refbench": (1_000_000, 1024, 0, 16, 1024),  # the reference's benches/query.rs:27-31 shape; use --k 100
     "c1": (1024, 4096, 0, 5, 64),          # vldb stand-in: n_clusters = ceil(sqrt(n)) = 32
+    "c2s2": (500_000, 128, 100, 8, 1024),   # what one rank of `c2 --gpus 2/4/8` searches (tuning aid)
+    "c2s4": (250_000, 128, 100, 8, 1024),
+    "c2s8": (125_000, 128, 100, 8, 1024),
     "tiny": (20_000, 64, 16, 4, 64),       # plumbing check
 }
 K = 10
@@ -212,9 +215,13 @@ def main():
     pairs_per_cluster = nq * nprobe / max(1, int(index.n_clusters))
     tile = mode == "tile" or (mode != "stream" and pairs_per_cluster >= 4)
     mean_len = n_shard / max(1, int(index.n_clusters))
+    wide = dim % 64 == 0 and dim <= 256 and args.layout == "ivf" and os.environ.get("PQV_FILTER_VARIANT", "0") == "0"
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
-        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 32 and pairs_per_cluster >= 24 and mean_len >= 4096))
-    kernel = ("tile_rerank_kernel seed window + tile_filter_kernel (batched cluster-major re-rank, 16 queries per "
+        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 32 and pairs_per_cluster >= 24
+        and mean_len >= (1024 if wide else 4096)))
+    kernel = ("tile_rerank_kernel seed window + wide_filter_kernel (batched cluster-major re-rank, 64 queries in LDS per "
+              "streamed row tile, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened and wide
+              else "tile_rerank_kernel seed window + tile_filter_kernel (batched cluster-major re-rank, 16 queries per "
               "streamed row tile, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened
               else "tile_rerank_kernel (batched cluster-major re-rank, 16 queries per streamed row tile)" if tile
               else "stream_kernel (one candidate stream per (query, probed list))")

@@ -883,12 +883,17 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         p.rr_rows_per_block = static_cast<uint32_t>(rpb);
         // MFMA screen: the first seed_rows rows of every probed list are evaluated exactly (that
         // seeds the per-query thresholds), the rest goes through the screened kernel
-        p.seed_rows = 256;
+        static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_SEED_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
+        p.seed_rows = seed_env ? std::max<uint32_t>(64, seed_env / 64 * 64) : 256;
         // The MFMA screen pays when the 16-query tiles are mostly full and lists are long compared
         // with the exact seed window; otherwise (measured on the reference bench shape: 16 pairs per
         // cluster, 1000-row lists, 130 k vs 103 k QPS) the exact kernel alone is faster.
         const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
-        p.filter = s->tile_filter && k <= 32 && pairs >= 24ull * s->n_clusters && mean_len >= 16ull * p.seed_rows;
+        // (the wide kernel -- dim % 64 == 0, dim <= 256, IVF-ordered rows -- screens ~3x faster than the
+        //  one-group kernel and already wins at 1250-row lists: 0.28 vs 0.36 ms on a 125 k-row C2 shard)
+        const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && s->dim <= 256 && !s->d_row_of;
+        p.filter = s->tile_filter && k <= 32 && pairs >= 24ull * s->n_clusters &&
+                   mean_len >= (wide_ok ? 4ull : 16ull) * p.seed_rows;
         if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
         // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
         // multiple of 8 the blocks of ALL query groups for one row chunk share an XCD (and its L2)

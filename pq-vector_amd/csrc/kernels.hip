@@ -628,13 +628,17 @@ __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int
 template <int S>
 __device__ __forceinline__ uint64_t tile_fold(uint64_t *gkeys, uint32_t *gvals, unsigned long long *gthr,
                                               uint64_t gseen, uint64_t local_kth, uint64_t mykey,
-                                              uint32_t myval, uint32_t k, int lane) {
+                                              uint32_t myval, uint32_t k, int lane, bool fresh = false) {
     WaveTopk<S> tk;
+    tk.init();
+    if (!fresh) {       // fresh (wave-uniform): this wave has not written the list yet -- it is still the
+                        // caller's EMPTY preset, no need to wait for a load to learn that
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const uint32_t e = s * 64 + lane;
-        tk.key[s] = e < k ? gkeys[e] : KEY_EMPTY;
-        tk.val[s] = e < k ? gvals[e] : 0xFFFFFFFFu;
+        for (int s = 0; s < S; ++s) {
+            const uint32_t e = s * 64 + lane;
+            tk.key[s] = e < k ? gkeys[e] : KEY_EMPTY;
+            tk.val[s] = e < k ? gvals[e] : 0xFFFFFFFFu;
+        }
     }
     if (readlane_u64(tk.key[0], 0) == KEY_EMPTY) {
         // empty list: sort the whole tile once instead of up to 64 single inserts
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     const uint32_t my_qrow = my_pair / a.nprobe;
     const uint64_t my_cbase = a.cand_base[my_pair];
     uint64_t my_lkth = KEY_EMPTY;          // k-th key of this wave's list of query `lane`
+    bool my_touched = false;               // this wave has folded into its list of query `lane`
     // this wave's list of query `lane`: slot (q, j, chunk, wave) of the partial-list buffer
     const uint32_t n_part = a.n_part;
     const uint64_t my_base =
@@ -857,8 +862,9 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
                 const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
                                                  a.gthr + readlane_u32(my_qrow, (int)qq),
                                                  readlane_u64(my_gthr, (int)qq), readlane_u64(my_lkth, (int)qq),
-                                                 mykey, srow, k, lane);
-                if ((uint32_t)lane == qq) my_lkth = nk;
+                                                 mykey, srow, k, lane,
+                                                 ((__ballot(my_touched) >> qq) & 1ull) == 0ull);
+                if ((uint32_t)lane == qq) { my_lkth = nk; my_touched = true; }
             }
         }
         wave_lds_fence();
