@@ -169,7 +169,7 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_gthr, s_tie,
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_gthr, s_tie,
         s_replay, s_qnorm;
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
@@ -926,7 +926,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             p.rr_rows_per_block = static_cast<uint32_t>(r);
             p.slots_per_pair = 4 * p.rr_bpl;
         }
-        p.n_part_rr = p.np * p.slots_per_pair + ((p.filter && p.quad) ? 1 : 0);   // + the candidate buffer's k best
+        p.n_part_rr = p.np * p.slots_per_pair;
         p.max_quads = static_cast<uint32_t>(pairs / std::max<uint32_t>(16, p.quad_width) + std::min<uint64_t>(s->n_clusters, pairs));
         p.max_groups = static_cast<uint32_t>(pairs / pqv::TILE_QB + std::min<uint64_t>(s->n_clusters, pairs));
         return p;
@@ -992,6 +992,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     HIP_TRY(launch_merge_probe(pm, stream));
 
     // 2. candidate re-rank + per-wave top-k
+    bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
         // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
@@ -1060,15 +1061,12 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(s->s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
                 ta.cand_keys = s->s_cand_keys.as<uint64_t>(); ta.cand_vals = s->s_cand_vals.as<uint32_t>();
                 ta.cand_cnt = s->s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap;
+                HIP_TRY(s->s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+                ta.spilled = s->s_spilled.as<uint32_t>();
                 HIP_TRY(launch_cand_seed(ta.part_keys, ta.part_vals, nq, p.np, p.slots_per_pair, p.n_part_rr, k, ta.gthr,
-                                         ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, stream));
+                                         ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, ta.spilled, stream));
                 HIP_TRY(launch_tile_filter(ta, stream));
-                // the buffer's k best become partial list number np * slots_per_pair of every query
-                const uint64_t extra = static_cast<uint64_t>(p.np) * p.slots_per_pair * k;
-                HIP_TRY(launch_cand_select(ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, nq, k, ta.gthr,
-                                           ta.part_keys + extra, ta.part_vals + extra,
-                                           static_cast<uint64_t>(p.n_part_rr) * k, stream));
-                s->counters.kernel_launches += 1;
+                use_cand = true;
             } else {
                 HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.slots_per_pair, k, ta.gthr, stream));
                 HIP_TRY(launch_tile_filter(ta, stream));
@@ -1100,6 +1098,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.nq = nq; fm.n_part = p.n_part_rr; fm.k_part = k; fm.k = k;
     fm.ids = s->d_final_ids; fm.row_idx = d_row_idx; fm.dist = d_dist; fm.n_found = d_n_found;
     fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
+    if (use_cand) {
+        fm.cand_keys = s->s_cand_keys.as<uint64_t>(); fm.cand_vals = s->s_cand_vals.as<uint32_t>();
+        fm.cand_cnt = s->s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->cand_cap, k);
+        fm.spilled = s->s_spilled.as<uint32_t>();
+    }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
     HIP_TRY(hipEventRecord(s->scratch_done, stream));

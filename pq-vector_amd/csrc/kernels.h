@@ -53,6 +53,13 @@ struct MergeArgs {
     uint32_t       *n_found;     // [nq] or nullptr
     int             sqrt_out;
     uint32_t        k_out;       // results written per query (<= k); 0 => k
+    // optional extra source (wide screened path): per-query candidate buffers; with `spilled` the partial
+    // lists of a query are read only if spilled[q] != 0
+    const uint64_t *cand_keys;   // [nq][cand_cap] or nullptr
+    const uint32_t *cand_vals;
+    const uint32_t *cand_cnt;    // [nq]
+    uint32_t        cand_cap;
+    const uint32_t *spilled;     // [nq] or nullptr
     uint32_t       *tie_flag;    // [nq] or nullptr: 1 iff two of the first k_out+1 merged entries
                                  // (k_out entries + the runner-up) have equal OUTPUT distance --
                                  // then the reference's order/survivors depend on heap history
@@ -128,6 +135,7 @@ struct TileArgs {
     uint32_t       *cand_vals;
     uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
     uint32_t        cand_cap;
+    uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
     unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
     uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
@@ -151,7 +159,7 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 // [q * out_stride + e] as one more partial list for the final merge.
 hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
                             uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
-                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, hipStream_t s);
+                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t *spilled, hipStream_t s);
 hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
                               uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
                               uint64_t out_stride, hipStream_t s);

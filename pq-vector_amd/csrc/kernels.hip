@@ -401,12 +401,27 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
     const uint64_t total = (uint64_t)a.n_part * a.k_part;
     const uint64_t *pk = a.part_keys + (uint64_t)q * total;
     const uint32_t *pv = a.part_vals + (uint64_t)q * total;
-    for (uint64_t i = 0; i < total; i += 64) {
+    // with a candidate buffer the partial lists hold something only if the query overflowed it
+    const uint64_t scan = (a.cand_keys && a.spilled && a.spilled[q] == 0) ? 0 : total;
+    for (uint64_t i = 0; i < scan; i += 64) {
         const uint64_t idx = i + lane;
         uint64_t key = KEY_EMPTY;
         uint32_t val = 0xFFFFFFFFu;
-        if (idx < total) { key = pk[idx]; val = pv[idx]; }
+        if (idx < scan) { key = pk[idx]; val = pv[idx]; }
         tk.offer(key, val, a.k, lane);
+    }
+    if (a.cand_keys) {
+        uint32_t n = a.cand_cnt[q];
+        if (n > a.cand_cap) n = a.cand_cap;
+        const uint64_t *ck = a.cand_keys + (uint64_t)q * a.cand_cap;
+        const uint32_t *cv = a.cand_vals + (uint64_t)q * a.cand_cap;
+        for (uint32_t i = 0; i < n; i += 64) {
+            const uint32_t idx = i + lane;
+            uint64_t key = KEY_EMPTY;
+            uint32_t val = 0xFFFFFFFFu;
+            if (idx < n) { key = ck[idx]; val = cv[idx]; }
+            tk.offer(key, val, a.k, lane);
+        }
     }
     if constexpr (!PROBE) {
         const uint32_t k_out = a.k_out ? a.k_out : a.k;
@@ -1156,9 +1171,11 @@ template <int S>
 __global__ __launch_bounds__(64) void cand_seed_kernel(uint64_t *part_keys, uint32_t *part_vals, uint32_t nprobe,
                                                       uint32_t slots_per_pair, uint32_t n_part, uint32_t k,
                                                       unsigned long long *gthr, uint64_t *cand_keys,
-                                                      uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap) {
+                                                      uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap,
+                                                      uint32_t *spilled) {
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    if (lane == 0) spilled[q] = 0u;
     WaveTopk<S> tk;
     tk.init();
     const uint32_t total = nprobe * 4 * k;
@@ -1228,11 +1245,11 @@ __global__ __launch_bounds__(64) void cand_select_kernel(uint64_t *cand_keys, ui
 
 hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
                             uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
-                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, hipStream_t s) {
+                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t *spilled, hipStream_t s) {
     if (nq == 0) return hipSuccess;
     if (k > cap) return hipErrorInvalidValue;
-    if (k <= 64) hipLaunchKernelGGL(cand_seed_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap);
-    else if (k <= 256) hipLaunchKernelGGL(cand_seed_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap);
+    if (k <= 64) hipLaunchKernelGGL(cand_seed_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap, spilled);
+    else if (k <= 256) hipLaunchKernelGGL(cand_seed_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap, spilled);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1379,6 +1396,7 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
                 a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = srow;
             } else {
                 spill = true;          // buffer full: fall back to this wave's sorted list (slow, exact)
+                a.spilled[qrow] = 1u;
             }
         }
         unsigned long long todo = __ballot(spill);
