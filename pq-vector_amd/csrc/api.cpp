@@ -959,8 +959,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     HIP_TRY(s->s_probe.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
     HIP_TRY(s->s_cand_base.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint64_t)));
     HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(nq) * sizeof(uint64_t)));
-    HIP_TRY(s->s_part_keys.ensure(static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint64_t)));
-    HIP_TRY(s->s_part_vals.ensure(static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint32_t)));
+    HIP_TRY(s->s_part_keys.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint64_t)));
+    HIP_TRY(s->s_part_vals.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint32_t)));
 
     const bool timing = s->timing;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
@@ -980,6 +980,17 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl;
     pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;   // find_closest_centroids always uses index.rs:461
     pa.part_keys = s->s_probe_keys.as<uint64_t>(); pa.part_vals = s->s_probe_vals.as<uint32_t>();
+    const uint32_t kc_pairs = s->n_clusters;
+    uint32_t *pair_u32 = nullptr;
+    if (p.tile) {
+        // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1];
+        // the probe kernel zeroes hist + cursor, the probe merge fills hist
+        HIP_TRY(s->s_pair_u32.ensure((5ull * kc_pairs + 5) * sizeof(uint32_t)));
+        pair_u32 = s->s_pair_u32.as<uint32_t>();
+        pa.zero_u32 = pair_u32; pa.zero_n = 2 * kc_pairs;
+        HIP_TRY(s->s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
+        if (p.filter) HIP_TRY(s->s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
+    }
     HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
 
     MergeArgs pm{};
@@ -989,26 +1000,28 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pm.probe = s->s_probe.as<uint32_t>(); pm.cand_base = s->s_cand_base.as<uint64_t>();
     pm.n_cand = d_n_cand ? d_n_cand : s->s_ncand.as<uint64_t>();
     pm.max_pos = max_pos;
+    if (p.tile) {
+        pm.hist = pair_u32; pm.gthr_init = s->s_gthr.as<unsigned long long>();
+        if (p.filter) { pm.qnorm_out = s->s_qnorm.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
+    }
     HIP_TRY(launch_merge_probe(pm, stream));
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
-        // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
-        HIP_TRY(s->s_pair_u32.ensure((5ull * kc + 5) * sizeof(uint32_t)));
         HIP_TRY(s->s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
         HIP_TRY(s->s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
         HIP_TRY(s->s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
-        uint32_t *u = s->s_pair_u32.as<uint32_t>();
-        HIP_TRY(hipMemsetAsync(u, 0, 2ull * kc * sizeof(uint32_t), stream));
-        HIP_TRY(s->s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(s->s_gthr.p, 0xFF, static_cast<size_t>(nq) * sizeof(unsigned long long), stream));
+        uint32_t *u = pair_u32;
         // every partial list starts EMPTY (all-ones keys and values)
-        HIP_TRY(hipMemsetAsync(s->s_part_keys.p, 0xFF, static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint64_t), stream));
-        HIP_TRY(hipMemsetAsync(s->s_part_vals.p, 0xFF, static_cast<size_t>(nq) * p.n_part_rr * k * sizeof(uint32_t), stream));
+        {
+            const uint64_t entries = (static_cast<uint64_t>(nq) * p.n_part_rr * k + 3) / 4 * 4;    // 16-byte multiples
+            HIP_TRY(launch_fill_ones2(s->s_part_keys.p, entries * sizeof(uint64_t), s->s_part_vals.p,
+                                      entries * sizeof(uint32_t), stream));
+        }
         PairSortArgs ps{};
-        ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc;
+        ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
         ps.hist = u; ps.cursor = u + kc; ps.pair_off = u + 2ull * kc; ps.group_off = u + 3ull * kc + 1;
         ps.n_groups = u + 4ull * kc + 2;
         ps.quad_off = u + 4ull * kc + 3; ps.n_quads = u + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
@@ -1042,11 +1055,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
         }
-        if (p.filter) {
-            HIP_TRY(s->s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
-            HIP_TRY(launch_row_norms(d_queries, nq, s->dim, 1, s->s_qnorm.as<float>(), stream));
-            ta.query_norm2 = s->s_qnorm.as<float>();
-        }
+        if (p.filter) ta.query_norm2 = s->s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
         if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0

@@ -37,6 +37,9 @@ struct StreamArgs {
     uint32_t       *part_vals;
     // DIST / MINUPD output, indexed by candidate position (single-list mode)
     float          *out_f32;
+    // optional: zero_u32[0 .. zero_n) = 0 (scratch of the kernels that follow in the stream)
+    uint32_t       *zero_u32;
+    uint32_t        zero_n;
 };
 
 // Streaming exact-order squared-L2 pass (the re-rank kernel).  Returns hipError_t.
@@ -69,6 +72,13 @@ struct MergeArgs {
     uint64_t       *cand_base;   // [nq, k]
     uint64_t       *n_cand;      // [nq] or nullptr
     uint64_t        max_pos;     // cap applied to n_cand
+    // probe mode extras for the batched path (all optional): cluster histogram of the (query, probe
+    // rank) pairs (zeroed beforehand), reset of the per-query admission thresholds, |q|^2
+    uint32_t       *hist;
+    unsigned long long *gthr_init;
+    float          *qnorm_out;
+    const float    *queries;
+    uint32_t        dim;
 };
 hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s);
 hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
@@ -82,6 +92,7 @@ constexpr int TILE_QB = 16;
 struct PairSortArgs {
     const uint32_t *probe;     // [nq * nprobe] cluster of pair p = q*nprobe + j
     uint32_t        n_pairs, n_clusters;
+    int             hist_done; // 1: hist was already filled (launch_merge_probe with MergeArgs::hist)
     uint32_t       *hist;      // [n_clusters]      (zeroed by the caller)
     uint32_t       *cursor;    // [n_clusters]      (zeroed by the caller)
     uint32_t       *pair_off;  // [n_clusters + 1]
@@ -212,6 +223,9 @@ hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const lon
 // (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)
 hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                              uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s);
+
+// a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
+hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

@@ -192,6 +192,9 @@ __device__ __forceinline__ float load1_uniform(const float *p) {
 // ------------------------------------------------------------------------------------
 template <int CG, int S, int MODE, bool SEQ, bool ALIGNED>
 __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs a) {
+    if (a.zero_u32 && blockIdx.x == 0 && blockIdx.y == 0) {     // scratch the NEXT kernels expect zeroed
+        for (uint32_t i = blockIdx.z * 256 + threadIdx.x; i < a.zero_n; i += gridDim.z * 256) a.zero_u32[i] = 0u;
+    }
     constexpr int RPI = 64 / CG;        // rows per load instruction
     constexpr int NI = CG;              // load instructions per 64-row tile
     constexpr int EPL = SEQ ? 4 : 1;    // LDS values per lane item
@@ -487,10 +490,19 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
             if (e < a.k) {
                 a.probe[(uint64_t)q * a.k + e] = c;
                 a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
+                if (a.hist && have) atomicAdd(&a.hist[c], 1u);       // pair bucketing: cluster histogram
             }
             carry += readlane_u64(incl, 63);
         }
         if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
+        if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
+        if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
+            float acc = 0.0f;
+            for (uint32_t d = lane; d < a.dim; d += 64) { const float v = a.queries[(uint64_t)q * a.dim + d]; acc += v * v; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if (lane == 0) a.qnorm_out[q] = acc;
+        }
     }
 }
 
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
 hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s) {
     if (a.n_pairs == 0) return hipSuccess;
     const uint32_t blocks = (a.n_pairs + 255) / 256;
-    hipLaunchKernelGGL(pair_hist_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (!a.hist_done) hipLaunchKernelGGL(pair_hist_kernel, dim3(blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(pair_scatter_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -2018,6 +2030,27 @@ hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const u
     const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
     hipLaunchKernelGGL(block_rows_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim,
                        static_cast<float4 *>(out));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// fill_ones2_kernel: two buffers set to all-ones bytes in ONE launch (the EMPTY preset of the
+// partial-list keys and values; hipMemsetAsync costs 2-3 launches per buffer).  16 B per lane.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_ones2_kernel(uint4 *a, uint64_t na16, uint4 *b, uint64_t nb16) {
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < na16 + nb16; i += stride) {
+        if (i < na16) a[i] = ones; else b[i - na16] = ones;
+    }
+}
+hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s) {
+    if ((a_bytes | b_bytes) & 15u) return hipErrorInvalidValue;
+    const uint64_t n16 = (a_bytes + b_bytes) / 16;
+    if (n16 == 0) return hipSuccess;
+    const uint64_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(fill_ones2_kernel, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s,
+                       static_cast<uint4 *>(a), a_bytes / 16, static_cast<uint4 *>(b), b_bytes / 16);
     return hipGetLastError();
 }
 
