@@ -169,7 +169,7 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_gthr, s_tie,
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_seed_ub, s_gthr, s_tie,
         s_replay, s_qnorm;
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
@@ -851,6 +851,8 @@ struct TopkPlan {
     uint32_t max_groups;
     bool filter;            // tile path: exact seed window + MFMA-screened remainder
     uint32_t seed_rows, filter_bpl;
+    bool mfma_seed;             // wide path: thresholds from MFMA upper bounds, no exact seed pass
+    uint32_t w1_rows, w1_bpl;   // wide path: a first screened window whose survivors tighten the thresholds (0 = none)
     bool quad;              // filter: wide_filter_kernel (quad_width queries per block)
     uint32_t filter_rows_per_block, max_quads, quad_width;
     uint32_t slots_per_pair;   // partial lists per (query, probe rank)
@@ -884,6 +886,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // MFMA screen: the first seed_rows rows of every probed list are evaluated exactly (that
         // seeds the per-query thresholds), the rest goes through the screened kernel
         static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_SEED_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
+        static const uint32_t w1_env = [] { const char *e = std::getenv("PQV_W1_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
         p.seed_rows = seed_env ? std::max<uint32_t>(64, seed_env / 64 * 64) : 256;
         // The MFMA screen pays when the 16-query tiles are mostly full and lists are long compared
         // with the exact seed window; otherwise (measured on the reference bench shape: 16 pairs per
@@ -917,8 +920,23 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                                      : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
             p.filter_rows_per_block = static_cast<uint32_t>(r);
             p.rr_rows_per_block = static_cast<uint32_t>(rpb);
-            p.rr_bpl = 1 + p.filter_bpl;
-            p.slots_per_pair = 4 * (1 + p.filter_bpl);
+            // wide path, long lists: rows [seed, seed + w1) are screened first and their survivors folded,
+            // so the bulk of the list meets thresholds drawn from a (seed + w1) * nprobe sample
+            p.w1_rows = 0; p.w1_bpl = 0;
+            if (p.quad && w1_env && max_len > p.seed_rows + 3ull * w1_env) {
+                p.w1_rows = static_cast<uint32_t>((w1_env + r - 1) / r * r);
+                p.w1_bpl = static_cast<uint32_t>(p.w1_rows / r);
+                p.filter_bpl = static_cast<uint32_t>((max_len - p.seed_rows - p.w1_rows + r - 1) / r);
+            }
+            p.rr_bpl = 1 + p.w1_bpl + p.filter_bpl;
+            p.slots_per_pair = 4 * (1 + p.w1_bpl + p.filter_bpl);
+            static const bool mfma_seed_env = [] { const char *e = std::getenv("PQV_MFMA_SEED"); return !(e && *e == '0'); }();
+            p.mfma_seed = p.quad && mfma_seed_env && !p.w1_rows;
+            if (p.mfma_seed) {          // the screened pass covers the whole list; the seed rows are only sampled
+                p.filter_bpl = static_cast<uint32_t>((max_len + r - 1) / r);
+                p.rr_bpl = p.filter_bpl;
+                p.slots_per_pair = 4 * p.filter_bpl;
+            }
         } else {
             uint64_t r = rpb;
             p.filter_bpl = 0;
@@ -1057,9 +1075,32 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         }
         if (p.filter) ta.query_norm2 = s->s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
-        if (p.filter) {
+        if (p.filter && p.mfma_seed) {
+            const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
+            HIP_TRY(s->s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
+            HIP_TRY(s->s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
+            HIP_TRY(s->s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+            HIP_TRY(s->s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+            ta.cand_keys = s->s_cand_keys.as<uint64_t>(); ta.cand_vals = s->s_cand_vals.as<uint32_t>();
+            ta.cand_cnt = s->s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = s->s_spilled.as<uint32_t>();
+            // thresholds: upper bounds of the first seed_rows rows of every probed list
+            TileArgs seed = ta;
+            seed.row_offset = 0; seed.row_end = p.seed_rows; seed.rows_per_block = 256;
+            seed.grid_x = (p.seed_rows + 255) / 256; seed.seed_sw = 4 * seed.grid_x;
+            const uint32_t n_vals = p.np * seed.seed_sw * 16;
+            HIP_TRY(s->s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
+            seed.seed_ub = s->s_seed_ub.as<float>();
+            HIP_TRY(launch_wide_seed(seed, stream));
+            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream));
+            ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
+            ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
+            HIP_TRY(launch_tile_filter(ta, stream));
+            use_cand = true;
+            s->counters.kernel_launches += 3;
+        } else if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
-            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.rows_per_block = p.seed_rows;
+            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows;
+            seed.rows_per_block = std::max<uint32_t>(256, p.seed_rows);     // one 64-row tile per wave at least
             HIP_TRY(launch_tile_rerank(seed, stream));
             ta.row_offset = p.seed_rows; ta.slot_base = 4; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = p.quad ? 0 : 1;
@@ -1074,6 +1115,14 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ta.spilled = s->s_spilled.as<uint32_t>();
                 HIP_TRY(launch_cand_seed(ta.part_keys, ta.part_vals, nq, p.np, p.slots_per_pair, p.n_part_rr, k, ta.gthr,
                                          ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, ta.spilled, stream));
+                if (p.w1_rows) {
+                    TileArgs w1 = ta;
+                    w1.grid_x = p.w1_bpl; w1.row_end = p.seed_rows + p.w1_rows;
+                    HIP_TRY(launch_tile_filter(w1, stream));
+                    HIP_TRY(launch_cand_select(ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, nq, k, ta.gthr, nullptr, nullptr, 0, stream));
+                    ta.row_offset = p.seed_rows + p.w1_rows; ta.slot_base = 4 + 4 * p.w1_bpl;
+                    s->counters.kernel_launches += 2;
+                }
                 HIP_TRY(launch_tile_filter(ta, stream));
                 use_cand = true;
             } else {

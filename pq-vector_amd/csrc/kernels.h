@@ -130,6 +130,7 @@ struct TileArgs {
     // rows_per_block).  Partial-list slots: a (query, probe rank j) pair owns slots_per_pair
     // lists; block bx of this launch writes slots slot_base + bx * 4 + wave (one list per wave)
     uint64_t        row_offset;
+    uint64_t        row_end;     // 0 = none: rows at list offsets >= row_end belong to a later launch
     uint32_t        slots_per_pair, slot_base;
     uint32_t        n_part;      // partial lists per query in part_keys (>= nprobe * slots_per_pair)
     uint32_t        grid_x;      // gridDim.x of this launch
@@ -147,6 +148,9 @@ struct TileArgs {
     uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
     uint32_t        cand_cap;
     uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
+    // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
+    float          *seed_ub;
+    uint32_t        seed_sw;
     unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
     uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
@@ -174,6 +178,13 @@ hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t n
 hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
                               uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
                               uint64_t out_stride, hipStream_t s);
+
+// Thresholds of the wide screened pass from MFMA upper bounds (no exact seed pass): launch_wide_seed over
+// the first rows of every list fills TileArgs::seed_ub, launch_seed_select turns a query's n_vals =
+// nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
+hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
+hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:

@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
     uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
+    if (a.row_end && r1 > a.row_end) r1 = a.row_end;     // window of this launch
     if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
@@ -940,6 +941,7 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
     uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
+    if (a.row_end && r1 > a.row_end) r1 = a.row_end;     // window of this launch
     if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
@@ -1276,6 +1278,194 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 }
 
 // ------------------------------------------------------------------------------------
+// wide_seed_kernel<NG>: admission thresholds for the wide screened pass WITHOUT an exact pass.
+//
+// For the first rows of every probed list the 16 NG x 64 score blocks are computed exactly like in
+// wide_filter_kernel; d~ + c (2 nn + |d~|) is then a rigorous UPPER bound of the reference's d2 (the
+// mirror image of the screen's lower bound).  Every lane keeps the minimum upper bound of the rows
+// it sees for each of its queries: lanes (and waves, lists) see DISJOINT rows, so the k-th smallest
+// of a query's minima (seed_select_kernel) is the upper bound of k distinct candidates' distances
+// -- a valid admission threshold, within the margin of the k-th smallest exact distance of the
+// sample.  The sample rows themselves are screened and evaluated by the main pass like all others.
+// Output: seed_ub[((qrow * nprobe + j) * seed_sw + blockIdx.x * 4 + wave) * 16 + (lane & 15)].
+// ------------------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
+    constexpr uint32_t NQ = 16 * NG;
+    const uint32_t bx = blockIdx.x;
+    if (blockIdx.y >= *a.n_quads) return;
+    const uint4 quad = a.quads[blockIdx.y];
+    const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
+    const uint32_t ng = (cnt + 15) >> 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    extern __shared__ float4 qs[];
+    __shared__ __attribute__((aligned(16))) float qn_all[4 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t lim_all[4 * 64];
+    float *qnl = qn_all + wave * 64;
+    uint32_t *liml = lim_all + wave * 64;
+
+    const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
+    const uint64_t len = lend - lbeg;
+    const uint64_t wrows = a.rows_per_block / 4;
+    uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows;
+    if (r1 > len) r1 = len;
+    if (a.row_end && r1 > a.row_end) r1 = a.row_end;
+    if (r0 > r1) r0 = r1;
+
+    const uint32_t dim = a.dim;
+    const uint32_t G = dim >> 2;
+    const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+
+    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
+    const uint32_t my_pair = a.pairs[my_slot];
+    const uint32_t my_qrow = my_pair / a.nprobe;
+    const uint64_t my_cbase = a.cand_base[my_pair];
+    // list offsets below my_lim are candidates of this query (max_candidates cap)
+    const uint64_t room = a.max_pos > my_cbase ? a.max_pos - my_cbase : 0;
+    qnl[lane] = a.query_norm2[my_qrow];
+    liml[lane] = (uint32_t)lane < cnt ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
+    {
+        constexpr uint32_t TPQ = 256 / NQ;
+        const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
+        const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
+        float4 *dst = qs + q * G;
+        const uint32_t sw = q & 15u;
+#pragma unroll 8
+        for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+    }
+    __syncthreads();
+
+    const int l15 = lane & 15, kk = lane >> 4;
+    const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
+    const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;
+    float mins[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mins[g][r] = INFINITY;
+
+    for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+        const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+        const float4 *xbase[4];
+        float xn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t rr = (uint32_t)(16 * t + l15);
+            if (rr >= nvalid) rr = nvalid - 1;
+            xn[t] = a.row_norm2[lbeg + t0 + rr];
+            uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
+            if (T > blk_last) T = blk_last;
+            xbase[t] = a.mat_blk + T * G * 16;
+        }
+        f32x4_acc acc[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+        for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+            float4 x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = xbase[t][k0 * 4 + lane_off];
+            const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if ((uint32_t)g < ng) {
+                    const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, x[t].y, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, x[t].z, acc[g][t], 0, 0, 0);
+                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, x[t].w, acc[g][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(qnl + 16 * g + 4 * kk);
+            const uint4 l4 = *reinterpret_cast<const uint4 *>(liml + 16 * g + 4 * kk);
+            const float qn[4] = {q4.x, q4.y, q4.z, q4.w};
+            const uint32_t lim[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t roff = (uint32_t)t0 + (uint32_t)(16 * t + l15);     // list offset (< 2^32 rows per list)
+                    const bool valid = (uint32_t)(16 * t + l15) < nvalid && roff < lim[r];
+                    const float nn = qn[r] + xn[t];
+                    const float dt = nn - 2.0f * acc[g][t][r];
+                    const float ub = dt + cmargin * (2.0f * nn + fabsf(dt));
+                    if (valid) mins[g][r] = fminf(mins[g][r], ub);                     // NaN bounds are ignored
+                }
+            }
+        }
+    }
+    // publish: one value per (query, this wave, lane & 15)
+    const uint32_t my_j = my_pair % a.nprobe;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t qi = (uint32_t)(16 * g + kk * 4 + r);
+            const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qi, 64);
+            const uint32_t j = (uint32_t)__shfl((int)my_j, (int)qi, 64);
+            if (qi < cnt)
+                a.seed_ub[(((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15] = fmaxf(mins[g][r], 0.0f);
+        }
+    }
+}
+
+// gthr[q] = key of the k-th smallest of q's n_vals upper bounds (none if fewer than k are finite); also
+// resets the query's candidate buffer and overflow flag.  One wave per query.
+template <int S>
+__global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
+                                                        unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    WaveTopk<S> tk;
+    tk.init();
+    for (uint32_t i = 0; i < n_vals; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        if (idx < n_vals) {
+            const float v = seed_ub[(uint64_t)q * n_vals + idx];
+            if (v < INFINITY) key = ((uint64_t)__float_as_uint(v) << 32) | idx;
+        }
+        tk.offer(key, 0u, k, lane);
+    }
+    const uint64_t kth = tk.kth(k);
+    if (lane == 0) {
+        cand_cnt[q] = 0u;
+        spilled[q] = 0u;
+        // every candidate whose distance is <= the bound must pass (key compare is on (d2, position))
+        if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)(kth | 0xFFFFFFFFull));
+    }
+}
+hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
+    if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
+    if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
+    const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+    if (a.quad_width == 64 && lds4 <= 32768)
+        hipLaunchKernelGGL((wide_seed_kernel<4>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+    else if (a.quad_width == 32 && lds2 <= 32768)
+        hipLaunchKernelGGL((wide_seed_kernel<2>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled);
+    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // wide_filter_kernel<NG, S>: the MFMA-screened re-rank with NG 16-query groups (a "quad" of up
 // to 16 NG queries of one cluster) per block.
 //
@@ -1321,6 +1511,7 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
     uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
+    if (a.row_end && r1 > a.row_end) r1 = a.row_end;     // window of this launch
     if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
