@@ -77,6 +77,8 @@ def main():
                     help="initialise RCCL and run the shard exchange even with one rank (path check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU (path check only; the real run uses RCCL)")
+    ap.add_argument("--no-timing", action="store_true",
+                    help="do not record HIP events around the kernels (roofline.kernel_ms is then 0)")
     ap.add_argument("--single", type=int, default=0,
                     help="also time this many single-query calls (latency mode) and report them")
     args = ap.parse_args()
@@ -190,7 +192,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    searcher.set_timing(True)
+    searcher.set_timing(not args.no_timing)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_d, out_r = step()
