@@ -217,7 +217,7 @@ def main():
     pairs_per_cluster = nq * nprobe / max(1, int(index.n_clusters))
     tile = mode == "tile" or (mode != "stream" and pairs_per_cluster >= 4)
     mean_len = n_shard / max(1, int(index.n_clusters))
-    wide = dim % 64 == 0 and dim <= 256 and args.layout == "ivf" and os.environ.get("PQV_FILTER_VARIANT", "0") == "0"
+    wide = dim % 64 == 0 and args.layout == "ivf" and os.environ.get("PQV_FILTER_VARIANT", "0") == "0"
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
         os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 32 and pairs_per_cluster >= 24
         and mean_len >= (1024 if wide else 4096)))

@@ -169,7 +169,7 @@ struct pqv_searcher {
     // scratch (guarded by mu)
     mutable std::mutex mu;
     mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_seed_ub, s_gthr, s_tie,
+        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_seed_ub, s_qblk, s_gthr, s_tie,
         s_replay, s_qnorm;
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
@@ -894,7 +894,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
         // (the wide kernel -- dim % 64 == 0, dim <= 256, IVF-ordered rows -- screens ~3x faster than the
         //  one-group kernel and already wins at 1250-row lists: 0.28 vs 0.36 ms on a 125 k-row C2 shard)
-        const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && s->dim <= 256 && !s->d_row_of;
+        const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && !s->d_row_of;
         p.filter = s->tile_filter && k <= 32 && pairs >= 24ull * s->n_clusters &&
                    mean_len >= (wide_ok ? 4ull : 16ull) * p.seed_rows;
         if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
@@ -913,7 +913,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         if (p.filter) {
             // wide kernel: 64 (dim <= 128) or 32 (dim <= 256) queries per block, staged in LDS
             const int variant = s->filter_variant;
-            p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : s->dim <= 256 ? 32 : 0;
+            p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : 32;     // dim > 256: queries from a blocked global copy
             p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
             uint64_t r = rpb;
             p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
@@ -1072,6 +1072,13 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             }
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
+            if (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768) {
+                // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
+                HIP_TRY(s->s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
+                HIP_TRY(launch_pack_queries(d_queries, ps.pairs, ps.quads, ps.n_quads, p.max_quads, p.np, s->dim,
+                                            p.quad_width / 16, s->s_qblk.p, stream));
+                ta.q_blk = static_cast<const float4 *>(s->s_qblk.p);
+            }
         }
         if (p.filter) ta.query_norm2 = s->s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));

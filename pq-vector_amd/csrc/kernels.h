@@ -139,6 +139,8 @@ struct TileArgs {
     // MFMA filter only: squared norms of the storage rows / of the queries
     const float4   *mat_blk;     // wide_filter_kernel: blocked copy of the IVF-ordered lists (launch_block_rows)
     const uint64_t *blk_off;     // [n_clusters + 1] first 16-row tile of every list in mat_blk
+    const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad
+                                 // (launch_pack_queries), [max_quads][quad_width / 16][dim / 4][16] float4
     const float    *row_norm2;   // indexed like mat rows
     const float    *query_norm2; // [nq]
     int             xcd_swizzle; // 1: XCD-aware workgroup remap (speed only)
@@ -234,6 +236,10 @@ hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const lon
 // (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)
 hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                              uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s);
+
+// blocked copy of every quad's queries (see TileArgs::q_blk); ngrp = quad_width / 16
+hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, const uint4 *quads, const uint32_t *n_quads,
+                               uint32_t max_quads, uint32_t nprobe, uint32_t dim, uint32_t ngrp, void *q_blk, hipStream_t s);
 
 // a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
 hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);

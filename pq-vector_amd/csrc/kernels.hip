@@ -1289,7 +1289,7 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 // sample.  The sample rows themselves are screened and evaluated by the main pass like all others.
 // Output: seed_ub[((qrow * nprobe + j) * seed_sw + blockIdx.x * 4 + wave) * 16 + (lane & 15)].
 // ------------------------------------------------------------------------------------
-template <int NG>
+template <int NG, bool QLDS>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr uint32_t NQ = 16 * NG;
     const uint32_t bx = blockIdx.x;
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const uint64_t room = a.max_pos > my_cbase ? a.max_pos - my_cbase : 0;
     qnl[lane] = a.query_norm2[my_qrow];
     liml[lane] = (uint32_t)lane < cnt ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
-    {
+    if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
@@ -1336,7 +1336,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 #pragma unroll 8
         for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
     }
-    __syncthreads();
+    __syncthreads();      // also orders the qnl / liml writes above
+    const float4 *qblk = a.q_blk + (uint64_t)blockIdx.y * NG * G * 16;
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
@@ -1373,7 +1374,9 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if ((uint32_t)g < ng) {
-                    const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+                    float4 qc;
+                    if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+                    else qc = qblk[(uint32_t)g * G * 16 + k0 * 4 + lane_off];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
@@ -1450,9 +1453,11 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
     if (a.quad_width == 64 && lds4 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<4>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<4, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
     else if (a.quad_width == 32 && lds2 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<2>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<2, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+    else if (a.quad_width == 32 && a.q_blk)
+        hipLaunchKernelGGL((wide_seed_kernel<2, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1482,7 +1487,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // Requires dim % 64 == 0 (swizzle closure), 16 NG * dim * 4 bytes of LDS, the IVF-ordered layout
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
-template <int NG, int S>
+template <int NG, int S, bool QLDS>
 __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 1024 + 64;
@@ -1531,9 +1536,11 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
     const uint64_t my_base =
         ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
 
-    // stage the quad's queries: 256 / NQ threads per query, 16-byte columns interleaved between them; the
-    // row pointer comes from the lane-parallel state (queries past cnt alias the last one, masked later)
-    {
+    // QLDS: stage the quad's queries: 256 / NQ threads per query, 16-byte columns interleaved between them;
+    // the row pointer comes from the lane-parallel state (queries past cnt alias the last one, masked later).
+    // !QLDS (rows too long for LDS): the A operands come from the quad's BLOCKED query copy in global
+    // memory (pack_queries_kernel; L2-resident), fetched like the B operands -- 1 KiB per load.
+    if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
@@ -1541,8 +1548,9 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
         const uint32_t sw = q & 15u;
 #pragma unroll 8
         for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+        __syncthreads();
     }
-    __syncthreads();
+    const float4 *qblk = a.q_blk + (uint64_t)blockIdx.y * NG * G * 16;   // + (g G + ch) 16 + query-in-group
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;   // the list's 16-row tiles
@@ -1561,17 +1569,24 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const float *x = a.mat + (uint64_t)srow * dim;
-        const float4 *ql = qs + qsl * G;              // the pair's query, staged (swizzled) in LDS
+        const float4 *ql = qs + qsl * G;              // QLDS: the pair's query, staged (swizzled) in LDS
         const uint32_t qsw = qsl & 15u;
+        const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
         float sum = 0.0f;
         // 8 row chunks in flight per lane, then the reference's ordered chain over them
         for (uint32_t g = 0; g < G; g += 8) {
             float4 xv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = load4<true>(x + (g + u) * 4);
+            float4 qvv[8];
+            if constexpr (!QLDS) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) qvv[u] = qg[g + u];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float4 qv = ql[(g + u) ^ qsw];
+                float4 qv;
+                if constexpr (QLDS) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
                 const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
                 const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
                 float t = d0 * d0 + d1 * d1;
@@ -1701,7 +1716,49 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
             mma(xa, k0, full);
             mma(xb, k0 + 16, full);
         };
-        if (ng == (uint32_t)NG) kloop(std::true_type{});
+        // !QLDS: both operands stream from global memory with the same ping-pong
+        auto kloop_gq = [&]() {
+            float4 qa[NG], qbb[NG];
+            auto mmag = [&](const float4 (&x)[4], const float4 (&q)[NG]) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if ((uint32_t)g < ng) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].x, x[t].x, acc[g][t], 0, 0, 0);
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].y, x[t].y, acc[g][t], 0, 0, 0);
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].z, x[t].z, acc[g][t], 0, 0, 0);
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].w, x[t].w, acc[g][t], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[t] = xbase[t][lane_off];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) qa[g] = qblk[(uint32_t)g * G * 16 + lane_off];
+            uint32_t k0 = 0;
+            for (; k0 + 32 < dim; k0 += 32) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) qbb[g] = qblk[(uint32_t)g * G * 16 + (k0 + 16) * 4 + lane_off];
+                mmag(xa, qa);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xa[t] = xbase[t][(k0 + 32) * 4 + lane_off];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) qa[g] = qblk[(uint32_t)g * G * 16 + (k0 + 32) * 4 + lane_off];
+                mmag(xb, qbb);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) qbb[g] = qblk[(uint32_t)g * G * 16 + (k0 + 16) * 4 + lane_off];
+            mmag(xa, qa);
+            mmag(xb, qbb);
+        };
+        if constexpr (!QLDS) kloop_gq();
+        else if (ng == (uint32_t)NG) kloop(std::true_type{});
         else kloop(std::false_type{});
 
 #ifdef PQV_PROFILE_PHASES
@@ -1841,9 +1898,11 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
         if (a.quad_width == 64 && lds4 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<4, S>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<4, S, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
         else if (a.quad_width == 32 && lds2 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<2, S>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<2, S, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+        else if (a.quad_width == 32 && a.q_blk)
+            hipLaunchKernelGGL((wide_filter_kernel<2, S, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -2221,6 +2280,36 @@ hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const u
     const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
     hipLaunchKernelGGL(block_rows_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim,
                        static_cast<float4 *>(out));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pack_queries_kernel: the blocked (MFMA A-operand) copy of every quad's queries, for rows too long
+// for LDS staging: q_blk[((quad * NG + g) * G + ch) * 16 + i] = 16-byte column ch of query 16 g + i
+// of the quad (queries past the quad's count alias its last one; they are masked by the kernels).
+// grid = max_quads blocks.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_queries_kernel(const float *__restrict__ queries, const uint32_t *__restrict__ pairs,
+                                                          const uint4 *__restrict__ quads, const uint32_t *__restrict__ n_quads,
+                                                          uint32_t nprobe, uint32_t dim, uint32_t ngrp,
+                                                          float4 *__restrict__ q_blk) {
+    if (blockIdx.x >= *n_quads) return;
+    const uint4 quad = quads[blockIdx.x];
+    const uint32_t p0 = quad.y, cnt = quad.z, G = dim >> 2;
+    float4 *dst = q_blk + (uint64_t)blockIdx.x * ngrp * G * 16;
+    const uint32_t total = ngrp * G * 16;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t i = e & 15u, ch = (e >> 4) % G, g = (e >> 4) / G;
+        const uint32_t q = 16 * g + i;
+        const uint32_t qrow = pairs[p0 + (q < cnt ? q : cnt - 1)] / nprobe;
+        dst[e] = *reinterpret_cast<const float4 *>(queries + (uint64_t)qrow * dim + ch * 4);
+    }
+}
+hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, const uint4 *quads, const uint32_t *n_quads,
+                               uint32_t max_quads, uint32_t nprobe, uint32_t dim, uint32_t ngrp, void *q_blk, hipStream_t s) {
+    if (max_quads == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(max_quads), dim3(256), 0, s, queries, pairs, quads, n_quads, nprobe, dim, ngrp,
+                       static_cast<float4 *>(q_blk));
     return hipGetLastError();
 }
 

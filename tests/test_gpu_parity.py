@@ -581,6 +581,8 @@ def test_brute_rejects_bad_arguments(pqv):
     (16000, 64, 6, 32, 3, 130),      # k = 32: the largest k the screen takes by default
     (9000, 192, 4, 5, 2, 77),        # dim % 64 == 0 but not a power of two; partial quads
     (12000, 96, 5, 10, 3, 100),      # dim % 64 != 0: one 16-query group per block (tile_filter_kernel)
+    (9000, 768, 4, 10, 3, 90),       # long rows: wide kernel with the queries in a blocked global copy
+    (8000, 320, 4, 7, 2, 70),        # same, dim / 64 odd
 ])
 @pytest.mark.parametrize("variant", ["default", "tiny_buffer", "narrow"])
 def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, nprobe, nq, variant):
