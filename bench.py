@@ -221,8 +221,9 @@ def main():
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
         os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 32 and pairs_per_cluster >= 24
         and mean_len >= (1024 if wide else 4096)))
-    kernel = ("tile_rerank_kernel seed window + wide_filter_kernel (batched cluster-major re-rank, 64 queries in LDS per "
-              "streamed row tile, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened and wide
+    kernel = ("wide_seed_kernel (MFMA upper-bound thresholds) + wide_filter_kernel (batched cluster-major re-rank, "
+              + ("64 queries staged in LDS" if dim <= 128 else "32 queries per quad") + " per streamed row tile from the blocked "
+              "copy, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened and wide
               else "tile_rerank_kernel seed window + tile_filter_kernel (batched cluster-major re-rank, 16 queries per "
               "streamed row tile, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened
               else "tile_rerank_kernel (batched cluster-major re-rank, 16 queries per streamed row tile)" if tile

@@ -946,6 +946,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         }
         p.n_part_rr = p.np * p.slots_per_pair;
         p.max_quads = static_cast<uint32_t>(pairs / std::max<uint32_t>(16, p.quad_width) + std::min<uint64_t>(s->n_clusters, pairs));
+        p.max_quads = (p.max_quads + 7) / 8 * 8;       // quad_xcd_remap
         p.max_groups = static_cast<uint32_t>(pairs / pqv::TILE_QB + std::min<uint64_t>(s->n_clusters, pairs));
         return p;
     }
@@ -1072,6 +1073,10 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             }
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
+            // quad-to-XCD affinity (PQV_QUAD_XCD=0/1 overrides): on by default for the global-query variant,
+            // whose per-quad operand copies must stay L2-resident
+            static const int quad_xcd_env = [] { const char *e = std::getenv("PQV_QUAD_XCD"); return e ? std::atoi(e) : -1; }();
+            ta.xcd_swizzle = quad_xcd_env >= 0 ? quad_xcd_env : (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768 ? 1 : 0);
             if (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
                 HIP_TRY(s->s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
@@ -1106,7 +1111,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             s->counters.kernel_launches += 3;
         } else if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
-            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows;
+            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows; seed.xcd_swizzle = xcd_swz;
             seed.rows_per_block = std::max<uint32_t>(256, p.seed_rows);     // one 64-row tile per wave at least
             HIP_TRY(launch_tile_rerank(seed, stream));
             ta.row_offset = p.seed_rows; ta.slot_base = 4; ta.grid_x = p.filter_bpl;

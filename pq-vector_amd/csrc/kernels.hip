@@ -612,6 +612,16 @@ hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s) {
 // XCD i the i-th CONTIGUOUS slice of the (chunk-fastest) block space puts the blocks of
 // consecutive query groups -- the groups of one cluster -- on one XCD, so a row chunk fetched
 // for one group is an L2 hit for the next.  Placement only affects speed, never results.
+// Quad-to-XCD affinity for the wide kernels: workgroup L runs on XCD L % 8; give XCD i the quads
+// i, i + 8, i + 16, ... with all their row chunks, so the blocks that share a quad's operands (its
+// blocked queries, its cluster's rows) also share an L2.  gridDim.y must be a multiple of 8.
+__device__ __forceinline__ void quad_xcd_remap(uint32_t &bx, uint32_t &by, int enable) {
+    if (!enable) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = L & 7u, i = L >> 3;
+    bx = i % gridDim.x;
+    by = (i / gridDim.x) * 8 + xcd;
+}
 __device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by, int enable) {
     if (!enable) { bx = blockIdx.x; by = blockIdx.y; return; }
     const uint32_t nwg = gridDim.x * gridDim.y;
@@ -1292,9 +1302,10 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 template <int NG, bool QLDS>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr uint32_t NQ = 16 * NG;
-    const uint32_t bx = blockIdx.x;
-    if (blockIdx.y >= *a.n_quads) return;
-    const uint4 quad = a.quads[blockIdx.y];
+    uint32_t bx, by;
+    quad_xcd_remap(bx, by, a.xcd_swizzle);
+    if (by >= *a.n_quads) return;
+    const uint4 quad = a.quads[by];
     const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
     const uint32_t ng = (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
@@ -1337,7 +1348,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
     }
     __syncthreads();      // also orders the qnl / liml writes above
-    const float4 *qblk = a.q_blk + (uint64_t)blockIdx.y * NG * G * 16;
+    const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
@@ -1495,9 +1506,10 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
 #ifdef PQV_PROFILE_PHASES
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    const uint32_t bx = blockIdx.x;
-    if (blockIdx.y >= *a.n_quads) return;
-    const uint4 quad = a.quads[blockIdx.y];          // {cluster, first pair slot, pair count <= NQ, 0}
+    uint32_t bx, by;
+    quad_xcd_remap(bx, by, a.xcd_swizzle);
+    if (by >= *a.n_quads) return;
+    const uint4 quad = a.quads[by];          // {cluster, first pair slot, pair count <= NQ, 0}
     const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
     const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
     const int lane = threadIdx.x & 63;
@@ -1550,7 +1562,7 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
         for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
         __syncthreads();
     }
-    const float4 *qblk = a.q_blk + (uint64_t)blockIdx.y * NG * G * 16;   // + (g G + ch) 16 + query-in-group
+    const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;   // the list's 16-row tiles
@@ -1716,9 +1728,21 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
             mma(xa, k0, full);
             mma(xb, k0 + 16, full);
         };
-        // !QLDS: both operands stream from global memory with the same ping-pong
+        // !QLDS: both operands stream from global memory through THREE rotating register stages, so the
+        // loads of K step s + 2 are issued before the MFMAs of step s (HBM latency is ~2 K steps of a
+        // wave that shares the matrix pipe).  Indices past the last step are clamped: branch-free, the
+        // compiler's wait counts stay exact.
         auto kloop_gq = [&]() {
-            float4 qa[NG], qbb[NG];
+            const uint32_t nks = dim >> 4;
+            float4 x0[4], x1[4], x2[4], q0[NG], q1[NG], q2[NG];
+            auto ld = [&](float4 (&x)[4], float4 (&q)[NG], uint32_t ks) {
+                const uint32_t kc = ks < nks ? ks : nks - 1;
+                const uint32_t off = kc * 64 + lane_off;             // 16 dims = 4 columns = 64 float4
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[t] = xbase[t][off];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) q[g] = qblk[(uint32_t)g * G * 16 + off];
+            };
             auto mmag = [&](const float4 (&x)[4], const float4 (&q)[NG]) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -1733,29 +1757,16 @@ __global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
                     }
                 }
             };
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xa[t] = xbase[t][lane_off];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) qa[g] = qblk[(uint32_t)g * G * 16 + lane_off];
-            uint32_t k0 = 0;
-            for (; k0 + 32 < dim; k0 += 32) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) qbb[g] = qblk[(uint32_t)g * G * 16 + (k0 + 16) * 4 + lane_off];
-                mmag(xa, qa);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) xa[t] = xbase[t][(k0 + 32) * 4 + lane_off];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) qa[g] = qblk[(uint32_t)g * G * 16 + (k0 + 32) * 4 + lane_off];
-                mmag(xb, qbb);
+            ld(x0, q0, 0);
+            ld(x1, q1, 1);
+            uint32_t ks = 0;
+            for (; ks + 3 <= nks; ks += 3) {
+                ld(x2, q2, ks + 2); mmag(x0, q0);
+                ld(x0, q0, ks + 3); mmag(x1, q1);
+                ld(x1, q1, ks + 4); mmag(x2, q2);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) qbb[g] = qblk[(uint32_t)g * G * 16 + (k0 + 16) * 4 + lane_off];
-            mmag(xa, qa);
-            mmag(xb, qbb);
+            if (ks < nks) mmag(x0, q0);
+            if (ks + 1 < nks) mmag(x1, q1);
         };
         if constexpr (!QLDS) kloop_gq();
         else if (ng == (uint32_t)NG) kloop(std::true_type{});
