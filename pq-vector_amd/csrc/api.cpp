@@ -153,6 +153,18 @@ struct pqv_corpus {
     }
 };
 
+// Per-call device scratch of a searcher (see pqv_searcher::lanes).
+constexpr int PQV_LANES = 2;
+struct Scratch {
+    DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
+        s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm;
+    hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
+    hipStream_t stream = nullptr;   // the stream of that call
+    bool used = false;
+    ~Scratch() { if (done) (void)hipEventDestroy(done); }
+};
+
 struct pqv_searcher {
     int device = 0;
     uint32_t dim = 0, n_clusters = 0;
@@ -166,29 +178,34 @@ struct pqv_searcher {
     const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout)
     const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout)
     hipStream_t stream = nullptr;
-    // scratch (guarded by mu)
+    // scratch (guarded by mu): PQV_LANES independent sets, one per stream in use, so calls enqueued on
+    // different streams overlap on the GPU (the tail of one batch's screen kernel is filled by the next
+    // batch's probe / bucketing / seed kernels) instead of serialising on shared buffers
     mutable std::mutex mu;
-    mutable DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys,
-        s_part_vals, s_queries, s_rows, s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, d_mat_blk, d_blk_off, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled, s_seed_ub, s_qblk, s_gthr, s_tie,
-        s_replay, s_qnorm;
+    mutable Scratch lanes[PQV_LANES];
+    mutable uint32_t lane_rr = 0;
+    mutable DevBuf d_mat_blk, d_blk_off;   // blocked MFMA-operand copy of the lists (built on first use)
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
     uint32_t cand_cap = 2048;              // PQV_CAND_CAP: candidate-buffer entries per query of the wide screened path
     int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
-    // the scratch above is reused by every call: a call on another stream first waits for the
-    // previous call's kernels (event recorded at the end of each enqueue)
-    mutable hipEvent_t scratch_done = nullptr;
-    mutable hipStream_t scratch_stream = nullptr;
     mutable pqv_counters_t counters{};
     // timing
     mutable bool timing = false;
     mutable std::vector<hipEvent_t> ev;    // triples: probe-start, rerank-start, rerank-stop, end
     ~pqv_searcher() {
         for (auto e : ev) (void)hipEventDestroy(e);
-        if (scratch_done) (void)hipEventDestroy(scratch_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+// The scratch lane of a call on `stream`: the lane that stream used last, else a free one, else the
+// least recently assigned one (the caller then waits for that lane's previous call).
+static Scratch &lane_for(const pqv_searcher *s, hipStream_t stream) {
+    for (auto &l : s->lanes) if (l.used && l.stream == stream) return l;
+    for (auto &l : s->lanes) if (!l.used) return l;
+    return s->lanes[s->lane_rr++ % PQV_LANES];
+}
 
 // ---------------------------------------------------------------------------------------
 // misc
@@ -970,16 +987,17 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     using namespace pqv;
     const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
-    if (!s->scratch_done) HIP_TRY(hipEventCreateWithFlags(&s->scratch_done, hipEventDisableTiming));
-    if (s->scratch_stream && s->scratch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->scratch_done, 0));
+    Scratch &sc = lane_for(s, stream);
+    if (!sc.done) HIP_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    if (sc.used && sc.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sc.done, 0));
 
-    HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
-    HIP_TRY(s->s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
-    HIP_TRY(s->s_probe.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
-    HIP_TRY(s->s_cand_base.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint64_t)));
-    HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(nq) * sizeof(uint64_t)));
-    HIP_TRY(s->s_part_keys.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint64_t)));
-    HIP_TRY(s->s_part_vals.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint32_t)));
+    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
+    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
+    HIP_TRY(sc.s_probe.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
+    HIP_TRY(sc.s_cand_base.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint64_t)));
+    HIP_TRY(sc.s_ncand.ensure(static_cast<size_t>(nq) * sizeof(uint64_t)));
+    HIP_TRY(sc.s_part_keys.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint64_t)));
+    HIP_TRY(sc.s_part_vals.ensure((static_cast<size_t>(nq) * p.n_part_rr * k + 4) * sizeof(uint32_t)));
 
     const bool timing = s->timing;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
@@ -998,17 +1016,17 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pa.queries = d_queries; pa.nq = nq; pa.nprobe = 1; pa.dim = s->dim; pa.k = p.np;
     pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl;
     pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;   // find_closest_centroids always uses index.rs:461
-    pa.part_keys = s->s_probe_keys.as<uint64_t>(); pa.part_vals = s->s_probe_vals.as<uint32_t>();
+    pa.part_keys = sc.s_probe_keys.as<uint64_t>(); pa.part_vals = sc.s_probe_vals.as<uint32_t>();
     const uint32_t kc_pairs = s->n_clusters;
     uint32_t *pair_u32 = nullptr;
     if (p.tile) {
         // u32 scratch: hist[kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1];
         // the probe kernel zeroes hist + cursor, the probe merge fills hist
-        HIP_TRY(s->s_pair_u32.ensure((5ull * kc_pairs + 5) * sizeof(uint32_t)));
-        pair_u32 = s->s_pair_u32.as<uint32_t>();
+        HIP_TRY(sc.s_pair_u32.ensure((5ull * kc_pairs + 5) * sizeof(uint32_t)));
+        pair_u32 = sc.s_pair_u32.as<uint32_t>();
         pa.zero_u32 = pair_u32; pa.zero_n = 2 * kc_pairs;
-        HIP_TRY(s->s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
-        if (p.filter) HIP_TRY(s->s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
+        HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
+        if (p.filter) HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
     }
     HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
 
@@ -1016,12 +1034,12 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals;
     pm.nq = nq; pm.n_part = p.n_part_probe; pm.k_part = p.np; pm.k = p.np;
     pm.list_off = s->d_list_off.as<uint64_t>();
-    pm.probe = s->s_probe.as<uint32_t>(); pm.cand_base = s->s_cand_base.as<uint64_t>();
-    pm.n_cand = d_n_cand ? d_n_cand : s->s_ncand.as<uint64_t>();
+    pm.probe = sc.s_probe.as<uint32_t>(); pm.cand_base = sc.s_cand_base.as<uint64_t>();
+    pm.n_cand = d_n_cand ? d_n_cand : sc.s_ncand.as<uint64_t>();
     pm.max_pos = max_pos;
     if (p.tile) {
-        pm.hist = pair_u32; pm.gthr_init = s->s_gthr.as<unsigned long long>();
-        if (p.filter) { pm.qnorm_out = s->s_qnorm.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
+        pm.hist = pair_u32; pm.gthr_init = sc.s_gthr.as<unsigned long long>();
+        if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
     }
     HIP_TRY(launch_merge_probe(pm, stream));
 
@@ -1029,33 +1047,33 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
-        HIP_TRY(s->s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
-        HIP_TRY(s->s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
-        HIP_TRY(s->s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
+        HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
+        HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
+        HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
         uint32_t *u = pair_u32;
         // every partial list starts EMPTY (all-ones keys and values)
         {
             const uint64_t entries = (static_cast<uint64_t>(nq) * p.n_part_rr * k + 3) / 4 * 4;    // 16-byte multiples
-            HIP_TRY(launch_fill_ones2(s->s_part_keys.p, entries * sizeof(uint64_t), s->s_part_vals.p,
+            HIP_TRY(launch_fill_ones2(sc.s_part_keys.p, entries * sizeof(uint64_t), sc.s_part_vals.p,
                                       entries * sizeof(uint32_t), stream));
         }
         PairSortArgs ps{};
-        ps.probe = s->s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
+        ps.probe = sc.s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
         ps.hist = u; ps.cursor = u + kc; ps.pair_off = u + 2ull * kc; ps.group_off = u + 3ull * kc + 1;
         ps.n_groups = u + 4ull * kc + 2;
         ps.quad_off = u + 4ull * kc + 3; ps.n_quads = u + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
-        ps.pairs = s->s_pairs.as<uint32_t>(); ps.groups = s->s_groups.as<uint4>(); ps.quads = s->s_quads.as<uint4>();
+        ps.pairs = sc.s_pairs.as<uint32_t>(); ps.groups = sc.s_groups.as<uint4>(); ps.quads = sc.s_quads.as<uint4>();
         HIP_TRY(launch_pair_sort(ps, stream));
         TileArgs ta{};
         ta.mat = s->d_mat; ta.row_of = s->d_row_of; ta.list_off = s->d_list_off.as<uint64_t>();
-        ta.queries = d_queries; ta.cand_base = s->s_cand_base.as<uint64_t>();
+        ta.queries = d_queries; ta.cand_base = sc.s_cand_base.as<uint64_t>();
         ta.pairs = ps.pairs; ta.groups = ps.groups; ta.n_groups = ps.n_groups; ta.max_groups = p.max_groups;
         ta.nq = nq; ta.nprobe = p.np; ta.dim = s->dim; ta.k = k;
         ta.quads = ps.quads; ta.n_quads = ps.n_quads; ta.max_quads = p.max_quads; ta.quad_width = p.quad_width;
         ta.rows_per_block = p.rr_rows_per_block; ta.blocks_per_list = p.rr_bpl; ta.max_pos = max_pos;
         ta.slots_per_pair = p.slots_per_pair; ta.slot_base = 0; ta.n_part = p.n_part_rr;
-        ta.gthr = s->s_gthr.as<unsigned long long>();
-        ta.part_keys = s->s_part_keys.as<uint64_t>(); ta.part_vals = s->s_part_vals.as<uint32_t>();
+        ta.gthr = sc.s_gthr.as<unsigned long long>();
+        ta.part_keys = sc.s_part_keys.as<uint64_t>(); ta.part_vals = sc.s_part_vals.as<uint32_t>();
         ta.row_norm2 = s->d_row_norm2.as<float>();
         ta.stats = s->d_stats.as<unsigned long long>();
         static const int xcd_swz = [] { const char *e = std::getenv("PQV_XCD_SWIZZLE"); return (e && *e == '1') ? 1 : 0; }();   // measured: no gain on C2, -30 % on C3
@@ -1070,6 +1088,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
                 HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                           (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+                HIP_TRY(hipStreamSynchronize(stream));      // one-off; calls on other streams may follow at once
             }
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
@@ -1079,29 +1098,29 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.xcd_swizzle = quad_xcd_env >= 0 ? quad_xcd_env : (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768 ? 1 : 0);
             if (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
-                HIP_TRY(s->s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
+                HIP_TRY(sc.s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
                 HIP_TRY(launch_pack_queries(d_queries, ps.pairs, ps.quads, ps.n_quads, p.max_quads, p.np, s->dim,
-                                            p.quad_width / 16, s->s_qblk.p, stream));
-                ta.q_blk = static_cast<const float4 *>(s->s_qblk.p);
+                                            p.quad_width / 16, sc.s_qblk.p, stream));
+                ta.q_blk = static_cast<const float4 *>(sc.s_qblk.p);
             }
         }
-        if (p.filter) ta.query_norm2 = s->s_qnorm.as<float>();     // filled by the probe merge
+        if (p.filter) ta.query_norm2 = sc.s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
         if (p.filter && p.mfma_seed) {
             const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
-            HIP_TRY(s->s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
-            HIP_TRY(s->s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
-            HIP_TRY(s->s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-            HIP_TRY(s->s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-            ta.cand_keys = s->s_cand_keys.as<uint64_t>(); ta.cand_vals = s->s_cand_vals.as<uint32_t>();
-            ta.cand_cnt = s->s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = s->s_spilled.as<uint32_t>();
+            HIP_TRY(sc.s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
+            HIP_TRY(sc.s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
+            HIP_TRY(sc.s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+            HIP_TRY(sc.s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+            ta.cand_keys = sc.s_cand_keys.as<uint64_t>(); ta.cand_vals = sc.s_cand_vals.as<uint32_t>();
+            ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = sc.s_spilled.as<uint32_t>();
             // thresholds: upper bounds of the first seed_rows rows of every probed list
             TileArgs seed = ta;
             seed.row_offset = 0; seed.row_end = p.seed_rows; seed.rows_per_block = 256;
             seed.grid_x = (p.seed_rows + 255) / 256; seed.seed_sw = 4 * seed.grid_x;
             const uint32_t n_vals = p.np * seed.seed_sw * 16;
-            HIP_TRY(s->s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
-            seed.seed_ub = s->s_seed_ub.as<float>();
+            HIP_TRY(sc.s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
+            seed.seed_ub = sc.s_seed_ub.as<float>();
             HIP_TRY(launch_wide_seed(seed, stream));
             HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
@@ -1118,13 +1137,13 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = p.quad ? 0 : 1;
             if (p.quad) {
                 const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
-                HIP_TRY(s->s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
-                HIP_TRY(s->s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
-                HIP_TRY(s->s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-                ta.cand_keys = s->s_cand_keys.as<uint64_t>(); ta.cand_vals = s->s_cand_vals.as<uint32_t>();
-                ta.cand_cnt = s->s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap;
-                HIP_TRY(s->s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-                ta.spilled = s->s_spilled.as<uint32_t>();
+                HIP_TRY(sc.s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
+                HIP_TRY(sc.s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
+                HIP_TRY(sc.s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+                ta.cand_keys = sc.s_cand_keys.as<uint64_t>(); ta.cand_vals = sc.s_cand_vals.as<uint32_t>();
+                ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap;
+                HIP_TRY(sc.s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
+                ta.spilled = sc.s_spilled.as<uint32_t>();
                 HIP_TRY(launch_cand_seed(ta.part_keys, ta.part_vals, nq, p.np, p.slots_per_pair, p.n_part_rr, k, ta.gthr,
                                          ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, ta.spilled, stream));
                 if (p.w1_rows) {
@@ -1151,11 +1170,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     }
     StreamArgs ra{};
     ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
-    ra.probe = s->s_probe.as<uint32_t>(); ra.cand_base = s->s_cand_base.as<uint64_t>();
+    ra.probe = sc.s_probe.as<uint32_t>(); ra.cand_base = sc.s_cand_base.as<uint64_t>();
     ra.queries = d_queries; ra.nq = nq; ra.nprobe = p.np; ra.dim = s->dim; ra.k = k;
     ra.rows_per_block = p.rr_rows_per_block; ra.blocks_per_list = p.rr_bpl;
     ra.max_pos = max_pos; ra.metric = metric;
-    ra.part_keys = s->s_part_keys.as<uint64_t>(); ra.part_vals = s->s_part_vals.as<uint32_t>();
+    ra.part_keys = sc.s_part_keys.as<uint64_t>(); ra.part_vals = sc.s_part_vals.as<uint32_t>();
     if (!p.tile) {
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
@@ -1169,14 +1188,14 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.ids = s->d_final_ids; fm.row_idx = d_row_idx; fm.dist = d_dist; fm.n_found = d_n_found;
     fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
     if (use_cand) {
-        fm.cand_keys = s->s_cand_keys.as<uint64_t>(); fm.cand_vals = s->s_cand_vals.as<uint32_t>();
-        fm.cand_cnt = s->s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->cand_cap, k);
-        fm.spilled = s->s_spilled.as<uint32_t>();
+        fm.cand_keys = sc.s_cand_keys.as<uint64_t>(); fm.cand_vals = sc.s_cand_vals.as<uint32_t>();
+        fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->cand_cap, k);
+        fm.spilled = sc.s_spilled.as<uint32_t>();
     }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
-    HIP_TRY(hipEventRecord(s->scratch_done, stream));
-    s->scratch_stream = stream;
+    HIP_TRY(hipEventRecord(sc.done, stream));
+    sc.stream = stream; sc.used = true;
     s->counters.kernel_launches += 4;
     return PQV_OK;
 }
@@ -1248,8 +1267,9 @@ int replay_query_exact(const pqv_searcher *s, const float *d_query, uint32_t qi,
                        uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
                        uint32_t *n_found) {
     using namespace pqv;
+    Scratch &sc = lane_for(s, s->stream);
     std::vector<uint32_t> clusters(np);
-    HIP_TRY(hipMemcpyAsync(clusters.data(), s->s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
+    HIP_TRY(hipMemcpyAsync(clusters.data(), sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
                            np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     uint64_t total = 0;
@@ -1257,17 +1277,17 @@ int replay_query_exact(const pqv_searcher *s, const float *d_query, uint32_t qi,
     const uint64_t use = max_candidates ? std::min<uint64_t>(total, max_candidates) : total;
     std::vector<float> d(std::max<uint64_t>(1, total));
     if (total) {
-        HIP_TRY(s->s_replay.ensure(total * sizeof(float)));
+        HIP_TRY(sc.s_replay.ensure(total * sizeof(float)));
         StreamArgs ra{};
         ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
-        ra.probe = s->s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np;
-        ra.cand_base = s->s_cand_base.as<uint64_t>() + static_cast<size_t>(qi) * np;
+        ra.probe = sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np;
+        ra.cand_base = sc.s_cand_base.as<uint64_t>() + static_cast<size_t>(qi) * np;
         ra.queries = d_query; ra.nq = 1; ra.nprobe = np; ra.dim = s->dim; ra.k = 1;
         ra.rows_per_block = 1024;
         ra.blocks_per_list = static_cast<uint32_t>((std::max<uint64_t>(1, s->max_list_len) + 1023) / 1024);
-        ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = s->s_replay.as<float>();
+        ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = sc.s_replay.as<float>();
         HIP_TRY(launch_stream(ra, STREAM_DIST, s->stream));
-        HIP_TRY(hipMemcpyAsync(d.data(), s->s_replay.p, total * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(d.data(), sc.s_replay.p, total * sizeof(float), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     std::vector<HeapEnt> heap;
@@ -1332,36 +1352,37 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     // One extra merged entry (the runner-up) lets the merge kernel see ties at the k-th
     // distance; queries it flags are replayed through the exact heap (replay_query_exact).
     const uint32_t k_int = k < 1024 ? k + 1 : k;
+    Scratch &sc = lane_for(s, s->stream);
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
     const TopkPlan p1 = plan_topk(s, 1, nprobe, k_int, metric);
     const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + 1;
     uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / per_query)));
-    HIP_TRY(s->s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));
-    HIP_TRY(s->s_rows.ensure(static_cast<size_t>(batch) * k * sizeof(uint32_t)));
-    HIP_TRY(s->s_dist.ensure(static_cast<size_t>(batch) * k * sizeof(float)));
-    HIP_TRY(s->s_nfound.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
-    HIP_TRY(s->s_ncand.ensure(static_cast<size_t>(batch) * sizeof(uint64_t)));
-    HIP_TRY(s->s_tie.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
+    HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));
+    HIP_TRY(sc.s_rows.ensure(static_cast<size_t>(batch) * k * sizeof(uint32_t)));
+    HIP_TRY(sc.s_dist.ensure(static_cast<size_t>(batch) * k * sizeof(float)));
+    HIP_TRY(sc.s_nfound.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
+    HIP_TRY(sc.s_ncand.ensure(static_cast<size_t>(batch) * sizeof(uint64_t)));
+    HIP_TRY(sc.s_tie.ensure(static_cast<size_t>(batch) * sizeof(uint32_t)));
     std::vector<uint64_t> h_ncand(batch);
     std::vector<uint32_t> h_tie(batch), h_nf(batch);
     const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
     for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
         const uint32_t b = std::min<uint32_t>(batch, nq - q0);
-        HIP_TRY(hipMemcpyAsync(s->s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
+        HIP_TRY(hipMemcpyAsync(sc.s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
                                static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
-        if (int rc = enqueue_topk(s, s->s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
-                                  sqrt_out, s->s_rows.as<uint32_t>(), s->s_dist.as<float>(),
-                                  s->s_nfound.as<uint32_t>(), nullptr, s->s_tie.as<uint32_t>(), s->stream))
+        if (int rc = enqueue_topk(s, sc.s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
+                                  sqrt_out, sc.s_rows.as<uint32_t>(), sc.s_dist.as<float>(),
+                                  sc.s_nfound.as<uint32_t>(), nullptr, sc.s_tie.as<uint32_t>(), s->stream))
             return rc;
-        HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, s->s_rows.p,
+        HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, sc.s_rows.p,
                                static_cast<size_t>(b) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, s->s_dist.p,
+        HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, sc.s_dist.p,
                                static_cast<size_t>(b) * k * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(h_nf.data(), s->s_nfound.p, static_cast<size_t>(b) * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(h_nf.data(), sc.s_nfound.p, static_cast<size_t>(b) * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(h_tie.data(), s->s_tie.p, static_cast<size_t>(b) * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(h_tie.data(), sc.s_tie.p, static_cast<size_t>(b) * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(h_ncand.data(), s->s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
+        HIP_TRY(hipMemcpyAsync(h_ncand.data(), sc.s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         for (uint32_t i = 0; i < b; ++i) {
@@ -1371,7 +1392,7 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
             if (n_candidates) n_candidates[q0 + i] = h_ncand[i];
             if (h_tie[i]) {
                 // tied output distances: survivors / order follow Rust's heap mechanics exactly
-                if (int rc = replay_query_exact(s, s->s_queries.as<float>() + static_cast<size_t>(i) * s->dim, i, np,
+                if (int rc = replay_query_exact(s, sc.s_queries.as<float>() + static_cast<size_t>(i) * s->dim, i, np,
                                                 k, max_candidates, metric, sqrt_out,
                                                 row_idx + static_cast<uint64_t>(q0 + i) * k,
                                                 dist + static_cast<uint64_t>(q0 + i) * k, &h_nf[i]))
@@ -1403,28 +1424,29 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     using namespace pqv;
+    Scratch &sc = lane_for(s, s->stream);
     const TopkPlan p = plan_topk(s, 1, nprobe);
-    HIP_TRY(s->s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
-    HIP_TRY(s->s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint64_t)));
-    HIP_TRY(s->s_probe_vals.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint32_t)));
-    HIP_TRY(s->s_probe.ensure(static_cast<size_t>(np) * sizeof(uint32_t)));
-    HIP_TRY(s->s_cand_base.ensure(static_cast<size_t>(np) * sizeof(uint64_t)));
-    HIP_TRY(s->s_ncand.ensure(sizeof(uint64_t)));
-    HIP_TRY(hipMemcpyAsync(s->s_queries.p, query, static_cast<size_t>(s->dim) * sizeof(float),
+    HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
+    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint64_t)));
+    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint32_t)));
+    HIP_TRY(sc.s_probe.ensure(static_cast<size_t>(np) * sizeof(uint32_t)));
+    HIP_TRY(sc.s_cand_base.ensure(static_cast<size_t>(np) * sizeof(uint64_t)));
+    HIP_TRY(sc.s_ncand.ensure(sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(sc.s_queries.p, query, static_cast<size_t>(s->dim) * sizeof(float),
                            hipMemcpyHostToDevice, s->stream));
     StreamArgs pa{};
     pa.mat = s->d_centroids.as<float>(); pa.single_begin = 0; pa.single_end = s->n_clusters;
-    pa.queries = s->s_queries.as<float>(); pa.nq = 1; pa.nprobe = 1; pa.dim = s->dim; pa.k = np;
+    pa.queries = sc.s_queries.as<float>(); pa.nq = 1; pa.nprobe = 1; pa.dim = s->dim; pa.k = np;
     pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl; pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;
-    pa.part_keys = s->s_probe_keys.as<uint64_t>(); pa.part_vals = s->s_probe_vals.as<uint32_t>();
+    pa.part_keys = sc.s_probe_keys.as<uint64_t>(); pa.part_vals = sc.s_probe_vals.as<uint32_t>();
     HIP_TRY(launch_stream(pa, STREAM_TOPK, s->stream));
     MergeArgs pm{};
     pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals; pm.nq = 1; pm.n_part = p.n_part_probe;
     pm.k_part = np; pm.k = np; pm.list_off = s->d_list_off.as<uint64_t>();
-    pm.probe = s->s_probe.as<uint32_t>(); pm.cand_base = s->s_cand_base.as<uint64_t>();
-    pm.n_cand = s->s_ncand.as<uint64_t>(); pm.max_pos = ~0ull;
+    pm.probe = sc.s_probe.as<uint32_t>(); pm.cand_base = sc.s_cand_base.as<uint64_t>();
+    pm.n_cand = sc.s_ncand.as<uint64_t>(); pm.max_pos = ~0ull;
     HIP_TRY(launch_merge_probe(pm, s->stream));
-    HIP_TRY(hipMemcpyAsync(clusters_out, s->s_probe.p, static_cast<size_t>(np) * sizeof(uint32_t),
+    HIP_TRY(hipMemcpyAsync(clusters_out, sc.s_probe.p, static_cast<size_t>(np) * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (n_out) *n_out = np;

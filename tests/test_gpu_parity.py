@@ -679,3 +679,35 @@ def test_merge_topk_device_matches_stable_sort(pqv):
         torch.cuda.synchronize()
         assert torch.equal(out_d, want_d), (w, nq, k)
         assert torch.equal(out_r, want_r), (w, nq, k)
+
+
+def test_calls_on_two_streams_use_independent_scratch(pqv, oracle):
+    """pqv_topk_device calls enqueued on two streams overlap on the GPU (one scratch lane per stream);
+    interleaved calls with DIFFERENT query batches must each return their own exact result."""
+    import torch
+    rng = np.random.default_rng(99)
+    n, dim, kc, k, nprobe, nq = 40000, 128, 16, 10, 4, 256
+    data, oidx = _random_index(oracle, rng, n, dim, kc)
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+    batches = [rng.random((nq, dim), dtype=np.float32) for _ in range(4)]
+    want = [oidx.topk_batch(data, q, k, nprobe) for q in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    q_t = [torch.from_numpy(q).cuda() for q in batches]
+    outs = []
+    torch.cuda.synchronize()
+    for rep in range(3):                       # 12 calls in flight, alternating streams
+        for i, q in enumerate(q_t):
+            st = streams[i % 2]
+            rows = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+            dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            nf = torch.empty((nq,), dtype=torch.int32, device="cuda")
+            with torch.cuda.stream(st):
+                s.topk_device(q.data_ptr(), nq, k, nprobe, rows.data_ptr(), dist.data_ptr(), nf.data_ptr(),
+                              stream=st.cuda_stream)
+            outs.append((i, rows, dist, nf))
+    torch.cuda.synchronize()
+    for i, rows, dist, nf in outs:
+        orows, odist, onf, _ = want[i]
+        got = (rows.cpu().numpy().view(np.uint32), dist.cpu().numpy(), nf.cpu().numpy().view(np.uint32))
+        _assert_topk_equal(got, (orows, odist, onf), k)
