@@ -711,3 +711,29 @@ def test_calls_on_two_streams_use_independent_scratch(pqv, oracle):
         orows, odist, onf, _ = want[i]
         got = (rows.cpu().numpy().view(np.uint32), dist.cpu().numpy(), nf.cpu().numpy().view(np.uint32))
         _assert_topk_equal(got, (orows, odist, onf), k)
+
+
+@pytest.mark.parametrize("dim", [64, 128, 320])
+def test_screened_path_unbalanced_lists(pqv, oracle, monkeypatch, dim):
+    """One huge dense cluster plus tiny and (possibly) empty ones, every list probed: the wide screened
+    kernels must cope with lists shorter than a tile / than the seed window next to 20 k-row lists."""
+    rng = np.random.default_rng(1234 + dim)
+    n_dense, n_sparse, kc, k, nq = 24000, 400, 12, 10, 96
+    dense = (0.5 + 0.02 * rng.standard_normal((n_dense, dim))).astype(np.float32)
+    sparse = (rng.random((n_sparse, dim)) * 4.0 - 1.5).astype(np.float32)
+    data = np.concatenate([dense, sparse])[rng.permutation(n_dense + n_sparse)]
+    oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=4)
+    lens = np.diff(oidx.list_off.astype(np.int64))
+    assert lens.max() > 5000 and lens.min() < 200, lens
+    queries = np.concatenate([(0.5 + 0.02 * rng.standard_normal((nq // 2, dim))).astype(np.float32),
+                              (rng.random((nq // 2, dim)) * 4.0 - 1.5).astype(np.float32)])
+    corpus = pqv.Corpus.upload(data)
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+    for nprobe in (kc, 3):
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all()
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+    assert s.counters()["screened_pairs"] > 0
