@@ -496,15 +496,137 @@ namespace {
 
 // Stable counting sort of rows by cluster == the reference's "ascending row ids per
 // cluster" (index.rs:193-206).
-void lists_from_assignment(const uint32_t *cluster_of, uint64_t n, uint32_t k,
+// false if an assignment is out of range (a kernel bug must surface as an error, not as host memory corruption)
+bool lists_from_assignment(const uint32_t *cluster_of, uint64_t n, uint32_t k,
                            std::vector<uint64_t> &off, std::vector<uint32_t> &rows) {
+    for (uint64_t r = 0; r < n; ++r) if (cluster_of[r] >= k) return false;
     off.assign(static_cast<size_t>(k) + 1, 0);
     for (uint64_t r = 0; r < n; ++r) off[cluster_of[r] + 1]++;
     for (uint32_t c = 0; c < k; ++c) off[c + 1] += off[c];
     rows.resize(n);
     std::vector<uint64_t> cur(off.begin(), off.end() - 1);
     for (uint64_t r = 0; r < n; ++r) rows[cur[cluster_of[r]]++] = static_cast<uint32_t>(r);
+    return true;
 }
+
+// ---------------------------------------------------------------------------------------
+// MFMA-screened assignment (index.rs:395-430 Lloyd assign, :189-206 + :244-257 final assignment).
+// cluster[r] = argmin_j d2(x_r, c_j), strict '<' in ascending j, is the top-1 of row r among the
+// centroids under the key (d2 bits, j) -- exactly what the wide screened search computes with the
+// rows as queries and one list holding all centroids: thresholds from MFMA upper bounds of the first
+// centroids (wide_seed_kernel), MFMA lower-bound screen of all of them, exact re-evaluation of the few
+// survivors in the reference's summation order (wide_filter_kernel), top-1 merge.  The exact VALU
+// kernel (assign_kernel) remains for dim % 64 != 0, for fewer than 512 centroids and for rows or
+// centroids with a non-finite norm (NaN ordering is the reference's `<`, not the key order).
+// ---------------------------------------------------------------------------------------
+struct ScreenedAssign {
+    uint32_t dim = 0, kc = 0, width = 0, chunk_q = 0, rpb = 0, bpl = 0, max_quads = 0, ccap = 32;
+    const float *d_centroids = nullptr;
+    DevBuf cblk, cnorm, list_off, blk_off, flag;
+    DevBuf qnorm, pairs, quads, nq_u32, cand_base, gthr, part_keys, part_vals, cand_keys, cand_vals, cand_cnt, spilled,
+        seed_ub, qblk, dist_out, nfound;
+
+    static bool applicable(uint32_t dim, uint32_t kc) {
+        // PQV_ASSIGN_SCREEN=0 disables, =N (N > 1) sets the smallest centroid count that takes this path
+        const char *e = std::getenv("PQV_ASSIGN_SCREEN");
+        const long v = e ? std::strtol(e, nullptr, 10) : 512;
+        return v != 0 && (dim % 64) == 0 && kc >= static_cast<uint32_t>(v > 1 ? v : 512);
+    }
+    // (re)load the centroids: blocked copy + norms; returns 1 in *nonfinite if a centroid norm is inf / NaN
+    int set_centroids(const float *d_c, uint32_t k, uint32_t d, hipStream_t stream, bool *nonfinite) {
+        using namespace pqv;
+        dim = d; kc = k; d_centroids = d_c;
+        width = dim <= 128 ? 64 : 32;
+        chunk_q = 65536;
+        rpb = 1024; bpl = (kc + rpb - 1) / rpb;
+        max_quads = (chunk_q / width + 7) / 8 * 8;
+        const uint64_t tiles = (static_cast<uint64_t>(kc) + 15) / 16;
+        const uint64_t h_off[2] = {0, kc}, h_blk[2] = {0, tiles};
+        HIP_TRY(list_off.ensure(sizeof h_off)); HIP_TRY(blk_off.ensure(sizeof h_blk)); HIP_TRY(flag.ensure(sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(list_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(blk_off.p, h_blk, sizeof h_blk, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));          // the two host arrays above are stack-allocated
+        HIP_TRY(cblk.ensure(tiles * 16 * dim * sizeof(float)));
+        HIP_TRY(cnorm.ensure(static_cast<size_t>(kc) * sizeof(float)));
+        HIP_TRY(launch_block_rows(d_c, list_off.as<uint64_t>(), blk_off.as<uint64_t>(), 1, tiles, dim, cblk.p, stream));
+        HIP_TRY(launch_row_norms(d_c, kc, dim, 1, cnorm.as<float>(), stream));
+        return check_finite(cnorm.as<float>(), kc, stream, nonfinite);
+    }
+    int check_finite(const float *v, uint64_t n, hipStream_t stream, bool *nonfinite) {
+        uint32_t h = 0;
+        HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), stream));
+        HIP_TRY(pqv::launch_nonfinite_flag(v, n, flag.as<uint32_t>(), stream));
+        HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *nonfinite = h != 0;
+        return PQV_OK;
+    }
+    // cluster[0 .. n) for rows d_rows[0 .. n); *fallback = true if a row norm is not finite (nothing written)
+    int run(const float *d_rows, uint64_t n, uint32_t *d_cluster, hipStream_t stream, bool *fallback) {
+        using namespace pqv;
+        *fallback = false;
+        HIP_TRY(qnorm.ensure(static_cast<size_t>(n) * sizeof(float)));
+        HIP_TRY(launch_row_norms(d_rows, n, dim, 1, qnorm.as<float>(), stream));
+        bool bad = false;
+        if (int rc = check_finite(qnorm.as<float>(), n, stream, &bad)) return rc;
+        if (bad) { *fallback = true; return PQV_OK; }
+        static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_ASSIGN_SEED"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 256u; }();
+        const uint32_t k = 1, slots = 4 * bpl, seed_rows = std::max<uint32_t>(64, seed_env / 64 * 64), seed_sw = 4;
+        HIP_TRY(pairs.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(quads.ensure(static_cast<size_t>(max_quads) * sizeof(uint4)));
+        HIP_TRY(nq_u32.ensure(16)); HIP_TRY(cand_base.ensure(static_cast<size_t>(chunk_q) * 8));
+        HIP_TRY(gthr.ensure(static_cast<size_t>(chunk_q) * 8));
+        const uint64_t entries = (static_cast<uint64_t>(chunk_q) * slots * k + 3) / 4 * 4;
+        HIP_TRY(part_keys.ensure((entries + 4) * 8)); HIP_TRY(part_vals.ensure((entries + 4) * 4));
+        HIP_TRY(cand_keys.ensure(static_cast<size_t>(chunk_q) * ccap * 8)); HIP_TRY(cand_vals.ensure(static_cast<size_t>(chunk_q) * ccap * 4));
+        HIP_TRY(cand_cnt.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(spilled.ensure(static_cast<size_t>(chunk_q) * 4));
+        HIP_TRY(seed_ub.ensure(static_cast<size_t>(chunk_q) * seed_sw * 16 * 4));
+        HIP_TRY(dist_out.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(nfound.ensure(static_cast<size_t>(chunk_q) * 4));
+        const bool qlds = static_cast<uint64_t>(width) * dim * sizeof(float) <= 32768;
+        if (!qlds) HIP_TRY(qblk.ensure(static_cast<size_t>(max_quads) * width * dim * sizeof(float)));
+        for (uint64_t r0 = 0; r0 < n; r0 += chunk_q) {
+            const uint32_t nq = static_cast<uint32_t>(std::min<uint64_t>(chunk_q, n - r0));
+            const float *q = d_rows + r0 * dim;
+            HIP_TRY(launch_assign_setup(pairs.as<uint32_t>(), quads.as<uint4>(), nq_u32.as<uint32_t>(), cand_base.as<uint64_t>(),
+                                        gthr.as<unsigned long long>(), nq, width, stream));
+            HIP_TRY(launch_fill_ones2(part_keys.p, entries * 8, part_vals.p, entries * 4, stream));
+            TileArgs ta{};
+            ta.mat = d_centroids; ta.row_of = nullptr; ta.list_off = list_off.as<uint64_t>();
+            ta.queries = q; ta.cand_base = cand_base.as<uint64_t>(); ta.pairs = pairs.as<uint32_t>();
+            ta.quads = quads.as<uint4>(); ta.n_quads = nq_u32.as<uint32_t>(); ta.max_quads = max_quads; ta.quad_width = width;
+            ta.max_groups = max_quads;          // only its being non-zero matters to the launcher
+            ta.nq = nq; ta.nprobe = 1; ta.dim = dim; ta.k = k;
+            ta.rows_per_block = rpb; ta.blocks_per_list = bpl; ta.max_pos = ~0ull;
+            ta.slots_per_pair = slots; ta.slot_base = 0; ta.n_part = slots;
+            ta.gthr = gthr.as<unsigned long long>();
+            ta.part_keys = part_keys.as<uint64_t>(); ta.part_vals = part_vals.as<uint32_t>();
+            ta.mat_blk = static_cast<const float4 *>(cblk.p); ta.blk_off = blk_off.as<uint64_t>();
+            ta.row_norm2 = cnorm.as<float>(); ta.query_norm2 = qnorm.as<float>() + r0;
+            ta.cand_keys = cand_keys.as<uint64_t>(); ta.cand_vals = cand_vals.as<uint32_t>();
+            ta.cand_cnt = cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = spilled.as<uint32_t>();
+            ta.xcd_swizzle = qlds ? 0 : 1;
+            if (!qlds) {
+                HIP_TRY(launch_pack_queries(q, ta.pairs, ta.quads, ta.n_quads, max_quads, 1, dim, width / 16, qblk.p, stream));
+                ta.q_blk = static_cast<const float4 *>(qblk.p);
+            }
+            TileArgs seed = ta;
+            seed.row_offset = 0; seed.row_end = seed_rows; seed.rows_per_block = 256; seed.grid_x = 1;
+            seed.seed_sw = seed_sw; seed.seed_ub = seed_ub.as<float>();
+            HIP_TRY(launch_wide_seed(seed, stream));
+            HIP_TRY(launch_seed_select(seed.seed_ub, nq, seed_sw * 16, k, ta.gthr, ta.cand_cnt, ta.spilled, stream));
+            ta.row_offset = 0; ta.grid_x = bpl; ta.filter_variant = 0;
+            HIP_TRY(launch_tile_filter(ta, stream));
+            MergeArgs fm{};
+            fm.part_keys = ta.part_keys; fm.part_vals = ta.part_vals;
+            fm.nq = nq; fm.n_part = slots; fm.k_part = k; fm.k = k; fm.k_out = k;
+            fm.ids = nullptr; fm.row_idx = d_cluster + r0; fm.dist = dist_out.as<float>(); fm.n_found = nfound.as<uint32_t>();
+            fm.sqrt_out = 0;
+            fm.cand_keys = ta.cand_keys; fm.cand_vals = ta.cand_vals; fm.cand_cnt = ta.cand_cnt; fm.cand_cap = ccap;
+            fm.spilled = ta.spilled;
+            HIP_TRY(launch_merge_final(fm, stream));
+        }
+        return PQV_OK;
+    }
+};
 
 // d_data [n, dim] resident; writes d_centroids [k, dim] (device) and optionally the final
 // assignment (host).
@@ -612,10 +734,23 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     std::vector<uint64_t> off;
     std::vector<uint32_t> rows;
     uint32_t iters = 0;
+    ScreenedAssign screen;
+    const bool use_screen = ScreenedAssign::applicable(dim, k);
     for (uint32_t iter = 0; iter < max_iters; ++iter) {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, (static_cast<size_t>(k) + 1) * sizeof(unsigned long long), stream));
         unsigned long long *d_changed = d_counts.as<unsigned long long>() + k;
-        HIP_TRY(launch_assign(d_data, n, dim, d_centroids, k, d_cur, d_prev, d_changed, nullptr, stream));
+        bool exact_assign = !use_screen;
+        if (use_screen) {
+            bool bad_c = false, bad_r = false;
+            if (int rc = screen.set_centroids(d_centroids, k, dim, stream, &bad_c)) return rc;
+            if (!bad_c) {
+                if (int rc = screen.run(d_data, n, d_cur, stream, &bad_r)) return rc;
+                if (!bad_r) HIP_TRY(launch_count_changed(d_cur, d_prev, n, d_changed, stream));
+            }
+            exact_assign = bad_c || bad_r;
+        }
+        if (exact_assign)
+            HIP_TRY(launch_assign(d_data, n, dim, d_centroids, k, d_cur, d_prev, d_changed, nullptr, stream));
         HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts.p, h_counts.size() * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(h_assign.data(), d_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -623,7 +758,8 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
         iters++;
         std::swap(d_prev, d_cur);
         if (h_counts[k] == 0) break;                                                   // :432
-        lists_from_assignment(h_assign.data(), n, k, off, rows);
+        if (!lists_from_assignment(h_assign.data(), n, k, off, rows))
+            return fail(PQV_ERR_HIP, "internal error: Lloyd assignment out of range");
         HIP_TRY(hipMemcpyAsync(d_list_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_list_rows.p, rows.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(launch_lloyd_update(d_data, dim, d_list_rows.as<uint32_t>(), d_list_off.as<uint64_t>(),
@@ -679,8 +815,20 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     const double t_fa0 = now_s();
     DevBuf d_cluster;
     HIP_TRY(d_cluster.alloc(n * sizeof(uint32_t)));
-    HIP_TRY(launch_assign(corpus->d_rows, n, dim, d_centroids.as<float>(), static_cast<uint32_t>(k),
-                          d_cluster.as<uint32_t>(), nullptr, nullptr, nullptr, stream));
+    bool exact_assign = true;
+    if (ScreenedAssign::applicable(dim, static_cast<uint32_t>(k))) {
+        ScreenedAssign screen;
+        bool bad_c = false, bad_r = false;
+        if (int rc = screen.set_centroids(d_centroids.as<float>(), static_cast<uint32_t>(k), dim, stream, &bad_c)) return rc;
+        if (!bad_c) {
+            if (int rc = screen.run(corpus->d_rows, n, d_cluster.as<uint32_t>(), stream, &bad_r)) return rc;
+            exact_assign = bad_r;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));     // the context's buffers are released at scope exit
+    }
+    if (exact_assign)
+        HIP_TRY(launch_assign(corpus->d_rows, n, dim, d_centroids.as<float>(), static_cast<uint32_t>(k),
+                              d_cluster.as<uint32_t>(), nullptr, nullptr, nullptr, stream));
     std::vector<uint32_t> cluster_of(n);
     pqv_index *idx = new (std::nothrow) pqv_index();
     if (!idx) return fail(PQV_ERR_OOM, "host allocation failed");
@@ -695,7 +843,10 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         return fail(PQV_ERR_HIP, std::string("final assignment: ") + hipGetErrorString(e));
     }
     const double t_fa1 = now_s();
-    lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows);
+    if (!lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows)) {
+        delete idx;
+        return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
+    }
     if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
                                 (unsigned long long)n, t_fa1 - t_fa0, now_s() - t_fa1);
     *out = idx;

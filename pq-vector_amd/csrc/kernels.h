@@ -241,6 +241,14 @@ hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const u
 hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, const uint4 *quads, const uint32_t *n_quads,
                                uint32_t max_quads, uint32_t nprobe, uint32_t dim, uint32_t ngrp, void *q_blk, hipStream_t s);
 
+// MFMA-screened assignment helpers (api.cpp: assign_screened).  assign_setup: pairs[i] = i, quads of `width`
+// consecutive queries of cluster 0, cand_base = 0, gthr = EMPTY, *n_quads.  nonfinite_flag: *flag |= 1 if any
+// v[i] is inf / NaN.  count_changed: *changed += #{i : cur[i] != prev[i]}.
+hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base, unsigned long long *gthr,
+                               uint32_t nq, uint32_t width, hipStream_t s);
+hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s);
+hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s);
+
 // a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
 hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);
 

@@ -1928,7 +1928,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s) {
-    if (a.max_groups == 0 || a.grid_x == 0) return hipSuccess;
+    if ((a.filter_variant == 0 ? a.max_quads : a.max_groups) == 0 || a.grid_x == 0) return hipSuccess;
     if (a.k <= 64) return launch_filter_s<1>(a, s);
     if (a.k <= 256) return launch_filter_s<4>(a, s);
     return hipErrorInvalidValue;
@@ -2321,6 +2321,56 @@ hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, cons
     if (max_quads == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_queries_kernel, dim3(max_quads), dim3(256), 0, s, queries, pairs, quads, n_quads, nprobe, dim, ngrp,
                        static_cast<float4 *>(q_blk));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Helpers of the MFMA-screened assignment (api.cpp: assign_screened): the k-means assignment of a
+// chunk of rows is the top-1 search of every row among the centroids, i.e. the wide screened path
+// with the rows as queries and ONE list holding all centroids.
+//   assign_setup_kernel : identity bucketing (pair i = query i, quads of `width` consecutive queries of
+//                         cluster 0), candidate bases 0, thresholds EMPTY
+//   nonfinite_flag_kernel / count_changed_kernel : see the launchers' comments in kernels.h
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assign_setup_kernel(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base,
+                                                          unsigned long long *gthr, uint32_t nq, uint32_t width) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *n_quads = (nq + width - 1) / width;
+    if (i >= nq) return;
+    pairs[i] = i;
+    cand_base[i] = 0;
+    gthr[i] = ~0ull;
+    if (i % width == 0) quads[i / width] = make_uint4(0u, i, nq - i < width ? nq - i : width, 0u);
+}
+hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base, unsigned long long *gthr,
+                               uint32_t nq, uint32_t width, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(assign_setup_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pairs, quads, n_quads, cand_base, gthr, nq, width);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *v, uint64_t n, uint32_t *flag) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bad |= !(fabsf(v[i]) < INFINITY);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, v, n, flag);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void count_changed_kernel(const uint32_t *cur, const uint32_t *prev, uint64_t n,
+                                                           unsigned long long *changed) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += cur[i] != prev[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_down((int)c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(changed, (unsigned long long)c);
+}
+hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, cur, prev, n, changed);
     return hipGetLastError();
 }
 

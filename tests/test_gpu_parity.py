@@ -737,3 +737,25 @@ def test_screened_path_unbalanced_lists(pqv, oracle, monkeypatch, dim):
         assert (nc == onc).all()
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
     assert s.counters()["screened_pairs"] > 0
+
+
+@pytest.mark.parametrize("n,dim,kc,min_k", [
+    (24000, 64, 600, None),      # natural dispatch (>= 512 centroids), queries staged in LDS
+    (9000, 128, 96, 2),          # forced at a small centroid count: fewer seeds than the seed window
+    (6000, 320, 70, 2),          # long rows: blocked global query copy
+    (5000, 768, 520, None),      # C3-shaped rows
+])
+def test_screened_assignment_builds_identical_index(pqv, oracle, monkeypatch, n, dim, kc, min_k):
+    """Index build with the MFMA-screened assignment (Lloyd iterations and final assignment) must produce
+    the oracle's blob byte for byte, and the same blob as the exact VALU assignment."""
+    rng = np.random.default_rng(n + dim + kc)
+    data = rng.random((n, dim), dtype=np.float32)
+    data[::5] = np.round(data[::5] * 4) / 4          # coarse values: exact distance ties between centroids occur
+    want = oracle.build_index(data, n_clusters=kc, workers=3, max_iters=4, seed=11).to_bytes()
+    corpus = pqv.Corpus.upload(data)
+    blobs = {}
+    for mode in ("screen", "exact"):
+        monkeypatch.setenv("PQV_ASSIGN_SCREEN", "0" if mode == "exact" else (str(min_k) if min_k else "1"))
+        blobs[mode] = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(4).seed(11).workers(3).build().to_bytes()
+    assert blobs["exact"] == want
+    assert blobs["screen"] == want
