@@ -536,7 +536,8 @@ struct ScreenedAssign {
     int set_centroids(const float *d_c, uint32_t k, uint32_t d, hipStream_t stream, bool *nonfinite) {
         using namespace pqv;
         dim = d; kc = k; d_centroids = d_c;
-        width = dim <= 128 ? 64 : 32;
+        static const uint32_t wide_env = [] { const char *e = std::getenv("PQV_ASSIGN_WIDTH"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
+        width = wide_env == 32 && dim > 128 ? 32 : 64;     // 64-row quads halve the re-streaming of the centroids
         chunk_q = 65536;
         rpb = 1024; bpl = (kc + rpb - 1) / rpb;
         max_quads = (chunk_q / width + 7) / 8 * 8;

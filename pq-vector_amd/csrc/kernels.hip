@@ -1469,6 +1469,8 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((wide_seed_kernel<2, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
     else if (a.quad_width == 32 && a.q_blk)
         hipLaunchKernelGGL((wide_seed_kernel<2, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+    else if (a.quad_width == 64 && a.q_blk)
+        hipLaunchKernelGGL((wide_seed_kernel<4, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1499,7 +1501,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
 template <int NG, int S, bool QLDS>
-__global__ __launch_bounds__(256, 3) void wide_filter_kernel(const TileArgs a) {
+__global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 1024 + 64;
     constexpr uint32_t NQ = 16 * NG;
@@ -1914,6 +1916,8 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
             hipLaunchKernelGGL((wide_filter_kernel<2, S, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
         else if (a.quad_width == 32 && a.q_blk)
             hipLaunchKernelGGL((wide_filter_kernel<2, S, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        else if (a.quad_width == 64 && a.q_blk)
+            hipLaunchKernelGGL((wide_filter_kernel<4, S, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
