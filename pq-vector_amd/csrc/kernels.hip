@@ -45,6 +45,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
     return v;
 }
+// 16-byte operand load through a buffer resource: scalar base (the descriptor) + scalar byte offset + a
+// per-lane byte offset that never changes -- no vector ALU address arithmetic per load.  On gfx950 VALU
+// work does not overlap the f32 MFMAs, not even across waves (tools/mfma_mix_ubench.hip), so every
+// address instruction in the K loop costs matrix throughput.
+typedef float f32x4_raw __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
+    const f32x4_raw v = __builtin_bit_cast(f32x4_raw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -1565,6 +1577,7 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         __syncthreads();
     }
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
+    const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;   // the list's 16-row tiles
@@ -1659,6 +1672,7 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
     };
 
     const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;   // this lane's float4 inside a 1 KiB operand block
+    const uint32_t lane_b = lane_off * 16u;                       // ... in bytes
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
@@ -1676,6 +1690,12 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
             if (T > blk_last) T = blk_last;             // tiles past the list's end: masked below
             xbase[t] = a.mat_blk + T * G * 16;
         }
+        // one descriptor per tile (base = its first 16-row sub-tile); the other sub-tiles and the K steps
+        // are scalar byte offsets (< 1 MiB)
+        const __amdgpu_buffer_rsrc_t xr = operand_rsrc(xbase[0]);
+        uint32_t xso[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
         const uint64_t my_gthr =
             __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
@@ -1715,18 +1735,18 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         };
         auto kloop = [&](auto full) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xa[t] = xbase[t][lane_off];
+            for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t]);
             uint32_t k0 = 0;
             for (; k0 + 32 < dim; k0 += 32) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+                for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 16) * 64);
                 mma(xa, k0, full);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xa[t] = xbase[t][(k0 + 32) * 4 + lane_off];
+                for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 32) * 64);
                 mma(xb, k0 + 16, full);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xb[t] = xbase[t][(k0 + 16) * 4 + lane_off];
+            for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 16) * 64);
             mma(xa, k0, full);
             mma(xb, k0 + 16, full);
         };
@@ -1739,11 +1759,11 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
             float4 x0[4], x1[4], x2[4], q0[NG], q1[NG], q2[NG];
             auto ld = [&](float4 (&x)[4], float4 (&q)[NG], uint32_t ks) {
                 const uint32_t kc = ks < nks ? ks : nks - 1;
-                const uint32_t off = kc * 64 + lane_off;             // 16 dims = 4 columns = 64 float4
+                const uint32_t off = kc * 1024;                      // 16 dims = 4 columns = 1 KiB (uniform)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x[t] = xbase[t][off];
+                for (int t = 0; t < 4; ++t) x[t] = buf_ld16(xr, lane_b, xso[t] + off);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) q[g] = qblk[(uint32_t)g * G * 16 + off];
+                for (int g = 0; g < NG; ++g) q[g] = buf_ld16(qr, lane_b, (uint32_t)g * G * 256 + off);
             };
             auto mmag = [&](const float4 (&x)[4], const float4 (&q)[NG]) {
 #pragma unroll
