@@ -1361,6 +1361,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     }
     __syncthreads();      // also orders the qnl / liml writes above
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;
+    const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
     const int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
@@ -1384,6 +1385,10 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
             if (T > blk_last) T = blk_last;
             xbase[t] = a.mat_blk + T * G * 16;
         }
+        const __amdgpu_buffer_rsrc_t xr = operand_rsrc(xbase[0]);
+        uint32_t xso[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
         f32x4_acc acc[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -1392,14 +1397,14 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
             float4 x[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = xbase[t][k0 * 4 + lane_off];
+            for (int t = 0; t < 4; ++t) x[t] = buf_ld16(xr, lane_off * 16u, xso[t] + k0 * 64);
             const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if ((uint32_t)g < ng) {
                     float4 qc;
                     if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
-                    else qc = qblk[(uint32_t)g * G * 16 + k0 * 4 + lane_off];
+                    else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + k0 * 64);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
