@@ -759,3 +759,50 @@ def test_screened_assignment_builds_identical_index(pqv, oracle, monkeypatch, n,
         blobs[mode] = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(4).seed(11).workers(3).build().to_bytes()
     assert blobs["exact"] == want
     assert blobs["screen"] == want
+
+
+def _fuzz_case(pqv, oracle, seed):
+    rng = np.random.default_rng(seed)
+    dim = int(rng.choice([64, 128, 192, 256, 320, 512]))
+    kc = int(rng.integers(2, 9))
+    n = int(rng.integers(1200, 6000)) * kc
+    k = int(rng.integers(1, 33))
+    nprobe = int(rng.integers(1, kc + 1))
+    nq = int(rng.integers(1, 180))
+    style = seed % 4
+    if style == 0:
+        data = rng.random((n, dim), dtype=np.float32)
+    elif style == 1:                                   # coarse grid: many exactly equal distances
+        data = (rng.integers(0, 3, size=(n, dim)) * 0.5).astype(np.float32)
+    elif style == 2:                                   # clustered, different scales per cluster
+        cen = rng.standard_normal((kc, dim)).astype(np.float32) * 3
+        data = (cen[rng.integers(0, kc, n)] + rng.standard_normal((n, dim)).astype(np.float32)
+                * rng.choice([0.01, 0.3, 2.0], size=(n, 1)).astype(np.float32)).astype(np.float32)
+    else:                                              # duplicated rows
+        base = rng.random((n // 4 + 1, dim), dtype=np.float32)
+        data = base[rng.integers(0, len(base), n)]
+    queries = data[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * rng.choice([0.0, 0.05])).astype(np.float32)
+    queries = queries.astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=3, seed=seed)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nc == onc).all(), seed
+    assert (nf == onf).all(), seed
+    # pqv_topk replays the reference heap when output distances tie: ids must match position by position
+    assert (_bits(dist) == _bits(odist)).all(), seed
+    assert (rows == orows).all(), seed
+    return s.counters()["screened_pairs"]
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_screened_search_against_oracle(pqv, oracle, monkeypatch, block):
+    """Random shapes / data styles (uniform, coarse grid with massive ties, multi-scale clusters,
+    duplicated rows), random k <= 32, nprobe and batch size, with the MFMA screen forced
+    wherever the lists are long enough: rows, distances and counts must equal the oracle exactly."""
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    screened = 0
+    for seed in range(1000 + 6 * block, 1000 + 6 * block + 6):
+        screened += _fuzz_case(pqv, oracle, seed)
+    assert screened > 0
