@@ -1994,11 +1994,15 @@ __device__ __forceinline__ float unsortable_bits(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-constexpr int BR_BM = 128, BR_BN = 128, BR_BK = 16, BR_ST = 17;
+constexpr int BR_BM = 128, BR_BN = 128, BR_BK = 16;
 
+template <bool FAST>      // FAST: dim % 16 == 0 -- operand fetches through buffer resources (no bounds or address VALU)
 __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
-    __shared__ float As[BR_BM * BR_ST];
-    __shared__ float Bs[BR_BN * BR_ST];
+    // two stages of [row][16 k] tiles as 16-byte chunks; chunk c of row r sits at position c ^ ((r >> 2) & 3),
+    // so the staging writes (one chunk per thread) and the operand reads (two chunks per lane, 16 lanes x 16
+    // distinct 16-byte slots of a 256-byte bank window) are both bank-conflict free without padding
+    __shared__ float4 As4[2][BR_BM * 4];
+    __shared__ float4 Bs4[2][BR_BN * 4];
     __shared__ unsigned long long thr_s[BR_BM];
     __shared__ float qaux_s[BR_BM];
 
@@ -2009,15 +2013,30 @@ __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
     const uint32_t dim = a.dim;
     const bool al4 = (dim & 3u) == 0;
 
-    // staging: thread -> (row ld_r / ld_r + 64, 4 consecutive k at ld_c)
-    const int ld_r = tid >> 2, ld_c = (tid & 3) * 4;
+    // staging: thread -> (row ld_r / ld_r + 64, chunk ld_ch = 4 consecutive k)
+    const int ld_r = tid >> 2, ld_ch = tid & 3;
     float4 ra[2], rb[2];
+    // FAST: descriptors at the tile's first query / row; rows past nq / row_end are out of range and read as 0
+    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * dim * 4 : 0, vleft = a.row_end > n0 ? (a.row_end - n0) * dim * 4 : 0;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.queries + (uint64_t)m0 * dim), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.rows + n0 * dim), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = ((uint32_t)ld_r * dim + (uint32_t)ld_ch * 4) * 4, half_b = 64u * dim * 4;
     auto fetch = [&](uint32_t k0) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ra[h] = buf_ld16(qres, lane_b, k0 * 4 + h * half_b);
+                rb[h] = buf_ld16(vres, lane_b, k0 * 4 + h * half_b);
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t qi = m0 + ld_r + 64 * h;
             const uint64_t vj = n0 + ld_r + 64 * h;
-            const uint32_t kk = k0 + ld_c;
+            const uint32_t kk = k0 + ld_ch * 4;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
             if (qi < a.nq) {
                 const float *p = a.queries + (uint64_t)qi * dim + kk;
@@ -2042,13 +2061,13 @@ __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
             ra[h] = va; rb[h] = vb;
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float *pa = As + (ld_r + 64 * h) * BR_ST + ld_c;
-            float *pb = Bs + (ld_r + 64 * h) * BR_ST + ld_c;
-            pa[0] = ra[h].x; pa[1] = ra[h].y; pa[2] = ra[h].z; pa[3] = ra[h].w;
-            pb[0] = rb[h].x; pb[1] = rb[h].y; pb[2] = rb[h].z; pb[3] = rb[h].w;
+            const int r = ld_r + 64 * h;
+            const int pos = r * 4 + (ld_ch ^ ((r >> 2) & 3));
+            As4[buf][pos] = ra[h];
+            Bs4[buf][pos] = rb[h];
         }
     };
 
@@ -2068,30 +2087,41 @@ __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
 
     const uint32_t nk = (dim + BR_BK - 1) / BR_BK;
     fetch(0);
-    stash();
+    stash(0);
     __syncthreads();
+    // MFMA operand roles: lane (l31, lk) owns row l31 of a 32-row tile and, per stage, the 8 consecutive k
+    // values 8 lk .. 8 lk + 7 (instruction j of the stage contracts k = 8 lk + j; the order of a dot
+    // product's terms is free here) -- two 16-byte LDS reads per tile and stage
     const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[2], rowb[2], swa[2], swb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3;
+        rowb[t] = wn * 64 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3;
+    }
     for (uint32_t kt = 0; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1u);
         if (kt + 1 < nk) fetch((kt + 1) * BR_BK);
+        float av[2][8], bv[2][8];
 #pragma unroll
-        for (int kk = 0; kk < BR_BK; kk += 2) {
-            float av[2], bv[2];
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                av[t] = As[(wm * 64 + t * 32 + l31) * BR_ST + kk + lk];
-                bv[t] = Bs[(wn * 64 + t * 32 + l31) * BR_ST + kk + lk];
+            for (int h = 0; h < 2; ++h) {
+                const float4 x = As4[buf][rowa[t] * 4 + ((2 * lk + h) ^ swa[t])];
+                const float4 y = Bs4[buf][rowb[t] * 4 + ((2 * lk + h) ^ swb[t])];
+                av[t][4 * h] = x.x; av[t][4 * h + 1] = x.y; av[t][4 * h + 2] = x.z; av[t][4 * h + 3] = x.w;
+                bv[t][4 * h] = y.x; bv[t][4 * h + 1] = y.y; bv[t][4 * h + 2] = y.z; bv[t][4 * h + 3] = y.w;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jj][j], acc[i][jj], 0, 0, 0);
+        if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
         __syncthreads();
-        if (kt + 1 < nk) {
-            stash();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -2126,7 +2156,9 @@ hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
     const uint64_t nb = (a.row_end - a.row_begin + BR_BN - 1) / BR_BN;
     if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)nb, (a.nq + BR_BM - 1) / BR_BM);
-    hipLaunchKernelGGL(brute_mfma_kernel, grid, dim3(256), 0, s, a);
+    // the fast variant needs 16-dim stages that never cross a row end and 32-bit byte offsets inside a tile
+    if ((a.dim % 16) == 0 && (uint64_t)a.dim * 4 * 192 < 0x7FFFFFFFull) hipLaunchKernelGGL(brute_mfma_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(brute_mfma_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
