@@ -154,7 +154,7 @@ struct pqv_corpus {
 };
 
 // Per-call device scratch of a searcher (see pqv_searcher::lanes).
-constexpr int PQV_LANES = 2;
+constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
