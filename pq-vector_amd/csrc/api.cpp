@@ -158,7 +158,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -185,6 +185,10 @@ struct pqv_searcher {
     mutable Scratch lanes[PQV_LANES];
     mutable uint32_t lane_rr = 0;
     mutable DevBuf d_mat_blk, d_blk_off;   // blocked MFMA-operand copy of the lists (built on first use)
+    // f16 operands for the wide screened path (PQV_SCREEN_F16=0 disables): values * f16_scale rounded to f16;
+    // possible when the stored rows are finite and the power-of-two scale and its square are representable
+    bool f16_ok = false;
+    float f16_scale = 1.0f;
     int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
     int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
     uint32_t cand_cap = 2048;              // PQV_CAND_CAP: candidate-buffer entries per query of the wide screened path
@@ -989,6 +993,25 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         S_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, n_storage) * sizeof(float)));
         S_TRY(pqv::launch_row_norms(s->d_mat, n_storage, s->dim, 1, s->d_row_norm2.as<float>(), s->stream));
     }
+    {   // corpus maximum -> power-of-two scale that maps it below 2^14 (f16 operand copy of the screened path)
+        DevBuf d_max;
+        S_TRY(d_max.alloc(sizeof(uint32_t)));
+        S_TRY(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), s->stream));
+        const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
+        S_TRY(pqv::launch_maxabs(s->d_mat, n_storage * s->dim, d_max.as<uint32_t>(), s->stream));
+        uint32_t bits = 0;
+        S_TRY(hipMemcpyAsync(&bits, d_max.p, sizeof bits, hipMemcpyDeviceToHost, s->stream));
+        S_TRY(hipStreamSynchronize(s->stream));
+        const char *env16 = std::getenv("PQV_SCREEN_F16");
+        float m;
+        std::memcpy(&m, &bits, sizeof m);
+        if (!(env16 && *env16 == '0') && bits < 0x7F800000u) {
+            int e = 0;
+            if (m > 0.0f) (void)std::frexp(m, &e);           // m = f * 2^e, f in [0.5, 1)  =>  m < 2^e
+            const int se = m > 0.0f ? 14 - e : 0;            // scale = 2^se: m * scale < 2^14
+            if (se >= -60 && se <= 60) { s->f16_ok = true; s->f16_scale = std::ldexp(1.0f, se); }
+        }
+    }
     S_TRY(hipStreamSynchronize(s->stream));
     if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
         (void)hipFree(corpus->d_rows);
@@ -1021,6 +1044,7 @@ struct TopkPlan {
     bool filter;            // tile path: exact seed window + MFMA-screened remainder
     uint32_t seed_rows, filter_bpl;
     bool mfma_seed;             // wide path: thresholds from MFMA upper bounds, no exact seed pass
+    bool f16;                   // wide path with f16 operands (dim % 128 == 0, 64-query quads staged in LDS)
     uint32_t w1_rows, w1_bpl;   // wide path: a first screened window whose survivors tighten the thresholds (0 = none)
     bool quad;              // filter: wide_filter_kernel (quad_width queries per block)
     uint32_t filter_rows_per_block, max_quads, quad_width;
@@ -1084,6 +1108,8 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             const int variant = s->filter_variant;
             p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : 32;     // dim > 256: queries from a blocked global copy
             p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
+            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 256;
+            if (p.f16) p.quad_width = 64;                   // 64 queries x dim f16 values fit the 32 KB of LDS
             uint64_t r = rpb;
             p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
                                      : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
@@ -1178,7 +1204,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         pair_u32 = sc.s_pair_u32.as<uint32_t>();
         pa.zero_u32 = pair_u32; pa.zero_n = 2 * kc_pairs;
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
-        if (p.filter) HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float)));
+        if (p.filter) { HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float))); HIP_TRY(sc.s_qmax.ensure(static_cast<size_t>(nq) * sizeof(float))); }
     }
     HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
 
@@ -1191,7 +1217,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pm.max_pos = max_pos;
     if (p.tile) {
         pm.hist = pair_u32; pm.gthr_init = sc.s_gthr.as<unsigned long long>();
-        if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
+        if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.qmax_out = sc.s_qmax.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
     }
     HIP_TRY(launch_merge_probe(pm, stream));
 
@@ -1237,13 +1263,23 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
                 HIP_TRY(s->d_blk_off.alloc(boff.size() * sizeof(uint64_t)));
                 HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-                HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
-                HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                          (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+                if (p.f16) {
+                    HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * 2));
+                    HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                                  (s->max_list_len + 15) / 16, s->dim, s->f16_scale, s->d_mat_blk.p, stream));
+                } else {
+                    HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
+                    HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                              (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+                }
                 HIP_TRY(hipStreamSynchronize(stream));      // one-off; calls on other streams may follow at once
             }
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
+            if (p.f16) {
+                ta.f16 = 1; ta.scale = s->f16_scale; ta.scale2 = s->f16_scale * s->f16_scale;
+                ta.query_maxabs = sc.s_qmax.as<float>();
+            }
             // quad-to-XCD affinity (PQV_QUAD_XCD=0/1 overrides): on by default for the global-query variant,
             // whose per-quad operand copies must stay L2-resident
             static const int quad_xcd_env = [] { const char *e = std::getenv("PQV_QUAD_XCD"); return e ? std::atoi(e) : -1; }();

@@ -77,6 +77,7 @@ struct MergeArgs {
     uint32_t       *hist;
     unsigned long long *gthr_init;
     float          *qnorm_out;
+    float          *qmax_out;    // max |q_i| per query (f16 screen)
     const float    *queries;
     uint32_t        dim;
 };
@@ -139,6 +140,11 @@ struct TileArgs {
     // MFMA filter only: squared norms of the storage rows / of the queries
     const float4   *mat_blk;     // wide_filter_kernel: blocked copy of the IVF-ordered lists (launch_block_rows)
     const uint64_t *blk_off;     // [n_clusters + 1] first 16-row tile of every list in mat_blk
+    // f16 operands (wide kernels, dim % 128 == 0): mat_blk is the launch_block_rows_f16 copy, the queries are
+    // converted while staged; scale is a power of two, scale2 = scale^2
+    int             f16;
+    float           scale, scale2;
+    const float    *query_maxabs;   // [nq] max |q_i| (merge probe)
     const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad
                                  // (launch_pack_queries), [max_quads][quad_width / 16][dim / 4][16] float4
     const float    *row_norm2;   // indexed like mat rows
@@ -251,6 +257,12 @@ hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint6
 
 // a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
 hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);
+
+// f16 form of the blocked copy (values * scale rounded to nearest f16, 8 dims per 16-byte column, tile T column
+// cc row j at 16-byte index (T * dim/8 + cc) * 16 + j) and the corpus maximum it is scaled by
+hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                 uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s);
+hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out_bits, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

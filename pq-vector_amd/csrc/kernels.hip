@@ -57,6 +57,28 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
     const f32x4_raw v = __builtin_bit_cast(f32x4_raw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+// One K step of the score contraction for a 16 x 16 tile.  f32 operands: 16 dims, four 16x16x4 MFMAs;
+// f16 operands (8 halves per lane, see launch_block_rows_f16): 32 dims, one 16x16x32 MFMA.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ void mfma_step(f32x4_acc &acc, const float4 q, const float4 x) {
+    if constexpr (F16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, q), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, x.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, x.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, x.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, x.w, acc, 0, 0, 0);
+    }
+}
+// eight f32 values scaled by a power of two and rounded to f16 (round to nearest even), packed as 16 bytes
+__device__ __forceinline__ float4 pack_f16x8(const float4 lo, const float4 hi, float scale) {
+    f16x8_t h;
+    h[0] = (_Float16)(lo.x * scale); h[1] = (_Float16)(lo.y * scale); h[2] = (_Float16)(lo.z * scale); h[3] = (_Float16)(lo.w * scale);
+    h[4] = (_Float16)(hi.x * scale); h[5] = (_Float16)(hi.y * scale); h[6] = (_Float16)(hi.z * scale); h[7] = (_Float16)(hi.w * scale);
+    return __builtin_bit_cast(float4, h);
+}
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -515,6 +537,13 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
             if (lane == 0) a.qnorm_out[q] = acc;
         }
+        if (a.qmax_out) {                                              // max |q_i| (f16 operand range check)
+            float m = 0.0f;
+            for (uint32_t d = lane; d < a.dim; d += 64) m = fmaxf(m, fabsf(a.queries[(uint64_t)q * a.dim + d]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+            if (lane == 0) a.qmax_out[q] = m;
+        }
     }
 }
 
@@ -939,7 +968,6 @@ __global__ __launch_bounds__(256) void tile_rerank_kernel(const TileArgs a) {
 // The k-order of the MFMA contraction is permuted (lane kk owns 4 consecutive dims of each
 // 16-dim step) so that every operand fetch is one 16-byte load; the bound is order-free.
 // ------------------------------------------------------------------------------------
-typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 template <int S, bool ALIGNED, bool PREFETCH>
 __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
@@ -1311,7 +1339,7 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 // sample.  The sample rows themselves are screened and evaluated by the main pass like all others.
 // Output: seed_ub[((qrow * nprobe + j) * seed_sw + blockIdx.x * 4 + wave) * 16 + (lane & 15)].
 // ------------------------------------------------------------------------------------
-template <int NG, bool QLDS>
+template <int NG, bool QLDS, bool F16>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr uint32_t NQ = 16 * NG;
     uint32_t bx, by;
@@ -1339,8 +1367,10 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     if (r0 > r1) r0 = r1;
 
     const uint32_t dim = a.dim;
-    const uint32_t G = dim >> 2;
+    const uint32_t G = F16 ? dim >> 3 : dim >> 2;    // 16-byte operand columns per row
     const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+    const float c16 = F16 ? 1.25f * 9.765625e-04f : 0.0f;               // f16 operands: see wide_filter_kernel
+    const float isc2 = F16 ? 1.0f / a.scale2 : 1.0f;                    // scores are contracted at scale^2
 
     const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
     const uint32_t my_pair = a.pairs[my_slot];
@@ -1349,15 +1379,22 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     // list offsets below my_lim are candidates of this query (max_candidates cap)
     const uint64_t room = a.max_pos > my_cbase ? a.max_pos - my_cbase : 0;
     qnl[lane] = a.query_norm2[my_qrow];
-    liml[lane] = (uint32_t)lane < cnt ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
+    const float my_qn0 = a.query_norm2[my_qrow];
+    const bool my_bad16 = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn0 * a.scale2 < 1.0f);   // no valid f16 bound
+    liml[lane] = ((uint32_t)lane < cnt && !my_bad16) ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
     if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
+        if constexpr (F16) {
+#pragma unroll 4
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
+        } else {
 #pragma unroll 8
-        for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+        }
     }
     __syncthreads();      // also orders the qnl / liml writes above
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;
@@ -1394,24 +1431,19 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
-        for (uint32_t k0 = 0; k0 < dim; k0 += 16) {
+        for (uint32_t ks = 0; ks < (G >> 2); ++ks) {
             float4 x[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = buf_ld16(xr, lane_off * 16u, xso[t] + k0 * 64);
-            const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
+            for (int t = 0; t < 4; ++t) x[t] = buf_ld16(xr, lane_off * 16u, xso[t] + ks * 1024);
+            const uint32_t chq = ks * 4 + (uint32_t)kk;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if ((uint32_t)g < ng) {
                     float4 qc;
                     if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
-                    else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + k0 * 64);
+                    else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + ks * 1024);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, x[t].y, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, x[t].z, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, x[t].w, acc[g][t], 0, 0, 0);
-                    }
+                    for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], qc, x[t]);
                 }
             }
         }
@@ -1428,8 +1460,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                     const uint32_t roff = (uint32_t)t0 + (uint32_t)(16 * t + l15);     // list offset (< 2^32 rows per list)
                     const bool valid = (uint32_t)(16 * t + l15) < nvalid && roff < lim[r];
                     const float nn = qn[r] + xn[t];
-                    const float dt = nn - 2.0f * acc[g][t][r];
-                    const float ub = dt + cmargin * (2.0f * nn + fabsf(dt));
+                    const float dt = nn - 2.0f * (acc[g][t][r] * isc2);
+                    const float ub = dt + cmargin * (2.0f * nn + fabsf(dt)) + c16 * nn;
                     if (valid) mins[g][r] = fminf(mins[g][r], ub);                     // NaN bounds are ignored
                 }
             }
@@ -1480,14 +1512,19 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+    if (a.f16) {      // f16 operands: the staged queries take half the LDS
+        if ((a.dim % 128) != 0 || a.quad_width != 64 || lds4 / 2 > 32768 || !a.query_maxabs) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+        return hipGetLastError();
+    }
     if (a.quad_width == 64 && lds4 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<4, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<4, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
     else if (a.quad_width == 32 && lds2 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<2, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<2, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
     else if (a.quad_width == 32 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<2, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<2, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else if (a.quad_width == 64 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<4, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<4, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1517,7 +1554,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // Requires dim % 64 == 0 (swizzle closure), 16 NG * dim * 4 bytes of LDS, the IVF-ordered layout
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
-template <int NG, int S, bool QLDS>
+template <int NG, int S, bool QLDS, bool F16>
 __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 1024 + 64;
@@ -1551,10 +1588,20 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
     if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
-    const uint32_t G = dim >> 2;                     // 16-byte columns per row (multiple of 4)
+    // 16-byte operand columns per row: 4 f32 or (F16) 8 f16 values each; a K step is 4 columns
+    const uint32_t G = F16 ? dim >> 3 : dim >> 2;
+    const uint32_t Gx = dim >> 2;                    // 16-byte chunks of a row-major f32 row (exact evaluation)
     const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
+    // F16: operands are round-to-nearest f16 images of scale * value (|scale * x| <= 2^14: no overflow), the
+    // products are exact in f32, so the score carries an extra error <= 2^-11 (1 + 2^-12) nn (relative
+    // 2^-11 per operand, sum |q x| <= nn / 2) and d~ an extra 2^-10 nn; sub-normal images (absolute error
+    // 2^-25) add < 3 % of that once scale^2 |q|^2 >= 1 -- queries below that, and queries whose image
+    // overflows, are never skipped (see aq below).  c16 = 1.25 * 2^-10 carries both with a margin.
+    const float c16 = F16 ? 1.25f * 9.765625e-04f : 0.0f;
     const float inv1c = 1.0f / (1.0f - cmargin);
-    const float alpha = 0.5f * (1.0f - 2.0f * cmargin * inv1c), beta = 0.5f * inv1c;
+    // scores are contracted at scale^2: alpha and beta absorb it (powers of two: exact)
+    const float sc2 = F16 ? a.scale2 : 1.0f;
+    const float alpha = sc2 * 0.5f * (1.0f - (2.0f * cmargin + c16) * inv1c), beta = sc2 * 0.5f * inv1c;
 
     // lane-parallel per-query state: lane q owns query q of the quad
     const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
@@ -1577,10 +1624,17 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
+        if constexpr (F16) {
+#pragma unroll 4
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
+        } else {
 #pragma unroll 8
-        for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+        }
         __syncthreads();
     }
+    // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
+    const bool my_noskip = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn * a.scale2 < 1.0f);
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
@@ -1606,19 +1660,19 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
         float sum = 0.0f;
         // 8 row chunks in flight per lane, then the reference's ordered chain over them
-        for (uint32_t g = 0; g < G; g += 8) {
+        for (uint32_t g = 0; g < Gx; g += 8) {
             float4 xv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = load4<true>(x + (g + u) * 4);
             float4 qvv[8];
-            if constexpr (!QLDS) {
+            if constexpr (!QLDS || F16) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) qvv[u] = qg[g + u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float4 qv;
-                if constexpr (QLDS) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
+                if constexpr (QLDS && !F16) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
                 const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
                 const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
                 float t = d0 * d0 + d1 * d1;
@@ -1722,45 +1776,40 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         // per-group branches it falls back to vmcnt(0) in front of every MFMA group, which serialises
         // the prefetch).
         float4 xa[4], xb[4];
-        auto mma = [&](const float4 (&x)[4], uint32_t k0, auto full) {
-            const uint32_t chq = (k0 >> 2) + (uint32_t)kk;
+        const uint32_t nks = G >> 2;          // K steps (4 operand columns = 1 KiB per 16-row sub-tile each)
+        auto mma = [&](const float4 (&x)[4], uint32_t ks, auto full) {
+            const uint32_t chq = ks * 4 + (uint32_t)kk;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (decltype(full)::value || (uint32_t)g < ng) {
                     const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.x, x[t].x, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.y, x[t].y, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.z, x[t].z, acc[g][t], 0, 0, 0);
-                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc.w, x[t].w, acc[g][t], 0, 0, 0);
-                    }
+                    for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], qc, x[t]);
                 }
             }
         };
         auto kloop = [&](auto full) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t]);
-            uint32_t k0 = 0;
-            for (; k0 + 32 < dim; k0 += 32) {
+            uint32_t ks = 0;
+            for (; ks + 2 < nks; ks += 2) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 16) * 64);
-                mma(xa, k0, full);
+                for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 1) * 1024);
+                mma(xa, ks, full);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 32) * 64);
-                mma(xb, k0 + 16, full);
+                for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 2) * 1024);
+                mma(xb, ks + 1, full);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (k0 + 16) * 64);
-            mma(xa, k0, full);
-            mma(xb, k0 + 16, full);
+            for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 1) * 1024);
+            mma(xa, ks, full);
+            mma(xb, ks + 1, full);
         };
         // !QLDS: both operands stream from global memory through THREE rotating register stages, so the
         // loads of K step s + 2 are issued before the MFMAs of step s (HBM latency is ~2 K steps of a
         // wave that shares the matrix pipe).  Indices past the last step are clamped: branch-free, the
         // compiler's wait counts stay exact.
         auto kloop_gq = [&]() {
-            const uint32_t nks = dim >> 4;
             float4 x0[4], x1[4], x2[4], q0[NG], q1[NG], q2[NG];
             auto ld = [&](float4 (&x)[4], float4 (&q)[NG], uint32_t ks) {
                 const uint32_t kc = ks < nks ? ks : nks - 1;
@@ -1775,12 +1824,7 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
                 for (int g = 0; g < NG; ++g) {
                     if ((uint32_t)g < ng) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].x, x[t].x, acc[g][t], 0, 0, 0);
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].y, x[t].y, acc[g][t], 0, 0, 0);
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].z, x[t].z, acc[g][t], 0, 0, 0);
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[g].w, x[t].w, acc[g][t], 0, 0, 0);
-                        }
+                        for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], q[g], x[t]);
                     }
                 }
             };
@@ -1819,7 +1863,7 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
         wave_lds_fence();
-        aq[lane] = (uint32_t)lane < cnt ? alpha * my_qn - beta * my_thr_d : INFINITY;
+        aq[lane] = (uint32_t)lane >= cnt ? INFINITY : my_noskip ? -INFINITY : alpha * my_qn - beta * my_thr_d;
         wave_lds_fence();
         uint32_t bits[(NG + 1) / 2];
 #pragma unroll
@@ -1935,14 +1979,19 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+        if (a.f16) {
+            if ((a.dim % 128) != 0 || a.quad_width != 64 || lds4 / 2 > 32768 || !a.query_maxabs) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+            return hipGetLastError();
+        }
         if (a.quad_width == 64 && lds4 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<4, S, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
         else if (a.quad_width == 32 && lds2 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<2, S, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
         else if (a.quad_width == 32 && a.q_blk)
-            hipLaunchKernelGGL((wide_filter_kernel<2, S, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
         else if (a.quad_width == 64 && a.q_blk)
-            hipLaunchKernelGGL((wide_filter_kernel<4, S, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -2382,6 +2431,60 @@ hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, cons
     if (max_quads == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_queries_kernel, dim3(max_quads), dim3(256), 0, s, queries, pairs, quads, n_quads, nprobe, dim, ngrp,
                        static_cast<float4 *>(q_blk));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// block_rows_f16_kernel: the f16 form of the blocked operand copy.  Values are multiplied by `scale` (a
+// power of two chosen so that the corpus maximum lands below 2^14: exact, no overflow) and rounded to
+// nearest f16; a 16-byte column holds 8 consecutive dims, tile T stores column cc of its row j at 16-byte
+// index (T * dim/8 + cc) * 16 + j -- a 16x16x32 MFMA operand fetch (16 rows x 4 columns) is one 1 KiB read.
+// maxabs_kernel: *out = max(*out, bits(max |v|)) (non-negative floats order like their bit patterns).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_rows_f16_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                            const uint64_t *__restrict__ blk_off, uint32_t dim, float scale,
+                                                            float4 *__restrict__ out) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 3;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        float4 *dst = out + (blk_off[c] + tl) * G * 16;
+        for (uint32_t e = threadIdx.x; e < G * 16; e += 256) {
+            const uint32_t cc = e >> 4, j = e & 15;
+            const uint64_t p = tl * 16 + j;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (p < len) {
+                const float4 *r = reinterpret_cast<const float4 *>(src + (lbeg + p) * dim + cc * 8);
+                lo = r[0]; hi = r[1];
+            }
+            dst[e] = pack_f16x8(lo, hi, scale);
+        }
+    }
+}
+hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                 uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    if (dim % 8) return hipErrorInvalidValue;
+    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(block_rows_f16_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, scale,
+                       static_cast<float4 *>(out));
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void maxabs_kernel(const float *v, uint64_t n, uint32_t *out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(v[i]) & 0x7FFFFFFFu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_down((int)m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(maxabs_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, v, n, out);
     return hipGetLastError();
 }
 
