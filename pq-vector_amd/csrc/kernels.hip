@@ -1555,7 +1555,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
 template <int NG, int S, bool QLDS, bool F16>
-__global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
+__global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 1024 + 64;
     constexpr uint32_t NQ = 16 * NG;
@@ -1732,6 +1732,37 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
 
     const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;   // this lane's float4 inside a 1 KiB operand block
     const uint32_t lane_b = lane_off * 16u;                       // ... in bytes
+    // Short f16 rows (<= 4 K steps = 128 dims): with the MFMA time gone the tile is latency-bound, so ALL of
+    // the next tile's operands (16 loads = 64 registers) and its row norms are requested right after the
+    // current tile's MFMAs and fly during its screen / expansion / exact evaluation.
+    constexpr bool CAN_PF = QLDS && F16;
+    const bool pf = CAN_PF && (G >> 2) <= 4;                     // wave-uniform
+    float4 xt[CAN_PF ? 4 : 1][4];
+    float xn_pf[4] = {0.f, 0.f, 0.f, 0.f};
+    auto issue_tile = [&](uint64_t tn) {
+        const uint32_t nv = (r1 - tn < 64) ? (uint32_t)(r1 - tn) : 64u;
+        const float4 *xb0 = nullptr;
+        uint32_t so[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t rr = (uint32_t)(16 * t + l15);
+            if (rr >= nv) rr = nv - 1;
+            xn_pf[t] = a.row_norm2[lbeg + tn + rr];
+            uint64_t T = blk0 + ((tn + 16 * t) >> 4);
+            if (T > blk_last) T = blk_last;
+            const float4 *xb = a.mat_blk + T * G * 16;
+            if (t == 0) xb0 = xb;
+            so[t] = (uint32_t)((xb - xb0) * 16);
+        }
+        const __amdgpu_buffer_rsrc_t r = operand_rsrc(xb0);
+#pragma unroll
+        for (int ks = 0; ks < (CAN_PF ? 4 : 1); ++ks)
+            if ((uint32_t)ks < (G >> 2)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xt[ks][t] = buf_ld16(r, lane_b, so[t] + ks * 1024);
+            }
+    };
+    if (pf && r0 < r1) issue_tile(r0);
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
@@ -1744,7 +1775,7 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
         for (int t = 0; t < 4; ++t) {
             uint32_t rr = (uint32_t)(16 * t + l15);
             if (rr >= nvalid) rr = nvalid - 1;
-            xn[t] = a.row_norm2[lbeg + t0 + rr];
+            xn[t] = pf ? xn_pf[t] : a.row_norm2[lbeg + t0 + rr];
             uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
             if (T > blk_last) T = blk_last;             // tiles past the list's end: masked below
             xbase[t] = a.mat_blk + T * G * 16;
@@ -1840,6 +1871,12 @@ __global__ __launch_bounds__(256, (NG == 4 && !QLDS) ? 2 : 3) void wide_filter_k
             if (ks + 1 < nks) mmag(x1, q1);
         };
         if constexpr (!QLDS) kloop_gq();
+        else if (pf) {
+#pragma unroll
+            for (int ks = 0; ks < (CAN_PF ? 4 : 1); ++ks)
+                if ((uint32_t)ks < nks) mma(xt[ks], (uint32_t)ks, std::false_type{});
+            if (t0 + 64 < r1) issue_tile(t0 + 64);
+        }
         else if (ng == (uint32_t)NG) kloop(std::true_type{});
         else kloop(std::false_type{});
 
