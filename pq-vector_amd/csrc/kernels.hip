@@ -1875,7 +1875,6 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #pragma unroll
             for (int ks = 0; ks < (CAN_PF ? 4 : 1); ++ks)
                 if ((uint32_t)ks < nks) mma(xt[ks], (uint32_t)ks, std::false_type{});
-            if (t0 + 64 < r1) issue_tile(t0 + 64);
         }
         else if (ng == (uint32_t)NG) kloop(std::true_type{});
         else kloop(std::false_type{});
@@ -1919,6 +1918,8 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             }
         }
         // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
+        // the accumulators are dead from here on: the next tile's operands can take their registers
+        if (pf && t0 + 64 < r1) issue_tile(t0 + 64);
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
         // expand group by group (<= 1024 entries each) with the drain in between; after the last tile one
         // extra pass flushes the queue
