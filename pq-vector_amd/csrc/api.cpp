@@ -1108,8 +1108,8 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             const int variant = s->filter_variant;
             p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : 32;     // dim > 256: queries from a blocked global copy
             p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
-            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 256;
-            if (p.f16) p.quad_width = 64;                   // 64 queries x dim f16 values fit the 32 KB of LDS
+            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 768;
+            if (p.f16) p.quad_width = s->dim <= 256 ? 64 : 32;   // the quad's f16 queries are staged in LDS (<= 48 KB)
             uint64_t r = rpb;
             p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
                                      : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
@@ -1283,8 +1283,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             // quad-to-XCD affinity (PQV_QUAD_XCD=0/1 overrides): on by default for the global-query variant,
             // whose per-quad operand copies must stay L2-resident
             static const int quad_xcd_env = [] { const char *e = std::getenv("PQV_QUAD_XCD"); return e ? std::atoi(e) : -1; }();
-            ta.xcd_swizzle = quad_xcd_env >= 0 ? quad_xcd_env : (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768 ? 1 : 0);
-            if (static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768) {
+            const bool q_global = !p.f16 && static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768;
+            ta.xcd_swizzle = quad_xcd_env >= 0 ? quad_xcd_env : (q_global ? 1 : 0);
+            if (q_global) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
                 HIP_TRY(sc.s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
                 HIP_TRY(launch_pack_queries(d_queries, ps.pairs, ps.quads, ps.n_quads, p.max_quads, p.np, s->dim,

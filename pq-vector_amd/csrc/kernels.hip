@@ -1513,8 +1513,12 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
     if (a.f16) {      // f16 operands: the staged queries take half the LDS
-        if ((a.dim % 128) != 0 || a.quad_width != 64 || lds4 / 2 > 32768 || !a.query_maxabs) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+        if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
+        if (a.quad_width == 64 && lds4 / 2 <= 32768)
+            hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+        else if (a.quad_width == 32 && lds2 / 2 <= 49152)
+            hipLaunchKernelGGL((wide_seed_kernel<2, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (a.quad_width == 64 && lds4 <= 32768)
@@ -1557,7 +1561,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 template <int NG, int S, bool QLDS, bool F16>
 __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
-    constexpr int PEND = 1024 + 64;
+    constexpr int PEND = 512 + 64;         // half a group's pairs of one tile + a partial batch
     constexpr uint32_t NQ = 16 * NG;
 #ifdef PQV_PROFILE_PHASES
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
@@ -1921,16 +1925,18 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // the accumulators are dead from here on: the next tile's operands can take their registers
         if (pf && t0 + 64 < r1) issue_tile(t0 + 64);
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
-        // expand group by group (<= 1024 entries each) with the drain in between; after the last tile one
-        // extra pass flushes the queue
-        const uint32_t gend = ng + (t0 + 64 >= r1 ? 1u : 0u);
+        // expand half a group at a time (queries r < 2 / r >= 2 of the lane: <= 512 entries) with the drain in
+        // between; after the last tile one extra pass flushes the queue
+        const uint32_t hend = 2 * ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
-        for (uint32_t g = 0; g < gend; ++g) {
+        for (uint32_t hg = 0; hg < hend; ++hg) {
+            const uint32_t g = hg >> 1;
             if (g < ng) {
                 uint32_t w = bits[0];
 #pragma unroll
                 for (int ww = 1; ww < (NG + 1) / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? bits[ww] : w;
                 uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
+                mm &= (hg & 1u) ? 0x00FFu : 0xFF00u;                     // c = 4 r + t lives in bit 15 - c
                 const uint32_t cntl = (uint32_t)__popc(mm);
                 const uint32_t incl = wave_incl_scan_u32(cntl);
                 uint32_t at = npend + incl - cntl;
@@ -1946,7 +1952,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
 #endif
-            drain(g == ng ? 1u : 64u);
+            drain(g == ng ? 1u : 64u);   // g == ng only in the flush pass
 #ifdef PQV_PROFILE_PHASES
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
@@ -2018,8 +2024,12 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
         if (a.f16) {
-            if ((a.dim % 128) != 0 || a.quad_width != 64 || lds4 / 2 > 32768 || !a.query_maxabs) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+            if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
+            if (a.quad_width == 64 && lds4 / 2 <= 32768)
+                hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+            else if (a.quad_width == 32 && lds2 / 2 <= 49152)      // + 10 KB of static LDS: two blocks per CU
+                hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a);
+            else return hipErrorInvalidValue;
             return hipGetLastError();
         }
         if (a.quad_width == 64 && lds4 <= 32768)
