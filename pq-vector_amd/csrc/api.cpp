@@ -158,7 +158,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_surv, s_surv_cnt;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -1314,6 +1314,27 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
+            // (measured: the recording pass is 20 % shorter, but a lane-per-pair exact pass pays one L1 tag look-up
+            //  per 16-byte chunk -- 157 us for C2's 540 k survivors -- so this stays opt-in until the exact pass
+            //  reads rows cooperatively: PQV_SURVIVOR_LIST=1)
+            static const bool list_mode = [] { const char *e = std::getenv("PQV_SURVIVOR_LIST"); return e && *e == '1'; }();
+            if (list_mode) {
+                // pass 1 records the screen's survivors, pass 2 evaluates them exactly at full occupancy; if a
+                // buffer ran full (pathological data) the flag makes the two guarded launches behind redo the
+                // batch with the self-contained kernel, which evaluates in place and spills into sorted lists
+                const uint32_t surv_cap = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(nq) * 8192), 1ull << 26));
+                HIP_TRY(sc.s_surv.ensure(static_cast<size_t>(surv_cap) * sizeof(uint2)));
+                HIP_TRY(sc.s_surv_cnt.ensure(2 * sizeof(uint32_t)));
+                HIP_TRY(hipMemsetAsync(sc.s_surv_cnt.p, 0, 2 * sizeof(uint32_t), stream));
+                TileArgs tl = ta;
+                tl.surv = static_cast<uint2 *>(sc.s_surv.p); tl.surv_cnt = sc.s_surv_cnt.as<uint32_t>(); tl.surv_cap = surv_cap;
+                tl.overflow = sc.s_surv_cnt.as<uint32_t>() + 1;
+                HIP_TRY(launch_tile_filter(tl, stream));
+                HIP_TRY(launch_survivor_eval(tl, sc.s_probe.as<uint32_t>(), stream));
+                ta.guard = tl.overflow;
+                HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, ta.guard));
+                s->counters.kernel_launches += 3;
+            }
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;

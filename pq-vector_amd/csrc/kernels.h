@@ -156,6 +156,13 @@ struct TileArgs {
     uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
     uint32_t        cand_cap;
     uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
+    // wide_filter_kernel, list mode (surv != nullptr): survivors {pair id, row offset in the list} are appended
+    // here instead of being evaluated in place; surv_cnt may run past surv_cap (then *overflow is raised)
+    uint2          *surv;
+    uint32_t       *surv_cnt;
+    uint32_t        surv_cap;
+    uint32_t       *overflow;    // raised by the list pass / survivor_eval_kernel when a buffer is full
+    const uint32_t *guard;       // non-null: the launch returns at once unless *guard != 0 (fallback launches)
     // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
     float          *seed_ub;
     uint32_t        seed_sw;
@@ -192,7 +199,9 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 // nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s);
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard = nullptr);
+// exact evaluation of the survivor list of a list-mode launch_tile_filter (probe = cluster of every pair)
+hipError_t launch_survivor_eval(const TileArgs &a, const uint32_t *probe, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:

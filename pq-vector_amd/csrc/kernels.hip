@@ -1486,7 +1486,9 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 // resets the query's candidate buffer and overflow flag.  One wave per query.
 template <int S>
 __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
-                                                        unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled) {
+                                                        unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
+                                                        const uint32_t *guard) {
+    if (guard && *guard == 0u) return;
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
     WaveTopk<S> tk;
@@ -1533,10 +1535,10 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s) {
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled);
-    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled);
+    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard);
+    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1558,7 +1560,7 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // Requires dim % 64 == 0 (swizzle closure), 16 NG * dim * 4 bytes of LDS, the IVF-ordered layout
 // (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
-template <int NG, int S, bool QLDS, bool F16>
+template <int NG, int S, bool QLDS, bool F16, bool LIST>
 __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
     constexpr int PEND = 512 + 64;         // half a group's pairs of one tile + a partial batch
@@ -1566,6 +1568,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #ifdef PQV_PROFILE_PHASES
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (a.guard && *a.guard == 0u) return;      // fallback launch: runs only if the list pass raised the flag
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle);
     if (by >= *a.n_quads) return;
@@ -1650,7 +1653,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     uint64_t ph_k = 0, ph_s = 0, ph_e = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
-    auto eval = [&](uint32_t start, uint32_t count) {
+    [[maybe_unused]] auto eval = [&](uint32_t start, uint32_t count) {
         wave_lds_fence();
         const bool have = (uint32_t)lane < count;
         const uint32_t pe = pend[start + (have ? lane : 0)];
@@ -1724,10 +1727,29 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             }
         }
     };
+    // LIST: the survivors are only recorded -- {pair id, row offset in the list} appended to a global list with
+    // one atomic per batch; survivor_eval_kernel evaluates them afterwards at full occupancy, so this kernel
+    // never waits on the scattered row reads of the exact arithmetic.  A full list raises *overflow; the
+    // caller has a guarded launch of the self-contained (!LIST) form queued behind, which then redoes the batch.
     auto drain = [&](uint32_t keep_below) {
         while (npend >= keep_below && npend > 0) {
             const uint32_t take = npend < 64 ? npend : 64;
-            eval(npend - take, take);
+            if constexpr (LIST) {
+                wave_lds_fence();
+                const bool have = (uint32_t)lane < take;
+                const uint32_t pe = pend[npend - take + (have ? lane : 0)];
+                const uint32_t pr = (uint32_t)__shfl((int)my_pair, (int)(pe >> 26), 64);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.surv_cnt, take);
+                base = readlane_u32(base, 0);
+                if (base + take <= a.surv_cap) {
+                    if (have) a.surv[base + lane] = make_uint2(pr, (uint32_t)(r0 + (pe & 0x03FFFFFFu)));
+                } else if (lane == 0) {
+                    *a.overflow = 1u;
+                }
+            } else {
+                eval(npend - take, take);
+            }
             n_exact += take;
             npend -= take;
         }
@@ -1977,6 +1999,58 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// survivor_eval_kernel: exact re-evaluation of the survivors recorded by wide_filter_kernel<.., LIST>: one lane
+// per {pair, row offset}, the reference's summation order, 4 + 4 sixteen-byte chunks in flight per lane and
+// eight waves per SIMD to hide the scattered reads.  A pair that beats its query's threshold is appended to
+// the query's candidate buffer; a full buffer raises *overflow (the guarded fallback then redoes the batch).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void survivor_eval_kernel(const TileArgs a, const uint32_t *probe) {
+    uint32_t n = *a.surv_cnt;
+    if (n > a.surv_cap) n = a.surv_cap;
+    const uint32_t dim = a.dim, G = dim >> 2;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint2 e = a.surv[i];
+        const uint32_t pr = e.x, roff = e.y;
+        const uint32_t qrow = pr / a.nprobe;
+        const uint64_t srow = a.list_off[probe[pr]] + roff;
+        const uint64_t pos = a.cand_base[pr] + roff;
+        if (pos >= a.max_pos) continue;
+        const float4 *x = reinterpret_cast<const float4 *>(a.mat + srow * dim);
+        const float4 *q = reinterpret_cast<const float4 *>(a.queries + (uint64_t)qrow * dim);
+        float sum = 0.0f;
+        for (uint32_t g = 0; g < G; g += 4) {
+            float4 xv[4], qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { xv[u] = x[g + u]; qv[u] = q[g + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y;
+                const float d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum = sum + t;
+            }
+        }
+        const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos;
+        if (key < a.gthr[qrow]) {
+            const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
+            if (idx < a.cand_cap) {
+                a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = key;
+                a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = (uint32_t)srow;
+            } else {
+                *a.overflow = 1u;
+            }
+        }
+    }
+}
+hipError_t launch_survivor_eval(const TileArgs &a, const uint32_t *probe, hipStream_t s) {
+    if ((a.dim % 16) != 0 || a.row_of || !a.surv) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(survivor_eval_kernel, dim3(4096), dim3(256), 0, s, a, probe);
+    return hipGetLastError();
+}
+
 template <int S>
 static hipError_t launch_tile_s(const TileArgs &a, hipStream_t s) {
     dim3 grid(a.grid_x, a.max_groups), block(256);
@@ -2026,20 +2100,20 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         if (a.f16) {
             if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
             if (a.quad_width == 64 && lds4 / 2 <= 32768)
-                hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
+                { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a); }
             else if (a.quad_width == 32 && lds2 / 2 <= 49152)      // + 10 KB of static LDS: two blocks per CU
-                hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a);
+                { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); }
             else return hipErrorInvalidValue;
             return hipGetLastError();
         }
         if (a.quad_width == 64 && lds4 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a); }
         else if (a.quad_width == 32 && lds2 <= 32768)
-            hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a); }
         else if (a.quad_width == 32 && a.q_blk)
-            hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); }
         else if (a.quad_width == 64 && a.q_blk)
-            hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); }
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
