@@ -1925,7 +1925,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
         wave_lds_fence();
-        aq[lane] = (uint32_t)lane >= cnt ? INFINITY : my_noskip ? -INFINITY : alpha * my_qn - beta * my_thr_d;
+        aq[lane] = (uint32_t)lane >= cnt ? INFINITY : (my_noskip || my_thr == KEY_EMPTY) ? -3.0e38f : alpha * my_qn - beta * my_thr_d;
         wave_lds_fence();
         uint32_t bits[(NG + 1) / 2];
 #pragma unroll
@@ -1944,6 +1944,9 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             }
         }
         // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
+        uint32_t rowmask4 = 0;                         // bit 3 - t: row 16 t + l15 of the tile belongs to this wave
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rowmask4 |= ((uint32_t)(16 * t + l15) < nvalid) ? (8u >> t) : 0u;
         // the accumulators are dead from here on: the next tile's operands can take their registers
         if (pf && t0 + 64 < r1) issue_tile(t0 + 64);
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
@@ -1958,6 +1961,13 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #pragma unroll
                 for (int ww = 1; ww < (NG + 1) / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? bits[ww] : w;
                 uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
+                // explicit validity (rows past the wave's range, queries past the quad's count): the compare
+                // above keeps a pair whenever its operands are NaN -- an unset threshold, non-finite data --
+                // and an out-of-range row must never reach the exact evaluation
+                uint32_t vm = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask4 << (12 - 4 * r) : 0u;
+                mm &= vm;
                 mm &= (hg & 1u) ? 0x00FFu : 0xFF00u;                     // c = 4 r + t lives in bit 15 - c
                 const uint32_t cntl = (uint32_t)__popc(mm);
                 const uint32_t incl = wave_incl_scan_u32(cntl);

@@ -806,3 +806,26 @@ def test_fuzz_screened_search_against_oracle(pqv, oracle, monkeypatch, block):
     for seed in range(1000 + 6 * block, 1000 + 6 * block + 6):
         screened += _fuzz_case(pqv, oracle, seed)
     assert screened > 0
+
+
+@pytest.mark.parametrize("outlier", [1e15, 3e-3])
+def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier):
+    """f16 operands are scaled by the corpus maximum: one huge row pushes every other value to zero in f16
+    (1e15), a corpus of tiny values is scaled up (3e-3); rows / queries the f16 image cannot represent must be
+    evaluated exactly instead of being screened, and the results must stay those of the oracle."""
+    rng = np.random.default_rng(321)
+    n, dim, kc, k, nprobe, nq = 16000, 128, 6, 10, 3, 120
+    data = (rng.random((n, dim), dtype=np.float32) * np.float32(min(1.0, outlier * 300 if outlier < 1 else 1.0))).astype(np.float32)
+    if outlier > 1:
+        data[rng.integers(0, n, 3)] = np.float32(outlier)                   # three enormous rows
+    queries = data[rng.integers(0, n, nq)] * np.float32(1.001)
+    queries[:4] *= np.float32(1e6)                                         # queries far outside the corpus range
+    oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=3)
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nc == onc).all() and (nf == onf).all()
+    assert (_bits(dist) == _bits(odist)).all()
+    assert (rows == orows).all()
