@@ -301,14 +301,26 @@ def main():
                          "speed-up figure there, not a utilisation"}
     if screened:
         mf = 2.0 * dim * cand_rows          # the Q.X^T contraction of the screen: 2 flops per (row, query, dim)
-        result["roofline"] = {"bound": "mfma", "kernel": kernel,
-                              "achieved": mf / (rr_ms * 1e-3) / 1e12 if rr_ms > 0 else 0.0, "peak": 157.3,
-                              "unit": "TFLOP/s", "frac": (mf / (rr_ms * 1e-3) / 1e12 / 157.3) if rr_ms > 0 else 0.0,
+        # f16 operands (default where dim % 128 == 0 and dim <= 768): the contraction runs on v_mfma_f32_16x16x32_f16,
+        # whose dense peak is ~2.5 PFLOP/s (MI355X_MICROARCH.md); f32 operands: 157.3 TFLOP/s
+        f16 = wide and dim % 128 == 0 and dim <= 768 and os.environ.get("PQV_SCREEN_F16", "1") != "0"
+        peak = 2500.0 if f16 else 157.3
+        ach = mf / (rr_ms * 1e-3) / 1e12 if rr_ms > 0 else 0.0
+        result["roofline"] = {"bound": "mfma", "kernel": kernel + (" [f16 operands]" if f16 else " [f32 operands]"),
+                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                               "traffic": traffic, "algo_flops_per_launch": mf, "kernel_ms": rr_ms,
                               "hot_path_ms_per_step": total_ms / max(1, ncalls),
-                              "note": "dominant work = the f32 MFMA contraction of the lower-bound screen (seed window, "
-                                      "threshold merge and exact re-evaluation of survivors are inside kernel_ms)",
+                              "note": ("dominant work = the MFMA contraction of the lower-bound screen (threshold seed, select and "
+                                       "exact re-evaluation of survivors are inside kernel_ms)"
+                                       + ("; with f16 operands the matrix pipe is busy only a few percent of the time -- the "
+                                          "kernel is bound by vector-ALU issue (which does not overlap MFMAs on gfx950) and "
+                                          "latency, see f32_mfma_view / valu_view / DESIGN.md 5.1c" if f16 else "")),
                               "hbm_view": hbm_view, "valu_view": valu_view}
+        if f16:
+            result["roofline"]["f32_mfma_view"] = {
+                "achieved_tflops": ach, "peak": 157.3, "frac": ach / 157.3,
+                "note": "the same flops against the f32 MFMA peak: what the f32-operand form of the kernel "
+                        "(PQV_SCREEN_F16=0) is bounded by; it measured 0.37 isolated on C2"}
     else:
         result["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
