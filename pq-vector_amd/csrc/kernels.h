@@ -143,6 +143,7 @@ struct TileArgs {
     // f16 operands (wide kernels, dim % 128 == 0): mat_blk is the launch_block_rows_f16 copy, the queries are
     // converted while staged; scale is a power of two, scale2 = scale^2
     int             f16;
+    int             q32_lds;      // set by the launcher: the f16 kernel also stages the exact f32 queries in LDS
     float           scale, scale2;
     const float    *query_maxabs;   // [nq] max |q_i| (merge probe)
     const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad

@@ -1634,6 +1634,11 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         if constexpr (F16) {
 #pragma unroll 4
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
+            if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
+                float4 *d32 = qs + NQ * G + q * Gx;
+#pragma unroll 8
+                for (uint32_t ch = c0; ch < Gx; ch += TPQ) d32[ch ^ sw] = src[ch];
+            }
         } else {
 #pragma unroll 8
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
@@ -1662,7 +1667,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const float *x = a.mat + (uint64_t)srow * dim;
-        const float4 *ql = qs + qsl * G;              // QLDS: the pair's query, staged (swizzled) in LDS
+        const float4 *ql = F16 ? qs + NQ * G + qsl * Gx : qs + qsl * G;   // the pair's f32 query, staged (swizzled) in LDS
         const uint32_t qsw = qsl & 15u;
         const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
         float sum = 0.0f;
@@ -1672,14 +1677,15 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = load4<true>(x + (g + u) * 4);
             float4 qvv[8];
-            if constexpr (!QLDS || F16) {
+            const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
+            if (q_global) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) qvv[u] = qg[g + u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float4 qv;
-                if constexpr (QLDS && !F16) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
+                if (!q_global) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
                 const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
                 const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
                 float t = d0 * d0 + d1 * d1;
@@ -2109,8 +2115,13 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
         if (a.f16) {
             if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
-            if (a.quad_width == 64 && lds4 / 2 <= 32768)
-                { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a); }
+            if (a.quad_width == 64 && lds4 / 2 <= 32768) {
+                TileArgs b = a;
+                b.q32_lds = lds4 / 2 + lds4 <= 49152 ? 1 : 0;          // rows of <= 128 dims: f16 and f32 queries both fit
+                const size_t lds = b.q32_lds ? lds4 / 2 + lds4 : lds4 / 2;
+                if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
+                else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
+            }
             else if (a.quad_width == 32 && lds2 / 2 <= 49152)      // + 10 KB of static LDS: two blocks per CU
                 { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); }
             else return hipErrorInvalidValue;
