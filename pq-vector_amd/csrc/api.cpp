@@ -158,7 +158,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_surv, s_surv_cnt;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_surv, s_surv_cnt, s_thr_hist, s_thr_bins;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -1080,11 +1080,13 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // seeds the per-query thresholds), the rest goes through the screened kernel
         static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_SEED_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
         static const uint32_t w1_env = [] { const char *e = std::getenv("PQV_W1_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
-        p.seed_rows = seed_env ? std::max<uint32_t>(64, seed_env / 64 * 64) : 256;
         // The MFMA screen pays when the 16-query tiles are mostly full and lists are long compared
         // with the exact seed window; otherwise (measured on the reference bench shape: 16 pairs per
         // cluster, 1000-row lists, 130 k vs 103 k QPS) the exact kernel alone is faster.
         const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
+        // threshold sample: 256 rows per probed list, 512 for lists of >= 4096 rows (survivors per query halve,
+        // the sampling pass doubles: C2 0.246 -> 0.226 ms, C3 7.99 -> 7.58 ms)
+        p.seed_rows = seed_env ? std::max<uint32_t>(64, seed_env / 64 * 64) : (mean_len >= 4096 ? 512 : 256);
         // (the wide kernel -- dim % 64 == 0, dim <= 256, IVF-ordered rows -- screens ~3x faster than the
         //  one-group kernel and already wins at 1250-row lists: 0.28 vs 0.36 ms on a 125 k-row C2 shard)
         const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && !s->d_row_of;
@@ -1111,6 +1113,15 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 768;
             if (p.f16) p.quad_width = s->dim <= 256 ? 64 : 32;   // the quad's f16 queries are staged in LDS (<= 48 KB)
             uint64_t r = rpb;
+            // wide kernel: a wave's fixed cost (staging the quad's queries, the last partial batch of exact
+            // evaluations) is about half its time at 1536 rows per block, and the lists are cut into equal
+            // pieces, so longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 ->
+            // 6.35 ms); PQV_WIDE_ROWS overrides.  The 2048-block floor above still applies.
+            static const uint64_t wide_rows = [] { const char *e = std::getenv("PQV_WIDE_ROWS"); return e ? std::strtoull(e, nullptr, 10) / 256 * 256 : 2304ull; }();
+            if (p.quad && wide_rows >= 256 && !std::getenv("PQV_TILE_ROWS")) {
+                r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
+                while (r > 256 && est_groups * ((max_len + r - 1) / r) < 2048) r -= 256;
+            }
             p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
                                      : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
             p.filter_rows_per_block = static_cast<uint32_t>(r);
@@ -1311,7 +1322,15 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(sc.s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
             seed.seed_ub = sc.s_seed_ub.as<float>();
             HIP_TRY(launch_wide_seed(seed, stream));
-            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream));
+            // running thresholds (PQV_RUNNING_THR=0 turns them off): see TileArgs::thr_hist
+            static const bool running_thr = [] { const char *e = std::getenv("PQV_RUNNING_THR"); return !(e && *e == '0'); }();
+            if (running_thr && k > 1) {
+                HIP_TRY(sc.s_thr_hist.ensure(static_cast<size_t>(nq) * 16 * sizeof(uint32_t)));
+                HIP_TRY(sc.s_thr_bins.ensure(static_cast<size_t>(nq) * sizeof(float4)));
+                ta.thr_hist = sc.s_thr_hist.as<uint32_t>(); ta.thr_bins = static_cast<const float4 *>(sc.s_thr_bins.p);
+            }
+            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, nullptr,
+                                       ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             // (measured: the recording pass is 20 % shorter, but a lane-per-pair exact pass pays one L1 tag look-up
@@ -1332,9 +1351,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(launch_tile_filter(tl, stream));
                 HIP_TRY(launch_survivor_eval(tl, sc.s_probe.as<uint32_t>(), stream));
                 ta.guard = tl.overflow;
-                HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, ta.guard));
+                HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, ta.guard,
+                                           ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
                 s->counters.kernel_launches += 3;
             }
+            if (std::getenv("PQV_DBG_NOMIN")) ta.seed_sw |= 0x80000000u;
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;

@@ -167,6 +167,12 @@ struct TileArgs {
     // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
     float          *seed_ub;
     uint32_t        seed_sw;
+    // running thresholds (wide_filter_kernel, optional): per query two 64-bit words of 8-bit counters --
+    // counter b = appended pairs at distance < thr0 - b w -- and the bin parameters {thr0, w, 1 / w, pad}
+    // (seed_select_kernel); an appending lane tightens gthr[q] to the upper edge of the nearest bin whose
+    // counter reached k
+    uint32_t       *thr_hist;
+    const float4   *thr_bins;
     unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
     uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
@@ -200,7 +206,8 @@ hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t
 // nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard = nullptr);
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard = nullptr,
+                              uint32_t *thr_hist = nullptr, float4 *thr_bins = nullptr);
 // exact evaluation of the survivor list of a list-mode launch_tile_filter (probe = cluster of every pair)
 hipError_t launch_survivor_eval(const TileArgs &a, const uint32_t *probe, hipStream_t s);
 

@@ -14,6 +14,9 @@
 //                   VALU-bound, lane-per-row with the centroid tile in SGPRs.
 //   lloyd_update    index.rs:436-453 with the reference's ascending-row f32 add order.
 //   gather_rows     sample_embeddings (index.rs:234-239) and the IVF-order re-layout.
+#ifndef PQV_COOP_EVAL
+#define PQV_COOP_EVAL 0
+#endif
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -75,8 +78,18 @@ __device__ __forceinline__ void mfma_step(f32x4_acc &acc, const float4 q, const 
 // eight f32 values scaled by a power of two and rounded to f16 (round to nearest even), packed as 16 bytes
 __device__ __forceinline__ float4 pack_f16x8(const float4 lo, const float4 hi, float scale) {
     f16x8_t h;
+    // (callers clamp where the image must stay finite: see pack_f16x8_clamped)
     h[0] = (_Float16)(lo.x * scale); h[1] = (_Float16)(lo.y * scale); h[2] = (_Float16)(lo.z * scale); h[3] = (_Float16)(lo.w * scale);
     h[4] = (_Float16)(hi.x * scale); h[5] = (_Float16)(hi.y * scale); h[6] = (_Float16)(hi.z * scale); h[7] = (_Float16)(hi.w * scale);
+    return __builtin_bit_cast(float4, h);
+}
+// the same with the scaled values clamped to the finite f16 range (NaN -> -65504): the screen of the
+// f16 kernels reads sign bits and must never see a NaN score
+__device__ __forceinline__ float4 pack_f16x8_clamped(const float4 lo, const float4 hi, float scale) {
+    auto c = [&](float v) { return (_Float16)fminf(fmaxf(v * scale, -65504.0f), 65504.0f); };
+    f16x8_t h;
+    h[0] = c(lo.x); h[1] = c(lo.y); h[2] = c(lo.z); h[3] = c(lo.w);
+    h[4] = c(hi.x); h[5] = c(hi.y); h[6] = c(hi.z); h[7] = c(hi.w);
     return __builtin_bit_cast(float4, h);
 }
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
@@ -656,11 +669,19 @@ hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s) {
 // Quad-to-XCD affinity for the wide kernels: workgroup L runs on XCD L % 8; give XCD i the quads
 // i, i + 8, i + 16, ... with all their row chunks, so the blocks that share a quad's operands (its
 // blocked queries, its cluster's rows) also share an L2.  gridDim.y must be a multiple of 8.
-__device__ __forceinline__ void quad_xcd_remap(uint32_t &bx, uint32_t &by, int enable) {
+// Mode 2 (n_quads known): XCD i takes the CONTIGUOUS quad range [i * per, (i + 1) * per), per =
+// ceil(n_quads / 8).  The quads of one cluster are adjacent, so they run on one XCD at about the same
+// time and the second one finds the cluster's rows in that XCD's L2 instead of fetching them again.
+__device__ __forceinline__ void quad_xcd_remap(uint32_t &bx, uint32_t &by, int enable, uint32_t n_quads = 0) {
     if (!enable) { bx = blockIdx.x; by = blockIdx.y; return; }
     const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t xcd = L & 7u, i = L >> 3;
     bx = i % gridDim.x;
+    if (enable == 2) {
+        const uint32_t per = (n_quads + 7u) >> 3, j = i / gridDim.x;
+        by = j < per ? xcd * per + j : 0xFFFFFFFFu;
+        return;
+    }
     by = (i / gridDim.x) * 8 + xcd;
 }
 __device__ __forceinline__ void xcd_remap(uint32_t &bx, uint32_t &by, int enable) {
@@ -1343,7 +1364,7 @@ template <int NG, bool QLDS, bool F16>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr uint32_t NQ = 16 * NG;
     uint32_t bx, by;
-    quad_xcd_remap(bx, by, a.xcd_swizzle);
+    quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
     if (by >= *a.n_quads) return;
     const uint4 quad = a.quads[by];
     const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
@@ -1487,7 +1508,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 template <int S>
 __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
                                                         unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                        const uint32_t *guard) {
+                                                        const uint32_t *guard, uint32_t *thr_hist, float4 *thr_bins) {
     if (guard && *guard == 0u) return;
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
@@ -1508,6 +1529,23 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
         spilled[q] = 0u;
         // every candidate whose distance is <= the bound must pass (key compare is on (d2, position))
         if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)(kth | 0xFFFFFFFFull));
+    }
+    if (thr_hist) {
+        // running thresholds: 16 bins below thr0 = the k-th bound.  The final k-th distance of a query
+        // usually lies a little below the SMALLEST sampled bound m1, so the bins span twice thr0 - m1.
+        if (lane < 4) thr_hist[(uint64_t)q * 4 + lane] = 0u;        // two 64-bit words of 8-bit counters
+        if (lane == 0) {
+            float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);            // 1 / w == 0: no running threshold
+            if (kth != KEY_EMPTY) {
+                const float thr0 = __uint_as_float((uint32_t)(kth >> 32));
+                const float m1 = __uint_as_float((uint32_t)(readlane_u64(tk.key[0], 0) >> 32));
+                float w = (thr0 - m1) * 0.125f;
+                if (!(w > thr0 * 1.0e-6f)) w = thr0 * 0.00390625f;      // degenerate sample: 2^-8 of the bound
+                if (w > 0.0f && w < INFINITY && thr0 < INFINITY)
+                    hb = make_float4(thr0, w, 1.0f / w, thr0 * 9.5367431640625e-07f + w * 1.52587890625e-05f);
+            }
+            thr_bins[q] = hb;
+        }
     }
 }
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
@@ -1535,10 +1573,11 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard) {
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard,
+                              uint32_t *thr_hist, float4 *thr_bins) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard);
-    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard);
+    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard, thr_hist, thr_bins);
+    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard, thr_hist, thr_bins);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1570,7 +1609,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #endif
     if (a.guard && *a.guard == 0u) return;      // fallback launch: runs only if the list pass raised the flag
     uint32_t bx, by;
-    quad_xcd_remap(bx, by, a.xcd_swizzle);
+    quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
     if (by >= *a.n_quads) return;
     const uint4 quad = a.quads[by];          // {cluster, first pair slot, pair count <= NQ, 0}
     const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
@@ -1587,8 +1626,17 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
-    const uint64_t wrows = a.rows_per_block / 4;
+    uint64_t wrows = a.rows_per_block / 4;
     uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
+    if (a.row_offset == 0 && a.row_end == 0) {
+        // the whole list in this launch: ceil(len / rows_per_block) blocks share it in EQUAL wave pieces (a
+        // multiple of the 64-row tile), so no block is left with a sliver of a last chunk -- its fixed cost
+        // (staging the quad's queries, the final partial batch of exact evaluations) would be wasted
+        const uint64_t nch = (len + a.rows_per_block - 1) / a.rows_per_block;
+        if (bx >= nch) return;
+        wrows = ((len + 4 * nch - 1) / (4 * nch) + 63) / 64 * 64;
+        r0 = ((uint64_t)bx * 4 + (uint64_t)wave) * wrows;
+    }
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
     if (a.row_end && r1 > a.row_end) r1 = a.row_end;     // window of this launch
@@ -1633,7 +1681,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint32_t sw = q & 15u;
         if constexpr (F16) {
 #pragma unroll 4
-            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8_clamped(src[2 * ch], src[2 * ch + 1], a.scale);
             if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
                 float4 *d32 = qs + NQ * G + q * Gx;
 #pragma unroll 8
@@ -1646,7 +1694,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         __syncthreads();
     }
     // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
-    const bool my_noskip = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn * a.scale2 < 1.0f);
+    const bool my_noskip = F16 && (!(a.query_maxabs[my_qrow] * a.scale <= 32768.0f) || !(my_qn * a.scale2 >= 1.0f) || !(my_qn <= 3.0e38f));
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
@@ -1655,10 +1703,14 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     uint32_t npend = 0;
     uint32_t n_exact = 0;
 #ifdef PQV_PROFILE_PHASES
-    uint64_t ph_k = 0, ph_s = 0, ph_e = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
+    uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
+    uint64_t cur_gthr = __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     [[maybe_unused]] auto eval = [&](uint32_t start, uint32_t count) {
+#ifdef PQV_PROFILE_PHASES
+        const uint64_t ph_e0 = __builtin_amdgcn_s_memtime();
+#endif
         wave_lds_fence();
         const bool have = (uint32_t)lane < count;
         const uint32_t pe = pend[start + (have ? lane : 0)];
@@ -1671,6 +1723,79 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint32_t qsw = qsl & 15u;
         const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
         float sum = 0.0f;
+#if PQV_COOP_EVAL
+        // Eight lanes per pair: one 128-byte line of the row per load instruction
+        // (8 tag lookups instead of 64), the reference's chain rebuilt in chunk order
+        // with row_shl adds on the group's first lane.
+        {
+            const int j = lane & 7, grp = lane >> 3;
+            const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
+            const uint32_t nsb = (count + 7) >> 3;
+            // load cursor (one step ahead of the compute cursor): sub-batch, chunk base
+            uint32_t lsb = 0, lc0 = 0, csb = 0, cc0 = 0;
+            float s = 0.0f;
+            auto fetch = [&](float4 (&xv)[4], float4 (&qv)[4]) {
+                if (lsb >= nsb) return;
+                int pl = (int)(lsb * 8) + grp;
+                pl = pl < (int)count ? pl : (int)count - 1;
+                const uint32_t qsl_p = (uint32_t)__shfl((int)pe, pl, 64) >> 26;
+                const uint32_t srow_p = (uint32_t)__shfl((int)srow, pl, 64);
+                const float *xp = a.mat + (uint64_t)srow_p * dim;
+                const float4 *qlp = F16 ? qs + NQ * G + qsl_p * Gx : qs + qsl_p * G;
+                const uint32_t qsw_p = qsl_p & 15u;
+                const float4 *qgp = reinterpret_cast<const float4 *>(
+                    a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl_p, 64) * dim);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = lc0 + 8 * u + j;
+                    if (lc0 + 8 * u < Gx) {
+                        xv[u] = load4<true>(xp + c * 4);
+                        qv[u] = q_global ? qgp[c] : qlp[c ^ qsw_p];
+                    }
+                }
+                lc0 += 32;
+                if (lc0 >= Gx) { lc0 = 0; ++lsb; }
+            };
+            auto fold = [&](const float4 (&xv)[4], const float4 (&qv)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (cc0 + 8 * u < Gx) {
+                        const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y;
+                        const float d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                        float t = d0 * d0 + d1 * d1;
+                        t = t + d2 * d2;
+                        t = t + d3 * d3;
+                        const int ti = __float_as_int(t);
+                        s = s + t;
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x101, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x102, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x103, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x104, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x105, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x106, 0xF, 0xF, true));
+                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x107, 0xF, 0xF, true));
+                    }
+                }
+                cc0 += 32;
+                if (cc0 >= Gx) {
+                    const float got = __shfl(s, 8 * (lane & 7), 64);
+                    if ((uint32_t)grp == csb) sum = got;
+                    s = 0.0f;
+                    cc0 = 0;
+                    ++csb;
+                }
+            };
+            float4 xa[4], qa[4], xb[4], qb[4];
+            fetch(xa, qa);
+            while (csb < nsb) {
+                fetch(xb, qb);
+                fold(xa, qa);
+                if (csb >= nsb) break;
+                fetch(xa, qa);
+                fold(xb, qb);
+            }
+        }
+#else
         // 8 row chunks in flight per lane, then the reference's ordered chain over them
         for (uint32_t g = 0; g < Gx; g += 8) {
             float4 xv[8];
@@ -1694,8 +1819,12 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                 sum = sum + t;
             }
         }
-        const uint64_t my_gthr =
-            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#ifdef PQV_PROFILE_PHASES
+        if (__float_as_uint(sum) == 0x7FC12345u) __builtin_trap();      // consume the sum before the timestamp
+        ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
+#endif
+        const uint64_t my_gthr = cur_gthr;         // the wave's view of the thresholds (refreshed every tile)
         const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
         const uint64_t pos = shfl_u64(my_cbase, (int)qsl) + roff;
         const uint64_t mykey_all =
@@ -1703,7 +1832,8 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // A pair that beats its query's threshold is APPENDED to the query's candidate buffer: one
         // atomic per lane, all lanes in parallel (a sorted per-wave list would cost one global
         // read-modify-write round trip per query, serially -- measured: half of the kernel).
-        const bool pass = mykey_all < shfl_u64(my_thr, (int)qsl);
+        const uint64_t pair_thr = shfl_u64(my_thr, (int)qsl);
+        const bool pass = mykey_all < pair_thr;
         bool spill = false;
         const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qsl, 64);
         if (pass) {
@@ -1714,6 +1844,48 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             } else {
                 spill = true;          // buffer full: fall back to this wave's sorted list (slow, exact)
                 a.spilled[qrow] = 1u;
+            }
+            // Running threshold.  k == 1: the exact distance itself.  Otherwise the query has 15 bins below
+            // its seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one
+            // 8-bit counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER, packed
+            // into two 64-bit words: an append adds 1 to the counters of bins 1..b with ONE returning atomic
+            // per word, and the returned word tells it directly whether some counter reached k -- then that
+            // bin's upper edge (+ the rounding pad of the bin arithmetic) bounds the final k-th distance.
+            // Counters only grow and only the first 255 appends of a query are counted (no field overflow):
+            // every snapshot is a valid lower bound of the true counts.  No look-up, no extra loads.
+            if (k == 1u) {
+                atomicMin(a.gthr + qrow, (unsigned long long)(mykey_all | 0xFFFFFFFFull));
+            } else if (a.thr_hist && idx < 255u) {
+                const float4 hb = a.thr_bins[qrow];
+                const int b = (int)fminf(fmaxf((hb.x - sum) * hb.z, 0.0f), 15.0f);
+                if (hb.z > 0.0f && b > 0) {
+                    unsigned long long *h2 = reinterpret_cast<unsigned long long *>(a.thr_hist) + (uint64_t)qrow * 2;
+                    const unsigned long long ones = 0x0101010101010101ull;
+                    const unsigned long long add0 = b >= 8 ? ones : (ones & ((1ull << (8 * b)) - 1ull));
+                    const unsigned long long add1 = b >= 9 ? (ones & ((1ull << (8 * (b - 8))) - 1ull)) : 0ull;
+                    unsigned long long w1 = 0ull;
+                    if (add1) w1 = atomicAdd(h2 + 1, add1) + add1;           // bins 9..15
+                    const unsigned long long w0 = atomicAdd(h2, add0) + add0;   // bins 1..8
+                    // the nearest bin whose counter reached k, and whether THIS add took it there (exactly one
+                    // lane sees the counter equal to k): only that lane publishes the bin's edge
+                    int bsel = 0;
+                    uint32_t fsel = 0;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        const uint32_t c = (uint32_t)((w0 >> (8 * f)) & 0xFFu);
+                        if (c >= k) { bsel = f + 1; fsel = c; }
+                    }
+#pragma unroll
+                    for (int f = 0; f < 7; ++f) {
+                        const uint32_t c = (uint32_t)((w1 >> (8 * f)) & 0xFFu);
+                        if (c >= k) { bsel = f + 9; fsel = c; }
+                    }
+                    if (bsel > 0 && bsel <= b && fsel == k && !(a.seed_sw & 0x80000000u)) {
+                        const float e = hb.x - (float)bsel * hb.y + hb.w;
+                        if (e < hb.x && e >= 0.0f)
+                            atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
+                    }
+                }
             }
         }
         unsigned long long todo = __ballot(spill);
@@ -1795,6 +1967,9 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             }
     };
     if (pf && r0 < r1) issue_tile(r0);
+    // the query thresholds are read one tile ahead (they tighten while the kernel runs, and a freshly
+    // modified line costs a fabric round trip that must not sit in front of the operand waits)
+    uint64_t gthr_next = cur_gthr;
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
@@ -1818,8 +1993,9 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         uint32_t xso[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
-        const uint64_t my_gthr =
-            __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t my_gthr = gthr_next;
+        cur_gthr = gthr_next;
+        gthr_next = __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
         // threshold DISTANCE of this lane's query; KEY_EMPTY gives NaN: "cannot skip"
         const float my_thr_d = __uint_as_float((uint32_t)(my_thr >> 32));
@@ -1936,6 +2112,36 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         uint32_t bits[(NG + 1) / 2];
 #pragma unroll
         for (int w = 0; w < (NG + 1) / 2; ++w) bits[w] = 0;
+        if constexpr (F16) {
+            // f16 operands: every term is finite by construction (rows scaled below 2^14, query images clamped
+            // to the f16 range, never-skip / unset thresholds carry -3e38, invalid ones +inf), so
+            // skip <=> acc - smin < 0 <=> its sign bit: two packed adds per TWO pairs and one v_alignbit
+            // per pair shift the sign into the lane's mask -- no compare, no scalar mask, no select.
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(aq + 16 * g + 4 * kk);
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const f32x2_t ar2 = rp ? f32x2_t{a4.z, a4.w} : f32x2_t{a4.x, a4.y};
+                    f32x2_t dd[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x2_t smin = ar2 + f32x2_t{bt[t], bt[t]};
+                        const f32x2_t av = {acc[g][t][2 * rp], acc[g][t][2 * rp + 1]};
+                        dd[t] = av - smin;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            bits[g >> 1] = __builtin_amdgcn_alignbit(bits[g >> 1], __float_as_uint(dd[t][rr]), 31);
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < (NG + 1) / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
+        } else {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float4 a4 = *reinterpret_cast<const float4 *>(aq + 16 * g + 4 * kk);
@@ -1948,6 +2154,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                     bits[g >> 1] = bits[g >> 1] + bits[g >> 1] + (keep ? 1u : 0u);
                 }
             }
+        }
         }
         // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
         uint32_t rowmask4 = 0;                         // bit 3 - t: row 16 t + l15 of the tile belongs to this wave
@@ -2008,7 +2215,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             if (wid < 65536ull) {
                 unsigned long long *rec = a.stats + 8 + 8 * wid;
                 rec[0] = ph_t0; rec[1] = ph_pro; rec[2] = ph_k; rec[3] = ph_s - ph_e; rec[4] = ph_e;
-                rec[5] = __builtin_amdgcn_s_memtime(); rec[6] = (unsigned long long)(r1 - r0); rec[7] = cnt | ((unsigned long long)n_exact << 32);
+                rec[5] = __builtin_amdgcn_s_memtime(); rec[6] = ph_em; rec[7] = cnt | ((unsigned long long)n_exact << 32);
             }
         }
 #endif

@@ -6,7 +6,9 @@ dur = end-start
 print("waves", n, "span", end.max(), "ticks")
 print("mean dur", dur.mean(), "prologue", rec[:,1].mean(), "kloop", rec[:,2].mean(), "screen", rec[:,3].mean(), "drain", rec[:,4].mean(), "other", (dur-rec[:,1]-rec[:,2]-rec[:,3]-rec[:,4]).mean())
 full = (rec[:,7] & 0xffffffff) == 64
-print("full quads: n", full.sum(), "dur", dur[full].mean(), "kloop", rec[full,2].mean(), "rows", rec[full,6].mean(), "evals", (rec[full,7]>>32).mean())
+em = rec[:,6] & ((1 << 48) - 1); ne = rec[:,6] >> 48
+print("eval calls/wave", ne.mean(), "eval distance part", em.mean(), "eval tail", (rec[:,4]-em).mean(), "pairs/wave", (rec[:,7]>>32).mean())
+print("full quads: n", full.sum(), "dur", dur[full].mean(), "kloop", rec[full,2].mean(), "evals", (rec[full,7]>>32).mean())
 # concurrency over time
 ev = np.concatenate([np.stack([start, np.ones(n)],1), np.stack([end, -np.ones(n)],1)])
 ev = ev[ev[:,0].argsort()]
