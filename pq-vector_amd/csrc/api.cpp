@@ -1355,7 +1355,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                                            ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
                 s->counters.kernel_launches += 3;
             }
-            if (std::getenv("PQV_DBG_NOMIN")) ta.seed_sw |= 0x80000000u;
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;

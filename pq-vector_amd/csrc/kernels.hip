@@ -14,9 +14,6 @@
 //                   VALU-bound, lane-per-row with the centroid tile in SGPRs.
 //   lloyd_update    index.rs:436-453 with the reference's ascending-row f32 add order.
 //   gather_rows     sample_embeddings (index.rs:234-239) and the IVF-order re-layout.
-#ifndef PQV_COOP_EVAL
-#define PQV_COOP_EVAL 0
-#endif
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -1723,103 +1720,36 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint32_t qsw = qsl & 15u;
         const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
         float sum = 0.0f;
-#if PQV_COOP_EVAL
-        // Eight lanes per pair: one 128-byte line of the row per load instruction
-        // (8 tag lookups instead of 64), the reference's chain rebuilt in chunk order
-        // with row_shl adds on the group's first lane.
-        {
-            const int j = lane & 7, grp = lane >> 3;
-            const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
-            const uint32_t nsb = (count + 7) >> 3;
-            // load cursor (one step ahead of the compute cursor): sub-batch, chunk base
-            uint32_t lsb = 0, lc0 = 0, csb = 0, cc0 = 0;
-            float s = 0.0f;
-            auto fetch = [&](float4 (&xv)[4], float4 (&qv)[4]) {
-                if (lsb >= nsb) return;
-                int pl = (int)(lsb * 8) + grp;
-                pl = pl < (int)count ? pl : (int)count - 1;
-                const uint32_t qsl_p = (uint32_t)__shfl((int)pe, pl, 64) >> 26;
-                const uint32_t srow_p = (uint32_t)__shfl((int)srow, pl, 64);
-                const float *xp = a.mat + (uint64_t)srow_p * dim;
-                const float4 *qlp = F16 ? qs + NQ * G + qsl_p * Gx : qs + qsl_p * G;
-                const uint32_t qsw_p = qsl_p & 15u;
-                const float4 *qgp = reinterpret_cast<const float4 *>(
-                    a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl_p, 64) * dim);
+        // 8 row chunks in flight per lane, then the reference's ordered chain over them (16 in flight -- two
+        // round trips per 128-dim row instead of four -- measured no faster and costs the last free registers)
+        const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
+        auto chain = [&](auto nb_c, auto qg_c) {
+            constexpr int NB = decltype(nb_c)::value;
+            constexpr bool QG = decltype(qg_c)::value;
+            for (uint32_t g = 0; g < Gx; g += NB) {
+                float4 xv[NB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t c = lc0 + 8 * u + j;
-                    if (lc0 + 8 * u < Gx) {
-                        xv[u] = load4<true>(xp + c * 4);
-                        qv[u] = q_global ? qgp[c] : qlp[c ^ qsw_p];
-                    }
+                for (int u = 0; u < NB; ++u) xv[u] = load4<true>(x + (g + u) * 4);
+                float4 qvv[QG ? NB : 1];
+                if constexpr (QG) {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) qvv[u] = qg[g + u];
                 }
-                lc0 += 32;
-                if (lc0 >= Gx) { lc0 = 0; ++lsb; }
-            };
-            auto fold = [&](const float4 (&xv)[4], const float4 (&qv)[4]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (cc0 + 8 * u < Gx) {
-                        const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y;
-                        const float d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
-                        float t = d0 * d0 + d1 * d1;
-                        t = t + d2 * d2;
-                        t = t + d3 * d3;
-                        const int ti = __float_as_int(t);
-                        s = s + t;
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x101, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x102, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x103, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x104, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x105, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x106, 0xF, 0xF, true));
-                        s = s + __int_as_float(__builtin_amdgcn_update_dpp(0, ti, 0x107, 0xF, 0xF, true));
-                    }
+                for (int u = 0; u < NB; ++u) {
+                    float4 qv;
+                    if constexpr (QG) qv = qvv[u]; else qv = ql[(g + u) ^ qsw];
+                    const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
+                    const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    sum = sum + t;
                 }
-                cc0 += 32;
-                if (cc0 >= Gx) {
-                    const float got = __shfl(s, 8 * (lane & 7), 64);
-                    if ((uint32_t)grp == csb) sum = got;
-                    s = 0.0f;
-                    cc0 = 0;
-                    ++csb;
-                }
-            };
-            float4 xa[4], qa[4], xb[4], qb[4];
-            fetch(xa, qa);
-            while (csb < nsb) {
-                fetch(xb, qb);
-                fold(xa, qa);
-                if (csb >= nsb) break;
-                fetch(xa, qa);
-                fold(xb, qb);
             }
-        }
-#else
-        // 8 row chunks in flight per lane, then the reference's ordered chain over them
-        for (uint32_t g = 0; g < Gx; g += 8) {
-            float4 xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = load4<true>(x + (g + u) * 4);
-            float4 qvv[8];
-            const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
-            if (q_global) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) qvv[u] = qg[g + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float4 qv;
-                if (!q_global) qv = ql[(g + u) ^ qsw]; else qv = qvv[u];
-                const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
-                const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
-                float t = d0 * d0 + d1 * d1;
-                t = t + d2 * d2;
-                t = t + d3 * d3;
-                sum = sum + t;
-            }
-        }
-#endif
+        };
+        if (q_global) chain(std::integral_constant<int, 8>{}, std::true_type{});
+        else chain(std::integral_constant<int, 8>{}, std::false_type{});
 #ifdef PQV_PROFILE_PHASES
         if (__float_as_uint(sum) == 0x7FC12345u) __builtin_trap();      // consume the sum before the timestamp
         ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
@@ -1880,7 +1810,7 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                         const uint32_t c = (uint32_t)((w1 >> (8 * f)) & 0xFFu);
                         if (c >= k) { bsel = f + 9; fsel = c; }
                     }
-                    if (bsel > 0 && bsel <= b && fsel == k && !(a.seed_sw & 0x80000000u)) {
+                    if (bsel > 0 && bsel <= b && fsel == k) {
                         const float e = hb.x - (float)bsel * hb.y + hb.w;
                         if (e < hb.x && e >= 0.0f)
                             atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
