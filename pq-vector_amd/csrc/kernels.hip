@@ -1677,12 +1677,18 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
         if constexpr (F16) {
-#pragma unroll 4
-            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8_clamped(src[2 * ch], src[2 * ch + 1], a.scale);
             if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
                 float4 *d32 = qs + NQ * G + q * Gx;
-#pragma unroll 8
-                for (uint32_t ch = c0; ch < Gx; ch += TPQ) d32[ch ^ sw] = src[ch];
+#pragma unroll 4
+                for (uint32_t ch = c0; ch < G; ch += TPQ) {
+                    const float4 lo = src[2 * ch], hi = src[2 * ch + 1];
+                    dst[ch ^ sw] = pack_f16x8_clamped(lo, hi, a.scale);
+                    d32[(2 * ch) ^ sw] = lo;
+                    d32[(2 * ch + 1) ^ sw] = hi;
+                }
+            } else {
+#pragma unroll 4
+                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8_clamped(src[2 * ch], src[2 * ch + 1], a.scale);
             }
         } else {
 #pragma unroll 8
