@@ -1772,7 +1772,32 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const bool pass = mykey_all < pair_thr;
         bool spill = false;
         const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qsl, 64);
+        // Running threshold.  k == 1: the exact distance itself.  Otherwise the query has 12 bins below its
+        // seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one 8-bit
+        // counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER: word 0 = bins 8..1,
+        // word 1 = bins 12..9, the NEARER bin in the LOWER byte.  An append adds 1 to the counters of bins
+        // 1..b with one returning atomic per word -- issued together with the append's own counter, one round
+        // trip in all -- and the returned word says whether this add took some counter to k: then that bin's
+        // upper edge (+ the rounding pad of the bin arithmetic) bounds the final k-th distance, and exactly one
+        // lane publishes it.  A counter that wraps (> 255 pairs) carries into the next byte, the counter of a
+        // FARTHER bin, which truly holds at least as many pairs (>= 256 > k): every value the bytes can show
+        // is either an under-count or the count of a bin that does hold k pairs.  No look-up, no extra loads.
+        int hb_bin = 0;
+        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pass && k > 1u && a.thr_hist) {
+            hb = a.thr_bins[qrow];
+            hb_bin = hb.z > 0.0f ? (int)fminf(fmaxf((hb.x - sum) * hb.z, 0.0f), 12.0f) : 0;
+        }
         if (pass) {
+            const unsigned long long ones = 0x0101010101010101ull;
+            unsigned long long w0 = 0ull, w1 = 0ull;
+            unsigned long long *h2 = reinterpret_cast<unsigned long long *>(a.thr_hist) + (uint64_t)qrow * 2;
+            const int b = hb_bin;
+            // byte j of word 0 = bin 8 - j: bins <= b are bytes j >= 8 - b;  byte j of word 1 = bin 12 - j
+            const unsigned long long add0 = b >= 8 ? ones : b >= 1 ? ones << (8 * (8 - b)) : 0ull;
+            const unsigned long long add1 = b >= 9 ? (ones & 0xFFFFFFFFull) << (8 * (12 - b)) & 0xFFFFFFFFull : 0ull;
+            if (add1) w1 = atomicAdd(h2 + 1, add1) + add1;
+            if (add0) w0 = atomicAdd(h2, add0) + add0;
             const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
             if (idx < a.cand_cap) {
                 a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = mykey_all;
@@ -1781,46 +1806,25 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                 spill = true;          // buffer full: fall back to this wave's sorted list (slow, exact)
                 a.spilled[qrow] = 1u;
             }
-            // Running threshold.  k == 1: the exact distance itself.  Otherwise the query has 15 bins below
-            // its seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one
-            // 8-bit counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER, packed
-            // into two 64-bit words: an append adds 1 to the counters of bins 1..b with ONE returning atomic
-            // per word, and the returned word tells it directly whether some counter reached k -- then that
-            // bin's upper edge (+ the rounding pad of the bin arithmetic) bounds the final k-th distance.
-            // Counters only grow and only the first 255 appends of a query are counted (no field overflow):
-            // every snapshot is a valid lower bound of the true counts.  No look-up, no extra loads.
             if (k == 1u) {
                 atomicMin(a.gthr + qrow, (unsigned long long)(mykey_all | 0xFFFFFFFFull));
-            } else if (a.thr_hist && idx < 255u) {
-                const float4 hb = a.thr_bins[qrow];
-                const int b = (int)fminf(fmaxf((hb.x - sum) * hb.z, 0.0f), 15.0f);
-                if (hb.z > 0.0f && b > 0) {
-                    unsigned long long *h2 = reinterpret_cast<unsigned long long *>(a.thr_hist) + (uint64_t)qrow * 2;
-                    const unsigned long long ones = 0x0101010101010101ull;
-                    const unsigned long long add0 = b >= 8 ? ones : (ones & ((1ull << (8 * b)) - 1ull));
-                    const unsigned long long add1 = b >= 9 ? (ones & ((1ull << (8 * (b - 8))) - 1ull)) : 0ull;
-                    unsigned long long w1 = 0ull;
-                    if (add1) w1 = atomicAdd(h2 + 1, add1) + add1;           // bins 9..15
-                    const unsigned long long w0 = atomicAdd(h2, add0) + add0;   // bins 1..8
-                    // the nearest bin whose counter reached k, and whether THIS add took it there (exactly one
-                    // lane sees the counter equal to k): only that lane publishes the bin's edge
-                    int bsel = 0;
-                    uint32_t fsel = 0;
+            } else if (b > 0) {
+                // the nearest bin <= b whose counter shows exactly k after this add
+                int bsel = 0;
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) {
-                        const uint32_t c = (uint32_t)((w0 >> (8 * f)) & 0xFFu);
-                        if (c >= k) { bsel = f + 1; fsel = c; }
-                    }
+                for (int jj = 7; jj >= 0; --jj) {            // far -> near: the last match is the nearest
+                    const int bin = 8 - jj;
+                    if (bin <= b && (uint32_t)((w0 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
+                }
 #pragma unroll
-                    for (int f = 0; f < 7; ++f) {
-                        const uint32_t c = (uint32_t)((w1 >> (8 * f)) & 0xFFu);
-                        if (c >= k) { bsel = f + 9; fsel = c; }
-                    }
-                    if (bsel > 0 && bsel <= b && fsel == k) {
-                        const float e = hb.x - (float)bsel * hb.y + hb.w;
-                        if (e < hb.x && e >= 0.0f)
-                            atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
-                    }
+                for (int jj = 3; jj >= 0; --jj) {
+                    const int bin = 12 - jj;
+                    if (bin <= b && (uint32_t)((w1 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
+                }
+                if (bsel > 0) {
+                    const float e = hb.x - (float)bsel * hb.y + hb.w;
+                    if (e < hb.x && e >= 0.0f)
+                        atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
                 }
             }
         }
