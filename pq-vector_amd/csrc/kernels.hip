@@ -1511,6 +1511,30 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
     const uint32_t q = blockIdx.x;
     WaveTopk<S> tk;
     tk.init();
+    // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
+    // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
+    uint64_t cut = KEY_EMPTY;
+    if (k <= 64u) {
+        uint64_t lmin = KEY_EMPTY;
+        for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {          // eight loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t idx = i0 + 64 * u + lane;
+                v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (v[u] < INFINITY) {
+                    const uint64_t key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
+                    lmin = key < lmin ? key : lmin;
+                }
+            }
+        }
+        uint32_t dummy = 0;
+        bitonic_sort64(lmin, dummy, lane);
+        cut = readlane_u64(lmin, (int)k - 1);
+    }
     for (uint32_t i = 0; i < n_vals; i += 64) {
         const uint32_t idx = i + lane;
         uint64_t key = KEY_EMPTY;
@@ -1518,7 +1542,8 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
             const float v = seed_ub[(uint64_t)q * n_vals + idx];
             if (v < INFINITY) key = ((uint64_t)__float_as_uint(v) << 32) | idx;
         }
-        tk.offer(key, 0u, k, lane);
+        if (key > cut) key = KEY_EMPTY;
+        if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
     }
     const uint64_t kth = tk.kth(k);
     if (lane == 0) {

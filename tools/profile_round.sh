@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r01b; mkdir -p $O
+O=$R/gpurun_out/prof_${1:-r01c}; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/kt -- python $R/bench.py --no-cpu --steps 10 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find $O/kt -name "*.db" | head -1) --match pqv > $O/c2_kernel_trace.txt
 for c in FETCH_SIZE WRITE_SIZE; do
