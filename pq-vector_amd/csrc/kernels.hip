@@ -1740,8 +1740,18 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint64_t ph_e0 = __builtin_amdgcn_s_memtime();
 #endif
         wave_lds_fence();
-        const bool have = (uint32_t)lane < count;
-        const uint32_t pe = pend[start + (have ? lane : 0)];
+        // A batch that does not fill the wave (the last one of every wave; most batches of long rows) gives each
+        // pair L = 2, 4 or 8 lanes: per round the L lanes of a pair fetch L x 8 consecutive row chunks -- the
+        // scattered reads are latency, and a 768-dim row is 24 round trips for one lane, 3 for eight -- and the
+        // reference's chain passes through them in chunk order (lane 0's eight adds, then lane 1's, ...), so the
+        // sum is bit-identical.  The pair's first lane carries on with the result.
+        uint32_t lg = 0;
+        while (lg < 3 && (count << (lg + 1)) <= 64u && (Gx % (16u << lg)) == 0u) ++lg;      // wave-uniform
+        const uint32_t L = 1u << lg;
+        const uint32_t pi = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);
+        const bool valid = pi < count;
+        const bool have = valid && pj == 0u;
+        const uint32_t pe = pend[start + (valid ? pi : 0)];
         const uint32_t qsl = pe >> 26;                        // query index in the quad
         const uint64_t roff = r0 + (pe & 0x03FFFFFFu);         // row offset in the list
         const uint64_t lpos = lbeg + roff;
@@ -1754,10 +1764,12 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // 8 row chunks in flight per lane, then the reference's ordered chain over them (16 in flight -- two
         // round trips per 128-dim row instead of four -- measured no faster and costs the last free registers)
         const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
-        auto chain = [&](auto nb_c, auto qg_c) {
-            constexpr int NB = decltype(nb_c)::value;
+        auto chain = [&](auto qg_c) {
+            constexpr int NB = 8;
             constexpr bool QG = decltype(qg_c)::value;
-            for (uint32_t g = 0; g < Gx; g += NB) {
+            const uint32_t first = (uint32_t)lane & ~(L - 1u);          // first lane of this pair's group
+            for (uint32_t g0 = 0; g0 < Gx; g0 += NB * L) {
+                const uint32_t g = g0 + NB * pj;
                 float4 xv[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) xv[u] = load4<true>(x + (g + u) * 4);
@@ -1766,21 +1778,32 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #pragma unroll
                     for (int u = 0; u < NB; ++u) qvv[u] = qg[g + u];
                 }
+                float t[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     float4 qv;
                     if constexpr (QG) qv = qvv[u]; else qv = ql[(g + u) ^ qsw];
                     const float d0 = qv.x - xv[u].x, d1 = qv.y - xv[u].y;
                     const float d2 = qv.z - xv[u].z, d3 = qv.w - xv[u].w;
-                    float t = d0 * d0 + d1 * d1;
-                    t = t + d2 * d2;
-                    t = t + d3 * d3;
-                    sum = sum + t;
+                    float tt = d0 * d0 + d1 * d1;
+                    tt = tt + d2 * d2;
+                    t[u] = tt + d3 * d3;
+                }
+                if (L == 1u) {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) sum = sum + t[u];
+                } else {
+                    for (uint32_t sl = 0; sl < L; ++sl) {                // the chain visits the group's lanes in order
+                        float sn = sum;
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) sn = sn + t[u];
+                        sum = __shfl(pj == sl ? sn : sum, (int)(first + sl), 64);
+                    }
                 }
             }
         };
-        if (q_global) chain(std::integral_constant<int, 8>{}, std::true_type{});
-        else chain(std::integral_constant<int, 8>{}, std::false_type{});
+        if (q_global) chain(std::true_type{});
+        else chain(std::false_type{});
 #ifdef PQV_PROFILE_PHASES
         if (__float_as_uint(sum) == 0x7FC12345u) __builtin_trap();      // consume the sum before the timestamp
         ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
