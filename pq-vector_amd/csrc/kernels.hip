@@ -2153,7 +2153,49 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
         // expand half a group at a time (queries r < 2 / r >= 2 of the lane: <= 512 entries) with the drain in
         // between; after the last tile one extra pass flushes the queue
-        const uint32_t hend = 2 * ng + (t0 + 64 >= r1 ? 1u : 0u);
+        // Fast path (almost every tile): all survivors of the tile fit the queue at once -- ONE prefix scan and
+        // one drain per tile instead of one per half group.
+        uint32_t vw[(NG + 1) / 2];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < (NG + 1) / 2; ++ww) {
+            uint32_t vmw = 0;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const uint32_t g = 2 * ww + gg;
+                uint32_t vm = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask4 << (12 - 4 * r) : 0u;
+                vmw |= (g < (uint32_t)NG && g < ng) ? (gg ? vm : vm << 16) : 0u;
+            }
+            vw[ww] = bits[ww] & vmw;
+            tot += (uint32_t)__popc(vw[ww]);
+        }
+        const uint32_t incl_all = wave_incl_scan_u32(tot);
+        const bool one_pass = readlane_u32(incl_all, 63) <= 512u - 64u;
+        if (one_pass) {
+            uint32_t at = npend + incl_all - tot;
+#pragma unroll
+            for (int ww = 0; ww < (NG + 1) / 2; ++ww) {
+                uint32_t mm = vw[ww];
+                while (mm) {
+                    const uint32_t b = 31u - (uint32_t)__clz(mm);        // bit 31 - (16 (g & 1) + 4 r + t) of word g / 2
+                    mm &= ~(1u << b);
+                    const uint32_t c = 31u - b;                          // c = 16 (g & 1) + 4 r + t
+                    const uint32_t qslot = 32u * ww + (c & 16u) + 4u * (uint32_t)kk + ((c >> 2) & 3u);
+                    pend[at++] = (qslot << 26) + rowbase + 16u * (c & 3u);
+                }
+            }
+            npend += readlane_u32(incl_all, 63);
+#ifdef PQV_PROFILE_PHASES
+            const uint64_t ph_c = __builtin_amdgcn_s_memtime();
+#endif
+            drain(t0 + 64 >= r1 ? 1u : 64u);
+#ifdef PQV_PROFILE_PHASES
+            ph_e += __builtin_amdgcn_s_memtime() - ph_c;
+#endif
+        }
+        const uint32_t hend = one_pass ? 0u : 2 * ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t hg = 0; hg < hend; ++hg) {
             const uint32_t g = hg >> 1;
