@@ -81,6 +81,12 @@ def main():
                     help="HIP streams the steps alternate between (1 = strictly serial steps)")
     ap.add_argument("--no-timing", action="store_true",
                     help="do not record HIP events around the kernels (roofline.kernel_ms is then 0)")
+    ap.add_argument("--multi", default="auto", choices=["auto", "replica", "shard"],
+                    help="N > 1: 'replica' = every rank holds the whole corpus and searches its OWN query batch "
+                         "(throughput mode, no data-path collective; the sharded-corpus path is then timed as well and "
+                         "reported under 'sharded'); 'shard' = the corpus is split N ways, every rank searches the same "
+                         "batch, top-k lists are exchanged over RCCL and merged.  auto: replica, except c4 (per-rank "
+                         "shards of a corpus that does not fit one GPU) and --force-dist")
     ap.add_argument("--single", type=int, default=0,
                     help="also time this many single-query calls (latency mode) and report them")
     args = ap.parse_args()
@@ -117,9 +123,14 @@ def main():
     nq = args.nq or nq_default
     from pq_vector_amd.sharding import ShardExchange, shard_range
     weak = args.workload == "c4"           # per-rank shard size fixed: N ranks hold N x rows
+    replica = world > 1 and not weak and not args.force_dist and args.multi != "shard"
+    if args.multi == "replica" and (weak or world == 1):
+        replica = False
     if weak:
         lo, hi = rank * n_total, (rank + 1) * n_total
         n_total = n_total * world
+    elif replica:
+        lo, hi = 0, n_total                # the whole corpus on every rank; the QUERIES are what is sharded
     else:
         lo, hi = shard_range(rank, world, n_total)
     n_shard = hi - lo
@@ -127,7 +138,7 @@ def main():
     # ---- synthetic data: the reference's bench recipe (benches/bench_util.rs:12-64) ------
     # i.i.d. uniform [0,1) f32 with 24-bit resolution, corpus seed 1234, query seed 7.
     g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
+    g.manual_seed(1234 if replica else 1234 + rank)
     corpus_t = torch.empty((n_shard, dim), dtype=torch.float32, device=dev)
     step_rows = max(1, (1 << 28) // (dim * 4))
     for s in range(0, n_shard, step_rows):
@@ -136,7 +147,7 @@ def main():
         corpus_t[s:e] = u.to(torch.float32) * (1.0 / (1 << 24))
         del u
     gq = torch.Generator(device=dev)
-    gq.manual_seed(7)
+    gq.manual_seed(7 + rank if replica else 7)          # replicas search different batches
     queries_t = (torch.randint(0, 1 << 24, (nq, dim), generator=gq, device=dev, dtype=torch.int32)
                  .to(torch.float32) * (1.0 / (1 << 24)))
     torch.cuda.synchronize()
@@ -190,7 +201,7 @@ def main():
             # hot path on this rank's shard; asynchronous on the lane's stream
             searcher.topk_device(queries_t.data_ptr(), nq, K, nprobe, rows_l[lane].data_ptr(), dist_l[lane].data_ptr(),
                                  nf_l[lane].data_ptr(), nc_l[lane].data_ptr(), stream=st.cuda_stream)
-            if not use_dist:
+            if not use_dist or replica:
                 return dist_l[lane], rows_l[lane]
             # exchange: one all-gather of k x {dist, row} per query, then the merge keyed (dist, shard,
             # position) -- pq_vector_amd/sharding.py
@@ -268,22 +279,26 @@ def main():
     flops = 3 * dim * cand_rows                       # sub, mul, add per element
     result = {
         "metric": f"topk_queries_per_s_k{K}",
-        "value": nq * args.steps / elapsed,
+        "value": (world if replica else 1) * nq * args.steps / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if weak else "strong",
+        "scaling": "weak" if (weak or replica) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n_total}x{dim} uniform f32, n_clusters {index.n_clusters}"
-                               f"{' per shard' if world > 1 else ''}, k {K}, nprobe {nprobe}, "
+                               f"{' per shard' if world > 1 and not replica else ''}, k {K}, nprobe {nprobe}, "
                                f"{nq} queries/step, layout {args.layout}",
                    "rows": n_total, "dim": dim, "n_clusters": int(index.n_clusters), "k": K,
-                   "nprobe": nprobe, "queries_per_step": nq, "shards": world},
+                   "nprobe": nprobe, "queries_per_step": nq, "shards": 1 if replica else world,
+                   "parallelism": ("replicas x%d: corpus replicated, query batches sharded (%d queries per step over "
+                                   "the job), no data-path collective" % (world, world * nq)) if replica
+                   else ("corpus sharded x%d, RCCL all-gather of the per-shard top-k + device merge" % world) if world > 1
+                   else "single GPU"},
         "index_build_vectors_per_s": n_shard / build_s,
         "index_build_s": build_s,
         "candidates_per_query": cand_rows / nq,
@@ -345,12 +360,17 @@ def main():
                      "region, matches rocprofv3) is the duration of a launch that shares the GPU with the "
                      "neighbouring step's kernels" % n_lanes).lstrip("; ")
     result["counters"] = searcher.counters()
-    if use_dist and xchg.fast:
+    if use_dist and not replica and xchg.fast:
         # the library merge kernel against the torch stable-sort merge of the same gathered lists
         ref_d, ref_r = xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, lo)
         ok = torch.tensor([int(torch.equal(ref_d, out_d) and torch.equal(ref_r, out_r))], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         result["exchange_check"] = bool(ok.item())
+
+    # ---- N > 1, replica mode: the sharded-corpus path (north_star's row-group shards + RCCL merge), timed too ----
+    if replica:
+        result["sharded"] = sharded_pass(args, pqv, torch, dist, corpus_t, n_total, dim, n_clusters, nprobe, nq, rank, world,
+                                         local_rank, dev, flags, n_lanes, lane_streams)
 
     # ---- optional latency mode: one query per call through the same device API ------------
     if args.single and rank == 0:
@@ -376,6 +396,61 @@ def main():
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+
+
+def sharded_pass(args, pqv, torch, dist, corpus_t, n_total, dim, n_clusters, nprobe, nq, rank, world, local_rank, dev,
+                 flags, n_lanes, lane_streams):
+    """The same corpus split N ways by contiguous row ranges (one index per shard, as the reference has one per
+    file): every rank searches the SAME batch on its shard, two all-gathers move k x {distance, row} per query and
+    every rank merges (pq_vector_amd/sharding.py).  Total work is fixed, so this is the strong-scaling number."""
+    from pq_vector_amd.sharding import ShardExchange, shard_range
+    lo, hi = shard_range(rank, world, n_total)
+    sub = corpus_t[lo:hi]
+    c_s = pqv.Corpus.from_device_ptr(sub.data_ptr(), hi - lo, dim, device=local_rank, keepalive=sub)
+    b = pqv.IndexBuilder(c_s).max_iters(20).seed(42).workers(os.cpu_count() or 1)
+    idx_s = b.n_clusters(n_clusters).build() if n_clusters else b.build()
+    srch = pqv.Searcher(idx_s, c_s, flags)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(7)                                     # one batch, identical on every rank
+    q = (torch.randint(0, 1 << 24, (nq, dim), generator=gq, device=dev, dtype=torch.int32).to(torch.float32) * (1.0 / (1 << 24)))
+    bases = [shard_range(r, world, n_total)[0] for r in range(world)]
+    xs = [ShardExchange(world, nq, K, dev, row_bases=bases if args.backend == "nccl" else None) for _ in range(n_lanes)]
+    rows_l = [torch.empty((nq, K), dtype=torch.int32, device=dev) for _ in range(n_lanes)]
+    dist_l = [torch.empty((nq, K), dtype=torch.float32, device=dev) for _ in range(n_lanes)]
+    nf_l = [torch.empty((nq,), dtype=torch.int32, device=dev) for _ in range(n_lanes)]
+    nc_l = [torch.empty((nq,), dtype=torch.int64, device=dev) for _ in range(n_lanes)]
+
+    def sstep(i):
+        lane = i % n_lanes
+        st = lane_streams[lane]
+        with torch.cuda.stream(st):
+            srch.topk_device(q.data_ptr(), nq, K, nprobe, rows_l[lane].data_ptr(), dist_l[lane].data_ptr(),
+                             nf_l[lane].data_ptr(), nc_l[lane].data_ptr(), stream=st.cuda_stream)
+            if xs[lane].fast:
+                return xs[lane].exchange_u32(dist_l[lane], rows_l[lane])
+            return xs[lane].exchange(dist_l[lane], rows_l[lane].to(torch.int64) & 0xFFFFFFFF, lo)
+
+    for i in range(args.warmup):
+        sstep(i)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out_d, out_r = sstep(i)
+    dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    out = {"value": nq * args.steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / args.steps * 1e3,
+           "scaling": "strong", "rows_per_rank": hi - lo,
+           "note": "same corpus split %d ways (one index per shard), every rank searches the same %d-query batch, "
+                   "RCCL all-gather of k x {distance, row} per query + device merge on every rank" % (world, nq)}
+    if xs[0].fast:
+        lane = (args.steps - 1) % n_lanes
+        ref_d, ref_r = xs[lane].exchange(dist_l[lane], rows_l[lane].to(torch.int64) & 0xFFFFFFFF, lo)
+        ok = torch.tensor([int(torch.equal(ref_d, out_d) and torch.equal(ref_r, out_r))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        out["exchange_check"] = bool(ok.item())
+    return out
 
 
 def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank, world, real_stdout):
