@@ -739,6 +739,36 @@ def test_screened_path_unbalanced_lists(pqv, oracle, monkeypatch, dim):
     assert s.counters()["screened_pairs"] > 0
 
 
+@pytest.mark.parametrize("k,copies", [(10, 700), (32, 300), (2, 1500)])
+def test_running_thresholds_with_hundreds_of_tied_candidates(pqv, oracle, monkeypatch, k, copies):
+    """The running thresholds count appended pairs in 8-bit per-bin counters that are allowed to wrap: here every
+    query has `copies` (> 255) candidates at EXACTLY the same small distance (duplicated rows placed late in the
+    lists, behind the seed window), so the counters wrap several times while blocks of one query run concurrently.
+    Rows, distances and counts must still equal the oracle (whose heap replay decides which tied rows survive)."""
+    rng = np.random.default_rng(900 + k)
+    dim, kc, nq, nprobe = 128, 4, 48, 4
+    n_bg = 20000
+    bg = rng.random((n_bg, dim), dtype=np.float32)
+    protos = rng.random((nq // 4, dim), dtype=np.float32)                 # 12 prototype rows ...
+    dup = np.repeat(protos, copies, axis=0)                               # ... each `copies` times
+    data = np.concatenate([bg, dup]).astype(np.float32)                   # duplicates have the highest row ids
+    queries = (protos[rng.integers(0, len(protos), nq)] + np.float32(1e-3) * rng.standard_normal((nq, dim))).astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=3, seed=5)
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    for rows_env in ("", "256"):                                          # default blocks / many concurrent blocks per list
+        if rows_env:
+            monkeypatch.setenv("PQV_WIDE_ROWS", rows_env)
+        s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (_bits(dist) == _bits(odist)).all()
+        assert (rows == orows).all()
+        c = s.counters()
+        assert c["screened_pairs"] > 0 and c["screen_survivors"] >= nq * min(copies, 255)
+
+
 @pytest.mark.parametrize("n,dim,kc,min_k", [
     (24000, 64, 600, None),      # natural dispatch (>= 512 centroids), queries staged in LDS
     (9000, 128, 96, 2),          # forced at a small centroid count: fewer seeds than the seed window
