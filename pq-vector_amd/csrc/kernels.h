@@ -75,6 +75,7 @@ struct MergeArgs {
     // probe mode extras for the batched path (all optional): cluster histogram of the (query, probe
     // rank) pairs (zeroed beforehand), reset of the per-query admission thresholds, |q|^2
     uint32_t       *hist;
+    uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
     unsigned long long *gthr_init;
     float          *qnorm_out;
     float          *qmax_out;    // max |q_i| per query (f16 screen)
@@ -90,11 +91,15 @@ hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 // the whole group (queries as wave-uniform scalar operands), instead of once per query.
 constexpr int TILE_QB = 16;
 
+constexpr uint32_t HIST_REPLICAS = 16;
+
 struct PairSortArgs {
     const uint32_t *probe;     // [nq * nprobe] cluster of pair p = q*nprobe + j
     uint32_t        n_pairs, n_clusters;
     int             hist_done; // 1: hist was already filled (launch_merge_probe with MergeArgs::hist)
     uint32_t       *hist;      // [n_clusters]      (zeroed by the caller)
+    uint32_t        hist_stride; // > 0: the histogram arrives as HIST_REPLICAS partial copies, stride apart; the scan sums
+                                 //      them into copy 0 (8 k atomics on the four lines of one copy serialise: 20 -> 9 us on C2)
     uint32_t       *cursor;    // [n_clusters]      (zeroed by the caller)
     uint32_t       *pair_off;  // [n_clusters + 1]
     uint32_t       *group_off; // [n_clusters + 1]

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
             if (e < a.k) {
                 a.probe[(uint64_t)q * a.k + e] = c;
                 a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
-                if (a.hist && have) atomicAdd(&a.hist[c], 1u);       // pair bucketing: cluster histogram
+                if (a.hist && have) atomicAdd(&a.hist[(uint64_t)(q % HIST_REPLICAS) * a.hist_stride + c], 1u);   // pair bucketing: cluster histogram
             }
             carry += readlane_u64(incl, 63);
         }
@@ -589,7 +589,11 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
         const uint32_t c = base + tid;
-        const uint32_t h = c < a.n_clusters ? a.hist[c] : 0;
+        uint32_t h = c < a.n_clusters ? a.hist[c] : 0;
+        if (a.hist_stride && c < a.n_clusters) {          // partial copies -> copy 0 (pair_scatter_kernel reads it)
+            for (uint32_t r = 1; r < HIST_REPLICAS; ++r) h += a.hist[(uint64_t)r * a.hist_stride + c];
+            a.hist[c] = h;
+        }
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
         const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
         s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd;
