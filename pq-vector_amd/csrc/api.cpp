@@ -1209,12 +1209,12 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     const uint32_t kc_pairs = s->n_clusters;
     uint32_t *pair_u32 = nullptr;
     if (p.tile) {
-        // u32 scratch: hist[R][kc] cursor[kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
-        // (R = HIST_REPLICAS partial histograms); the probe kernel zeroes hist + cursor, the probe merge fills hist
+        // u32 scratch: hist[R][kc] cursor[R][kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
+        // (R = HIST_REPLICAS partial copies); the probe kernel zeroes hist, the probe merge fills it, the scan sets cursor
         constexpr uint64_t R = pqv::HIST_REPLICAS;
-        HIP_TRY(sc.s_pair_u32.ensure(((R + 4) * kc_pairs + 5) * sizeof(uint32_t)));
+        HIP_TRY(sc.s_pair_u32.ensure(((2 * R + 3) * kc_pairs + 5) * sizeof(uint32_t)));
         pair_u32 = sc.s_pair_u32.as<uint32_t>();
-        pa.zero_u32 = pair_u32; pa.zero_n = static_cast<uint32_t>((R + 1) * kc_pairs);
+        pa.zero_u32 = pair_u32; pa.zero_n = static_cast<uint32_t>(R * kc_pairs);
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
         if (p.filter) { HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float))); HIP_TRY(sc.s_qmax.ensure(static_cast<size_t>(nq) * sizeof(float))); }
     }
@@ -1249,8 +1249,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         }
         PairSortArgs ps{};
         ps.probe = sc.s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
-        uint32_t *v = u + (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc);        // past the extra histogram copies
-        ps.hist = u; ps.hist_stride = kc; ps.cursor = v + kc; ps.pair_off = v + 2ull * kc; ps.group_off = v + 3ull * kc + 1;
+        uint32_t *v = u + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc);    // past the extra histogram / cursor copies
+        ps.hist = u; ps.hist_stride = kc; ps.nprobe = p.np; ps.cursor = u + pqv::HIST_REPLICAS * static_cast<uint64_t>(kc);
+        ps.pair_off = v + 2ull * kc; ps.group_off = v + 3ull * kc + 1;
         ps.n_groups = v + 4ull * kc + 2;
         ps.quad_off = v + 4ull * kc + 3; ps.n_quads = v + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
         ps.pairs = sc.s_pairs.as<uint32_t>(); ps.groups = sc.s_groups.as<uint4>(); ps.quads = sc.s_quads.as<uint4>();

@@ -100,7 +100,9 @@ struct PairSortArgs {
     uint32_t       *hist;      // [n_clusters]      (zeroed by the caller)
     uint32_t        hist_stride; // > 0: the histogram arrives as HIST_REPLICAS partial copies, stride apart; the scan sums
                                  //      them into copy 0 (8 k atomics on the four lines of one copy serialise: 20 -> 9 us on C2)
-    uint32_t       *cursor;    // [n_clusters]      (zeroed by the caller)
+    uint32_t       *cursor;    // [n_clusters] zeroed by the caller; with hist_stride > 0: [HIST_REPLICAS][hist_stride], set by the
+                               // scan to each copy's first index in its cluster's bucket (the scatter's atomics spread likewise)
+    uint32_t        nprobe;    // pairs per query (pair p belongs to query p / nprobe: selects the copy)
     uint32_t       *pair_off;  // [n_clusters + 1]
     uint32_t       *group_off; // [n_clusters + 1]
     uint32_t       *pairs;     // [n_pairs] pair ids bucketed by cluster

@@ -577,7 +577,7 @@ hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s) { return launch
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pair_hist_kernel(const PairSortArgs a) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p < a.n_pairs) atomicAdd(&a.hist[a.probe[p]], 1u);
+    if (p < a.n_pairs) atomicAdd(&a.hist[(uint64_t)(a.hist_stride ? (p / a.nprobe) % HIST_REPLICAS : 0u) * a.hist_stride + a.probe[p]], 1u);
 }
 
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
@@ -590,8 +590,16 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
         const uint32_t c = base + tid;
         uint32_t h = c < a.n_clusters ? a.hist[c] : 0;
-        if (a.hist_stride && c < a.n_clusters) {          // partial copies -> copy 0 (pair_scatter_kernel reads it)
-            for (uint32_t r = 1; r < HIST_REPLICAS; ++r) h += a.hist[(uint64_t)r * a.hist_stride + c];
+        if (a.hist_stride && c < a.n_clusters) {          // partial copies -> total in copy 0 (pair_scatter_kernel reads it),
+            uint32_t hv[HIST_REPLICAS];                   // and each copy's first index in the cluster's bucket
+#pragma unroll
+            for (uint32_t r = 1; r < HIST_REPLICAS; ++r) hv[r] = a.hist[(uint64_t)r * a.hist_stride + c];   // loads in flight together
+            a.cursor[c] = 0u;
+#pragma unroll
+            for (uint32_t r = 1; r < HIST_REPLICAS; ++r) {
+                a.cursor[(uint64_t)r * a.hist_stride + c] = h;
+                h += hv[r];
+            }
             a.hist[c] = h;
         }
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= a.n_pairs) return;
     const uint32_t c = a.probe[p];
-    const uint32_t i = atomicAdd(&a.cursor[c], 1u);
+    const uint32_t i = atomicAdd(&a.cursor[(uint64_t)(a.hist_stride ? (p / a.nprobe) % HIST_REPLICAS : 0u) * a.hist_stride + c], 1u);
     const uint32_t slot = a.pair_off[c] + i;
     a.pairs[slot] = p;
     if (i % TILE_QB == 0) {
