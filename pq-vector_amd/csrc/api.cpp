@@ -984,8 +984,8 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     S_TRY(s->d_stats.alloc((8 + 8 * 65536) * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 8 * 65536) * sizeof(unsigned long long), s->stream));
 #else
-    S_TRY(s->d_stats.alloc(8 * sizeof(unsigned long long)));
-    S_TRY(hipMemsetAsync(s->d_stats.p, 0, 8 * sizeof(unsigned long long), s->stream));
+    S_TRY(s->d_stats.alloc((8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long)));
+    S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long), s->stream));
 #endif
     // squared norms of the storage rows, for the MFMA screen of the batched re-rank
     {
@@ -1727,6 +1727,14 @@ static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     std::lock_guard<std::mutex> lock(s->mu);
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(st, s->d_stats.p, sizeof st, hipMemcpyDeviceToHost));   // synchronises the device
+#ifndef PQV_PROFILE_PHASES
+    {   // wide_filter_kernel spreads its two counters over STATS_SLOTS lines
+        std::vector<unsigned long long> slots(16 * pqv::STATS_SLOTS);
+        HIP_TRY(hipMemcpy(slots.data(), static_cast<const unsigned long long *>(s->d_stats.p) + 8,
+                          slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < pqv::STATS_SLOTS; ++i) { st[0] += slots[16 * i]; st[1] += slots[16 * i + 1]; }
+    }
+#endif
 #ifdef PQV_PROFILE_PHASES
     {
         std::vector<unsigned long long> rec(8 + 8 * 65536);

@@ -92,6 +92,8 @@ hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 constexpr int TILE_QB = 16;
 
 constexpr uint32_t HIST_REPLICAS = 16;
+// wide_filter_kernel's two statistics counters live in STATS_SLOTS copies at stats[8 + 16 i + {0, 1}]
+constexpr uint32_t STATS_SLOTS = 64;
 
 struct PairSortArgs {
     const uint32_t *probe;     // [nq * nprobe] cluster of pair p = q*nprobe + j

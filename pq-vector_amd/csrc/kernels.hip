@@ -1245,9 +1245,14 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
         drain(last ? 1u : 64u);
         if (last) break;
     }
-    if (a.stats && lane == 0) {
-        atomicAdd(&a.stats[0], (unsigned long long)(r1 - r0) * cnt);
-        atomicAdd(&a.stats[1], (unsigned long long)n_exact);
+    if (a.stats && lane == 0) {      // counter pairs spread over STATS_SLOTS lines, see wide_filter_kernel
+#ifdef PQV_PROFILE_PHASES
+        unsigned long long *st = a.stats;
+#else
+        unsigned long long *st = a.stats + 8 + 16 * ((blockIdx.y * gridDim.x + blockIdx.x + (uint32_t)wave * 17u) % STATS_SLOTS);
+#endif
+        atomicAdd(&st[0], (unsigned long long)(r1 - r0) * cnt);
+        atomicAdd(&st[1], (unsigned long long)n_exact);
     }
 }
 
@@ -2249,8 +2254,16 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
 #endif
     }
     if (a.stats && lane == 0) {
+#ifdef PQV_PROFILE_PHASES
         atomicAdd(&a.stats[0], (unsigned long long)(r1 - r0) * cnt);
         atomicAdd(&a.stats[1], (unsigned long long)n_exact);
+#else
+        // 64 counter pairs, one cache line apart (STATS_SLOTS; the host sums them): thousands of waves adding to
+        // ONE line serialise at the memory side
+        unsigned long long *st = a.stats + 8 + 16 * ((blockIdx.y * gridDim.x + blockIdx.x + (uint32_t)wave * 17u) % STATS_SLOTS);
+        atomicAdd(&st[0], (unsigned long long)(r1 - r0) * cnt);
+        atomicAdd(&st[1], (unsigned long long)n_exact);
+#endif
 #ifdef PQV_PROFILE_PHASES
         {   // per-wave record: [start, prologue, kloop, screen, drain, end, rows, cnt] at stats[8 + 8 * wave id]
             const unsigned long long wid = atomicAdd(&a.stats[6], 1ull);
