@@ -2884,12 +2884,19 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float *v, uint64_t n,
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_down((int)m, off, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    __shared__ uint32_t wm[4];                       // one atomic per block, not per wave: a single address
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
+        const uint32_t mm = a01 > a23 ? a01 : a23;
+        if (mm) atomicMax(out, mm);
+    }
 }
 hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(maxabs_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, v, n, out);
+    hipLaunchKernelGGL(maxabs_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, v, n, out);
     return hipGetLastError();
 }
 
@@ -3149,10 +3156,21 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         wave_lds_fence();
     }
 
-    if (valid) {
-        cluster[r] = bestc;
-        if (sizes) atomicAdd(&sizes[bestc], 1ull);
-        if (prev && changed && prev[r] != bestc) atomicAdd(changed, 1ull);
+    if (valid) cluster[r] = bestc;
+    // counters: one atomic per wave and distinct cluster / per wave (every row adding to `changed` and to a
+    // hundred cluster sizes on four cache lines serialises at the memory side)
+    if (sizes) {
+        unsigned long long m = __ballot(valid);
+        while (m) {
+            const uint32_t c = readlane_u32(bestc, __builtin_ctzll(m));
+            const unsigned long long same = __ballot(valid && bestc == c);
+            if (lane == __builtin_ctzll(m)) atomicAdd(&sizes[c], (unsigned long long)__popcll(same));
+            m &= ~same;
+        }
+    }
+    if (prev && changed) {
+        const unsigned long long ch = __ballot(valid && prev[r] != bestc);
+        if (lane == 0 && ch) atomicAdd(changed, (unsigned long long)__popcll(ch));
     }
 }
 
