@@ -286,7 +286,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if (weak or replica) else "strong",
+        # N = 1 is the first point of the default (replica) series: per-GPU work fixed as N grows
+        "scaling": "weak" if (weak or replica or (world == 1 and args.multi != "shard" and not args.force_dist)) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
