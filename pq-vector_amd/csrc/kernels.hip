@@ -462,12 +462,18 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
         if (n > a.cand_cap) n = a.cand_cap;
         const uint64_t *ck = a.cand_keys + (uint64_t)q * a.cand_cap;
         const uint32_t *cv = a.cand_vals + (uint64_t)q * a.cand_cap;
-        for (uint32_t i = 0; i < n; i += 64) {
-            const uint32_t idx = i + lane;
-            uint64_t key = KEY_EMPTY;
-            uint32_t val = 0xFFFFFFFFu;
-            if (idx < n) { key = ck[idx]; val = cv[idx]; }
-            tk.offer(key, val, a.k, lane);
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {               // four key / value loads in flight per lane
+            uint64_t kv[4];
+            uint32_t vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t idx = i0 + 64 * u + lane;
+                kv[u] = idx < n ? ck[idx] : KEY_EMPTY;
+                vv[u] = idx < n ? cv[idx] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 64 * u < n) tk.offer(kv[u], vv[u], a.k, lane);
         }
     }
     if constexpr (!PROBE) {
@@ -1552,15 +1558,20 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
         bitonic_sort64(lmin, dummy, lane);
         cut = readlane_u64(lmin, (int)k - 1);
     }
-    for (uint32_t i = 0; i < n_vals; i += 64) {
-        const uint32_t idx = i + lane;
-        uint64_t key = KEY_EMPTY;
-        if (idx < n_vals) {
-            const float v = seed_ub[(uint64_t)q * n_vals + idx];
-            if (v < INFINITY) key = ((uint64_t)__float_as_uint(v) << 32) | idx;
+    for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {              // eight loads in flight per lane again
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t idx = i0 + 64 * u + lane;
+            v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
         }
-        if (key > cut) key = KEY_EMPTY;
-        if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint64_t key = KEY_EMPTY;
+            if (v[u] < INFINITY) key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
+            if (key > cut) key = KEY_EMPTY;
+            if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
+        }
     }
     const uint64_t kth = tk.kth(k);
     if (lane == 0) {
