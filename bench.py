@@ -257,8 +257,8 @@ def main():
     mean_len = n_shard / max(1, int(index.n_clusters))
     wide = dim % 64 == 0 and args.layout == "ivf" and os.environ.get("PQV_FILTER_VARIANT", "0") == "0"
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
-        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 32 and pairs_per_cluster >= 24
-        and mean_len >= (1024 if wide else 4096)))
+        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= (128 if wide else 32) and pairs_per_cluster >= (4 if wide else 24)
+        and mean_len >= (768 if wide else 4096)))
     kernel = ("wide_seed_kernel (MFMA upper-bound thresholds) + wide_filter_kernel (batched cluster-major re-rank, "
               + ("64 queries staged in LDS" if dim <= 128 else "32 queries per quad") + " per streamed row tile from the blocked "
               "copy, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened and wide

@@ -1090,8 +1090,13 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // (the wide kernel -- dim % 64 == 0, dim <= 256, IVF-ordered rows -- screens ~3x faster than the
         //  one-group kernel and already wins at 1250-row lists: 0.28 vs 0.36 ms on a 125 k-row C2 shard)
         const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && !s->d_row_of;
-        p.filter = s->tile_filter && k <= 32 && pairs >= 24ull * s->n_clusters &&
-                   mean_len >= (wide_ok ? 4ull : 16ull) * p.seed_rows;
+        // k <= 128 (the running-threshold counters are 8 bits wide, the candidate buffers 2048 entries); the wide
+        // kernel pays from lists of three seed windows on -- measured on the reference's own bench shape, 1000-row
+        // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel keeps k <= 32
+        // (and from 4 pairs per cluster on, i.e. whenever the batched path is taken at all: 1.8x at 4 pairs per
+        //  cluster, 2.2-2.4x at 16 on that shape, k = 10 and k = 100 alike)
+        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 4ull : 24ull) * s->n_clusters &&
+                   mean_len >= (wide_ok ? 3ull : 16ull) * p.seed_rows;
         if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
         // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
         // multiple of 8 the blocks of ALL query groups for one row chunk share an XCD (and its L2)

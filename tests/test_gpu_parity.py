@@ -796,7 +796,7 @@ def _fuzz_case(pqv, oracle, seed):
     dim = int(rng.choice([64, 128, 192, 256, 320, 512]))
     kc = int(rng.integers(2, 9))
     n = int(rng.integers(1200, 6000)) * kc
-    k = int(rng.integers(1, 33))
+    k = int(rng.integers(1, 33)) if seed % 5 else int(rng.integers(33, 129))     # every fifth case: 32 < k <= 128
     nprobe = int(rng.integers(1, kc + 1))
     nq = int(rng.integers(1, 180))
     style = seed % 4
