@@ -317,9 +317,9 @@ def main():
                          "speed-up figure there, not a utilisation"}
     if screened:
         mf = 2.0 * dim * cand_rows          # the Q.X^T contraction of the screen: 2 flops per (row, query, dim)
-        # f16 operands (default where dim % 128 == 0 and dim <= 768): the contraction runs on v_mfma_f32_16x16x32_f16,
+        # f16 operands (default where dim % 128 == 0 and dim <= 1024): the contraction runs on v_mfma_f32_16x16x32_f16,
         # whose dense peak is ~2.5 PFLOP/s (MI355X_MICROARCH.md); f32 operands: 157.3 TFLOP/s
-        f16 = wide and dim % 128 == 0 and dim <= 768 and os.environ.get("PQV_SCREEN_F16", "1") != "0"
+        f16 = wide and dim % 128 == 0 and dim <= 1024 and os.environ.get("PQV_SCREEN_F16", "1") != "0"
         peak = 2500.0 if f16 else 157.3
         ach = mf / (rr_ms * 1e-3) / 1e12 if rr_ms > 0 else 0.0
         result["roofline"] = {"bound": "mfma", "kernel": kernel + (" [f16 operands]" if f16 else " [f32 operands]"),

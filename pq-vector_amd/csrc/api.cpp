@@ -1115,7 +1115,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             const int variant = s->filter_variant;
             p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : 32;     // dim > 256: queries from a blocked global copy
             p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
-            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 768;
+            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024;
             if (p.f16) p.quad_width = s->dim <= 256 ? 64 : 32;   // the quad's f16 queries are staged in LDS (<= 48 KB)
             uint64_t r = rpb;
             // wide kernel: a wave's fixed cost (staging the quad's queries, the last partial batch of exact

@@ -1606,7 +1606,7 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
         if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
         if (a.quad_width == 64 && lds4 / 2 <= 32768)
             hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
-        else if (a.quad_width == 32 && lds2 / 2 <= 49152)
+        else if (a.quad_width == 32 && lds2 / 2 <= 65536)
             hipLaunchKernelGGL((wide_seed_kernel<2, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
@@ -2395,7 +2395,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                 if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
                 else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
             }
-            else if (a.quad_width == 32 && lds2 / 2 <= 49152)      // + 10 KB of static LDS: two blocks per CU
+            else if (a.quad_width == 32 && lds2 / 2 <= 65536)      // + 10 KB of static LDS: two blocks per CU (160 KB)
                 { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); }
             else return hipErrorInvalidValue;
             return hipGetLastError();

@@ -793,7 +793,7 @@ def test_screened_assignment_builds_identical_index(pqv, oracle, monkeypatch, n,
 
 def _fuzz_case(pqv, oracle, seed):
     rng = np.random.default_rng(seed)
-    dim = int(rng.choice([64, 128, 192, 256, 320, 512]))
+    dim = int(rng.choice([64, 128, 192, 256, 320, 512, 1024])) if seed % 7 else 1024     # 1024: the widest f16-screened rows
     kc = int(rng.integers(2, 9))
     n = int(rng.integers(1200, 6000)) * kc
     k = int(rng.integers(1, 33)) if seed % 5 else int(rng.integers(33, 129))     # every fifth case: 32 < k <= 128
