@@ -253,12 +253,14 @@ def main():
 
     mode = os.environ.get("PQV_RERANK_MODE", "auto")
     pairs_per_cluster = nq * nprobe / max(1, int(index.n_clusters))
-    tile = mode == "tile" or (mode != "stream" and pairs_per_cluster >= 4)
     mean_len = n_shard / max(1, int(index.n_clusters))
     wide = dim % 64 == 0 and args.layout == "ivf" and os.environ.get("PQV_FILTER_VARIANT", "0") == "0"
+    wide_any = (wide and os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= 128
+                and mean_len >= 3 * (512 if mean_len >= 4096 else 256))           # api.cpp: wide_any_batch
+    tile = mode == "tile" or (mode != "stream" and (pairs_per_cluster >= 4 or wide_any))
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
-        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= (128 if wide else 32) and pairs_per_cluster >= (4 if wide else 24)
-        and mean_len >= (768 if wide else 4096)))
+        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= (128 if wide else 32) and pairs_per_cluster >= (0 if wide else 24)
+        and mean_len >= (3 * (512 if mean_len >= 4096 else 256) if wide else 4096)))
     kernel = ("wide_seed_kernel (MFMA upper-bound thresholds) + wide_filter_kernel (batched cluster-major re-rank, "
               + ("64 queries staged in LDS" if dim <= 128 else "32 queries per quad") + " per streamed row tile from the blocked "
               "copy, MFMA lower-bound screen, exact re-evaluation of the survivors)" if screened and wide
@@ -388,7 +390,7 @@ def main():
         result["single_query"] = {"calls": int(lat.size), "p50_us": float(np.percentile(lat, 50)),
                                   "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()),
                                   "qps": float(1e6 / lat.mean()),
-                                  "note": "one query per call, host-synchronised after each (4 kernel launches)"}
+                                  "note": "one query per call, host-synchronised after each (9 launches on the screened path, 4 on the streaming path)"}
     # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled, one thread -----------
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq)

@@ -1064,6 +1064,13 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     // Tile path: worth it once several queries share a cluster (each streamed row is then
     // reused by up to TILE_QB queries).  k <= 256; REF4 order only.
     p.tile = metric == PQV_L2SQ_REF4 && k <= 256 && pairs >= 4ull * s->n_clusters;
+    // ... except where the wide screened kernels apply (5.1c): they read the f16 copy of a list instead of its f32
+    // rows and skip the exact arithmetic, which beats the streaming kernel at EVERY batch size -- one query on C2
+    // 123 -> 78 us, on C3 2.0 -> 0.34 ms; 32 queries on C3 15.8 -> 2.2 ms
+    const uint64_t mean_len_all = s->n / std::max<uint32_t>(1, s->n_clusters);
+    const bool wide_any_batch = metric == PQV_L2SQ_REF4 && s->tile_filter && k <= 128 && s->filter_variant == 0 &&
+                                (s->dim % 64) == 0 && !s->d_row_of && mean_len_all >= 3ull * (mean_len_all >= 4096 ? 512 : 256);
+    if (wide_any_batch) p.tile = true;
     if (s->rerank_mode == 1) p.tile = false;
     if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 256;
     if (p.tile) {
@@ -1095,7 +1102,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel keeps k <= 32
         // (and from 4 pairs per cluster on, i.e. whenever the batched path is taken at all: 1.8x at 4 pairs per
         //  cluster, 2.2-2.4x at 16 on that shape, k = 10 and k = 100 alike)
-        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 4ull : 24ull) * s->n_clusters &&
+        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 0ull : 24ull) * s->n_clusters &&
                    mean_len >= (wide_ok ? 3ull : 16ull) * p.seed_rows;
         if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
         // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
