@@ -259,7 +259,7 @@ def main():
                 and mean_len >= 3 * (512 if mean_len >= 4096 else 256))           # api.cpp: wide_any_batch
     tile = mode == "tile" or (mode != "stream" and (pairs_per_cluster >= 4 or wide_any))
     screened = tile and (os.environ.get("PQV_TILE_FILTER", "1") == "2" or (
-        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= (128 if wide else 32) and pairs_per_cluster >= (0 if wide else 24)
+        os.environ.get("PQV_TILE_FILTER", "1") != "0" and K <= (128 if wide else 32) and pairs_per_cluster >= (0 if wide else 4)
         and mean_len >= (3 * (512 if mean_len >= 4096 else 256) if wide else 4096)))
     kernel = ("wide_seed_kernel (MFMA upper-bound thresholds) + wide_filter_kernel (batched cluster-major re-rank, "
               + ("64 queries staged in LDS" if dim <= 128 else "32 queries per quad") + " per streamed row tile from the blocked "

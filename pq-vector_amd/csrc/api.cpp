@@ -1101,8 +1101,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         // kernel pays from lists of three seed windows on -- measured on the reference's own bench shape, 1000-row
         // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel keeps k <= 32
         // (and from 4 pairs per cluster on, i.e. whenever the batched path is taken at all: 1.8x at 4 pairs per
-        //  cluster, 2.2-2.4x at 16 on that shape, k = 10 and k = 100 alike)
-        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 0ull : 24ull) * s->n_clusters &&
+        //  cluster, 2.2-2.4x at 16 on that shape, k = 10 and k = 100 alike; the one-group kernel, used for the
+        //  row-order layout and dim % 64 != 0, also wins from 4 pairs per cluster on 10 k-row lists: 0.45 -> 0.25 ms
+        //  at 64 queries, 0.52 -> 0.34 at 256 -- it used to wait for 24)
+        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 0ull : 4ull) * s->n_clusters &&
                    mean_len >= (wide_ok ? 3ull : 16ull) * p.seed_rows;
         if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
         // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
