@@ -1243,6 +1243,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pm.max_pos = max_pos;
     if (p.tile) {
         pm.hist = pair_u32; pm.hist_stride = kc_pairs; pm.gthr_init = sc.s_gthr.as<unsigned long long>();
+        // every partial list of the re-rank starts EMPTY: preset by the probe merge (one wave per query)
+        pm.preset_keys = sc.s_part_keys.as<uint64_t>(); pm.preset_vals = sc.s_part_vals.as<uint32_t>();
+        pm.preset_n = p.n_part_rr * k;
         if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.qmax_out = sc.s_qmax.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
     }
     HIP_TRY(launch_merge_probe(pm, stream));
@@ -1255,12 +1258,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
         HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
         uint32_t *u = pair_u32;
-        // every partial list starts EMPTY (all-ones keys and values)
-        {
-            const uint64_t entries = (static_cast<uint64_t>(nq) * p.n_part_rr * k + 3) / 4 * 4;    // 16-byte multiples
-            HIP_TRY(launch_fill_ones2(sc.s_part_keys.p, entries * sizeof(uint64_t), sc.s_part_vals.p,
-                                      entries * sizeof(uint32_t), stream));
-        }
         PairSortArgs ps{};
         ps.probe = sc.s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
         uint32_t *v = u + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc);    // past the extra histogram / cursor copies

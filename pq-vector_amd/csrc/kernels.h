@@ -76,6 +76,11 @@ struct MergeArgs {
     // rank) pairs (zeroed beforehand), reset of the per-query admission thresholds, |q|^2
     uint32_t       *hist;
     uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
+    // probe mode, optional: the query's per-wave partial lists of the re-rank start EMPTY (all-ones keys / values);
+    // preset_n entries per query, written by the query's wave (saves a launch per step)
+    uint64_t       *preset_keys;
+    uint32_t       *preset_vals;
+    uint32_t        preset_n;
     unsigned long long *gthr_init;
     float          *qnorm_out;
     float          *qmax_out;    // max |q_i| per query (f16 screen)

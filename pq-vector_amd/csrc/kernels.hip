@@ -544,6 +544,11 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
             }
             carry += readlane_u64(incl, 63);
         }
+        if (a.preset_keys) {
+            uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
+            uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
+            for (uint32_t i = lane; i < a.preset_n; i += 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
+        }
         if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
         if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
         if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
