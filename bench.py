@@ -390,7 +390,7 @@ def main():
         result["single_query"] = {"calls": int(lat.size), "p50_us": float(np.percentile(lat, 50)),
                                   "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()),
                                   "qps": float(1e6 / lat.mean()),
-                                  "note": "one query per call, host-synchronised after each (9 launches on the screened path, 4 on the streaming path)"}
+                                  "note": "one query per call, host-synchronised after each (8 launches on the screened path, 4 on the streaming path)"}
     # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled, one thread -----------
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, queries_t, rows_t, dist_t, nprobe, nq)
