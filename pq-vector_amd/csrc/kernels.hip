@@ -440,9 +440,20 @@ hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s) {
 //                 position base of each probed list (index.rs:57-63's concatenation).
 // ------------------------------------------------------------------------------------
 template <int S, bool PROBE>
-__global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
+    const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
+    if (threadIdx.x >= 64) {
+        // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
+        if constexpr (PROBE) {
+            if (a.preset_keys) {
+                uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
+                uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
+                for (uint32_t i = threadIdx.x - 64; i < a.preset_n; i += blockDim.x - 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
+            }
+        }
+        return;
+    }
     WaveTopk<S> tk;
     tk.init();
     const uint64_t total = (uint64_t)a.n_part * a.k_part;
@@ -544,11 +555,6 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
             }
             carry += readlane_u64(incl, 63);
         }
-        if (a.preset_keys) {
-            uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
-            uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
-            for (uint32_t i = lane; i < a.preset_n; i += 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
-        }
         if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
         if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
         if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
 template <bool PROBE>
 static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
-    dim3 grid(a.nq), block(64);
+    dim3 grid(a.nq), block(PROBE && a.preset_keys ? 256 : 64);       // probe merge with a preset: three helper waves
     if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);
