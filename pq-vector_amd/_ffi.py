@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpqv_hip.so")
+# PQV_LIB_PATH: diagnostic builds of the same library (tools/ only; e.g. the phase-timestamp build)
+LIB_PATH = os.environ.get("PQV_LIB_PATH") or os.path.join(_HERE, "libpqv_hip.so")
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

@@ -185,14 +185,29 @@ struct pqv_searcher {
     mutable Scratch lanes[PQV_LANES];
     mutable uint32_t lane_rr = 0;
     mutable DevBuf d_mat_blk, d_blk_off;   // blocked MFMA-operand copy of the lists (built on first use)
-    // f16 operands for the wide screened path (PQV_SCREEN_F16=0 disables): values * f16_scale rounded to f16;
-    // possible when the stored rows are finite and the power-of-two scale and its square are representable
+    // f16 operands for the wide screened path: values * f16_scale rounded to f16; possible when the stored rows
+    // are finite and the power-of-two scale and its square are representable
     bool f16_ok = false;
     float f16_scale = 1.0f;
-    int tile_filter = 1;                   // MFMA lower-bound screen in the batched path (PQV_TILE_FILTER=0 disables)
-    int filter_variant = 0;                // PQV_FILTER_VARIANT=1: one 16-query group per block (tile_filter_kernel)
-    uint32_t cand_cap = 2048;              // PQV_CAND_CAP: candidate-buffer entries per query of the wide screened path
-    int rerank_mode = 0;                   // 0 auto, 1 stream_kernel, 2 tile_rerank_kernel
+    mutable bool blk_f16 = false;          // form of d_mat_blk
+    // Tunables.  Defaults are what the dispatch rules below were measured with; every one can be set per
+    // searcher through pqv_searcher_set_option (tests and benches use that to force a path) and, for the
+    // profiling scripts, through a PQV_<NAME> environment variable read ONCE, when the searcher is created.
+    struct Opts {
+        int rerank_mode = 0;               // 0 auto, 1 stream_kernel, 2 tile path
+        int tile_filter = 1;               // MFMA lower-bound screen in the batched path: 0 off, 1 by rule, 2 forced
+        int filter_variant = 0;            // 1: one 16-query group per block (tile_filter_kernel)
+        uint32_t cand_cap = 2048;          // candidate-buffer entries per query of the wide screened path
+        int screen_f16 = 1;                // f16 operands where possible
+        uint32_t seed_rows = 0;            // rows per list sampled for the thresholds (0 = by rule)
+        uint32_t wide_rows = 0;            // rows per block of the wide kernel (0 = by rule)
+        uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
+        int running_thr = 1;               // running thresholds of the wide kernel
+        int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
+        int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
+        uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
+    };
+    mutable Opts opt;
     mutable pqv_counters_t counters{};
     // timing
     mutable bool timing = false;
@@ -203,12 +218,25 @@ struct pqv_searcher {
     }
 };
 
-// The scratch lane of a call on `stream`: the lane that stream used last, else a free one, else the
-// least recently assigned one (the caller then waits for that lane's previous call).
-static Scratch &lane_for(const pqv_searcher *s, hipStream_t stream) {
-    for (auto &l : s->lanes) if (l.used && l.stream == stream) return l;
-    for (auto &l : s->lanes) if (!l.used) return l;
-    return s->lanes[s->lane_rr++ % PQV_LANES];
+// The scratch lane of a call on `stream`: the lane that stream used last, else a free one, else the least
+// recently assigned one.  Resolved ONCE per public entry point (under s->mu) and handed down: a lane taken
+// over from another stream is first ordered behind that stream's last call (its `done` event), and
+// lane_release() records the new owner when the call's last kernel has been enqueued.
+static int lane_acquire(const pqv_searcher *s, hipStream_t stream, Scratch **out) {
+    Scratch *sc = nullptr;
+    for (auto &l : s->lanes) if (l.used && l.stream == stream) { sc = &l; break; }
+    if (!sc) for (auto &l : s->lanes) if (!l.used) { sc = &l; break; }
+    if (!sc) sc = &s->lanes[s->lane_rr++ % PQV_LANES];     // only an eviction advances the cursor
+    if (!sc->done) HIP_TRY(hipEventCreateWithFlags(&sc->done, hipEventDisableTiming));
+    if (sc->used && sc->stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sc->done, 0));
+    // owned by `stream` from here on, also if the call fails half-way: whatever it enqueued runs on `stream`
+    sc->stream = stream; sc->used = true;
+    *out = sc;
+    return PQV_OK;
+}
+static int lane_release(Scratch &sc, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(sc.done, stream));
+    return PQV_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -923,6 +951,54 @@ extern "C" int pqv_kmeans(const pqv_corpus *sample, uint32_t k, uint32_t max_ite
 // ---------------------------------------------------------------------------------------
 // searcher
 // ---------------------------------------------------------------------------------------
+namespace {
+
+void opts_from_env(pqv_searcher::Opts &o) {
+    auto num = [](const char *name, long long dflt) { const char *e = std::getenv(name); return e && *e ? std::strtoll(e, nullptr, 10) : dflt; };
+    if (const char *m = std::getenv("PQV_RERANK_MODE")) o.rerank_mode = !std::strcmp(m, "stream") ? 1 : !std::strcmp(m, "tile") ? 2 : 0;
+    o.tile_filter = static_cast<int>(std::min<long long>(2, std::max<long long>(0, num("PQV_TILE_FILTER", o.tile_filter))));
+    o.filter_variant = static_cast<int>(num("PQV_FILTER_VARIANT", o.filter_variant));
+    o.cand_cap = static_cast<uint32_t>(std::max<long long>(1, num("PQV_CAND_CAP", o.cand_cap)));
+    o.screen_f16 = num("PQV_SCREEN_F16", o.screen_f16) != 0;
+    o.seed_rows = static_cast<uint32_t>(num("PQV_SEED_ROWS", o.seed_rows));
+    o.wide_rows = static_cast<uint32_t>(num("PQV_WIDE_ROWS", o.wide_rows));
+    o.tile_rows = static_cast<uint32_t>(num("PQV_TILE_ROWS", o.tile_rows));
+    o.running_thr = num("PQV_RUNNING_THR", o.running_thr) != 0;
+    o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
+    o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
+    o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
+}
+
+// the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
+bool wide_path_possible(const pqv_searcher *s) { return (s->dim % 64) == 0 && !s->d_row_of && s->n > 0; }
+
+// One-off: the blocked MFMA-operand copy of the lists (a second, f16: half-size, copy of the corpus in HBM)
+int ensure_blocked_copy(const pqv_searcher *s, bool f16, hipStream_t stream) {
+    using namespace pqv;
+    if (s->d_mat_blk.p && s->blk_f16 == f16) return PQV_OK;
+    const uint32_t kc = s->n_clusters;
+    HIP_TRY(hipDeviceSynchronize());           // a form change must not pull the copy from under a running query
+    s->d_mat_blk.release();
+    std::vector<uint64_t> boff(static_cast<size_t>(kc) + 1, 0);
+    for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
+    HIP_TRY(s->d_blk_off.ensure(boff.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (f16) {
+        HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * 2));
+        HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                      (s->max_list_len + 15) / 16, s->dim, s->f16_scale, s->d_mat_blk.p, stream));
+    } else {
+        HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
+        HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                  (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    s->blk_f16 = f16;
+    return PQV_OK;
+}
+
+}  // namespace
+
 static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, uint32_t flags,
                                    pqv_searcher **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
@@ -950,10 +1026,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
             return cleanup(_e == hipErrorOutOfMemory ? PQV_ERR_OOM : PQV_ERR_HIP,         \
                            std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
-    if (const char *m = std::getenv("PQV_RERANK_MODE")) {   // A/B switch for benchmarking
-        if (!std::strcmp(m, "stream")) s->rerank_mode = 1;
-        else if (!std::strcmp(m, "tile")) s->rerank_mode = 2;
-    }
+    opts_from_env(s->opt);
     S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
     S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
@@ -977,9 +1050,6 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         s->d_row_of = nullptr;
         s->d_final_ids = s->d_ids.as<uint32_t>();
     }
-    if (const char *m = std::getenv("PQV_TILE_FILTER")) s->tile_filter = (*m == '2') ? 2 : (*m && *m != '0') ? 1 : 0;
-    if (const char *m = std::getenv("PQV_FILTER_VARIANT")) s->filter_variant = std::atoi(m);
-    if (const char *m = std::getenv("PQV_CAND_CAP")) s->cand_cap = std::max<uint32_t>(1, static_cast<uint32_t>(std::strtoul(m, nullptr, 10)));
 #ifdef PQV_PROFILE_PHASES
     S_TRY(s->d_stats.alloc((8 + 8 * 65536) * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 8 * 65536) * sizeof(unsigned long long), s->stream));
@@ -1002,15 +1072,19 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         uint32_t bits = 0;
         S_TRY(hipMemcpyAsync(&bits, d_max.p, sizeof bits, hipMemcpyDeviceToHost, s->stream));
         S_TRY(hipStreamSynchronize(s->stream));
-        const char *env16 = std::getenv("PQV_SCREEN_F16");
         float m;
         std::memcpy(&m, &bits, sizeof m);
-        if (!(env16 && *env16 == '0') && bits < 0x7F800000u) {
+        if (bits < 0x7F800000u) {
             int e = 0;
             if (m > 0.0f) (void)std::frexp(m, &e);           // m = f * 2^e, f in [0.5, 1)  =>  m < 2^e
             const int se = m > 0.0f ? 14 - e : 0;            // scale = 2^se: m * scale < 2^14
             if (se >= -60 && se <= 60) { s->f16_ok = true; s->f16_scale = std::ldexp(1.0f, se); }
         }
+    }
+    // the blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide
+    // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
+    if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 768) {
+        if (int rc = ensure_blocked_copy(s, s->opt.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024, s->stream)) { delete s; return rc; }
     }
     S_TRY(hipStreamSynchronize(s->stream));
     if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
@@ -1041,18 +1115,18 @@ struct TopkPlan {
     uint32_t n_part_probe, n_part_rr;
     bool tile;              // batched cluster-major tiles instead of one stream per (query, list)
     uint32_t max_groups;
-    bool filter;            // tile path: exact seed window + MFMA-screened remainder
+    bool filter;            // tile path with the MFMA lower-bound screen
     uint32_t seed_rows, filter_bpl;
-    bool mfma_seed;             // wide path: thresholds from MFMA upper bounds, no exact seed pass
-    bool f16;                   // wide path with f16 operands (dim % 128 == 0, 64-query quads staged in LDS)
-    uint32_t w1_rows, w1_bpl;   // wide path: a first screened window whose survivors tighten the thresholds (0 = none)
-    bool quad;              // filter: wide_filter_kernel (quad_width queries per block)
+    bool f16;               // wide path with f16 operands (dim % 128 == 0, queries staged in LDS)
+    bool quad;              // filter: wide_filter_kernel (quad_width queries per block); else tile_filter_kernel
     uint32_t filter_rows_per_block, max_quads, quad_width;
+    uint32_t block_waves;   // wide kernel: waves per block (4, or 8 sharing one staged quad on a whole CU)
     uint32_t slots_per_pair;   // partial lists per (query, probe rank)
 };
 
 TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
     TopkPlan p{};
+    const pqv_searcher::Opts &o = s->opt;
     p.np = std::min<uint32_t>(nprobe, s->n_clusters);
     // probe pass: every block scans 256 centroids (64 per wave)
     p.probe_bpl = (s->n_clusters + 255) / 256;
@@ -1067,101 +1141,80 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     // ... except where the wide screened kernels apply (5.1c): they read the f16 copy of a list instead of its f32
     // rows and skip the exact arithmetic, which beats the streaming kernel at EVERY batch size -- one query on C2
     // 123 -> 78 us, on C3 2.0 -> 0.34 ms; 32 queries on C3 15.8 -> 2.2 ms
-    const uint64_t mean_len_all = s->n / std::max<uint32_t>(1, s->n_clusters);
-    const bool wide_any_batch = metric == PQV_L2SQ_REF4 && s->tile_filter && k <= 128 && s->filter_variant == 0 &&
-                                (s->dim % 64) == 0 && !s->d_row_of && mean_len_all >= 3ull * (mean_len_all >= 4096 ? 512 : 256);
+    const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
+    const bool wide_ok = o.filter_variant == 0 && wide_path_possible(s);
+    const bool wide_any_batch = metric == PQV_L2SQ_REF4 && o.tile_filter && k <= 128 && wide_ok &&
+                                mean_len >= 3ull * (mean_len >= 4096 ? 512 : 256);
     if (wide_any_batch) p.tile = true;
-    if (s->rerank_mode == 1) p.tile = false;
-    if (s->rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 256;
+    if (o.rerank_mode == 1) p.tile = false;
+    if (o.rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 256;
     if (p.tile) {
         const uint64_t est_groups = std::max<uint64_t>(1, pairs / pqv::TILE_QB);
         // Rows per block: long enough to amortise a block's setup and top-k warm-up, short
         // enough that imbalanced lists do not leave a tail (measured optimum ~1.5 k on C2/C3);
         // shrink only when that would leave the GPU with too few blocks.
-        static const uint64_t tile_rows = [] { const char *e = std::getenv("PQV_TILE_ROWS"); return e ? std::strtoull(e, nullptr, 10) : 1536ull; }();
+        const uint64_t tile_rows = o.tile_rows ? o.tile_rows : 1536;
         uint64_t rpb = std::min<uint64_t>(tile_rows, (max_len + 255) / 256 * 256);
         while (rpb > 256 && est_groups * ((max_len + rpb - 1) / rpb) < 2048) rpb -= 256;
         (void)max_bpl;
         p.rr_rows_per_block = static_cast<uint32_t>(rpb);
-        // MFMA screen: the first seed_rows rows of every probed list are evaluated exactly (that
-        // seeds the per-query thresholds), the rest goes through the screened kernel
-        static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_SEED_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
-        static const uint32_t w1_env = [] { const char *e = std::getenv("PQV_W1_ROWS"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
-        // The MFMA screen pays when the 16-query tiles are mostly full and lists are long compared
-        // with the exact seed window; otherwise (measured on the reference bench shape: 16 pairs per
-        // cluster, 1000-row lists, 130 k vs 103 k QPS) the exact kernel alone is faster.
-        const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
         // threshold sample: 256 rows per probed list, 512 for lists of >= 4096 rows (survivors per query halve,
         // the sampling pass doubles: C2 0.246 -> 0.226 ms, C3 7.99 -> 7.58 ms)
-        p.seed_rows = seed_env ? std::max<uint32_t>(64, seed_env / 64 * 64) : (mean_len >= 4096 ? 512 : 256);
-        // (the wide kernel -- dim % 64 == 0, dim <= 256, IVF-ordered rows -- screens ~3x faster than the
-        //  one-group kernel and already wins at 1250-row lists: 0.28 vs 0.36 ms on a 125 k-row C2 shard)
-        const bool wide_ok = s->filter_variant == 0 && (s->dim % 64) == 0 && !s->d_row_of;
+        p.seed_rows = o.seed_rows ? std::max<uint32_t>(64, o.seed_rows / 64 * 64) : (mean_len >= 4096 ? 512 : 256);
         // k <= 128 (the running-threshold counters are 8 bits wide, the candidate buffers 2048 entries); the wide
         // kernel pays from lists of three seed windows on -- measured on the reference's own bench shape, 1000-row
-        // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel keeps k <= 32
-        // (and from 4 pairs per cluster on, i.e. whenever the batched path is taken at all: 1.8x at 4 pairs per
-        //  cluster, 2.2-2.4x at 16 on that shape, k = 10 and k = 100 alike; the one-group kernel, used for the
-        //  row-order layout and dim % 64 != 0, also wins from 4 pairs per cluster on 10 k-row lists: 0.45 -> 0.25 ms
-        //  at 64 queries, 0.52 -> 0.34 at 256 -- it used to wait for 24)
-        p.filter = s->tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 0ull : 4ull) * s->n_clusters &&
+        // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel (row-order layout, dim % 64 != 0) keeps k <= 32
+        // and wins from 4 pairs per cluster on 10 k-row lists: 0.45 -> 0.25 ms at 64 queries, 0.52 -> 0.34 at 256
+        p.filter = o.tile_filter && k <= (wide_ok ? 128u : 32u) && pairs >= (wide_ok ? 0ull : 4ull) * s->n_clusters &&
                    mean_len >= (wide_ok ? 3ull : 16ull) * p.seed_rows;
-        if (s->tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows;   // PQV_TILE_FILTER=2: force
-        // XCD affinity: workgroup id -> XCD is id % 8 and ids run x-fastest, so with gridDim.x a
-        // multiple of 8 the blocks of ALL query groups for one row chunk share an XCD (and its L2)
-        // and are dispatched together: a chunk is then fetched from HBM once, not once per group.
-        auto chunks_x8 = [&](uint64_t rows, uint64_t &rows_per_block) {
-            uint64_t b = (rows + rows_per_block - 1) / rows_per_block;
-            b = (b + 7) / 8 * 8;
-            rows_per_block = ((rows + b - 1) / b + 255) / 256 * 256;
-            return static_cast<uint32_t>((rows + rows_per_block - 1) / rows_per_block + 7) / 8 * 8;
-        };
-        // (measured: it UNBALANCES the XCDs, because high chunk indices exist only for long lists:
-        //  C3 33 -> 60 ms.  Kept behind PQV_XCD_ALIGN=1 for experiments; off by default.)
-        static const bool xcd_align = [] { const char *e = std::getenv("PQV_XCD_ALIGN"); return e && *e == '1'; }();
+        if (o.tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows && k <= 256;   // forced
         if (p.filter) {
-            // wide kernel: 64 (dim <= 128) or 32 (dim <= 256) queries per block, staged in LDS
-            const int variant = s->filter_variant;
-            p.quad_width = (s->dim % 64) != 0 ? 0 : s->dim <= 128 ? 64 : 32;     // dim > 256: queries from a blocked global copy
-            p.quad = variant == 0 && p.quad_width != 0 && !s->d_row_of;
-            p.f16 = p.quad && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024;
-            if (p.f16) p.quad_width = s->dim <= 256 ? 64 : 32;   // the quad's f16 queries are staged in LDS (<= 48 KB)
+            p.quad = wide_ok;
+            p.f16 = p.quad && o.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024;
+            // Quad width = queries that share one pass over a list.  f32 operands: 64 (dim <= 128) or 32 staged in
+            // LDS, longer rows read a blocked per-quad copy from global memory.  f16 operands: everything the LDS of
+            // a CU holds next to the queues -- 144 KB: 128 queries up to 512 dims, 96 at 768, 64 at 1024 -- in ONE
+            // 8-wave block per CU, because how often a list is streamed is what bounds long rows (C3, PMC: the
+            // 32-query form moves 41 GB per step through the fabric at 6.8 TB/s for 15 GB of distinct rows).
+            p.block_waves = 4;
+            if (p.f16) {
+                const uint64_t per_q = static_cast<uint64_t>(s->dim) * (s->dim <= 128 ? 6 : 2);     // f16 image (+ f32 original)
+                const uint32_t fit8 = static_cast<uint32_t>(std::min<uint64_t>(128, 147456 / per_q / 32 * 32));
+                const uint32_t fit4 = s->dim <= 256 ? 64 : 32;
+                int waves = o.wide_waves == 4 || o.wide_waves == 8 ? o.wide_waves : (s->dim > 128 ? 8 : 4);
+                if (fit8 < 64) waves = 4;
+                p.block_waves = static_cast<uint32_t>(waves);
+                p.quad_width = waves == 8 ? fit8 : fit4;
+                if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width <= p.quad_width && (waves == 4 || o.quad_width >= 64))
+                    p.quad_width = o.quad_width;
+            } else {
+                p.quad_width = s->dim <= 128 ? 64 : 32;
+            }
             uint64_t r = rpb;
-            // wide kernel: a wave's fixed cost (staging the quad's queries, the last partial batch of exact
-            // evaluations) is about half its time at 1536 rows per block, and the lists are cut into equal
-            // pieces, so longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 ->
-            // 6.35 ms); PQV_WIDE_ROWS overrides.  The 2048-block floor above still applies.
-            static const uint64_t wide_rows = [] { const char *e = std::getenv("PQV_WIDE_ROWS"); return e ? std::strtoull(e, nullptr, 10) / 256 * 256 : 2304ull; }();
-            if (p.quad && wide_rows >= 256 && !std::getenv("PQV_TILE_ROWS")) {
+            if (p.quad) {
+                // a wave's fixed cost (staging the quad's queries, the last partial batch of exact evaluations) is
+                // about half its time at 1536 rows per 4-wave block, and the lists are cut into equal pieces, so
+                // longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 -> 6.35 ms);
+                // the 8-wave blocks take twice the rows for the same piece per wave
+                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256 : 2304ull * (p.block_waves / 4);
+                const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
+                const uint64_t min_blocks = p.block_waves == 8 ? 1024 : 2048;
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
-                while (r > 256 && est_groups * ((max_len + r - 1) / r) < 2048) r -= 256;
+                while (r > 256 * (p.block_waves / 4) && est_quads * (p.quad_width / 16) * ((max_len + r - 1) / r) < min_blocks) r -= 256;
             }
-            p.filter_bpl = xcd_align ? chunks_x8(max_len - p.seed_rows, r)
-                                     : static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
             p.filter_rows_per_block = static_cast<uint32_t>(r);
-            p.rr_rows_per_block = static_cast<uint32_t>(rpb);
-            // wide path, long lists: rows [seed, seed + w1) are screened first and their survivors folded,
-            // so the bulk of the list meets thresholds drawn from a (seed + w1) * nprobe sample
-            p.w1_rows = 0; p.w1_bpl = 0;
-            if (p.quad && w1_env && max_len > p.seed_rows + 3ull * w1_env) {
-                p.w1_rows = static_cast<uint32_t>((w1_env + r - 1) / r * r);
-                p.w1_bpl = static_cast<uint32_t>(p.w1_rows / r);
-                p.filter_bpl = static_cast<uint32_t>((max_len - p.seed_rows - p.w1_rows + r - 1) / r);
-            }
-            p.rr_bpl = 1 + p.w1_bpl + p.filter_bpl;
-            p.slots_per_pair = 4 * (1 + p.w1_bpl + p.filter_bpl);
-            static const bool mfma_seed_env = [] { const char *e = std::getenv("PQV_MFMA_SEED"); return !(e && *e == '0'); }();
-            p.mfma_seed = p.quad && mfma_seed_env && !p.w1_rows;
-            if (p.mfma_seed) {          // the screened pass covers the whole list; the seed rows are only sampled
+            if (p.quad) {           // the screened pass covers the whole list; the seed rows are only sampled
                 p.filter_bpl = static_cast<uint32_t>((max_len + r - 1) / r);
                 p.rr_bpl = p.filter_bpl;
-                p.slots_per_pair = 4 * p.filter_bpl;
+                p.slots_per_pair = p.block_waves * p.filter_bpl;
+            } else {                // narrow kernel: exact seed window (slot chunk 0), screened remainder
+                p.filter_bpl = static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
+                p.rr_bpl = 1 + p.filter_bpl;
+                p.slots_per_pair = 4 * (1 + p.filter_bpl);
             }
         } else {
-            uint64_t r = rpb;
             p.filter_bpl = 0;
-            p.rr_bpl = xcd_align ? chunks_x8(max_len, r) : static_cast<uint32_t>((max_len + rpb - 1) / rpb);
-            p.rr_rows_per_block = static_cast<uint32_t>(r);
+            p.rr_bpl = static_cast<uint32_t>((max_len + rpb - 1) / rpb);
             p.slots_per_pair = 4 * p.rr_bpl;
         }
         p.n_part_rr = p.np * p.slots_per_pair;
@@ -1186,13 +1239,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
 int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uint32_t k,
                  uint32_t k_out, uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                  uint32_t *d_row_idx, float *d_dist, uint32_t *d_n_found, uint64_t *d_n_cand,
-                 uint32_t *d_tie, hipStream_t stream) {
+                 uint32_t *d_tie, hipStream_t stream, Scratch &sc) {
     using namespace pqv;
     const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
-    Scratch &sc = lane_for(s, stream);
-    if (!sc.done) HIP_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
-    if (sc.used && sc.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sc.done, 0));
 
     HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
     HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
@@ -1241,6 +1291,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     pm.probe = sc.s_probe.as<uint32_t>(); pm.cand_base = sc.s_cand_base.as<uint64_t>();
     pm.n_cand = d_n_cand ? d_n_cand : sc.s_ncand.as<uint64_t>();
     pm.max_pos = max_pos;
+    pm.stats = s->d_stats.as<unsigned long long>();
     if (p.tile) {
         pm.hist = pair_u32; pm.hist_stride = kc_pairs; pm.gthr_init = sc.s_gthr.as<unsigned long long>();
         // every partial list of the re-rank starts EMPTY: preset by the probe merge (one wave per query)
@@ -1279,37 +1330,20 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.part_keys = sc.s_part_keys.as<uint64_t>(); ta.part_vals = sc.s_part_vals.as<uint32_t>();
         ta.row_norm2 = s->d_row_norm2.as<float>();
         ta.stats = s->d_stats.as<unsigned long long>();
-        static const int xcd_swz = [] { const char *e = std::getenv("PQV_XCD_SWIZZLE"); return (e && *e == '1') ? 1 : 0; }();   // measured: no gain on C2, -30 % on C3
-        ta.xcd_swizzle = xcd_swz;
+        ta.xcd_swizzle = 0;
         if (p.filter && p.quad) {
-            if (!s->d_mat_blk.p) {
-                // one-off: the blocked MFMA-operand copy of the lists (second copy of the corpus in HBM)
-                std::vector<uint64_t> boff(static_cast<size_t>(kc) + 1, 0);
-                for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
-                HIP_TRY(s->d_blk_off.alloc(boff.size() * sizeof(uint64_t)));
-                HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-                if (p.f16) {
-                    HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * 2));
-                    HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                                  (s->max_list_len + 15) / 16, s->dim, s->f16_scale, s->d_mat_blk.p, stream));
-                } else {
-                    HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
-                    HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                              (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
-                }
-                HIP_TRY(hipStreamSynchronize(stream));      // one-off; calls on other streams may follow at once
-            }
+            if (int rc = ensure_blocked_copy(s, p.f16, stream)) return rc;     // built at creation; here only after an option change
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
+            ta.block_waves = p.block_waves;
             if (p.f16) {
                 ta.f16 = 1; ta.scale = s->f16_scale; ta.scale2 = s->f16_scale * s->f16_scale;
                 ta.query_maxabs = sc.s_qmax.as<float>();
             }
-            // quad-to-XCD affinity (PQV_QUAD_XCD=0/1 overrides): on by default for the global-query variant,
-            // whose per-quad operand copies must stay L2-resident
-            static const int quad_xcd_env = [] { const char *e = std::getenv("PQV_QUAD_XCD"); return e ? std::atoi(e) : -1; }();
+            // quad-to-XCD affinity: on by default for the global-query variant, whose per-quad operand copies
+            // must stay L2-resident
             const bool q_global = !p.f16 && static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768;
-            ta.xcd_swizzle = quad_xcd_env >= 0 ? quad_xcd_env : (q_global ? 1 : 0);
+            ta.xcd_swizzle = s->opt.quad_xcd >= 0 ? s->opt.quad_xcd : (q_global ? 1 : 0);
             if (q_global) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
                 HIP_TRY(sc.s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));
@@ -1320,8 +1354,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         }
         if (p.filter) ta.query_norm2 = sc.s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
-        if (p.filter && p.mfma_seed) {
-            const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
+        if (p.filter && p.quad) {
+            const uint32_t ccap = std::max<uint32_t>(s->opt.cand_cap, k);
             HIP_TRY(sc.s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
             HIP_TRY(sc.s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
             HIP_TRY(sc.s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
@@ -1336,74 +1370,28 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(sc.s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
             seed.seed_ub = sc.s_seed_ub.as<float>();
             HIP_TRY(launch_wide_seed(seed, stream));
-            // running thresholds (PQV_RUNNING_THR=0 turns them off): see TileArgs::thr_hist
-            static const bool running_thr = [] { const char *e = std::getenv("PQV_RUNNING_THR"); return !(e && *e == '0'); }();
-            if (running_thr && k > 1) {
+            // running thresholds: see TileArgs::thr_hist
+            if (s->opt.running_thr && k > 1) {
                 HIP_TRY(sc.s_thr_hist.ensure(static_cast<size_t>(nq) * 16 * sizeof(uint32_t)));
                 HIP_TRY(sc.s_thr_bins.ensure(static_cast<size_t>(nq) * sizeof(float4)));
                 ta.thr_hist = sc.s_thr_hist.as<uint32_t>(); ta.thr_bins = static_cast<const float4 *>(sc.s_thr_bins.p);
             }
-            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, nullptr,
+            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream,
                                        ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
-            // (measured: the recording pass is 20 % shorter, but a lane-per-pair exact pass pays one L1 tag look-up
-            //  per 16-byte chunk -- 157 us for C2's 540 k survivors -- so this stays opt-in until the exact pass
-            //  reads rows cooperatively: PQV_SURVIVOR_LIST=1)
-            static const bool list_mode = [] { const char *e = std::getenv("PQV_SURVIVOR_LIST"); return e && *e == '1'; }();
-            if (list_mode) {
-                // pass 1 records the screen's survivors, pass 2 evaluates them exactly at full occupancy; if a
-                // buffer ran full (pathological data) the flag makes the two guarded launches behind redo the
-                // batch with the self-contained kernel, which evaluates in place and spills into sorted lists
-                const uint32_t surv_cap = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(nq) * 8192), 1ull << 26));
-                HIP_TRY(sc.s_surv.ensure(static_cast<size_t>(surv_cap) * sizeof(uint2)));
-                HIP_TRY(sc.s_surv_cnt.ensure(2 * sizeof(uint32_t)));
-                HIP_TRY(hipMemsetAsync(sc.s_surv_cnt.p, 0, 2 * sizeof(uint32_t), stream));
-                TileArgs tl = ta;
-                tl.surv = static_cast<uint2 *>(sc.s_surv.p); tl.surv_cnt = sc.s_surv_cnt.as<uint32_t>(); tl.surv_cap = surv_cap;
-                tl.overflow = sc.s_surv_cnt.as<uint32_t>() + 1;
-                HIP_TRY(launch_tile_filter(tl, stream));
-                HIP_TRY(launch_survivor_eval(tl, sc.s_probe.as<uint32_t>(), stream));
-                ta.guard = tl.overflow;
-                HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream, ta.guard,
-                                           ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
-                s->counters.kernel_launches += 3;
-            }
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
         } else if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
-            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows; seed.xcd_swizzle = xcd_swz;
+            seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows;
             seed.rows_per_block = std::max<uint32_t>(256, p.seed_rows);     // one 64-row tile per wave at least
             HIP_TRY(launch_tile_rerank(seed, stream));
             ta.row_offset = p.seed_rows; ta.slot_base = 4; ta.grid_x = p.filter_bpl;
-            ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = p.quad ? 0 : 1;
-            if (p.quad) {
-                const uint32_t ccap = std::max<uint32_t>(s->cand_cap, k);
-                HIP_TRY(sc.s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
-                HIP_TRY(sc.s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
-                HIP_TRY(sc.s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-                ta.cand_keys = sc.s_cand_keys.as<uint64_t>(); ta.cand_vals = sc.s_cand_vals.as<uint32_t>();
-                ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap;
-                HIP_TRY(sc.s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
-                ta.spilled = sc.s_spilled.as<uint32_t>();
-                HIP_TRY(launch_cand_seed(ta.part_keys, ta.part_vals, nq, p.np, p.slots_per_pair, p.n_part_rr, k, ta.gthr,
-                                         ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, ta.spilled, stream));
-                if (p.w1_rows) {
-                    TileArgs w1 = ta;
-                    w1.grid_x = p.w1_bpl; w1.row_end = p.seed_rows + p.w1_rows;
-                    HIP_TRY(launch_tile_filter(w1, stream));
-                    HIP_TRY(launch_cand_select(ta.cand_keys, ta.cand_vals, ta.cand_cnt, ccap, nq, k, ta.gthr, nullptr, nullptr, 0, stream));
-                    ta.row_offset = p.seed_rows + p.w1_rows; ta.slot_base = 4 + 4 * p.w1_bpl;
-                    s->counters.kernel_launches += 2;
-                }
-                HIP_TRY(launch_tile_filter(ta, stream));
-                use_cand = true;
-            } else {
-                HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.slots_per_pair, k, ta.gthr, stream));
-                HIP_TRY(launch_tile_filter(ta, stream));
-            }
+            ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 1;
+            HIP_TRY(launch_seed_threshold(ta.part_keys, nq, p.np, p.slots_per_pair, k, ta.gthr, stream));
+            HIP_TRY(launch_tile_filter(ta, stream));
             s->counters.kernel_launches += 2;
         } else {
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.rr_bpl;
@@ -1433,13 +1421,12 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
     if (use_cand) {
         fm.cand_keys = sc.s_cand_keys.as<uint64_t>(); fm.cand_vals = sc.s_cand_vals.as<uint32_t>();
-        fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->cand_cap, k);
+        fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->opt.cand_cap, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
     }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
-    HIP_TRY(hipEventRecord(sc.done, stream));
-    sc.stream = stream; sc.used = true;
+    if (int rc = lane_release(sc, stream)) return rc;
     s->counters.kernel_launches += 4;
     return PQV_OK;
 }
@@ -1507,11 +1494,10 @@ inline void heap_pop(std::vector<HeapEnt> &h) {
 
 // Recompute one query's candidate distances on the device (STREAM_DIST), then replay them
 // through the heap in candidate order.  qi indexes the current sub-batch's probe scratch.
-int replay_query_exact(const pqv_searcher *s, const float *d_query, uint32_t qi, uint32_t np, uint32_t k,
+int replay_query_exact(const pqv_searcher *s, Scratch &sc, const float *d_query, uint32_t qi, uint32_t np, uint32_t k,
                        uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
                        uint32_t *n_found) {
     using namespace pqv;
-    Scratch &sc = lane_for(s, s->stream);
     std::vector<uint32_t> clusters(np);
     HIP_TRY(hipMemcpyAsync(clusters.data(), sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
                            np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1568,10 +1554,12 @@ static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, ui
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    Scratch *lane = nullptr;
+    if (int rc = lane_acquire(s, stream, &lane)) return rc;
     const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, k, k, nprobe, max_candidates,
                                 metric, sqrt_out, static_cast<uint32_t *>(d_row_idx),
                                 static_cast<float *>(d_dist), static_cast<uint32_t *>(d_n_found),
-                                static_cast<uint64_t *>(d_n_candidates), nullptr, stream);
+                                static_cast<uint64_t *>(d_n_candidates), nullptr, stream, *lane);
     if (rc == PQV_OK) s->counters.queries += nq;
     return rc;
 }
@@ -1596,7 +1584,9 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     // One extra merged entry (the runner-up) lets the merge kernel see ties at the k-th
     // distance; queries it flags are replayed through the exact heap (replay_query_exact).
     const uint32_t k_int = k < 1024 ? k + 1 : k;
-    Scratch &sc = lane_for(s, s->stream);
+    Scratch *lane = nullptr;
+    if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
+    Scratch &sc = *lane;
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
     const TopkPlan p1 = plan_topk(s, 1, nprobe, k_int, metric);
     const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + 1;
@@ -1616,7 +1606,7 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
                                static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
         if (int rc = enqueue_topk(s, sc.s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
                                   sqrt_out, sc.s_rows.as<uint32_t>(), sc.s_dist.as<float>(),
-                                  sc.s_nfound.as<uint32_t>(), nullptr, sc.s_tie.as<uint32_t>(), s->stream))
+                                  sc.s_nfound.as<uint32_t>(), nullptr, sc.s_tie.as<uint32_t>(), s->stream, sc))
             return rc;
         HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, sc.s_rows.p,
                                static_cast<size_t>(b) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1629,14 +1619,11 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
         HIP_TRY(hipMemcpyAsync(h_ncand.data(), sc.s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        for (uint32_t i = 0; i < b; ++i) {
-            s->counters.candidate_rows += h_ncand[i];
-            s->counters.embeddings_fetched +=
-                max_candidates ? std::min<uint64_t>(h_ncand[i], max_candidates) : h_ncand[i];
+        for (uint32_t i = 0; i < b; ++i) {      // (candidate_rows / embeddings_fetched are counted on the device)
             if (n_candidates) n_candidates[q0 + i] = h_ncand[i];
             if (h_tie[i]) {
                 // tied output distances: survivors / order follow Rust's heap mechanics exactly
-                if (int rc = replay_query_exact(s, sc.s_queries.as<float>() + static_cast<size_t>(i) * s->dim, i, np,
+                if (int rc = replay_query_exact(s, sc, sc.s_queries.as<float>() + static_cast<size_t>(i) * s->dim, i, np,
                                                 k, max_candidates, metric, sqrt_out,
                                                 row_idx + static_cast<uint64_t>(q0 + i) * k,
                                                 dist + static_cast<uint64_t>(q0 + i) * k, &h_nf[i]))
@@ -1668,7 +1655,9 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     using namespace pqv;
-    Scratch &sc = lane_for(s, s->stream);
+    Scratch *lane = nullptr;
+    if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
+    Scratch &sc = *lane;
     const TopkPlan p = plan_topk(s, 1, nprobe);
     HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
     HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint64_t)));
@@ -1692,6 +1681,7 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     HIP_TRY(launch_merge_probe(pm, s->stream));
     HIP_TRY(hipMemcpyAsync(clusters_out, sc.s_probe.p, static_cast<size_t>(np) * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, s->stream));
+    if (int rc = lane_release(sc, s->stream)) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (n_out) *n_out = np;
     s->counters.kernel_launches += 2;
@@ -1743,7 +1733,9 @@ static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
         std::vector<unsigned long long> slots(16 * pqv::STATS_SLOTS);
         HIP_TRY(hipMemcpy(slots.data(), static_cast<const unsigned long long *>(s->d_stats.p) + 8,
                           slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < pqv::STATS_SLOTS; ++i) { st[0] += slots[16 * i]; st[1] += slots[16 * i + 1]; }
+        for (uint32_t i = 0; i < pqv::STATS_SLOTS; ++i) {
+            st[0] += slots[16 * i]; st[1] += slots[16 * i + 1]; st[2] += slots[16 * i + 2]; st[3] += slots[16 * i + 3];
+        }
     }
 #endif
 #ifdef PQV_PROFILE_PHASES
@@ -1758,6 +1750,8 @@ static int pqv_counters_impl(const pqv_searcher *s, pqv_counters_t *out) {
     *out = s->counters;
     out->screened_pairs = st[0];
     out->screen_survivors = st[1];
+    out->candidate_rows += st[2];         // top-k calls (device counters) + pqv_candidate_rows (host counter)
+    out->embeddings_fetched += st[3];
     return PQV_OK;
 }
 extern "C" int pqv_counters(const pqv_searcher *s, pqv_counters_t *out) {

@@ -72,6 +72,11 @@ struct MergeArgs {
     uint64_t       *cand_base;   // [nq, k]
     uint64_t       *n_cand;      // [nq] or nullptr
     uint64_t        max_pos;     // cap applied to n_cand
+    // probe mode, optional: the searcher's statistics block -- every query adds its candidate count to the
+    // candidate_rows / embeddings_fetched counters (slot q % STATS_SLOTS, words 2 and 3: the plan metrics of
+    // src/df_vector/index_exec.rs:289-299 and exec.rs:411-427, kept on the device so that the asynchronous
+    // pqv_topk_device path counts too)
+    unsigned long long *stats;
     // probe mode extras for the batched path (all optional): cluster histogram of the (query, probe
     // rank) pairs (zeroed beforehand), reset of the per-query admission thresholds, |q|^2
     uint32_t       *hist;
@@ -97,7 +102,8 @@ hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 constexpr int TILE_QB = 16;
 
 constexpr uint32_t HIST_REPLICAS = 16;
-// wide_filter_kernel's two statistics counters live in STATS_SLOTS copies at stats[8 + 16 i + {0, 1}]
+// statistics counters live in STATS_SLOTS copies one cache line apart: stats[8 + 16 i + {0, 1}] screened pairs /
+// survivors (wide_filter_kernel), + {2, 3} candidate rows / embeddings fetched (probe merge)
 constexpr uint32_t STATS_SLOTS = 64;
 
 struct PairSortArgs {
@@ -137,6 +143,7 @@ struct TileArgs {
     const uint4    *quads;       // wide_filter_kernel: gridDim.y = max_quads
     const uint32_t *n_quads;
     uint32_t        max_quads, quad_width;
+    uint32_t        block_waves; // wide_filter_kernel: waves per block, 4 (default when 0) or 8 (one block per CU sharing a staged quad of up to 128 queries)
     uint32_t        nq, nprobe, dim, k;
     uint32_t        rows_per_block, blocks_per_list;
     uint64_t        max_pos;
@@ -171,13 +178,6 @@ struct TileArgs {
     uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
     uint32_t        cand_cap;
     uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
-    // wide_filter_kernel, list mode (surv != nullptr): survivors {pair id, row offset in the list} are appended
-    // here instead of being evaluated in place; surv_cnt may run past surv_cap (then *overflow is raised)
-    uint2          *surv;
-    uint32_t       *surv_cnt;
-    uint32_t        surv_cap;
-    uint32_t       *overflow;    // raised by the list pass / survivor_eval_kernel when a buffer is full
-    const uint32_t *guard;       // non-null: the launch returns at once unless *guard != 0 (fallback launches)
     // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
     float          *seed_ub;
     uint32_t        seed_sw;
@@ -204,26 +204,13 @@ hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s);
 hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
                                  uint32_t k, unsigned long long *gthr, hipStream_t s);
 
-// Candidate buffers of the wide screened path (see kernels.hip).  cand_seed: k best of the seed lists
-// (slots 0..3 of every probe rank; cleared) -> buffer front, gthr = their k-th key.  cand_select: fold
-// the appended candidates to the k best (buffer front), tighten gthr; optional copy to out_keys/vals
-// [q * out_stride + e] as one more partial list for the final merge.
-hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
-                            uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
-                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t *spilled, hipStream_t s);
-hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
-                              uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
-                              uint64_t out_stride, hipStream_t s);
-
 // Thresholds of the wide screened pass from MFMA upper bounds (no exact seed pass): launch_wide_seed over
 // the first rows of every list fills TileArgs::seed_ub, launch_seed_select turns a query's n_vals =
 // nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard = nullptr,
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
                               uint32_t *thr_hist = nullptr, float4 *thr_bins = nullptr);
-// exact evaluation of the survivor list of a list-mode launch_tile_filter (probe = cluster of every pair)
-hipError_t launch_survivor_eval(const TileArgs &a, const uint32_t *probe, hipStream_t s);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:

@@ -556,6 +556,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
             carry += readlane_u64(incl, 63);
         }
         if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
+        if (a.stats && lane == 0) {                       // plan metrics, spread over STATS_SLOTS lines
+#ifdef PQV_PROFILE_PHASES
+            unsigned long long *st = a.stats;
+#else
+            unsigned long long *st = a.stats + 8 + 16 * (q % STATS_SLOTS);
+#endif
+            atomicAdd(&st[2], (unsigned long long)carry);
+            atomicAdd(&st[3], (unsigned long long)(carry < a.max_pos ? carry : a.max_pos));
+        }
         if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
         if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
             float acc = 0.0f;
@@ -1274,111 +1283,9 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// Per-query candidate buffers of the wide screened path: cand_keys/vals [nq][cap], cand_cnt[nq].
-//   cand_seed_kernel   : after the exact seed window -- the k best of q's seed lists (slots 0..3 of
-//                        every probe rank) become the buffer's first entries, gthr[q] their k-th key;
-//                        the seed slots are cleared (their content now lives in the buffer).
-//   cand_select_kernel : folds the appended candidates to the k best (kept at the buffer's front),
-//                        tightens gthr[q]; with out_keys it also writes them as one more partial
-//                        list for the final merge.
-// One wave per query.
+// Per-query candidate buffers of the wide screened path: cand_keys/vals [nq][cap], cand_cnt[nq] -- reset by
+// seed_select_kernel, appended to by wide_filter_kernel (one atomic per verified pair), folded by merge_kernel.
 // ------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(64) void cand_seed_kernel(uint64_t *part_keys, uint32_t *part_vals, uint32_t nprobe,
-                                                      uint32_t slots_per_pair, uint32_t n_part, uint32_t k,
-                                                      unsigned long long *gthr, uint64_t *cand_keys,
-                                                      uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap,
-                                                      uint32_t *spilled) {
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    if (lane == 0) spilled[q] = 0u;
-    WaveTopk<S> tk;
-    tk.init();
-    const uint32_t total = nprobe * 4 * k;
-    for (uint32_t i = 0; i < total; i += 64) {
-        const uint32_t idx = i + lane;
-        uint64_t key = KEY_EMPTY;
-        uint32_t val = 0xFFFFFFFFu;
-        if (idx < total) {
-            const uint32_t list = idx / k, e = idx % k;          // list = j * 4 + wave
-            const uint64_t src = ((uint64_t)q * n_part + (list >> 2) * slots_per_pair + (list & 3)) * k + e;
-            key = part_keys[src]; val = part_vals[src];
-            part_keys[src] = KEY_EMPTY; part_vals[src] = 0xFFFFFFFFu;
-        }
-        tk.offer(key, val, k, lane);
-    }
-    uint32_t found = 0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const uint32_t e = s * 64 + lane;
-        const bool have = e < k && tk.key[s] != KEY_EMPTY;
-        if (have) { cand_keys[(uint64_t)q * cap + e] = tk.key[s]; cand_vals[(uint64_t)q * cap + e] = tk.val[s]; }
-        found += (uint32_t)__popcll(__ballot(have));
-    }
-    const uint64_t kth = tk.kth(k);
-    if (lane == 0) {
-        cand_cnt[q] = found;
-        if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(64) void cand_select_kernel(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt,
-                                                        uint32_t cap, uint32_t k, unsigned long long *gthr,
-                                                        uint64_t *out_keys, uint32_t *out_vals, uint64_t out_stride) {
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    uint32_t n = cand_cnt[q];
-    if (n > cap) n = cap;
-    WaveTopk<S> tk;
-    tk.init();
-    for (uint32_t i = 0; i < n; i += 64) {
-        const uint32_t idx = i + lane;
-        uint64_t key = KEY_EMPTY;
-        uint32_t val = 0xFFFFFFFFu;
-        if (idx < n) { key = cand_keys[(uint64_t)q * cap + idx]; val = cand_vals[(uint64_t)q * cap + idx]; }
-        tk.offer(key, val, k, lane);
-    }
-    uint32_t found = 0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const uint32_t e = s * 64 + lane;
-        if (e < k) {
-            const bool have = tk.key[s] != KEY_EMPTY;
-            if (have) { cand_keys[(uint64_t)q * cap + e] = tk.key[s]; cand_vals[(uint64_t)q * cap + e] = tk.val[s]; }
-            if (out_keys) { out_keys[(uint64_t)q * out_stride + e] = tk.key[s]; out_vals[(uint64_t)q * out_stride + e] = tk.val[s]; }
-            found += (uint32_t)__popcll(__ballot(have));
-        } else {
-            found += (uint32_t)__popcll(__ballot(false));
-        }
-    }
-    const uint64_t kth = tk.kth(k);
-    if (lane == 0) {
-        cand_cnt[q] = found;
-        if (kth != KEY_EMPTY) atomicMin(&gthr[q], (unsigned long long)kth);
-    }
-}
-
-hipError_t launch_cand_seed(uint64_t *part_keys, uint32_t *part_vals, uint32_t nq, uint32_t nprobe, uint32_t slots_per_pair,
-                            uint32_t n_part, uint32_t k, unsigned long long *gthr, uint64_t *cand_keys,
-                            uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t *spilled, hipStream_t s) {
-    if (nq == 0) return hipSuccess;
-    if (k > cap) return hipErrorInvalidValue;
-    if (k <= 64) hipLaunchKernelGGL(cand_seed_kernel<1>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap, spilled);
-    else if (k <= 256) hipLaunchKernelGGL(cand_seed_kernel<4>, dim3(nq), dim3(64), 0, s, part_keys, part_vals, nprobe, slots_per_pair, n_part, k, gthr, cand_keys, cand_vals, cand_cnt, cap, spilled);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-hipError_t launch_cand_select(uint64_t *cand_keys, uint32_t *cand_vals, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
-                              uint32_t k, unsigned long long *gthr, uint64_t *out_keys, uint32_t *out_vals,
-                              uint64_t out_stride, hipStream_t s) {
-    if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(cand_select_kernel<1>, dim3(nq), dim3(64), 0, s, cand_keys, cand_vals, cand_cnt, cap, k, gthr, out_keys, out_vals, out_stride);
-    else if (k <= 256) hipLaunchKernelGGL(cand_select_kernel<4>, dim3(nq), dim3(64), 0, s, cand_keys, cand_vals, cand_cnt, cap, k, gthr, out_keys, out_vals, out_stride);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------
 // wide_seed_kernel<NG>: admission thresholds for the wide screened pass WITHOUT an exact pass.
 //
@@ -1398,7 +1305,11 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
     if (by >= *a.n_quads) return;
     const uint4 quad = a.quads[by];
-    const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
+    // a quad wider than this kernel's 16 NG queries (the 8-wave filter kernel takes up to 128) is sampled in
+    // slices of 16 NG: blockIdx.z
+    const uint32_t sub = blockIdx.z * NQ;
+    if (sub >= quad.z) return;
+    const uint32_t c = quad.x, p0 = quad.y + sub, cnt = quad.z - sub < NQ ? quad.z - sub : NQ;
     const uint32_t ng = (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1539,8 +1450,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 template <int S>
 __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
                                                         unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                        const uint32_t *guard, uint32_t *thr_hist, float4 *thr_bins) {
-    if (guard && *guard == 0u) return;
+                                                        uint32_t *thr_hist, float4 *thr_bins) {
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
     WaveTopk<S> tk;
@@ -1613,12 +1523,12 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
-    if (a.f16) {      // f16 operands: the staged queries take half the LDS
-        if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
-        if (a.quad_width == 64 && lds4 / 2 <= 32768)
-            hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4 / 2, s, a);
-        else if (a.quad_width == 32 && lds2 / 2 <= 65536)
-            hipLaunchKernelGGL((wide_seed_kernel<2, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a);
+    if (a.f16) {      // f16 operands: the staged queries take half the LDS; 64 queries per block up to 256 dims, else 32
+        if ((a.dim % 128) != 0 || !a.query_maxabs || a.dim > 1024) return hipErrorInvalidValue;
+        if (lds4 / 2 <= 32768 && (a.quad_width % 64) == 0)
+            hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads, a.quad_width / 64), dim3(256), lds4 / 2, s, a);
+        else if ((a.quad_width % 32) == 0)
+            hipLaunchKernelGGL((wide_seed_kernel<2, true, true>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), lds2 / 2, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -1634,18 +1544,18 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
-                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s, const uint32_t *guard,
+                              uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
                               uint32_t *thr_hist, float4 *thr_bins) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard, thr_hist, thr_bins);
-    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, guard, thr_hist, thr_bins);
+    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins);
+    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------
-// wide_filter_kernel<NG, S>: the MFMA-screened re-rank with NG 16-query groups (a "quad" of up
-// to 16 NG queries of one cluster) per block.
+// wide_filter_kernel<NG, NW, S>: the MFMA-screened re-rank with NG 16-query groups (a "quad" of up
+// to 16 NG queries of one cluster) per block of NW waves.
 //
 // tile_filter_kernel fetches 5 operand vectors from global memory per 16 MFMAs and re-reads a
 // cluster's rows once per 16-query group (8 flop per byte).  Here the block's queries are staged
@@ -1654,21 +1564,60 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 // 64-row x 16-dim B operand it loads is contracted against all NG query groups: 4 global loads per
 // 16 NG MFMAs, rows re-read once per 16 NG queries, and -- unlike staging the ROWS in LDS, which
 // was tried first and lost to barrier skew -- the waves never synchronise after the prologue.
-// Screening bound, pending queue (drained after every group's screen, so one tile's worth of
+//
+// How often a list is streamed is what bounds the kernel on long rows: PMC on C3 (10 M x 768, 32-query
+// quads, round 2) shows 53 GB of operand loads per 1024-query step, 82 % of them L2 misses, 41 GB at the
+// fabric = 6.8 TB/s -- the kernel sits at the memory system's ceiling while reading every probed list
+// 3x (sum over clusters of len * ceil(pairs / 32) = 30 M rows against 10 M distinct ones).  Hence the
+// widest quad the LDS can hold: NW = 8 waves share ONE staged quad of up to 128 queries (96 at 768 dims:
+// 144 KB of f16 images), one block per CU -- the same eight waves per CU as two 4-wave blocks, but a
+// list is streamed ceil(pairs / 96) times instead of ceil(pairs / 32): 13.6 M rows on C3.
+//
+// Screening bound, pending queue (drained after every tile's screen, so one tile's worth of
 // capacity still suffices), exact re-evaluation and fold are those of tile_filter_kernel.
-// Per-query state is lane-parallel over all 64 lanes (lane = query index in the quad).
-// Requires dim % 64 == 0 (swizzle closure), 16 NG * dim * 4 bytes of LDS, the IVF-ordered layout
-// (row_of == nullptr) and its blocked copy (mat_blk / blk_off).
+// Per-query state is lane-parallel: query i of the quad lives in lane i % 64 of state slot i / 64.
+// Requires dim % 64 == 0 (swizzle closure), the IVF-ordered layout (row_of == nullptr) and its blocked
+// copy (mat_blk / blk_off).
 // ------------------------------------------------------------------------------------
-template <int NG, int S, bool QLDS, bool F16, bool LIST>
-__global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
-    static_assert(TILE_QB == 16 && (NG == 2 || NG == 4), "16x16x4 MFMA tiles, 2 or 4 groups");
-    constexpr int PEND = 512 + 64;         // half a group's pairs of one tile + a partial batch
+// lane-parallel per-query state of a quad: value of query qi (per-lane index / wave-uniform index)
+template <int QS>
+__device__ __forceinline__ uint32_t qsel_u32(const uint32_t (&v)[QS], uint32_t qi) {
+    uint32_t r = (uint32_t)__shfl((int)v[0], (int)(qi & 63u), 64);
+    if constexpr (QS > 1) { const uint32_t r1 = (uint32_t)__shfl((int)v[1], (int)(qi & 63u), 64); r = qi < 64u ? r : r1; }
+    return r;
+}
+template <int QS>
+__device__ __forceinline__ uint64_t qsel_u64(const uint64_t (&v)[QS], uint32_t qi) {
+    uint64_t r = shfl_u64(v[0], (int)(qi & 63u));
+    if constexpr (QS > 1) { const uint64_t r1 = shfl_u64(v[1], (int)(qi & 63u)); r = qi < 64u ? r : r1; }
+    return r;
+}
+template <int QS>
+__device__ __forceinline__ uint32_t qread_u32(const uint32_t (&v)[QS], uint32_t qq) {      // qq wave-uniform
+    if constexpr (QS > 1) return readlane_u32(qq < 64u ? v[0] : v[1], (int)(qq & 63u));
+    else return readlane_u32(v[0], (int)qq);
+}
+template <int QS>
+__device__ __forceinline__ uint64_t qread_u64(const uint64_t (&v)[QS], uint32_t qq) {
+    if constexpr (QS > 1) return readlane_u64(qq < 64u ? v[0] : v[1], (int)(qq & 63u));
+    else return readlane_u64(v[0], (int)qq);
+}
+
+template <int NG, int NW, int S, bool QLDS, bool F16, bool PF>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
+    static_assert(!PF || (QLDS && F16), "whole-tile operand prefetch: f16 rows of <= 128 dims");
+    static_assert(TILE_QB == 16 && NG >= 2 && NG <= 8 && (NG % 2) == 0 && (NW == 4 || NW == 8), "16-row MFMA tiles, 2..8 groups, 4 or 8 waves");
     constexpr uint32_t NQ = 16 * NG;
+    constexpr int QS = (NQ + 63) / 64;        // state slots per lane
+    // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
+    // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
+    // (<= 256) for the 8-wave blocks, whose LDS belongs to the staged queries
+    constexpr int PASS = NW == 8 ? 256 : 512;
+    constexpr int PEND = PASS + 64;        // one pass + a partial batch
+    constexpr int NT = 64 * NW;
 #ifdef PQV_PROFILE_PHASES
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (a.guard && *a.guard == 0u) return;      // fallback launch: runs only if the list pass raised the flag
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
     if (by >= *a.n_quads) return;
@@ -1680,14 +1629,14 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     const uint32_t k = a.k;
 
     extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
-    __shared__ uint32_t pend_all[4 * PEND];          // (query index << 26) | row offset from the wave's r0
+    __shared__ uint32_t pend_all[NW * PEND];         // (query index << 25) | row offset from the wave's r0
     uint32_t *pend = pend_all + wave * PEND;
-    __shared__ __attribute__((aligned(16))) float aq_all[4 * 64];   // per-wave, per-query screen terms
-    float *aq = aq_all + wave * 64;
+    __shared__ __attribute__((aligned(16))) float aq_all[NW * NQ];   // per-wave, per-query screen terms
+    float *aq = aq_all + wave * NQ;
 
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
-    uint64_t wrows = a.rows_per_block / 4;
+    uint64_t wrows = a.rows_per_block / NW;
     uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     if (a.row_offset == 0 && a.row_end == 0) {
         // the whole list in this launch: ceil(len / rows_per_block) blocks share it in EQUAL wave pieces (a
@@ -1695,8 +1644,8 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // (staging the quad's queries, the final partial batch of exact evaluations) would be wasted
         const uint64_t nch = (len + a.rows_per_block - 1) / a.rows_per_block;
         if (bx >= nch) return;
-        wrows = ((len + 4 * nch - 1) / (4 * nch) + 63) / 64 * 64;
-        r0 = ((uint64_t)bx * 4 + (uint64_t)wave) * wrows;
+        wrows = ((len + NW * nch - 1) / (NW * nch) + 63) / 64 * 64;
+        r0 = ((uint64_t)bx * NW + (uint64_t)wave) * wrows;
     }
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
@@ -1719,49 +1668,60 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     const float sc2 = F16 ? a.scale2 : 1.0f;
     const float alpha = sc2 * 0.5f * (1.0f - (2.0f * cmargin + c16) * inv1c), beta = sc2 * 0.5f * inv1c;
 
-    // lane-parallel per-query state: lane q owns query q of the quad
-    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
-    const uint32_t my_pair = a.pairs[my_slot];
-    const uint32_t my_qrow = my_pair / a.nprobe;
-    const uint64_t my_cbase = a.cand_base[my_pair];
-    const float my_qn = a.query_norm2[my_qrow];
-    uint64_t my_lkth = KEY_EMPTY;
+    // lane-parallel per-query state: slot s, lane l own query 64 s + l of the quad (queries past cnt alias the
+    // last one; they are masked wherever it matters)
+    uint32_t my_pair[QS], my_qrow[QS];
+    uint64_t my_cbase[QS], my_lkth[QS], my_base[QS];
+    float my_qn[QS];
+    bool my_noskip[QS];
     const uint32_t n_part = a.n_part;
-    const uint64_t my_base =
-        ((uint64_t)my_qrow * n_part + (my_pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * 4 + wave) * k;
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+        my_pair[s] = a.pairs[p0 + (qi < cnt ? qi : cnt - 1)];
+        my_qrow[s] = my_pair[s] / a.nprobe;
+        my_cbase[s] = a.cand_base[my_pair[s]];
+        my_qn[s] = a.query_norm2[my_qrow[s]];
+        my_lkth[s] = KEY_EMPTY;
+        my_base[s] = ((uint64_t)my_qrow[s] * n_part + (my_pair[s] % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
+        // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
+        my_noskip[s] = F16 && (!(a.query_maxabs[my_qrow[s]] * a.scale <= 32768.0f) || !(my_qn[s] * a.scale2 >= 1.0f) || !(my_qn[s] <= 3.0e38f));
+    }
 
-    // QLDS: stage the quad's queries: 256 / NQ threads per query, 16-byte columns interleaved between them;
-    // the row pointer comes from the lane-parallel state (queries past cnt alias the last one, masked later).
+    // QLDS: stage the quad's queries: TPQ threads per query, 16-byte columns interleaved between them;
+    // the row pointer comes from the lane-parallel state.
     // !QLDS (rows too long for LDS): the A operands come from the quad's BLOCKED query copy in global
     // memory (pack_queries_kernel; L2-resident), fetched like the B operands -- 1 KiB per load.
     if constexpr (QLDS) {
-        constexpr uint32_t TPQ = 256 / NQ;
+        constexpr uint32_t NQP2 = NQ <= 32 ? 32 : NQ <= 64 ? 64 : 128;
+        constexpr uint32_t TPQ = NT / NQP2;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
-        const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
-        float4 *dst = qs + q * G;
-        const uint32_t sw = q & 15u;
-        if constexpr (F16) {
-            if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
-                float4 *d32 = qs + NQ * G + q * Gx;
+        const uint32_t q_src = qsel_u32<QS>(my_qrow, q < NQ ? q : NQ - 1);
+        if (q < 16u * ng) {        // only the active groups are ever read
+            const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)q_src * dim);
+            float4 *dst = qs + q * G;
+            const uint32_t sw = q & 15u;
+            if constexpr (F16) {
+                if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
+                    float4 *d32 = qs + NQ * G + q * Gx;
 #pragma unroll 4
-                for (uint32_t ch = c0; ch < G; ch += TPQ) {
-                    const float4 lo = src[2 * ch], hi = src[2 * ch + 1];
-                    dst[ch ^ sw] = pack_f16x8_clamped(lo, hi, a.scale);
-                    d32[(2 * ch) ^ sw] = lo;
-                    d32[(2 * ch + 1) ^ sw] = hi;
+                    for (uint32_t ch = c0; ch < G; ch += TPQ) {
+                        const float4 lo = src[2 * ch], hi = src[2 * ch + 1];
+                        dst[ch ^ sw] = pack_f16x8_clamped(lo, hi, a.scale);
+                        d32[(2 * ch) ^ sw] = lo;
+                        d32[(2 * ch + 1) ^ sw] = hi;
+                    }
+                } else {
+#pragma unroll 4
+                    for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8_clamped(src[2 * ch], src[2 * ch + 1], a.scale);
                 }
             } else {
-#pragma unroll 4
-                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8_clamped(src[2 * ch], src[2 * ch + 1], a.scale);
-            }
-        } else {
 #pragma unroll 8
-            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = src[ch];
+            }
         }
         __syncthreads();
     }
-    // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
-    const bool my_noskip = F16 && (!(a.query_maxabs[my_qrow] * a.scale <= 32768.0f) || !(my_qn * a.scale2 >= 1.0f) || !(my_qn <= 3.0e38f));
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
@@ -1773,8 +1733,10 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
-    uint64_t cur_gthr = __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    [[maybe_unused]] auto eval = [&](uint32_t start, uint32_t count) {
+    uint64_t cur_gthr[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto eval = [&](uint32_t start, uint32_t count) {
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_e0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1791,14 +1753,15 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         const bool valid = pi < count;
         const bool have = valid && pj == 0u;
         const uint32_t pe = pend[start + (valid ? pi : 0)];
-        const uint32_t qsl = pe >> 26;                        // query index in the quad
-        const uint64_t roff = r0 + (pe & 0x03FFFFFFu);         // row offset in the list
+        const uint32_t qsl = pe >> 25;                        // query index in the quad
+        const uint64_t roff = r0 + (pe & 0x01FFFFFFu);         // row offset in the list
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const float *x = a.mat + (uint64_t)srow * dim;
         const float4 *ql = F16 ? qs + NQ * G + qsl * Gx : qs + qsl * G;   // the pair's f32 query, staged (swizzled) in LDS
         const uint32_t qsw = qsl & 15u;
-        const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)qsl, 64) * dim);
+        const uint32_t qrow = qsel_u32<QS>(my_qrow, qsl);
+        const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)qrow * dim);
         float sum = 0.0f;
         // 8 row chunks in flight per lane, then the reference's ordered chain over them (16 in flight -- two
         // round trips per 128-dim row instead of four -- measured no faster and costs the last free registers)
@@ -1847,18 +1810,19 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         if (__float_as_uint(sum) == 0x7FC12345u) __builtin_trap();      // consume the sum before the timestamp
         ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
 #endif
-        const uint64_t my_gthr = cur_gthr;         // the wave's view of the thresholds (refreshed every tile)
-        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
-        const uint64_t pos = shfl_u64(my_cbase, (int)qsl) + roff;
+        // the wave's view of the thresholds (refreshed every tile)
+        uint64_t my_thr[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+        const uint64_t pos = qsel_u64<QS>(my_cbase, qsl) + roff;
         const uint64_t mykey_all =
             (have && pos < a.max_pos) ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
         // A pair that beats its query's threshold is APPENDED to the query's candidate buffer: one
         // atomic per lane, all lanes in parallel (a sorted per-wave list would cost one global
         // read-modify-write round trip per query, serially -- measured: half of the kernel).
-        const uint64_t pair_thr = shfl_u64(my_thr, (int)qsl);
+        const uint64_t pair_thr = qsel_u64<QS>(my_thr, qsl);
         const bool pass = mykey_all < pair_thr;
         bool spill = false;
-        const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qsl, 64);
         // Running threshold.  k == 1: the exact distance itself.  Otherwise the query has 12 bins below its
         // seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one 8-bit
         // counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER: word 0 = bins 8..1,
@@ -1921,40 +1885,23 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             const bool mine = spill && qsl == qq;
             todo &= ~__ballot(mine);
             const uint64_t mykey = mine ? mykey_all : KEY_EMPTY;
-            const uint64_t thr = readlane_u64(my_thr, (int)qq);
+            const uint64_t thr = qread_u64<QS>(my_thr, qq);
             if (__ballot(mykey < thr) != 0ull) {
-                const uint64_t base = readlane_u64(my_base, (int)qq);
+                const uint64_t base = qread_u64<QS>(my_base, qq);
                 const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
-                                                 a.gthr + readlane_u32(my_qrow, (int)qq),
-                                                 readlane_u64(my_gthr, (int)qq), readlane_u64(my_lkth, (int)qq),
+                                                 a.gthr + qread_u32<QS>(my_qrow, qq),
+                                                 qread_u64<QS>(cur_gthr, qq), qread_u64<QS>(my_lkth, qq),
                                                  mykey, srow, k, lane);
-                if ((uint32_t)lane == qq) my_lkth = nk;
+#pragma unroll
+                for (int s = 0; s < QS; ++s)
+                    if ((uint32_t)(64 * s + lane) == qq) my_lkth[s] = nk;
             }
         }
     };
-    // LIST: the survivors are only recorded -- {pair id, row offset in the list} appended to a global list with
-    // one atomic per batch; survivor_eval_kernel evaluates them afterwards at full occupancy, so this kernel
-    // never waits on the scattered row reads of the exact arithmetic.  A full list raises *overflow; the
-    // caller has a guarded launch of the self-contained (!LIST) form queued behind, which then redoes the batch.
     auto drain = [&](uint32_t keep_below) {
         while (npend >= keep_below && npend > 0) {
             const uint32_t take = npend < 64 ? npend : 64;
-            if constexpr (LIST) {
-                wave_lds_fence();
-                const bool have = (uint32_t)lane < take;
-                const uint32_t pe = pend[npend - take + (have ? lane : 0)];
-                const uint32_t pr = (uint32_t)__shfl((int)my_pair, (int)(pe >> 26), 64);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.surv_cnt, take);
-                base = readlane_u32(base, 0);
-                if (base + take <= a.surv_cap) {
-                    if (have) a.surv[base + lane] = make_uint2(pr, (uint32_t)(r0 + (pe & 0x03FFFFFFu)));
-                } else if (lane == 0) {
-                    *a.overflow = 1u;
-                }
-            } else {
-                eval(npend - take, take);
-            }
+            eval(npend - take, take);
             n_exact += take;
             npend -= take;
         }
@@ -1966,8 +1913,8 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     // Short f16 rows (<= 4 K steps = 128 dims): with the MFMA time gone the tile is latency-bound, so ALL of
     // the next tile's operands (16 loads = 64 registers) and its row norms are requested right after the
     // current tile's MFMAs and fly during its screen / expansion / exact evaluation.
-    constexpr bool CAN_PF = QLDS && F16;
-    const bool pf = CAN_PF && (G >> 2) <= 4;                     // wave-uniform
+    constexpr bool CAN_PF = PF;
+    constexpr bool pf = PF;                                      // (the launcher picks PF iff G / 4 <= 4)
     float4 xt[CAN_PF ? 4 : 1][4];
     float xn_pf[4] = {0.f, 0.f, 0.f, 0.f};
     auto issue_tile = [&](uint64_t tn) {
@@ -1996,7 +1943,9 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
     if (pf && r0 < r1) issue_tile(r0);
     // the query thresholds are read one tile ahead (they tighten while the kernel runs, and a freshly
     // modified line costs a fabric round trip that must not sit in front of the operand waits)
-    uint64_t gthr_next = cur_gthr;
+    uint64_t gthr_next[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) gthr_next[s] = cur_gthr[s];
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
@@ -2020,12 +1969,13 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         uint32_t xso[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
-        const uint64_t my_gthr = gthr_next;
-        cur_gthr = gthr_next;
-        gthr_next = __hip_atomic_load(a.gthr + my_qrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t my_thr = my_lkth < my_gthr ? my_lkth : my_gthr;
-        // threshold DISTANCE of this lane's query; KEY_EMPTY gives NaN: "cannot skip"
-        const float my_thr_d = __uint_as_float((uint32_t)(my_thr >> 32));
+        uint64_t my_thr[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            cur_gthr[s] = gthr_next[s];
+            gthr_next[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+        }
 
         f32x4_acc acc[NG][4];
 #pragma unroll
@@ -2134,11 +2084,17 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
         wave_lds_fence();
-        aq[lane] = (uint32_t)lane >= cnt ? INFINITY : (my_noskip || my_thr == KEY_EMPTY) ? -3.0e38f : alpha * my_qn - beta * my_thr_d;
-        wave_lds_fence();
-        uint32_t bits[(NG + 1) / 2];
 #pragma unroll
-        for (int w = 0; w < (NG + 1) / 2; ++w) bits[w] = 0;
+        for (int s = 0; s < QS; ++s) {
+            const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+            // threshold DISTANCE of this lane's query; KEY_EMPTY: "cannot skip"
+            const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
+            if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (my_noskip[s] || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * my_qn[s] - beta * thr_d;
+        }
+        wave_lds_fence();
+        uint32_t bits[NG / 2];
+#pragma unroll
+        for (int w = 0; w < NG / 2; ++w) bits[w] = 0;
         if constexpr (F16) {
             // f16 operands: every term is finite by construction (rows scaled below 2^14, query images clamped
             // to the f16 range, never-skip / unset thresholds carry -3e38, invalid ones +inf), so
@@ -2167,21 +2123,21 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                 }
             }
 #pragma unroll
-            for (int w = 0; w < (NG + 1) / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
+            for (int w = 0; w < NG / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
         } else {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(aq + 16 * g + 4 * kk);
-            const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+            for (int g = 0; g < NG; ++g) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(aq + 16 * g + 4 * kk);
+                const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const bool keep = !(acc[g][t][r] < ar[r] + bt[t]);
-                    bits[g >> 1] = bits[g >> 1] + bits[g >> 1] + (keep ? 1u : 0u);
+                    for (int t = 0; t < 4; ++t) {
+                        const bool keep = !(acc[g][t][r] < ar[r] + bt[t]);
+                        bits[g >> 1] = bits[g >> 1] + bits[g >> 1] + (keep ? 1u : 0u);
+                    }
                 }
             }
-        }
         }
         // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
         uint32_t rowmask4 = 0;                         // bit 3 - t: row 16 t + l15 of the tile belongs to this wave
@@ -2190,14 +2146,16 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         // the accumulators are dead from here on: the next tile's operands can take their registers
         if (pf && t0 + 64 < r1) issue_tile(t0 + 64);
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
-        // expand half a group at a time (queries r < 2 / r >= 2 of the lane: <= 512 entries) with the drain in
-        // between; after the last tile one extra pass flushes the queue
         // Fast path (almost every tile): all survivors of the tile fit the queue at once -- ONE prefix scan and
-        // one drain per tile instead of one per half group.
-        uint32_t vw[(NG + 1) / 2];
+        // one drain per tile.  Otherwise the bits are expanded a pass (PASS / 256 of a lane's four queries per
+        // group) at a time with the drain in between; after the last tile one extra pass flushes the queue.
+        // Explicit validity (rows past the wave's range, queries past the quad's count): the compare above keeps
+        // a pair whenever its operands are NaN -- an unset threshold, non-finite data -- and an out-of-range row
+        // must never reach the exact evaluation.
+        uint32_t vw[NG / 2];
         uint32_t tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < (NG + 1) / 2; ++ww) {
+        for (int ww = 0; ww < NG / 2; ++ww) {
             uint32_t vmw = 0;
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
@@ -2205,24 +2163,24 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
                 uint32_t vm = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask4 << (12 - 4 * r) : 0u;
-                vmw |= (g < (uint32_t)NG && g < ng) ? (gg ? vm : vm << 16) : 0u;
+                vmw |= g < ng ? (gg ? vm : vm << 16) : 0u;
             }
             vw[ww] = bits[ww] & vmw;
             tot += (uint32_t)__popc(vw[ww]);
         }
         const uint32_t incl_all = wave_incl_scan_u32(tot);
-        const bool one_pass = readlane_u32(incl_all, 63) <= 512u - 64u;
+        const bool one_pass = readlane_u32(incl_all, 63) <= (uint32_t)PASS - 64u;
         if (one_pass) {
             uint32_t at = npend + incl_all - tot;
 #pragma unroll
-            for (int ww = 0; ww < (NG + 1) / 2; ++ww) {
+            for (int ww = 0; ww < NG / 2; ++ww) {
                 uint32_t mm = vw[ww];
                 while (mm) {
                     const uint32_t b = 31u - (uint32_t)__clz(mm);        // bit 31 - (16 (g & 1) + 4 r + t) of word g / 2
                     mm &= ~(1u << b);
-                    const uint32_t c = 31u - b;                          // c = 16 (g & 1) + 4 r + t
-                    const uint32_t qslot = 32u * ww + (c & 16u) + 4u * (uint32_t)kk + ((c >> 2) & 3u);
-                    pend[at++] = (qslot << 26) + rowbase + 16u * (c & 3u);
+                    const uint32_t cc = 31u - b;                         // cc = 16 (g & 1) + 4 r + t
+                    const uint32_t qslot = 32u * ww + (cc & 16u) + 4u * (uint32_t)kk + ((cc >> 2) & 3u);
+                    pend[at++] = (qslot << 25) + rowbase + 16u * (cc & 3u);
                 }
             }
             npend += readlane_u32(incl_all, 63);
@@ -2234,32 +2192,29 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
         }
-        const uint32_t hend = one_pass ? 0u : 2 * ng + (t0 + 64 >= r1 ? 1u : 0u);
+        // slow path: passes of PASS / 64 / 4 = RP of the lane's four queries (r) per group
+        constexpr uint32_t RP = PASS / 256;                  // 2 (half a group per pass) or 1 (a quarter)
+        constexpr uint32_t PPG = 4 / RP;                     // passes per group
+        const uint32_t hend = one_pass ? 0u : PPG * ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t hg = 0; hg < hend; ++hg) {
-            const uint32_t g = hg >> 1;
+            const uint32_t g = hg / PPG, ps = hg % PPG;
             if (g < ng) {
-                uint32_t w = bits[0];
+                uint32_t w = vw[0];
 #pragma unroll
-                for (int ww = 1; ww < (NG + 1) / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? bits[ww] : w;
+                for (int ww = 1; ww < NG / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? vw[ww] : w;
                 uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
-                // explicit validity (rows past the wave's range, queries past the quad's count): the compare
-                // above keeps a pair whenever its operands are NaN -- an unset threshold, non-finite data --
-                // and an out-of-range row must never reach the exact evaluation
-                uint32_t vm = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask4 << (12 - 4 * r) : 0u;
-                mm &= vm;
-                mm &= (hg & 1u) ? 0x00FFu : 0xFF00u;                     // c = 4 r + t lives in bit 15 - c
+                // cc = 4 r + t lives in bit 15 - cc: pass ps takes r in [ps RP, ps RP + RP)
+                mm &= (RP == 2 ? 0xFF00u : 0xF000u) >> (4 * RP * ps);
                 const uint32_t cntl = (uint32_t)__popc(mm);
                 const uint32_t incl = wave_incl_scan_u32(cntl);
                 uint32_t at = npend + incl - cntl;
-                const uint32_t qb = (16 * g + 4 * (uint32_t)kk) << 26;
+                const uint32_t qb = (16 * g + 4 * (uint32_t)kk) << 25;
                 while (mm) {
                     const uint32_t b = 31u - (uint32_t)__clz(mm);        // highest set bit first
                     mm &= ~(1u << b);
-                    const uint32_t c = 15u - b;                          // c = 4 r + t
-                    pend[at++] = qb + ((c >> 2) << 26) + rowbase + 16u * (c & 3u);
+                    const uint32_t cc = 15u - b;                         // cc = 4 r + t
+                    pend[at++] = qb + ((cc >> 2) << 25) + rowbase + 16u * (cc & 3u);
                 }
                 npend += readlane_u32(incl, 63);
             }
@@ -2297,58 +2252,6 @@ __global__ __launch_bounds__(256, ((NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3)
         }
 #endif
     }
-}
-
-// ------------------------------------------------------------------------------------
-// survivor_eval_kernel: exact re-evaluation of the survivors recorded by wide_filter_kernel<.., LIST>: one lane
-// per {pair, row offset}, the reference's summation order, 4 + 4 sixteen-byte chunks in flight per lane and
-// eight waves per SIMD to hide the scattered reads.  A pair that beats its query's threshold is appended to
-// the query's candidate buffer; a full buffer raises *overflow (the guarded fallback then redoes the batch).
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void survivor_eval_kernel(const TileArgs a, const uint32_t *probe) {
-    uint32_t n = *a.surv_cnt;
-    if (n > a.surv_cap) n = a.surv_cap;
-    const uint32_t dim = a.dim, G = dim >> 2;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint2 e = a.surv[i];
-        const uint32_t pr = e.x, roff = e.y;
-        const uint32_t qrow = pr / a.nprobe;
-        const uint64_t srow = a.list_off[probe[pr]] + roff;
-        const uint64_t pos = a.cand_base[pr] + roff;
-        if (pos >= a.max_pos) continue;
-        const float4 *x = reinterpret_cast<const float4 *>(a.mat + srow * dim);
-        const float4 *q = reinterpret_cast<const float4 *>(a.queries + (uint64_t)qrow * dim);
-        float sum = 0.0f;
-        for (uint32_t g = 0; g < G; g += 4) {
-            float4 xv[4], qv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { xv[u] = x[g + u]; qv[u] = q[g + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y;
-                const float d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
-                float t = d0 * d0 + d1 * d1;
-                t = t + d2 * d2;
-                t = t + d3 * d3;
-                sum = sum + t;
-            }
-        }
-        const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos;
-        if (key < a.gthr[qrow]) {
-            const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
-            if (idx < a.cand_cap) {
-                a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = key;
-                a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = (uint32_t)srow;
-            } else {
-                *a.overflow = 1u;
-            }
-        }
-    }
-}
-hipError_t launch_survivor_eval(const TileArgs &a, const uint32_t *probe, hipStream_t s) {
-    if ((a.dim % 16) != 0 || a.row_of || !a.surv) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(survivor_eval_kernel, dim3(4096), dim3(256), 0, s, a, probe);
-    return hipGetLastError();
 }
 
 template <int S>
@@ -2392,35 +2295,61 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
     return hipGetLastError();
 }
 
+// dynamic LDS beyond 64 KB has to be allowed per kernel once
+template <int NG, int NW, int S, bool QLDS, bool F16, bool PF = false>
+static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
+    auto kern = wide_filter_kernel<NG, NW, S, QLDS, F16, PF>;
+    if (lds > 65536) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.grid_x, a.max_quads), dim3(64 * NW), lds, s, a);
+    return hipGetLastError();
+}
+
+// LDS the wide kernel needs for a quad of `width` queries (f16 images, + the f32 originals for rows of <= 128 dims)
+static size_t wide_lds_bytes(uint32_t width, uint32_t dim, bool f16, bool *q32) {
+    const size_t q16 = (size_t)width * dim * 2, q32b = (size_t)width * dim * 4;
+    if (!f16) { *q32 = false; return q32b; }
+    *q32 = dim <= 128;
+    return *q32 ? q16 + q32b : q16;
+}
+
 template <int S>
 static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
-        const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+        const uint32_t nw = a.block_waves ? a.block_waves : 4;
         if (a.f16) {
             if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
-            if (a.quad_width == 64 && lds4 / 2 <= 32768) {
-                TileArgs b = a;
-                b.q32_lds = lds4 / 2 + lds4 <= 49152 ? 1 : 0;          // rows of <= 128 dims: f16 and f32 queries both fit
-                const size_t lds = b.q32_lds ? lds4 / 2 + lds4 : lds4 / 2;
-                if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
-                else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds, s, b);
+            TileArgs b = a;
+            bool q32 = false;
+            const size_t lds = wide_lds_bytes(a.quad_width, a.dim, true, &q32);
+            b.q32_lds = q32 ? 1 : 0;
+            const bool pf = a.dim <= 128;       // <= 4 K steps per tile: whole-tile operand prefetch
+            if (nw == 8) {            // one block per CU: up to 144 KB of staged queries + 14 KB of queues
+                if (lds > 147456) return hipErrorInvalidValue;
+                if (a.quad_width == 128 && pf) return launch_wide<8, 8, S, true, true, true>(b, lds, s);
+                if (pf) return hipErrorInvalidValue;
+                if (a.quad_width == 128) return launch_wide<8, 8, S, true, true>(b, lds, s);
+                if (a.quad_width == 96) return launch_wide<6, 8, S, true, true>(b, lds, s);
+                if (a.quad_width == 64) return launch_wide<4, 8, S, true, true>(b, lds, s);
+                return hipErrorInvalidValue;
             }
-            else if (a.quad_width == 32 && lds2 / 2 <= 65536)      // + 10 KB of static LDS: two blocks per CU (160 KB)
-                { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2 / 2, s, a); }
-            else return hipErrorInvalidValue;
-            return hipGetLastError();
+            if (lds > 65536) return hipErrorInvalidValue;           // + 10 KB of static LDS: two blocks per CU
+            if (a.quad_width == 64 && pf) return launch_wide<4, 4, S, true, true, true>(b, lds, s);
+            if (pf) return hipErrorInvalidValue;
+            if (a.quad_width == 64) return launch_wide<4, 4, S, true, true>(b, lds, s);
+            if (a.quad_width == 32) return launch_wide<2, 4, S, true, true>(b, lds, s);
+            return hipErrorInvalidValue;
         }
-        if (a.quad_width == 64 && lds4 <= 32768)
-            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, true, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a); }
-        else if (a.quad_width == 32 && lds2 <= 32768)
-            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, true, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a); }
-        else if (a.quad_width == 32 && a.q_blk)
-            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); else hipLaunchKernelGGL((wide_filter_kernel<2, S, false, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); }
-        else if (a.quad_width == 64 && a.q_blk)
-            { if (a.surv) hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false, true>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); else hipLaunchKernelGGL((wide_filter_kernel<4, S, false, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a); }
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
+        if (nw != 4) return hipErrorInvalidValue;
+        const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+        if (a.quad_width == 64 && lds4 <= 32768) return launch_wide<4, 4, S, true, false>(a, lds4, s);
+        if (a.quad_width == 32 && lds2 <= 32768) return launch_wide<2, 4, S, true, false>(a, lds2, s);
+        if (a.quad_width == 32 && a.q_blk) return launch_wide<2, 4, S, false, false>(a, 0, s);
+        if (a.quad_width == 64 && a.q_blk) return launch_wide<4, 4, S, false, false>(a, 0, s);
+        return hipErrorInvalidValue;
     }
     dim3 grid(a.grid_x, a.max_groups), block(256);
     if ((a.dim % 4) == 0) {
