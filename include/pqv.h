@@ -141,6 +141,31 @@ int  pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t fl
                          pqv_searcher **out);
 void pqv_searcher_free(pqv_searcher *searcher);
 
+/* Tunables of one searcher (all optional; the defaults are the measured dispatch rules of DESIGN.md 5.1c).
+ * The reference has no such knobs -- its topk() is one fixed loop (src/ivf/search.rs:112-127) -- so nothing here
+ * changes results, only which kernels produce them; tests use it to force every path through the same oracle.
+ *   "rerank_mode"   0 by rule, 1 streaming kernel, 2 batched tile path
+ *   "tile_filter"   MFMA lower-bound screen in the batched path: 0 off, 1 by rule, 2 forced
+ *   "filter_variant" 1 = one 16-query group per block instead of the wide kernel
+ *   "cand_cap"      candidate-buffer entries per query of the wide screened path (default 2048)
+ *   "screen_f16"    f16 screen operands where the data allows (default 1)
+ *   "seed_rows", "wide_rows", "tile_rows"   rows sampled for thresholds / per block (0 = by rule)
+ *   "running_thr"   running thresholds of the wide kernel (default 1)
+ *   "quad_xcd"      quad-to-XCD affinity of the wide kernels (-1 by rule)
+ *   "wide_waves"    waves per block of the wide kernel: 0 by rule, 4 or 8
+ *   "quad_width"    queries per quad of the wide kernel (0 by rule; a multiple of 32)
+ * The same names, upper-cased with a PQV_ prefix, are read from the environment ONCE when a searcher is created
+ * (profiling scripts). */
+int pqv_searcher_set_option(pqv_searcher *searcher, const char *name, int64_t value);
+/* Which kernels a pqv_topk_device call of this shape would run on this searcher (one line of text, for bench
+ * records): written NUL-terminated into buf (truncated to len). */
+int pqv_searcher_describe(const pqv_searcher *searcher, uint32_t nq, uint32_t k, uint32_t nprobe, int metric,
+                          char *buf, size_t len);
+/* Device memory held for this searcher, in bytes: the corpus' row-order copy (0 once released), the IVF-ordered
+ * f32 rows, the blocked screen-operand copy, and everything else (centroids, lists, norms, scratch lanes). */
+int pqv_searcher_footprint(const pqv_searcher *searcher, uint64_t *row_order_bytes, uint64_t *ivf_rows_bytes,
+                           uint64_t *blocked_bytes, uint64_t *other_bytes);
+
 /* IvfIndex::find_closest_centroids (src/ivf/index.rs:130-149): clusters_out has room for
  * min(nprobe, n_clusters); *n_out receives the count. */
 int pqv_probe(const pqv_searcher *searcher, const float *query, uint32_t query_len,
@@ -165,7 +190,8 @@ void pqv_rows_free(uint32_t *rows);
  * queries through the same heap mechanics on the host (distances still computed on the GPU),
  * so its results equal the reference's in every non-NaN case.  pqv_topk_device never leaves
  * the GPU: it returns the k smallest by (d2, candidate position), identical to the reference
- * whenever no such tie exists.
+ * whenever no such tie exists.  (k == 1024, the largest supported, has no runner-up slot: a tie between the
+ * 1024th result and the first excluded candidate is then not detected.)
  *   n_found      host [nq] (may be NULL)
  *   n_candidates host [nq] (may be NULL): sum of the probed lists' lengths, before the cap */
 int pqv_topk(const pqv_searcher *searcher, const float *queries, uint32_t nq,
@@ -215,6 +241,11 @@ int pqv_merge_topk(const float *dist, const uint32_t *rows, const uint32_t *coun
 int pqv_merge_topk_device(int device, const void *d_dist, const void *d_rows, const void *d_row_base,
                           uint32_t n_lists, uint32_t nq, uint32_t k, void *d_out_dist,
                           void *d_out_rows, void *hip_stream);
+
+/* The same merge over PACKED lists: d_pairs [n_lists, nq, k] of {f32 distance, u32 row} (8 bytes per result), the
+ * form in which ONE all-gather delivers every rank's top-k (pq_vector_amd/sharding.py). */
+int pqv_merge_topk_packed_device(int device, const void *d_pairs, const void *d_row_base, uint32_t n_lists,
+                                 uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream);
 
 /* Counters mirroring the reference's plan metrics (src/df_vector/index_exec.rs:289-299,
  * src/df_vector/exec.rs:411-427), accumulated per searcher since creation. */

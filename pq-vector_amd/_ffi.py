@@ -47,6 +47,10 @@ SIGNATURES = {
     "pqv_last_error": (C.c_char_p, []),
     "pqv_device_count": (C.c_int, []),
     "pqv_abi_version": (C.c_int, []),
+    "pqv_merge_topk_packed_device": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "pqv_searcher_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "pqv_searcher_describe": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]),
+    "pqv_searcher_footprint": (C.c_int, [vp, u64p, u64p, u64p, u64p]),
     "pqv_corpus_upload": (C.c_int, [C.c_int, f32p, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "pqv_corpus_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "pqv_corpus_append": (C.c_int, [vp, f32p, C.c_uint64]),
@@ -95,6 +99,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so.7; if this library is
+    loaded first it binds /opt/rocm's copy, and torch's later initialisation in the same process then finds
+    "No HIP GPUs" (two runtimes on one device).  With torch imported first the dynamic linker hands us the copy
+    torch already loaded (same SONAME) and everything shares one runtime -- so when torch is installed but not
+    yet loaded, map its copy before ours.  Without torch (a Rust host) nothing happens."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libpqv_hip.so; raises loudly if the HIP extension has not been built."""
     global _lib
@@ -104,6 +132,7 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C pq-vector_amd/csrc). "
                 "pq_vector_amd has no CPU fallback.")
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol

@@ -379,6 +379,22 @@ class Searcher:
                 "exact_replays": c.exact_replays, "screened_pairs": c.screened_pairs,
                 "screen_survivors": c.screen_survivors}
 
+    def set_option(self, name, value):
+        """Force a dispatch choice (pqv.h: pqv_searcher_set_option); results never change."""
+        _check(_ffi.lib().pqv_searcher_set_option(self._h, str(name).encode(), int(value)))
+        return self
+
+    def describe(self, nq, k, nprobe, metric=_ffi.PQV_L2SQ_REF4):
+        buf = C.create_string_buffer(640)
+        _check(_ffi.lib().pqv_searcher_describe(self._h, nq, k, nprobe, metric, buf, len(buf)))
+        return buf.value.decode()
+
+    def footprint(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        _check(_ffi.lib().pqv_searcher_footprint(self._h, *[C.byref(x) for x in v]))
+        return {"row_order_bytes": v[0].value, "ivf_rows_bytes": v[1].value, "blocked_bytes": v[2].value,
+                "other_bytes": v[3].value, "total_bytes": sum(x.value for x in v)}
+
     def set_timing(self, enabled):
         _check(_ffi.lib().pqv_set_timing(self._h, 1 if enabled else 0))
 

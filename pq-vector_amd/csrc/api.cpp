@@ -158,7 +158,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_surv, s_surv_cnt, s_thr_hist, s_thr_bins;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -250,7 +250,7 @@ extern "C" int pqv_device_count(void) {
     return count < 0 ? 0 : count;
 }
 
-extern "C" int pqv_abi_version(void) { return 100; }
+extern "C" int pqv_abi_version(void) { return 101; }
 
 // ---------------------------------------------------------------------------------------
 // corpus
@@ -1642,6 +1642,80 @@ extern "C" int pqv_topk(const pqv_searcher *s, const float *queries, uint32_t nq
     return guard([&] { return pqv_topk_impl(s, queries, nq, query_len, k, nprobe, max_candidates, metric, sqrt_out, row_idx, dist, n_found, n_candidates); });
 }
 
+static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64_t value) {
+    if (!s || !name) return fail(PQV_ERR_INVALID, "searcher/name must not be NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    pqv_searcher::Opts &o = s->opt;
+    const std::string n(name);
+    if (n == "rerank_mode") o.rerank_mode = static_cast<int>(value);
+    else if (n == "tile_filter") o.tile_filter = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));
+    else if (n == "filter_variant") o.filter_variant = static_cast<int>(value);
+    else if (n == "cand_cap") o.cand_cap = static_cast<uint32_t>(std::max<int64_t>(1, value));
+    else if (n == "screen_f16") o.screen_f16 = value != 0;
+    else if (n == "seed_rows") o.seed_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "wide_rows") o.wide_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "tile_rows") o.tile_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "running_thr") o.running_thr = value != 0;
+    else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
+    else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
+    else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else return fail(PQV_ERR_INVALID, "unknown searcher option: " + n);
+    return PQV_OK;
+}
+extern "C" int pqv_searcher_set_option(pqv_searcher *s, const char *name, int64_t value) {
+    return guard([&] { return pqv_searcher_set_option_impl(s, name, value); });
+}
+
+static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32_t k, uint32_t nprobe, int metric,
+                                      char *buf, size_t len) {
+    if (!s || !buf || !len) return fail(PQV_ERR_INVALID, "searcher/buf must not be NULL");
+    if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    const TopkPlan p = plan_topk(s, std::max<uint32_t>(1, nq), nprobe, k, metric);
+    char t[512];
+    if (p.tile && p.filter && p.quad)
+        std::snprintf(t, sizeof t, "wide_seed_kernel + seed_select_kernel + wide_filter_kernel: %s screen operands, quads of %u queries "
+                      "staged %s, %u waves per block, %u rows per block, threshold sample %u rows per list",
+                      p.f16 ? "f16" : "f32", p.quad_width,
+                      (p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768) ? "in LDS" : "as a blocked copy in global memory",
+                      p.block_waves, p.filter_rows_per_block, p.seed_rows);
+    else if (p.tile && p.filter)
+        std::snprintf(t, sizeof t, "tile_rerank_kernel (exact seed window of %u rows) + tile_filter_kernel: 16-query groups, f32 screen operands, "
+                      "%u rows per block", p.seed_rows, p.filter_rows_per_block);
+    else if (p.tile)
+        std::snprintf(t, sizeof t, "tile_rerank_kernel: exact arithmetic, 16-query groups, %u rows per block", p.rr_rows_per_block);
+    else
+        std::snprintf(t, sizeof t, "stream_kernel: one candidate stream per (query, probed list), %u rows per block", p.rr_rows_per_block);
+    std::snprintf(buf, len, "%s", t);
+    return PQV_OK;
+}
+extern "C" int pqv_searcher_describe(const pqv_searcher *s, uint32_t nq, uint32_t k, uint32_t nprobe, int metric,
+                                     char *buf, size_t len) {
+    return guard([&] { return pqv_searcher_describe_impl(s, nq, k, nprobe, metric, buf, len); });
+}
+
+static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_order_bytes, uint64_t *ivf_rows_bytes,
+                                       uint64_t *blocked_bytes, uint64_t *other_bytes) {
+    if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (row_order_bytes) *row_order_bytes = s->corpus && s->corpus->d_rows ? s->corpus->capacity * s->corpus->dim * sizeof(float) : 0;
+    if (ivf_rows_bytes) *ivf_rows_bytes = s->d_mat_ivf.p ? s->d_mat_ivf.bytes : 0;
+    if (blocked_bytes) *blocked_bytes = s->d_mat_blk.p ? s->d_mat_blk.bytes : 0;
+    uint64_t other = s->d_centroids.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes;
+    for (const Scratch &l : s->lanes)
+        for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
+                                &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads,
+                                &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
+                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins})
+            other += b->p ? b->bytes : 0;
+    if (other_bytes) *other_bytes = other;
+    return PQV_OK;
+}
+extern "C" int pqv_searcher_footprint(const pqv_searcher *s, uint64_t *row_order_bytes, uint64_t *ivf_rows_bytes,
+                                      uint64_t *blocked_bytes, uint64_t *other_bytes) {
+    return guard([&] { return pqv_searcher_footprint_impl(s, row_order_bytes, ivf_rows_bytes, blocked_bytes, other_bytes); });
+}
+
 static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t query_len, uint32_t nprobe,
                          uint32_t *clusters_out, uint32_t *n_out) {
     if (!s) return fail(PQV_ERR_INVALID, "searcher must not be NULL");
@@ -1986,6 +2060,27 @@ extern "C" int pqv_merge_topk_device(int device, const void *d_dist, const void 
                                      void *d_out_rows, void *hip_stream) {
     return guard([&] { return pqv_merge_topk_device_impl(device, d_dist, d_rows, d_row_base, n_lists, nq, k,
                                                          d_out_dist, d_out_rows, hip_stream); });
+}
+
+static int pqv_merge_topk_packed_device_impl(int device, const void *d_pairs, const void *d_row_base, uint32_t n_lists,
+                                             uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream) {
+    if (!d_pairs || !d_row_base || !d_out_dist || !d_out_rows)
+        return fail(PQV_ERR_INVALID, "device pointers must not be NULL");
+    if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (n_lists == 0 || nq == 0) return PQV_OK;
+    if (int rc = use_device(device)) return rc;
+    const float *base = static_cast<const float *>(d_pairs);
+    HIP_TRY(pqv::launch_shard_merge(base, reinterpret_cast<const uint32_t *>(base) + 1,
+                                    static_cast<const long long *>(d_row_base), n_lists, nq, k,
+                                    static_cast<float *>(d_out_dist), static_cast<long long *>(d_out_rows),
+                                    static_cast<hipStream_t>(hip_stream), 2));
+    return PQV_OK;
+}
+extern "C" int pqv_merge_topk_packed_device(int device, const void *d_pairs, const void *d_row_base, uint32_t n_lists,
+                                            uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream) {
+    return guard([&] { return pqv_merge_topk_packed_device_impl(device, d_pairs, d_row_base, n_lists, nq, k, d_out_dist,
+                                                                d_out_rows, hip_stream); });
 }
 
 // ---------------------------------------------------------------------------------------

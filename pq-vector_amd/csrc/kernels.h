@@ -252,9 +252,11 @@ hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *c
 // Merge of per-shard top-k lists gathered from all ranks: dist/rows [n_shards, nq, k] (unused
 // slots: +inf / 0xFFFFFFFF), row_base[n_shards] the shards' first global row.  One wave per
 // query; order = ascending (distance, shard, position in the shard's list).
+// `stride` = elements between consecutive results in dist / rows (1: two dense arrays; 2: one packed array of
+// {f32 distance, u32 row} pairs, dist = base, rows = base + 1)
 hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
                               uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
-                              long long *out_rows, hipStream_t s);
+                              long long *out_rows, hipStream_t s, uint32_t stride = 1);
 
 // MFMA-operand copy of the IVF-ordered lists: 16-row tiles, tile T column ch row j at float4 index
 // (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)

@@ -2677,7 +2677,7 @@ __global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict
                                                         const long long *__restrict__ row_base,
                                                         uint32_t n_shards, uint32_t nq, uint32_t k,
                                                         float *__restrict__ out_dist,
-                                                        long long *__restrict__ out_rows) {
+                                                        long long *__restrict__ out_rows, uint32_t stride) {
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
     WaveTopk<S> tk;
@@ -2689,7 +2689,7 @@ __global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict
         uint32_t val = 0xFFFFFFFFu;
         if (idx < total) {
             const uint32_t sh = idx / k, e = idx % k;
-            const uint64_t src = ((uint64_t)sh * nq + q) * k + e;
+            const uint64_t src = (((uint64_t)sh * nq + q) * k + e) * stride;
             const uint32_t r = rows[src];
             if (r != 0xFFFFFFFFu) {
                 key = ((uint64_t)sortable_bits(dist[src]) << 32) | (uint64_t)idx;   // idx = shard * k + position
@@ -2706,7 +2706,7 @@ __global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict
             long long gr = -1;
             if (tk.key[s] != KEY_EMPTY) {
                 const uint32_t idx = tk.val[s];
-                const uint64_t src = ((uint64_t)(idx / k) * nq + q) * k + (idx % k);
+                const uint64_t src = (((uint64_t)(idx / k) * nq + q) * k + (idx % k)) * stride;
                 d = dist[src];
                 gr = row_base[idx / k] + (long long)rows[src];
             }
@@ -2718,11 +2718,11 @@ __global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict
 
 hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
                               uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
-                              long long *out_rows, hipStream_t s) {
+                              long long *out_rows, hipStream_t s, uint32_t stride) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(shard_merge_kernel<1>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
-    else if (k <= 256) hipLaunchKernelGGL(shard_merge_kernel<4>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
-    else if (k <= 1024) hipLaunchKernelGGL(shard_merge_kernel<16>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows);
+    if (k <= 64) hipLaunchKernelGGL(shard_merge_kernel<1>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
+    else if (k <= 256) hipLaunchKernelGGL(shard_merge_kernel<4>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
+    else if (k <= 1024) hipLaunchKernelGGL(shard_merge_kernel<16>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -3,7 +3,7 @@
 The reference handles a multi-file table as independent per-file IVF indexes probed one by
 one and merged in a single heap (src/df_vector/index_exec.rs:85-164,
 src/df_vector/exec.rs:264-267).  Here a shard = one contiguous row range + its own index on
-one GPU; the only exchange is one all-gather of k x {distance, global row id} per query
+one GPU; the only exchange is ONE all-gather of k packed {distance, row id} pairs per query
 (RCCL when the tensors live on GPUs, gloo on CPU), followed by the same deterministic merge
 on every rank: ascending by (distance, shard, position in the shard's list).
 
@@ -31,38 +31,39 @@ def merge_gathered(gath_dist, gath_rows, k):
 
 
 class ShardExchange:
-    """Pre-allocated all-gather buffers for a fixed (nq, k); one collective per tensor.
+    """Pre-allocated all-gather buffers for a fixed (nq, k); ONE collective per step: distance and row of
+    every result travel as one packed element.
 
-    On GPUs the merge is one library kernel (pqv_merge_topk_device, ordered by (distance, shard,
+    On GPUs the merge is one library kernel (pqv_merge_topk_packed_device, ordered by (distance, shard,
     position)); on CPU tensors (gloo tests) the same order comes from a stable torch sort."""
 
     def __init__(self, world, nq, k, device, always_collective=False, row_bases=None):
         self.world, self.nq, self.k = world, nq, k
         self.always_collective = always_collective
         self.device = torch.device(device)
-        self.gath_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
-        self.gath_r = torch.empty((world, nq, k), dtype=torch.int64, device=device)
+        # generic path: {f32 distance bits, i64 global row} as two int64 words per result
+        self.gath = torch.empty((world, nq, k, 2), dtype=torch.int64, device=device)
         self.fast = self.device.type == "cuda" and row_bases is not None
         if self.fast:
-            self.gath_r32 = torch.empty((world, nq, k), dtype=torch.int32, device=device)
+            # GPU path: {f32 distance, u32 shard-local row} as two int32 words per result (8 bytes)
+            self.gath32 = torch.empty((world, nq, k, 2), dtype=torch.int32, device=device)
             self.bases = torch.tensor(list(row_bases), dtype=torch.int64, device=device)
             self.out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
             self.out_r = torch.empty((nq, k), dtype=torch.int64, device=device)
 
     def exchange_u32(self, local_dist, local_rows_i32):
         """GPU fast path: local_rows_i32 [nq,k] is the searcher's raw u32 output viewed as int32
-        (0xFFFFFFFF = empty).  Two all-gathers + one merge kernel on the current stream."""
+        (0xFFFFFFFF = empty).  One pack, ONE all-gather, one merge kernel on the current stream."""
         from . import _ffi
+        packed = torch.stack((local_dist.view(torch.int32), local_rows_i32), dim=-1)      # [nq, k, 2]
         if self.world == 1 and not self.always_collective:
-            self.gath_d[0].copy_(local_dist)
-            self.gath_r32[0].copy_(local_rows_i32)
+            self.gath32[0].copy_(packed)
         else:
-            dist.all_gather_into_tensor(self.gath_d.view(self.world * self.nq, self.k), local_dist.contiguous())
-            dist.all_gather_into_tensor(self.gath_r32.view(self.world * self.nq, self.k), local_rows_i32.contiguous())
-        rc = _ffi.lib().pqv_merge_topk_device(
-            self.device.index or 0, _ffi.vp(self.gath_d.data_ptr()), _ffi.vp(self.gath_r32.data_ptr()),
-            _ffi.vp(self.bases.data_ptr()), self.world, self.nq, self.k, _ffi.vp(self.out_d.data_ptr()),
-            _ffi.vp(self.out_r.data_ptr()), _ffi.vp(torch.cuda.current_stream().cuda_stream))
+            dist.all_gather_into_tensor(self.gath32.view(self.world * self.nq, self.k * 2), packed.view(self.nq, self.k * 2))
+        rc = _ffi.lib().pqv_merge_topk_packed_device(
+            self.device.index or 0, _ffi.vp(self.gath32.data_ptr()), _ffi.vp(self.bases.data_ptr()), self.world, self.nq,
+            self.k, _ffi.vp(self.out_d.data_ptr()), _ffi.vp(self.out_r.data_ptr()),
+            _ffi.vp(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError(_ffi.lib().pqv_last_error().decode())
         return self.out_d, self.out_r
@@ -73,7 +74,8 @@ class ShardExchange:
         grow = torch.where(empty, torch.full_like(local_rows_i64, -1), local_rows_i64 + row_base)
         if self.world == 1 and not self.always_collective:
             return local_dist, grow
+        packed = torch.stack((local_dist.contiguous().view(torch.int32).to(torch.int64), grow), dim=-1)   # [nq, k, 2]
         # rank-major concatenation along dim 0: the layout both RCCL and gloo accept
-        dist.all_gather_into_tensor(self.gath_d.view(self.world * self.nq, self.k), local_dist.contiguous())
-        dist.all_gather_into_tensor(self.gath_r.view(self.world * self.nq, self.k), grow.contiguous())
-        return merge_gathered(self.gath_d, self.gath_r, self.k)
+        dist.all_gather_into_tensor(self.gath.view(self.world * self.nq, self.k * 2), packed.view(self.nq, self.k * 2))
+        gd = self.gath[..., 0].to(torch.int32).view(torch.float32)
+        return merge_gathered(gd, self.gath[..., 1], self.k)

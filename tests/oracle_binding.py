@@ -33,11 +33,11 @@ def build_oracle(target="all"):
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, target])
 
 
-def load(native=False):
-    name = "libpqv_oracle_native.so" if native else "libpqv_oracle.so"
+def load(native=False, fast=False):
+    name = "libpqv_oracle_fast.so" if fast else "libpqv_oracle_native.so" if native else "libpqv_oracle.so"
     path = os.path.join(ORACLE_DIR, name)
     if not os.path.exists(path):
-        build_oracle("native" if native else "all")
+        build_oracle("fast" if fast else "native" if native else "all")
     lib = C.CDLL(path)
     P = C.POINTER
     lib.pqo_squared_l2_ref4.restype = C.c_float
@@ -107,8 +107,8 @@ class OracleError(Exception):
 class Oracle:
     """Thin object wrapper: numpy in, numpy out."""
 
-    def __init__(self, native=False):
-        self.lib = load(native)
+    def __init__(self, native=False, fast=False):
+        self.lib = load(native, fast)
 
     # -- distances ------------------------------------------------------------------
     def l2_ref4(self, a, b):

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version(lib):
-    assert lib.pqv_abi_version() == 100
+    assert lib.pqv_abi_version() == 101
 
 
 def test_no_cpu_fallback(lib):

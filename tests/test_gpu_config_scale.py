@@ -1,0 +1,155 @@
+"""GPU parity at BASELINE.json's configuration PARAMETERS with the library's NATURAL dispatch (no path forcing):
+
+  C3 / C4 shape: dim 768, n_clusters 1024, nprobe 32, k 10, 1024-query batches -- on 1 M rows (the oracle's
+                 brute-force cross-check of a 10 M-row corpus would not finish in a test; the 10 M / 12.5 M row
+                 runs are checked inside bench.py's cpu_baseline leg on every bench run);
+  C5 shape:      1 M x 1536, cosine, 1024-query batch, against an f64 brute force.
+
+Bar as everywhere: bit-identical row ids and distances for the IVF path (oracle built from the GPU index blob,
+exactly as test_full_size_c2_properties does), 1e-4 relative for the cosine MFMA extension."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _uniform24(rng, n, dim):
+    # the bench recipe (benches/bench_util.rs:40): 24-bit uniform [0, 1); generated in slabs to bound memory
+    out = np.empty((n, dim), dtype=np.float32)
+    step = max(1, (1 << 26) // dim)
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        out[s:e] = rng.integers(0, 1 << 24, size=(e - s, dim), dtype=np.int32).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return out
+
+
+@pytest.fixture(scope="module")
+def c3_shape(pqv):
+    n, dim, kc = 1_000_000, 768, 1024
+    rng = np.random.default_rng(1234)
+    data = _uniform24(rng, n, dim)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(8).build()
+    return data, corpus, index, rng
+
+
+@pytest.mark.timeout(1200)
+def test_c3_parameters_natural_dispatch(pqv, oracle, c3_shape):
+    data, corpus, index, rng = c3_shape
+    n, dim = data.shape
+    kc, k, nprobe, nq = 1024, 10, 32, 1024
+    # index invariants at this size (the >= 512-centroid build takes the MFMA-screened assignment by itself)
+    off, rows = index.list_offsets, index.list_rows
+    assert index.n_clusters == kc and int(off[-1]) == n
+    assert np.array_equal(np.sort(rows), np.arange(n, dtype=np.uint32))
+    blob = index.to_bytes()
+    assert pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(8).build().to_bytes() == blob
+
+    queries = _uniform24(np.random.default_rng(7), nq, dim)
+    queries[:64] = data[rng.choice(n, 64, replace=False)]            # some self-queries
+    s = pqv.Searcher(index, corpus)
+    plan = s.describe(nq, k, nprobe)
+    assert "wide_filter_kernel" in plan and "f16 screen operands" in plan and "8 waves per block" in plan, plan
+    rows_t, dist_t, nf, nc = s.topk(queries, k, nprobe)                 # host API: exact under ties
+    assert (nf == k).all()
+    assert (np.diff(dist_t.astype(np.float64), axis=1) >= 0).all()
+    assert (dist_t[:64, 0] == 0).all() and (np.abs(data[rows_t[:64, 0]] - queries[:64]).max(axis=1) == 0).all()
+    for q in range(nq):
+        assert len(set(rows_t[q].tolist())) == k
+    # the asynchronous device path returns the same thing (no ties in float data)
+    import torch
+    dev = torch.device("cuda", 0)
+    q_t = torch.from_numpy(queries).to(dev)
+    r_t = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    d_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    nc_t = torch.empty((nq,), dtype=torch.int64, device=dev)
+    before = s.counters()
+    s.topk_device(q_t.data_ptr(), nq, k, nprobe, r_t.data_ptr(), d_t.data_ptr(), 0, nc_t.data_ptr(),
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(r_t.cpu().numpy().view(np.uint32), rows_t)
+    assert np.array_equal(_bits(d_t.cpu().numpy()), _bits(dist_t))
+    assert np.array_equal(nc_t.cpu().numpy().astype(np.uint64), nc)
+    after = s.counters()
+    # plan metrics are kept on the device path too (src/df_vector/index_exec.rs:289-299)
+    assert after["candidate_rows"] - before["candidate_rows"] == int(nc.sum())
+    assert after["embeddings_fetched"] - before["embeddings_fetched"] == int(nc.sum())
+    # the other paths agree bit for bit: 4-wave 32-query quads, f32 operands, the exact tile kernel, the stream kernel
+    for opts in ({"wide_waves": 4}, {"screen_f16": 0}, {"tile_filter": 0, "rerank_mode": 2}, {"rerank_mode": 1}):
+        s2 = pqv.Searcher(index, corpus)
+        for name, v in opts.items():
+            s2.set_option(name, v)
+        sel = slice(0, 128) if opts.get("rerank_mode") else slice(0, nq)
+        r2, d2, nf2, nc2 = s2.topk(queries[sel], k, nprobe)
+        assert np.array_equal(r2, rows_t[sel]) and np.array_equal(_bits(d2), _bits(dist_t[sel])), opts
+        assert np.array_equal(nc2, nc[sel])
+    # oracle spot check on the same index (bit-exact), queries spread over the batch
+    oidx = oracle.index_from_bytes(blob)
+    sel = np.arange(0, nq, 32)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries[sel], k, nprobe)
+    assert (rows_t[sel] == orows).all() and (_bits(dist_t[sel]) == _bits(odist)).all()
+    assert (nc[sel] == onc).all() and (nf[sel] == onf).all()
+    # small batches and single queries take the same kernels (any batch size) and must agree as well
+    for b in (1, 3, 40):
+        r3, d3, _, _ = s.topk(queries[100:100 + b], k, nprobe)
+        assert np.array_equal(r3, rows_t[100:100 + b]) and np.array_equal(_bits(d3), _bits(dist_t[100:100 + b]))
+
+
+@pytest.mark.timeout(1200)
+def test_c3_parameters_candidate_cap_and_k(pqv, oracle, c3_shape):
+    """Same corpus: a candidate cap in the middle of a probed list and k up to 100, against the oracle."""
+    data, corpus, index, rng = c3_shape
+    nprobe = 32
+    queries = _uniform24(np.random.default_rng(11), 96, data.shape[1])
+    s = pqv.Searcher(index, corpus)
+    oidx = oracle.index_from_bytes(index.to_bytes())
+    for k, cap in ((10, 0), (10, 12345), (100, 0)):
+        rows_t, dist_t, nf, nc = s.topk(queries, k, nprobe, max_candidates=cap)
+        for q in range(0, 96, 8):
+            cand = oidx.candidate_rows(queries[q], nprobe)
+            if cap:
+                cand = cand[:cap]
+            d2 = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
+            order = np.lexsort((np.arange(len(cand)), d2.view(np.uint32)))[:k]
+            assert (rows_t[q, :len(order)] == cand[order]).all(), (k, cap, q)
+            assert (_bits(dist_t[q, :len(order)]) == _bits(np.sqrt(d2[order]))).all()
+
+
+@pytest.mark.timeout(1800)
+def test_c5_parameters_cosine_batch(pqv):
+    """BASELINE configs[4] shape: 1 M x 1536, cosine, one 1024-query batch through pqv_brute_topk."""
+    n, dim, nq, k = 1_000_000, 1536, 1024, 10
+    rng = np.random.default_rng(5)
+    data = _uniform24(rng, n, dim)
+    data -= np.float32(0.5)                                   # ada-002-like: signed components
+    queries = _uniform24(np.random.default_rng(6), nq, dim) - np.float32(0.5)
+    corpus = pqv.Corpus.upload(data)
+    rows, dist, nf = corpus.brute_topk(queries, k, pqv.PQV_COSINE)
+    assert (nf == k).all() and (np.diff(dist.astype(np.float64), axis=1) >= -1e-7).all()
+    vn = np.sqrt((data.astype(np.float64) ** 2).sum(axis=1))
+    # every returned distance is right (f64 recomputation of the returned rows, all 1024 queries) ...
+    for q in range(nq):
+        x = data[rows[q]].astype(np.float64)
+        qq = queries[q].astype(np.float64)
+        d = 1.0 - (x @ qq) / (vn[rows[q]] * np.sqrt((qq ** 2).sum()))
+        assert np.allclose(d, dist[q], rtol=1e-4, atol=1e-6), q
+        assert len(set(rows[q].tolist())) == k
+    # ... and nothing closer was missed: full f64 brute force for a sample of the batch
+    sel = np.arange(0, nq, 32)
+    qs = queries[sel].astype(np.float64)
+    full = np.empty((len(sel), n))
+    for s0 in range(0, n, 100_000):
+        blk = data[s0:s0 + 100_000].astype(np.float64)
+        full[:, s0:s0 + 100_000] = 1.0 - (qs @ blk.T) / (np.sqrt((qs ** 2).sum(axis=1))[:, None] * vn[None, s0:s0 + 100_000])
+    order = np.argsort(full, axis=1, kind="stable")[:, :k]
+    od = np.take_along_axis(full, order, axis=1)
+    for i, q in enumerate(sel):
+        assert np.allclose(od[i], dist[q], rtol=1e-4, atol=1e-6)
+        kth = od[i, -1]
+        tol = 1e-4 * max(abs(kth), 1e-3) + 1e-6
+        clearly_in = order[i][od[i] < kth - tol]
+        assert set(clearly_in.tolist()) <= set(rows[q].tolist())
