@@ -81,20 +81,26 @@ def pmc_traffic(workload, kernels):
     """HBM-side bytes per launch of the dominant kernels from the committed rocprofv3 PMC summaries of THIS
     workload (profiles/<round>_<workload>_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_round.sh from
     separate --pmc passes): FETCH_SIZE x 2 (the gfx950 half-reporting of 16-byte coalesced reads,
-    MI355X_MICROARCH.md #HBM) + WRITE_SIZE, KiB -> bytes, summed over the named kernels."""
+    MI355X_MICROARCH.md #HBM) + WRITE_SIZE, KiB -> bytes, summed over the named kernels.  `kernels`: exact
+    instantiation names as the library's dispatch description gives them, optionally "name@grid_x_threads"
+    (the index build launches some of the same templates with other grids)."""
     total, srcs = 0.0, []
     for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc_{ctr}.txt")
         if not os.path.exists(path):
             return None, None
-        got = 0
+        got = set()
         for line in open(path):
             f = line.split()
-            if ctr in f and any(line.startswith("pqv::" + kname) for kname in kernels):
-                i = f.index(ctr)
-                total += mult * float(f[i + 2]) * 1024.0          # counter, dispatches, avg_value, avg_us
-                got += 1
-        if not got:
+            if ctr not in f:
+                continue
+            i = f.index(ctr)
+            for kname in kernels:
+                name, _, grid = kname.partition("@")
+                if line.startswith("pqv::" + name + " ") and (not grid or f[i - 1].split("x")[0] == grid):
+                    total += mult * float(f[i + 2]) * 1024.0          # counter, dispatches, avg_value, avg_us
+                    got.add(kname)
+        if len(got) != len(kernels):
             return None, None
         srcs.append(os.path.relpath(path, ROOT))
     return total, srcs
@@ -322,12 +328,14 @@ def main():
         min_bytes = distinct_rows * (opb * dim + 8) + survivors_per_step * 4 * dim
     else:
         min_bytes = ref_algo_bytes if "stream_kernel" in plan_text else distinct_rows * (4 * dim + 4)
-    kernels = (["wide_filter_kernel", "wide_seed_kernel", "seed_select_kernel"] if wide else
-               ["tile_filter_kernel", "tile_rerank_kernel", "seed_threshold_kernel"] if screened else
-               ["tile_rerank_kernel"] if "tile_rerank_kernel" in plan_text else ["stream_kernel<64, 1, 0", "stream_kernel<32, 1, 0"])
+    if " | kernels: " in plan_text:
+        kernels = [x.strip() for x in plan_text.split(" | kernels: ")[1].split(";")]
+    else:
+        kernels = (["tile_filter_kernel", "tile_rerank_kernel", "seed_threshold_kernel"] if screened else
+                   ["tile_rerank_kernel"] if "tile_rerank_kernel" in plan_text else ["stream_kernel"])
     traffic, traffic_src = (None, None)
     if world == 1 and nq == nq_default and K == 10:
-        traffic, traffic_src = pmc_traffic(args.workload, kernels)
+        traffic, traffic_src = pmc_traffic(args.workload, kernels) if " | kernels: " in plan_text else (None, None)
 
     k_ms = serial_rr_ms if serial_rr_ms else rr_ms          # isolated launches: what rocprofv3 --kernel-trace reports
     achieved = (traffic if traffic else min_bytes) / (k_ms * 1e-3) / 1e9 if k_ms and k_ms > 0 else 0.0
@@ -371,7 +379,7 @@ def main():
         "dispatch": plan_text,
     }
     result["roofline"] = {
-        "bound": "hbm", "kernel": "+".join(k.split("<")[0] for k in kernels),
+        "bound": "hbm", "kernel": " + ".join(k.split("@")[0] for k in kernels),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src,
         "min_bytes": min_bytes,

@@ -1686,7 +1686,18 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         std::snprintf(t, sizeof t, "tile_rerank_kernel: exact arithmetic, 16-query groups, %u rows per block", p.rr_rows_per_block);
     else
         std::snprintf(t, sizeof t, "stream_kernel: one candidate stream per (query, probed list), %u rows per block", p.rr_rows_per_block);
-    std::snprintf(buf, len, "%s", t);
+    // exact instantiations (as rocprofv3 prints them), so that a profile line can be matched to this dispatch
+    char kn[384] = "";
+    if (p.tile && p.filter && p.quad) {
+        const int S = k <= 64 ? 1 : 4;
+        const bool qlds = p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768;
+        const bool pf = p.f16 && s->dim <= 128;
+        const int seed_ng = p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
+        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %s, %s>; wide_seed_kernel<%d, %s, %s>; seed_select_kernel<%d>@%u",
+                      p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", p.f16 ? "true" : "false", pf ? "true" : "false",
+                      seed_ng, qlds ? "true" : "false", p.f16 ? "true" : "false", S, std::max<uint32_t>(1, nq) * 64);
+    }
+    std::snprintf(buf, len, "%s%s", t, kn);
     return PQV_OK;
 }
 extern "C" int pqv_searcher_describe(const pqv_searcher *s, uint32_t nq, uint32_t k, uint32_t nprobe, int metric,
