@@ -309,6 +309,7 @@ def main():
     screened = "wide_filter_kernel" in plan_text or "tile_filter_kernel" in plan_text
     wide = "wide_filter_kernel" in plan_text
     f16 = "f16 screen operands" in plan_text
+    i8 = "int8 screen operands" in plan_text
     # distinct probed rows of one step (every list that at least one query of the batch probes, once)
     off = index.list_offsets.astype(np.int64)
     lens = np.diff(off)
@@ -324,7 +325,7 @@ def main():
     if wide:
         # what the screened path must move as designed: the operand image of every probed list ONCE
         # (2 or 4 bytes per value) + 8 bytes per row (norm, id) + the f32 row of every survivor
-        opb = 2 if f16 else 4
+        opb = 1 if i8 else 2 if f16 else 4
         min_bytes = distinct_rows * (opb * dim + 8) + survivors_per_step * 4 * dim
     else:
         min_bytes = ref_algo_bytes if "stream_kernel" in plan_text else distinct_rows * (4 * dim + 4)
@@ -400,8 +401,8 @@ def main():
                     "serves up to 128 queries from one pass over a list and reads 2-byte operand images, so this is a speed-up "
                     "figure, not a utilisation"},
         "mfma_view": {"flops_per_launch": mf, "achieved_tflops": mf / (k_ms * 1e-3) / 1e12 if k_ms else 0.0,
-                      "peak_tflops": 2500.0 if f16 else 157.3,
-                      "frac": (mf / (k_ms * 1e-3) / 1e12 / (2500.0 if f16 else 157.3)) if k_ms else 0.0} if screened else None,
+                      "peak_tflops": 5000.0 if i8 else 2500.0 if f16 else 157.3,
+                      "frac": (mf / (k_ms * 1e-3) / 1e12 / (5000.0 if i8 else 2500.0 if f16 else 157.3)) if k_ms else 0.0} if screened else None,
     }
     result["counters"] = ctr
     if exchange and xchg.fast:

@@ -158,7 +158,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -189,7 +189,14 @@ struct pqv_searcher {
     // are finite and the power-of-two scale and its square are representable
     bool f16_ok = false;
     float f16_scale = 1.0f;
-    mutable bool blk_f16 = false;          // form of d_mat_blk
+    // int8 operands (rows of a multiple of 256 dims): images of (x - centre) * i8_scale, centre = per-dimension
+    // mid-range of the stored rows, one global scale mapping the largest |x - centre| to 127; per row |xi|^2 and an
+    // upper bound of the residual norm (see kernels.hip: block_rows_i8_kernel)
+    bool i8_ok = false;
+    float i8_scale = 1.0f, i8_half = 0.0f;
+    DevBuf d_center;
+    mutable DevBuf d_row_n2i, d_row_res;
+    mutable int blk_op = -1;               // form of d_mat_blk: 0 f32, 1 f16, 2 int8 (-1: none yet)
     // Tunables.  Defaults are what the dispatch rules below were measured with; every one can be set per
     // searcher through pqv_searcher_set_option (tests and benches use that to force a path) and, for the
     // profiling scripts, through a PQV_<NAME> environment variable read ONCE, when the searcher is created.
@@ -199,6 +206,7 @@ struct pqv_searcher {
         int filter_variant = 0;            // 1: one 16-query group per block (tile_filter_kernel)
         uint32_t cand_cap = 2048;          // candidate-buffer entries per query of the wide screened path
         int screen_f16 = 1;                // f16 operands where possible
+        int screen_i8 = 1;                 // int8 operands where possible (dim % 256 == 0)
         uint32_t seed_rows = 0;            // rows per list sampled for the thresholds (0 = by rule)
         uint32_t wide_rows = 0;            // rows per block of the wide kernel (0 = by rule)
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
@@ -960,6 +968,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.filter_variant = static_cast<int>(num("PQV_FILTER_VARIANT", o.filter_variant));
     o.cand_cap = static_cast<uint32_t>(std::max<long long>(1, num("PQV_CAND_CAP", o.cand_cap)));
     o.screen_f16 = num("PQV_SCREEN_F16", o.screen_f16) != 0;
+    o.screen_i8 = num("PQV_SCREEN_I8", o.screen_i8) != 0;
     o.seed_rows = static_cast<uint32_t>(num("PQV_SEED_ROWS", o.seed_rows));
     o.wide_rows = static_cast<uint32_t>(num("PQV_WIDE_ROWS", o.wide_rows));
     o.tile_rows = static_cast<uint32_t>(num("PQV_TILE_ROWS", o.tile_rows));
@@ -972,10 +981,18 @@ void opts_from_env(pqv_searcher::Opts &o) {
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
 bool wide_path_possible(const pqv_searcher *s) { return (s->dim % 64) == 0 && !s->d_row_of && s->n > 0; }
 
-// One-off: the blocked MFMA-operand copy of the lists (a second, f16: half-size, copy of the corpus in HBM)
-int ensure_blocked_copy(const pqv_searcher *s, bool f16, hipStream_t stream) {
+// Operand form of the screen for this searcher (pqv::ScreenOp numbering: 0 f32, 1 f16, 2 int8)
+int screen_op(const pqv_searcher *s) {
+    if (s->opt.screen_i8 && s->i8_ok && (s->dim % 256) == 0 && s->dim >= 256 && static_cast<uint64_t>(64) * s->dim <= 147456) return 2;
+    if (s->opt.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024) return 1;
+    return 0;
+}
+
+// One-off: the blocked MFMA-operand copy of the lists (a second copy of the corpus in HBM: f16 half its size,
+// int8 a quarter)
+int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
     using namespace pqv;
-    if (s->d_mat_blk.p && s->blk_f16 == f16) return PQV_OK;
+    if (s->d_mat_blk.p && s->blk_op == op) return PQV_OK;
     const uint32_t kc = s->n_clusters;
     HIP_TRY(hipDeviceSynchronize());           // a form change must not pull the copy from under a running query
     s->d_mat_blk.release();
@@ -983,17 +1000,25 @@ int ensure_blocked_copy(const pqv_searcher *s, bool f16, hipStream_t stream) {
     for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
     HIP_TRY(s->d_blk_off.ensure(boff.size() * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (f16) {
-        HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * 2));
+    const uint64_t tiles = std::max<uint64_t>(1, boff[kc]);
+    if (op == 2) {
+        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim));
+        HIP_TRY(s->d_row_n2i.ensure(std::max<uint64_t>(1, s->n) * sizeof(int)));
+        HIP_TRY(s->d_row_res.ensure(std::max<uint64_t>(1, s->n) * sizeof(float)));
+        HIP_TRY(launch_block_rows_i8(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
+                                     (s->max_list_len + 15) / 16, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
+                                     s->d_mat_blk.p, s->d_row_n2i.as<int>(), s->d_row_res.as<float>(), stream));
+    } else if (op == 1) {
+        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim * 2));
         HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                       (s->max_list_len + 15) / 16, s->dim, s->f16_scale, s->d_mat_blk.p, stream));
     } else {
-        HIP_TRY(s->d_mat_blk.alloc(std::max<uint64_t>(1, boff[kc]) * 16 * s->dim * sizeof(float)));
+        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim * sizeof(float)));
         HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                   (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    s->blk_f16 = f16;
+    s->blk_op = op;
     return PQV_OK;
 }
 
@@ -1083,8 +1108,29 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     }
     // the blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide
     // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
+    if (s->f16_ok && (s->dim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0) {
+        // int8 form: per-dimension mid-range centre and the global scale (finite data only: f16_ok)
+        DevBuf d_mm;
+        S_TRY(d_mm.alloc((2ull * s->dim + 4) * sizeof(uint32_t)));
+        uint32_t *kmin = d_mm.as<uint32_t>(), *kmax = kmin + s->dim, *half = kmax + s->dim;
+        S_TRY(hipMemsetAsync(kmin, 0xFF, s->dim * sizeof(uint32_t), s->stream));
+        S_TRY(hipMemsetAsync(kmax, 0, (s->dim + 4ull) * sizeof(uint32_t), s->stream));
+        S_TRY(s->d_center.alloc(s->dim * sizeof(float)));
+        S_TRY(pqv::launch_col_minmax(s->d_mat, s->n, s->dim, kmin, kmax, s->stream));
+        S_TRY(pqv::launch_col_center(kmin, kmax, s->dim, s->d_center.as<float>(), half, s->stream));
+        uint32_t hb = 0;
+        S_TRY(hipMemcpyAsync(&hb, half, sizeof hb, hipMemcpyDeviceToHost, s->stream));
+        S_TRY(hipStreamSynchronize(s->stream));
+        float h;
+        std::memcpy(&h, &hb, sizeof h);
+        if (hb < 0x7F800000u) {
+            s->i8_half = h;
+            s->i8_scale = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+            s->i8_ok = std::isfinite(s->i8_scale) && s->i8_scale > 0.0f && std::isfinite(s->i8_scale * s->i8_scale);
+        }
+    }
     if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 768) {
-        if (int rc = ensure_blocked_copy(s, s->opt.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024, s->stream)) { delete s; return rc; }
+        if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
     }
     S_TRY(hipStreamSynchronize(s->stream));
     if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
@@ -1118,6 +1164,7 @@ struct TopkPlan {
     bool filter;            // tile path with the MFMA lower-bound screen
     uint32_t seed_rows, filter_bpl;
     bool f16;               // wide path with f16 operands (dim % 128 == 0, queries staged in LDS)
+    bool i8;                // wide path with int8 operands (dim % 256 == 0, 8-wave blocks)
     bool quad;              // filter: wide_filter_kernel (quad_width queries per block); else tile_filter_kernel
     uint32_t filter_rows_per_block, max_quads, quad_width;
     uint32_t block_waves;   // wide kernel: waves per block (4, or 8 sharing one staged quad on a whole CU)
@@ -1170,14 +1217,22 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         if (o.tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows && k <= 256;   // forced
         if (p.filter) {
             p.quad = wide_ok;
-            p.f16 = p.quad && o.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024;
+            const int op = p.quad ? screen_op(s) : 0;
+            p.i8 = op == 2;
+            p.f16 = op == 1;
             // Quad width = queries that share one pass over a list.  f32 operands: 64 (dim <= 128) or 32 staged in
             // LDS, longer rows read a blocked per-quad copy from global memory.  f16 operands: everything the LDS of
             // a CU holds next to the queues -- 144 KB: 128 queries up to 512 dims, 96 at 768, 64 at 1024 -- in ONE
             // 8-wave block per CU, because how often a list is streamed is what bounds long rows (C3, PMC: the
             // 32-query form moves 41 GB per step through the fabric at 6.8 TB/s for 15 GB of distinct rows).
             p.block_waves = 4;
-            if (p.f16) {
+            if (p.i8) {             // int8 images: a byte per value -- 128 queries up to 1024 dims, 96 at 1536, 64 at 2048
+                p.block_waves = 8;
+                // (the 128-query form keeps 128 accumulator registers per lane and spills inside the K loop: 96 by default)
+                const uint32_t fit = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / s->dim / 32 * 32));
+                p.quad_width = std::min<uint32_t>(96, fit);
+                if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width >= 64 && o.quad_width <= fit) p.quad_width = o.quad_width;
+            } else if (p.f16) {
                 const uint64_t per_q = static_cast<uint64_t>(s->dim) * (s->dim <= 128 ? 6 : 2);     // f16 image (+ f32 original)
                 const uint32_t fit8 = static_cast<uint32_t>(std::min<uint64_t>(128, 147456 / per_q / 32 * 32));
                 const uint32_t fit4 = s->dim <= 256 ? 64 : 32;
@@ -1332,7 +1387,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.stats = s->d_stats.as<unsigned long long>();
         ta.xcd_swizzle = 0;
         if (p.filter && p.quad) {
-            if (int rc = ensure_blocked_copy(s, p.f16, stream)) return rc;     // built at creation; here only after an option change
+            if (int rc = ensure_blocked_copy(s, p.i8 ? 2 : p.f16 ? 1 : 0, stream)) return rc;     // built at creation; here only after an option change
             ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
             ta.block_waves = p.block_waves;
@@ -1340,9 +1395,20 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ta.f16 = 1; ta.scale = s->f16_scale; ta.scale2 = s->f16_scale * s->f16_scale;
                 ta.query_maxabs = sc.s_qmax.as<float>();
             }
+            if (p.i8) {
+                HIP_TRY(sc.s_qi8.ensure(static_cast<size_t>(nq) * s->dim));
+                HIP_TRY(sc.s_qn2i.ensure(static_cast<size_t>(nq) * sizeof(int)));
+                HIP_TRY(sc.s_qres.ensure(static_cast<size_t>(nq) * sizeof(float)));
+                HIP_TRY(launch_quantize_queries_i8(d_queries, nq, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
+                                                   sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), stream));
+                ta.i8 = 1; ta.scale = s->i8_scale; ta.scale2 = s->i8_scale * s->i8_scale;
+                ta.q_i8 = static_cast<const int8_t *>(sc.s_qi8.p); ta.q_n2i = sc.s_qn2i.as<int>(); ta.q_res = sc.s_qres.as<float>();
+                ta.row_n2i = s->d_row_n2i.as<int>(); ta.row_res = s->d_row_res.as<float>();
+                s->counters.kernel_launches += 1;
+            }
             // quad-to-XCD affinity: on by default for the global-query variant, whose per-quad operand copies
             // must stay L2-resident
-            const bool q_global = !p.f16 && static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768;
+            const bool q_global = !p.f16 && !p.i8 && static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768;
             ta.xcd_swizzle = s->opt.quad_xcd >= 0 ? s->opt.quad_xcd : (q_global ? 1 : 0);
             if (q_global) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
@@ -1652,6 +1718,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "filter_variant") o.filter_variant = static_cast<int>(value);
     else if (n == "cand_cap") o.cand_cap = static_cast<uint32_t>(std::max<int64_t>(1, value));
     else if (n == "screen_f16") o.screen_f16 = value != 0;
+    else if (n == "screen_i8") o.screen_i8 = value != 0;
     else if (n == "seed_rows") o.seed_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "wide_rows") o.wide_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "tile_rows") o.tile_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
@@ -1676,8 +1743,8 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     if (p.tile && p.filter && p.quad)
         std::snprintf(t, sizeof t, "wide_seed_kernel + seed_select_kernel + wide_filter_kernel: %s screen operands, quads of %u queries "
                       "staged %s, %u waves per block, %u rows per block, threshold sample %u rows per list",
-                      p.f16 ? "f16" : "f32", p.quad_width,
-                      (p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768) ? "in LDS" : "as a blocked copy in global memory",
+                      p.i8 ? "int8" : p.f16 ? "f16" : "f32", p.quad_width,
+                      (p.i8 || p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768) ? "in LDS" : "as a blocked copy in global memory",
                       p.block_waves, p.filter_rows_per_block, p.seed_rows);
     else if (p.tile && p.filter)
         std::snprintf(t, sizeof t, "tile_rerank_kernel (exact seed window of %u rows) + tile_filter_kernel: 16-query groups, f32 screen operands, "
@@ -1690,12 +1757,13 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     char kn[384] = "";
     if (p.tile && p.filter && p.quad) {
         const int S = k <= 64 ? 1 : 4;
-        const bool qlds = p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768;
+        const bool qlds = p.i8 || p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768;
         const bool pf = p.f16 && s->dim <= 128;
-        const int seed_ng = p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
-        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %s, %s>; wide_seed_kernel<%d, %s, %s>; seed_select_kernel<%d>@%u",
-                      p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", p.f16 ? "true" : "false", pf ? "true" : "false",
-                      seed_ng, qlds ? "true" : "false", p.f16 ? "true" : "false", S, std::max<uint32_t>(1, nq) * 64);
+        const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
+        const int seed_ng = p.i8 ? 2 : p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
+        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",
+                      p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
+                      seed_ng, qlds ? "true" : "false", op, S, std::max<uint32_t>(1, nq) * 64);
     }
     std::snprintf(buf, len, "%s%s", t, kn);
     return PQV_OK;
@@ -1712,12 +1780,13 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
     if (row_order_bytes) *row_order_bytes = s->corpus && s->corpus->d_rows ? s->corpus->capacity * s->corpus->dim * sizeof(float) : 0;
     if (ivf_rows_bytes) *ivf_rows_bytes = s->d_mat_ivf.p ? s->d_mat_ivf.bytes : 0;
     if (blocked_bytes) *blocked_bytes = s->d_mat_blk.p ? s->d_mat_blk.bytes : 0;
-    uint64_t other = s->d_centroids.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes;
+    uint64_t other = s->d_centroids.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes +
+                     s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
                                 &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads,
                                 &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
-                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins})
+                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres})
             other += b->p ? b->bytes : 0;
     if (other_bytes) *other_bytes = other;
     return PQV_OK;

@@ -167,6 +167,13 @@ struct TileArgs {
     int             q32_lds;      // set by the launcher: the f16 kernel also stages the exact f32 queries in LDS
     float           scale, scale2;
     const float    *query_maxabs;   // [nq] max |q_i| (merge probe)
+    // int8 operands (8-wave wide kernel, dim % 256 == 0): mat_blk is the launch_block_rows_i8 copy; `scale` = S
+    int             i8;
+    const int8_t   *q_i8;        // [nq][dim] int8 images of the batch's queries (launch_quantize_queries_i8)
+    const int      *q_n2i;       // [nq] |qi|^2
+    const float    *q_res;       // [nq] upper bound of |q - c - qi / S| (+inf: never skip this query)
+    const int      *row_n2i;     // per storage row: |xi|^2
+    const float    *row_res;     // per storage row: upper bound of |x - c - xi / S|
     const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad
                                  // (launch_pack_queries), [max_quads][quad_width / 16][dim / 4][16] float4
     const float    *row_norm2;   // indexed like mat rows
@@ -283,6 +290,16 @@ hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_byte
 hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                                  uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s);
 hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out_bits, hipStream_t s);
+// int8 form (see kernels.hip): per-dimension min / max keys (kmin preset to 0xFF bytes, kmax to 0), the mid-range centre
+// and the largest |x - centre| (float bits, preset 0), the blocked int8 copy + per-row |xi|^2 and residual bound, and
+// the per-batch query images
+hipError_t launch_col_minmax(const float *rows, uint64_t n, uint32_t dim, uint32_t *kmin, uint32_t *kmax, hipStream_t s);
+hipError_t launch_col_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t dim, float *center, uint32_t *half_bits, hipStream_t s);
+hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                uint64_t max_tiles, uint32_t dim, float scale, const float *center, float maxabs, void *out,
+                                int *row_n2i, float *row_res, hipStream_t s);
+hipError_t launch_quantize_queries_i8(const float *queries, uint32_t nq, uint32_t dim, float scale, const float *center,
+                                      float maxabs, void *q_i8, int *q_n2i, float *q_res, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

@@ -61,9 +61,12 @@ typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 // One K step of the score contraction for a 16 x 16 tile.  f32 operands: 16 dims, four 16x16x4 MFMAs;
 // f16 operands (8 halves per lane, see launch_block_rows_f16): 32 dims, one 16x16x32 MFMA.
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-template <bool F16>
+// Operand forms of the screen contraction: f32 (exact products), f16 images, int8 images (see wide_filter_kernel)
+enum ScreenOp : int { OP_F32 = 0, OP_F16 = 1, OP_I8 = 2 };
+typedef int i32x4_acc __attribute__((ext_vector_type(4)));
+template <int OP>
 __device__ __forceinline__ void mfma_step(f32x4_acc &acc, const float4 q, const float4 x) {
-    if constexpr (F16) {
+    if constexpr (OP == OP_F16) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, q), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, x.x, acc, 0, 0, 0);
@@ -71,6 +74,12 @@ __device__ __forceinline__ void mfma_step(f32x4_acc &acc, const float4 q, const 
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, x.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, x.w, acc, 0, 0, 0);
     }
+}
+// int8 operands: 16 bytes per lane = 64 dims per step, exact int32 accumulation (v_mfma_i32_16x16x64_i8)
+template <int OP>
+__device__ __forceinline__ void mfma_step(i32x4_acc &acc, const float4 q, const float4 x) {
+    static_assert(OP == OP_I8, "integer accumulators belong to the int8 form");
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_acc, q), __builtin_bit_cast(i32x4_acc, x), acc, 0, 0, 0);
 }
 // eight f32 values scaled by a power of two and rounded to f16 (round to nearest even), packed as 16 bytes
 __device__ __forceinline__ float4 pack_f16x8(const float4 lo, const float4 hi, float scale) {
@@ -1298,8 +1307,10 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
 // sample.  The sample rows themselves are screened and evaluated by the main pass like all others.
 // Output: seed_ub[((qrow * nprobe + j) * seed_sw + blockIdx.x * 4 + wave) * 16 + (lane & 15)].
 // ------------------------------------------------------------------------------------
-template <int NG, bool QLDS, bool F16>
+template <int NG, bool QLDS, int OP>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
+    constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
+    static_assert(!I8 || QLDS, "int8 operands: queries staged in LDS");
     constexpr uint32_t NQ = 16 * NG;
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
@@ -1330,7 +1341,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     if (r0 > r1) r0 = r1;
 
     const uint32_t dim = a.dim;
-    const uint32_t G = F16 ? dim >> 3 : dim >> 2;    // 16-byte operand columns per row
+    const uint32_t G = I8 ? dim >> 4 : F16 ? dim >> 3 : dim >> 2;    // 16-byte operand columns per row
     const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
     const float c16 = F16 ? 1.25f * 9.765625e-04f : 0.0f;               // f16 operands: see wide_filter_kernel
     const float isc2 = F16 ? 1.0f / a.scale2 : 1.0f;                    // scores are contracted at scale^2
@@ -1343,7 +1354,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const uint64_t room = a.max_pos > my_cbase ? a.max_pos - my_cbase : 0;
     qnl[lane] = a.query_norm2[my_qrow];
     const float my_qn0 = a.query_norm2[my_qrow];
-    const bool my_bad16 = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn0 * a.scale2 < 1.0f);   // no valid f16 bound
+    bool my_bad16 = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn0 * a.scale2 < 1.0f);   // no valid f16 bound
+    if constexpr (I8) my_bad16 = !(a.q_res[my_qrow] <= 3.0e38f);         // non-finite query: no bound
     liml[lane] = ((uint32_t)lane < cnt && !my_bad16) ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
     if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
@@ -1351,7 +1363,11 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
-        if constexpr (F16) {
+        if constexpr (I8) {
+            const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
+#pragma unroll 4
+            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
+        } else if constexpr (F16) {
 #pragma unroll 4
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
         } else {
@@ -1367,19 +1383,28 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
     const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;
     float mins[NG][4];
+    // I8: the largest dot - ceil(Nx / 2) a lane sees per query bounds the smallest |qi - xi|^2 from above
+    [[maybe_unused]] int maxs[NG][4];
+    [[maybe_unused]] float rmax = 0.0f;          // largest residual bound among the rows this lane saw
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mins[g][r] = INFINITY;
+        for (int r = 0; r < 4; ++r) { mins[g][r] = INFINITY; maxs[g][r] = -(1 << 30); }
 
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         const float4 *xbase[4];
         float xn[4];
+        [[maybe_unused]] int xn2i[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             uint32_t rr = (uint32_t)(16 * t + l15);
             if (rr >= nvalid) rr = nvalid - 1;
+            if constexpr (I8) {
+                xn[t] = 0.0f;
+                xn2i[t] = a.row_n2i[lbeg + t0 + rr];
+                if ((uint32_t)(16 * t + l15) < nvalid) rmax = fmaxf(rmax, a.row_res[lbeg + t0 + rr]);
+            } else
             xn[t] = a.row_norm2[lbeg + t0 + rr];
             uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
             if (T > blk_last) T = blk_last;
@@ -1389,11 +1414,15 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         uint32_t xso[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
-        f32x4_acc acc[NG][4];
+        using acc_t = std::conditional_t<I8, i32x4_acc, f32x4_acc>;
+        acc_t acc[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (I8) { const int init = -((xn2i[t] + 1) >> 1); acc[g][t] = (i32x4_acc){init, init, init, init}; }
+                else acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+            }
         for (uint32_t ks = 0; ks < (G >> 2); ++ks) {
             float4 x[4];
 #pragma unroll
@@ -1406,7 +1435,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                     if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
                     else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + ks * 1024);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], qc, x[t]);
+                    for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
                 }
             }
         }
@@ -1422,10 +1451,14 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t roff = (uint32_t)t0 + (uint32_t)(16 * t + l15);     // list offset (< 2^32 rows per list)
                     const bool valid = (uint32_t)(16 * t + l15) < nvalid && roff < lim[r];
-                    const float nn = qn[r] + xn[t];
-                    const float dt = nn - 2.0f * (acc[g][t][r] * isc2);
-                    const float ub = dt + cmargin * (2.0f * nn + fabsf(dt)) + c16 * nn;
-                    if (valid) mins[g][r] = fminf(mins[g][r], ub);                     // NaN bounds are ignored
+                    if constexpr (I8) {
+                        if (valid) maxs[g][r] = max(maxs[g][r], acc[g][t][r]);
+                    } else {
+                        const float nn = qn[r] + xn[t];
+                        const float dt = nn - 2.0f * (acc[g][t][r] * isc2);
+                        const float ub = dt + cmargin * (2.0f * nn + fabsf(dt)) + c16 * nn;
+                        if (valid) mins[g][r] = fminf(mins[g][r], ub);                     // NaN bounds are ignored
+                    }
                 }
             }
         }
@@ -1439,6 +1472,15 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
             const uint32_t qi = (uint32_t)(16 * g + kk * 4 + r);
             const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qi, 64);
             const uint32_t j = (uint32_t)__shfl((int)my_j, (int)qi, 64);
+            if constexpr (I8) {
+                // |q - x| <= |qi - xi| / S + rq + rx, |qi - xi|^2 = Nq + Nx - 2 dot <= Nq - 2 (dot - ceil(Nx / 2)); the reference's
+                // computed d2 exceeds the real one by at most the summation margin
+                if (qi < cnt && maxs[g][r] > -(1 << 30)) {
+                    const float n_ub = fmaxf((float)(a.q_n2i[qrow] - 2 * maxs[g][r]) * 1.000001f + 2.0f, 0.0f);
+                    const float d = sqrtf(n_ub) * 1.000001f / a.scale + a.q_res[qrow] + rmax;
+                    mins[g][r] = d * d * (1.0f + 4.0f * cmargin) * 1.000002f;
+                }
+            }
             if (qi < cnt)
                 a.seed_ub[(((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15] = fmaxf(mins[g][r], 0.0f);
         }
@@ -1523,23 +1565,29 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+    if (a.i8) {       // int8 images: 32 queries x dim bytes per block
+        if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
+            32ull * a.dim > 65536) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_I8>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), 32ull * a.dim, s, a);
+        return hipGetLastError();
+    }
     if (a.f16) {      // f16 operands: the staged queries take half the LDS; 64 queries per block up to 256 dims, else 32
         if ((a.dim % 128) != 0 || !a.query_maxabs || a.dim > 1024) return hipErrorInvalidValue;
         if (lds4 / 2 <= 32768 && (a.quad_width % 64) == 0)
-            hipLaunchKernelGGL((wide_seed_kernel<4, true, true>), dim3(a.grid_x, a.max_quads, a.quad_width / 64), dim3(256), lds4 / 2, s, a);
+            hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_F16>), dim3(a.grid_x, a.max_quads, a.quad_width / 64), dim3(256), lds4 / 2, s, a);
         else if ((a.quad_width % 32) == 0)
-            hipLaunchKernelGGL((wide_seed_kernel<2, true, true>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), lds2 / 2, s, a);
+            hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_F16>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), lds2 / 2, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (a.quad_width == 64 && lds4 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<4, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
     else if (a.quad_width == 32 && lds2 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<2, true, false>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
     else if (a.quad_width == 32 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<2, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else if (a.quad_width == 64 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<4, false, false>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1603,9 +1651,11 @@ __device__ __forceinline__ uint64_t qread_u64(const uint64_t (&v)[QS], uint32_t 
     else return readlane_u64(v[0], (int)qq);
 }
 
-template <int NG, int NW, int S, bool QLDS, bool F16, bool PF>
-__global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && F16)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && OP != OP_F32)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
+    constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
     static_assert(!PF || (QLDS && F16), "whole-tile operand prefetch: f16 rows of <= 128 dims");
+    static_assert(!I8 || (QLDS && NW == 8), "int8 operands: queries staged in LDS, 8-wave blocks");
     static_assert(TILE_QB == 16 && NG >= 2 && NG <= 8 && (NG % 2) == 0 && (NW == 4 || NW == 8), "16-row MFMA tiles, 2..8 groups, 4 or 8 waves");
     constexpr uint32_t NQ = 16 * NG;
     constexpr int QS = (NQ + 63) / 64;        // state slots per lane
@@ -1653,8 +1703,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     if (r0 > len) r0 = len;
 
     const uint32_t dim = a.dim;
-    // 16-byte operand columns per row: 4 f32 or (F16) 8 f16 values each; a K step is 4 columns
-    const uint32_t G = F16 ? dim >> 3 : dim >> 2;
+    // 16-byte operand columns per row: 4 f32, 8 f16 or 16 int8 values each; a K step is 4 columns
+    const uint32_t G = I8 ? dim >> 4 : F16 ? dim >> 3 : dim >> 2;
     const uint32_t Gx = dim >> 2;                    // 16-byte chunks of a row-major f32 row (exact evaluation)
     const float cmargin = (float)(dim + 16) * 2.384185791015625e-07f;   // (dim + 16) * 2^-22
     // F16: operands are round-to-nearest f16 images of scale * value (|scale * x| <= 2^14: no overflow), the
@@ -1674,6 +1724,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint64_t my_cbase[QS], my_lkth[QS], my_base[QS];
     float my_qn[QS];
     bool my_noskip[QS];
+    [[maybe_unused]] int my_qn2i[QS];          // I8: |qi|^2 and the residual norm of the query image
+    [[maybe_unused]] float my_qres[QS];
     const uint32_t n_part = a.n_part;
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -1686,6 +1738,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         my_base[s] = ((uint64_t)my_qrow[s] * n_part + (my_pair[s] % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
         // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
         my_noskip[s] = F16 && (!(a.query_maxabs[my_qrow[s]] * a.scale <= 32768.0f) || !(my_qn[s] * a.scale2 >= 1.0f) || !(my_qn[s] <= 3.0e38f));
+        if constexpr (I8) {
+            my_qn2i[s] = a.q_n2i[my_qrow[s]];
+            my_qres[s] = a.q_res[my_qrow[s]];
+            my_noskip[s] = !(my_qres[s] <= 3.0e38f);       // a query with non-finite components is never skipped
+        }
     }
 
     // QLDS: stage the quad's queries: TPQ threads per query, 16-byte columns interleaved between them;
@@ -1701,7 +1758,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)q_src * dim);
             float4 *dst = qs + q * G;
             const uint32_t sw = q & 15u;
-            if constexpr (F16) {
+            if constexpr (I8) {        // the int8 images were made once per batch (quantize_queries_i8_kernel)
+                const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)q_src * dim);
+#pragma unroll 4
+                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
+            } else if constexpr (F16) {
                 if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
                     float4 *d32 = qs + NQ * G + q * Gx;
 #pragma unroll 4
@@ -1765,7 +1826,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         float sum = 0.0f;
         // 8 row chunks in flight per lane, then the reference's ordered chain over them (16 in flight -- two
         // round trips per 128-dim row instead of four -- measured no faster and costs the last free registers)
-        const bool q_global = !QLDS || (F16 && !a.q32_lds);      // wave-uniform
+        const bool q_global = !QLDS || I8 || (F16 && !a.q32_lds);      // wave-uniform
         auto chain = [&](auto qg_c) {
             constexpr int NB = 8;
             constexpr bool QG = decltype(qg_c)::value;
@@ -1946,6 +2007,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint64_t gthr_next[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) gthr_next[s] = cur_gthr[s];
+    [[maybe_unused]] int xn2i_next[4] = {0, 0, 0, 0};
+    [[maybe_unused]] float xres_next[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (I8) {
+        if (r0 < r1) {
+            const uint32_t nv = (r1 - r0 < 64) ? (uint32_t)(r1 - r0) : 64u;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint32_t rr = (uint32_t)(16 * t + l15);
+                if (rr >= nv) rr = nv - 1;
+                xn2i_next[t] = a.row_n2i[lbeg + r0 + rr];
+                xres_next[t] = a.row_res[lbeg + r0 + rr];
+            }
+        }
+    }
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
@@ -1958,10 +2033,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         for (int t = 0; t < 4; ++t) {
             uint32_t rr = (uint32_t)(16 * t + l15);
             if (rr >= nvalid) rr = nvalid - 1;
-            xn[t] = pf ? xn_pf[t] : a.row_norm2[lbeg + t0 + rr];
+            if constexpr (I8) xn[t] = 0.0f; else xn[t] = pf ? xn_pf[t] : a.row_norm2[lbeg + t0 + rr];
             uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
             if (T > blk_last) T = blk_last;             // tiles past the list's end: masked below
             xbase[t] = a.mat_blk + T * G * 16;
+        }
+        // I8: the rows' integer norms and residual bounds feed the accumulators' start values, so they are fetched
+        // one tile ahead (their latency would otherwise sit in front of the K loop)
+        [[maybe_unused]] int xn2i[4];
+        [[maybe_unused]] float xres[4];
+        if constexpr (I8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { xn2i[t] = xn2i_next[t]; xres[t] = xres_next[t]; }
+            const uint64_t tn = t0 + 64;
+            if (tn < r1) {
+                const uint32_t nv = (r1 - tn < 64) ? (uint32_t)(r1 - tn) : 64u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t rr = (uint32_t)(16 * t + l15);
+                    if (rr >= nv) rr = nv - 1;
+                    xn2i_next[t] = a.row_n2i[lbeg + tn + rr];
+                    xres_next[t] = a.row_res[lbeg + tn + rr];
+                }
+            }
         }
         // one descriptor per tile (base = its first 16-row sub-tile); the other sub-tiles and the K steps
         // are scalar byte offsets (< 1 MiB)
@@ -1977,11 +2071,57 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
         }
 
-        f32x4_acc acc[NG][4];
+        using acc_t = std::conditional_t<I8, i32x4_acc, f32x4_acc>;
+        acc_t acc[NG][4];
+        if constexpr (I8) {
+            // int8 operands.  x = c + xi / S + e_x and q = c + qi / S + e_q (c = per-dimension mid-range, S one global
+            // scale, xi / qi the int8 images, |e_x| <= rx and |e_q| <= rq stored upper bounds of the residual norms), so
+            //     |q - x| >= |qi - xi| / S - rq - rx        (triangle inequality; |qi - xi|^2 = Nq + Nx - 2 qi.xi EXACTLY)
+            // and a pair whose reference distance could still pass the threshold thr has
+            //     |qi - xi| <= S (sqrt(thr (1 + c)) + rq + rx)  =>  Nq + Nx - 2 dot <= Tq2 + bx,
+            //     Tq2 = S^2 tq^2, tq = sqrt(thr (1 + c)) + rq,  bx = S^2 (2 U rx + rx^2), U >= every tq of the quad.
+            // skip  <=>  dot + ceil((bx - Nx) / 2) + ceil((Tq2 - Nq) / 2) < 0: the row term is the accumulator's START
+            // value, the query term one integer add per pair, the sign bit the answer.  All roundings go up (never skip
+            // wrongly); the contraction itself is exact.
+            float tq[QS], U = 0.0f;
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
+                const bool open = my_noskip[s] || my_thr[s] == KEY_EMPTY || !(thr_d <= 3.0e38f);
+                tq[s] = open ? -1.0f : sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + my_qres[s];
+                if (qi < cnt && !open) U = fmaxf(U, tq[s]);
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+            for (int off = 32; off > 0; off >>= 1) U = fmaxf(U, __shfl_xor(U, off, 64));
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+                int a2 = 1 << 29;                              // never skip
+                if (qi >= cnt) a2 = -(1 << 30);                // not a query of this quad: always "skipped"
+                else if (tq[s] >= 0.0f) {
+                    const float v = a.scale * tq[s];
+                    const float v2 = fminf(v * v * 1.000002f, 1.0e9f);
+                    a2 = ((int)ceilf(v2) + 1 - my_qn2i[s] + 1) >> 1;
+                }
+                if (qi < NQ) reinterpret_cast<int *>(aq)[qi] = a2;
+            }
+            wave_lds_fence();
+            const float s2 = a.scale * a.scale;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bx = s2 * (2.0f * U * xres[t] + xres[t] * xres[t]) * 1.000002f;
+                const int init = ((int)ceilf(fminf(bx, 1.0e9f)) + 1 - xn2i[t] + 1) >> 1;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g][t] = (i32x4_acc){init, init, init, init};
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+        }
 
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_a = __builtin_amdgcn_s_memtime();
@@ -2000,7 +2140,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 if (decltype(full)::value || (uint32_t)g < ng) {
                     const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], qc, x[t]);
+                    for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
                 }
             }
         };
@@ -2040,7 +2180,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 for (int g = 0; g < NG; ++g) {
                     if ((uint32_t)g < ng) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) mfma_step<F16>(acc[g][t], q[g], x[t]);
+                        for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], q[g], x[t]);
                     }
                 }
             };
@@ -2083,19 +2223,36 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         for (int t = 0; t < 4; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
-        wave_lds_fence();
+        if constexpr (!I8) {
+            wave_lds_fence();
 #pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-            // threshold DISTANCE of this lane's query; KEY_EMPTY: "cannot skip"
-            const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
-            if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (my_noskip[s] || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * my_qn[s] - beta * thr_d;
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+                // threshold DISTANCE of this lane's query; KEY_EMPTY: "cannot skip"
+                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
+                if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (my_noskip[s] || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * my_qn[s] - beta * thr_d;
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();
         uint32_t bits[NG / 2];
 #pragma unroll
         for (int w = 0; w < NG / 2; ++w) bits[w] = 0;
-        if constexpr (F16) {
+        if constexpr (I8) {
+            // skip <=> acc + A2 < 0: one integer add per pair, the sign bit shifted into the lane's mask
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int4 a4 = *reinterpret_cast<const int4 *>(reinterpret_cast<const int *>(aq) + 16 * g + 4 * kk);
+                const int ar[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        bits[g >> 1] = __builtin_amdgcn_alignbit(bits[g >> 1], (uint32_t)(acc[g][t][r] + ar[r]), 31);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < NG / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
+        } else if constexpr (F16) {
             // f16 operands: every term is finite by construction (rows scaled below 2^14, query images clamped
             // to the f16 range, never-skip / unset thresholds carry -3e38, invalid ones +inf), so
             // skip <=> acc - smin < 0 <=> its sign bit: two packed adds per TWO pairs and one v_alignbit
@@ -2296,9 +2453,9 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 }
 
 // dynamic LDS beyond 64 KB has to be allowed per kernel once
-template <int NG, int NW, int S, bool QLDS, bool F16, bool PF = false>
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false>
 static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
-    auto kern = wide_filter_kernel<NG, NW, S, QLDS, F16, PF>;
+    auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF>;
     if (lds > 65536) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
         if (attr != hipSuccess) return attr;
@@ -2320,6 +2477,15 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const uint32_t nw = a.block_waves ? a.block_waves : 4;
+        if (a.i8) {           // int8 images: 8-wave blocks, up to 128 queries x dim bytes of LDS
+            if ((a.dim % 256) != 0 || nw != 8 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
+            const size_t lds = (size_t)a.quad_width * a.dim;
+            if (lds > 147456) return hipErrorInvalidValue;
+            if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_I8>(a, lds, s);
+            if (a.quad_width == 96) return launch_wide<6, 8, S, true, OP_I8>(a, lds, s);
+            if (a.quad_width == 64) return launch_wide<4, 8, S, true, OP_I8>(a, lds, s);
+            return hipErrorInvalidValue;
+        }
         if (a.f16) {
             if ((a.dim % 128) != 0 || !a.query_maxabs) return hipErrorInvalidValue;
             TileArgs b = a;
@@ -2329,26 +2495,26 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
             const bool pf = a.dim <= 128;       // <= 4 K steps per tile: whole-tile operand prefetch
             if (nw == 8) {            // one block per CU: up to 144 KB of staged queries + 14 KB of queues
                 if (lds > 147456) return hipErrorInvalidValue;
-                if (a.quad_width == 128 && pf) return launch_wide<8, 8, S, true, true, true>(b, lds, s);
+                if (a.quad_width == 128 && pf) return launch_wide<8, 8, S, true, OP_F16, true>(b, lds, s);
                 if (pf) return hipErrorInvalidValue;
-                if (a.quad_width == 128) return launch_wide<8, 8, S, true, true>(b, lds, s);
-                if (a.quad_width == 96) return launch_wide<6, 8, S, true, true>(b, lds, s);
-                if (a.quad_width == 64) return launch_wide<4, 8, S, true, true>(b, lds, s);
+                if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_F16>(b, lds, s);
+                if (a.quad_width == 96) return launch_wide<6, 8, S, true, OP_F16>(b, lds, s);
+                if (a.quad_width == 64) return launch_wide<4, 8, S, true, OP_F16>(b, lds, s);
                 return hipErrorInvalidValue;
             }
             if (lds > 65536) return hipErrorInvalidValue;           // + 10 KB of static LDS: two blocks per CU
-            if (a.quad_width == 64 && pf) return launch_wide<4, 4, S, true, true, true>(b, lds, s);
+            if (a.quad_width == 64 && pf) return launch_wide<4, 4, S, true, OP_F16, true>(b, lds, s);
             if (pf) return hipErrorInvalidValue;
-            if (a.quad_width == 64) return launch_wide<4, 4, S, true, true>(b, lds, s);
-            if (a.quad_width == 32) return launch_wide<2, 4, S, true, true>(b, lds, s);
+            if (a.quad_width == 64) return launch_wide<4, 4, S, true, OP_F16>(b, lds, s);
+            if (a.quad_width == 32) return launch_wide<2, 4, S, true, OP_F16>(b, lds, s);
             return hipErrorInvalidValue;
         }
         if (nw != 4) return hipErrorInvalidValue;
         const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
-        if (a.quad_width == 64 && lds4 <= 32768) return launch_wide<4, 4, S, true, false>(a, lds4, s);
-        if (a.quad_width == 32 && lds2 <= 32768) return launch_wide<2, 4, S, true, false>(a, lds2, s);
-        if (a.quad_width == 32 && a.q_blk) return launch_wide<2, 4, S, false, false>(a, 0, s);
-        if (a.quad_width == 64 && a.q_blk) return launch_wide<4, 4, S, false, false>(a, 0, s);
+        if (a.quad_width == 64 && lds4 <= 32768) return launch_wide<4, 4, S, true, OP_F32>(a, lds4, s);
+        if (a.quad_width == 32 && lds2 <= 32768) return launch_wide<2, 4, S, true, OP_F32>(a, lds2, s);
+        if (a.quad_width == 32 && a.q_blk) return launch_wide<2, 4, S, false, OP_F32>(a, 0, s);
+        if (a.quad_width == 64 && a.q_blk) return launch_wide<4, 4, S, false, OP_F32>(a, 0, s);
         return hipErrorInvalidValue;
     }
     dim3 grid(a.grid_x, a.max_groups), block(256);
@@ -2848,6 +3014,171 @@ hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out, hipStream_t 
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(maxabs_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, v, n, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// int8 form of the blocked operand copy (wide_filter_kernel<.., OP_I8>).
+//   col_minmax_kernel      per-dimension minimum and maximum of the stored rows, as order-preserving uint keys
+//                          (sortable_bits) so plain atomicMin / atomicMax work for any sign
+//   block_rows_i8_kernel   xi = clamp(rint((x - c) S), -127, 127) with c the per-dimension mid-range and S one global
+//                          scale; a 16-byte column holds 16 consecutive dims, tile T stores column cc of its row j at
+//                          16-byte index (T * dim/16 + cc) * 16 + j -- a 16x16x64 MFMA operand fetch (16 rows x 4
+//                          columns) is one 1 KiB read.  Per row also Nx = |xi|^2 (exact) and an UPPER bound of the
+//                          residual norm |x - c - xi / S| (f32 sum + 0.1 % + the rounding of the residuals themselves).
+//   quantize_queries_i8_kernel   the same image of every query of a batch (row-major [nq, dim] int8), |qi|^2 and the
+//                          residual bound; a query with a non-finite component gets +inf (never skipped).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_minmax_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
+                                                        uint32_t *__restrict__ kmin, uint32_t *__restrict__ kmax) {
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint64_t r = r0; r < r1; ++r) {
+            const uint32_t kb = sortable_bits(rows[r * dim + d]);
+            lo = kb < lo ? kb : lo;
+            hi = kb > hi ? kb : hi;
+        }
+        if (r0 < r1) { atomicMin(&kmin[d], lo); atomicMax(&kmax[d], hi); }
+    }
+}
+hipError_t launch_col_minmax(const float *rows, uint64_t n, uint32_t dim, uint32_t *kmin, uint32_t *kmax, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = n < 4096 ? n : 4096;
+    hipLaunchKernelGGL(col_minmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, n, dim, kmin, kmax);
+    return hipGetLastError();
+}
+// centre[d] = (min + max) / 2, *half_bits = float bits of the largest |x - centre| over all dims (atomicMax); one block
+__global__ __launch_bounds__(256) void col_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
+                                                        uint32_t dim, float *__restrict__ center, uint32_t *half_bits) {
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        const float lo = unsortable_bits(kmin[d]), hi = unsortable_bits(kmax[d]);
+        const float c = 0.5f * lo + 0.5f * hi;
+        center[d] = c;
+        const float h = fmaxf(hi - c, c - lo);
+        atomicMax(half_bits, __float_as_uint(fabsf(h)));
+    }
+}
+hipError_t launch_col_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t dim, float *center, uint32_t *half_bits, hipStream_t s) {
+    hipLaunchKernelGGL(col_center_kernel, dim3(1), dim3(256), 0, s, kmin, kmax, dim, center, half_bits);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ int quant_i8(float t, float scale) {
+    const float v = rintf(t * scale);
+    return (int)fminf(fmaxf(v, -127.0f), 127.0f);      // NaN -> -127 (callers flag non-finite inputs separately)
+}
+
+__global__ __launch_bounds__(256) void block_rows_i8_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                           const uint64_t *__restrict__ blk_off, uint32_t dim, float scale,
+                                                           const float *__restrict__ center, float maxabs, uint4 *__restrict__ out,
+                                                           int *__restrict__ row_n2i, float *__restrict__ row_res) {
+    __shared__ int s_n2[16][17];
+    __shared__ float s_e2[16][17];
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 4;
+    const uint32_t j = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const float inv = 1.0f / scale;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        uint4 *dst = out + (blk_off[c] + tl) * G * 16;
+        const uint64_t p = tl * 16 + j;
+        int n2 = 0;
+        float e2 = 0.0f;
+        for (uint32_t cc = cg; cc < G; cc += 16) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (p < len) {
+                const float4 *r = reinterpret_cast<const float4 *>(src + (lbeg + p) * dim + cc * 16);
+                const float4 *cv = reinterpret_cast<const float4 *>(center + cc * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 x = r[u], cx = cv[u];
+                    const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = quant_i8(t[e], scale);
+                        const float res = t[e] - (float)q * inv;
+                        n2 += q * q;
+                        e2 = fmaf(res, res, e2);
+                        w[u] |= (uint32_t)(q & 0xFF) << (8 * e);
+                    }
+                }
+            }
+            dst[cc * 16 + j] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        s_n2[j][cg] = n2; s_e2[j][cg] = e2;
+        __syncthreads();
+        if (threadIdx.x < 16 && tl * 16 + threadIdx.x < len) {
+            int tn = 0; float te = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { tn += s_n2[threadIdx.x][g]; te += s_e2[threadIdx.x][g]; }
+            row_n2i[lbeg + tl * 16 + threadIdx.x] = tn;
+            // upper bound: the f32 sum (+ 0.1 %), plus the roundings of (x - c) and q / S in every residual
+            row_res[lbeg + tl * 16 + threadIdx.x] = sqrtf(te) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (maxabs + 127.0f * inv);
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                uint64_t max_tiles, uint32_t dim, float scale, const float *center, float maxabs, void *out,
+                                int *row_n2i, float *row_res, hipStream_t s) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    if (dim % 16) return hipErrorInvalidValue;
+    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(block_rows_i8_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, scale, center,
+                       maxabs, static_cast<uint4 *>(out), row_n2i, row_res);
+    return hipGetLastError();
+}
+
+// one wave per query
+__global__ __launch_bounds__(64) void quantize_queries_i8_kernel(const float *__restrict__ queries, uint32_t dim, float scale,
+                                                                const float *__restrict__ center, float maxabs,
+                                                                int8_t *__restrict__ q_i8, int *__restrict__ q_n2i,
+                                                                float *__restrict__ q_res) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float inv = 1.0f / scale;
+    int n2 = 0;
+    float e2 = 0.0f, big = 0.0f;
+    bool bad = false;
+    for (uint32_t d0 = lane * 4; d0 < dim; d0 += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim + d0);
+        const float4 cx = *reinterpret_cast<const float4 *>(center + d0);
+        const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bad |= !(fabsf(t[e]) < INFINITY);
+            const int v = quant_i8(t[e], scale);
+            const float res = t[e] - (float)v * inv;
+            n2 += v * v;
+            e2 = fmaf(res, res, e2);
+            big = fmaxf(big, fabsf(t[e]));
+            w |= (uint32_t)(v & 0xFF) << (8 * e);
+        }
+        *reinterpret_cast<uint32_t *>(q_i8 + (uint64_t)q * dim + d0) = w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+        big = fmaxf(big, __shfl_xor(big, off, 64));
+    }
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        q_n2i[q] = n2;
+        const float r = sqrtf(e2) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (big + maxabs + 127.0f * inv);
+        q_res[q] = (bad || !(r < INFINITY)) ? INFINITY : r;
+    }
+}
+hipError_t launch_quantize_queries_i8(const float *queries, uint32_t nq, uint32_t dim, float scale, const float *center,
+                                      float maxabs, void *q_i8, int *q_n2i, float *q_res, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_queries_i8_kernel, dim3(nq), dim3(64), 0, s, queries, dim, scale, center, maxabs,
+                       static_cast<int8_t *>(q_i8), q_n2i, q_res);
     return hipGetLastError();
 }
 
