@@ -859,3 +859,39 @@ def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier)
     assert (nc == onc).all() and (nf == onf).all()
     assert (_bits(dist) == _bits(odist)).all()
     assert (rows == orows).all()
+
+
+@pytest.mark.parametrize("case", ["huge_rows", "tiny_values", "constant", "signed_offset"])
+@pytest.mark.parametrize("dim", [256, 512])
+def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, case):
+    """int8 operands are images of (x - centre) * S with ONE global scale: a few enormous rows squeeze every other row
+    into the same few levels (the residual bounds then make the screen useless and everything is evaluated exactly,
+    overflowing the candidate buffers), tiny values are scaled up, a constant corpus has no range at all, and data far
+    from the origin relies on the centring.  Queries far outside the corpus range are clamped images with large
+    residuals.  Results must stay those of the oracle bit for bit."""
+    rng = np.random.default_rng(77 + dim)
+    n, kc, k, nprobe, nq = 14000, 5, 10, 3, 100
+    data = rng.random((n, dim), dtype=np.float32)
+    if case == "huge_rows":
+        data[rng.integers(0, n, 3)] = np.float32(1e15)
+    elif case == "tiny_values":
+        data *= np.float32(1e-3)
+    elif case == "constant":
+        data[:] = np.float32(0.37)
+        data[::2, 0] = np.float32(0.38)                  # two distinct rows so that k-means has something to split
+    else:
+        data = (data * np.float32(0.01) - np.float32(1000.0)).astype(np.float32)      # |x| ~ 1000, spread 0.01
+    queries = (data[rng.integers(0, n, nq)] * np.float32(1.0005)).astype(np.float32)
+    queries[:4] = queries[:4] * np.float32(1e6) + np.float32(3.0)                    # far outside the corpus range
+    oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=3)
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    assert "int8 screen operands" in s.describe(nq, k, nprobe)
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nc == onc).all() and (nf == onf).all()
+    assert (_bits(dist) == _bits(odist)).all()
+    _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+    if case != "constant":
+        assert (rows == orows).all()
