@@ -38,9 +38,11 @@ int fail(int code, const std::string &msg) {
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
-        if (_e != hipSuccess)                                                             \
+        if (_e != hipSuccess) {                                                           \
+            (void)hipGetLastError();   /* the runtime's sticky last-error must not leak into the next call */ \
             return fail(_e == hipErrorOutOfMemory ? PQV_ERR_OOM : PQV_ERR_HIP,            \
                         std::string(#expr) + ": " + hipGetErrorString(_e));              \
+        }                                                                                 \
     } while (0)
 
 // No C++ exception may cross the C ABI: every entry point runs its body through guard().
@@ -1250,8 +1252,8 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // a wave's fixed cost (staging the quad's queries, the last partial batch of exact evaluations) is
                 // about half its time at 1536 rows per 4-wave block, and the lists are cut into equal pieces, so
                 // longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 -> 6.35 ms);
-                // the 8-wave blocks take twice the rows for the same piece per wave
-                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256 : 2304ull * (p.block_waves / 4);
+                // the 8-wave blocks (one per CU) measured best at 3072 on C3 (2.60 -> 2.51 ms against 4608)
+                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256 : (p.block_waves == 8 ? 3072ull : 2304ull);
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
                 const uint64_t min_blocks = p.block_waves == 8 ? 1024 : 2048;
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
@@ -1409,7 +1411,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             // quad-to-XCD affinity: on by default for the global-query variant, whose per-quad operand copies
             // must stay L2-resident
             const bool q_global = !p.f16 && !p.i8 && static_cast<uint64_t>(p.quad_width) * s->dim * sizeof(float) > 32768;
-            ta.xcd_swizzle = s->opt.quad_xcd >= 0 ? s->opt.quad_xcd : (q_global ? 1 : 0);
+            // (8-wave blocks: the quads of one cluster on one XCD, so a list's second pass finds rows in that L2: C3 2.51 -> 2.44 ms)
+            ta.xcd_swizzle = s->opt.quad_xcd >= 0 ? s->opt.quad_xcd : (q_global ? 1 : p.block_waves == 8 ? 2 : 0);
             if (q_global) {
                 // rows too long to stage a quad's queries in LDS: blocked copy per quad in global memory
                 HIP_TRY(sc.s_qblk.ensure(static_cast<size_t>(p.max_quads) * p.quad_width * s->dim * sizeof(float)));

@@ -17,6 +17,7 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 #include <math.h>
@@ -1720,28 +1721,45 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 
     // lane-parallel per-query state: slot s, lane l own query 64 s + l of the quad (queries past cnt alias the
     // last one; they are masked wherever it matters)
-    uint32_t my_pair[QS], my_qrow[QS];
-    uint64_t my_cbase[QS], my_lkth[QS], my_base[QS];
-    float my_qn[QS];
-    bool my_noskip[QS];
-    [[maybe_unused]] int my_qn2i[QS];          // I8: |qi|^2 and the residual norm of the query image
-    [[maybe_unused]] float my_qres[QS];
+    // The 8-wave blocks keep the per-query CONSTANTS (candidate base, norms, int8 terms) in LDS, written once by
+    // every wave with the same values: in registers they were the first thing the allocator spilled, and a spill
+    // reload is a VMEM load -- consuming it drains the wave's whole queue of prefetched operands (vmcnt(0)) at the
+    // top of every tile.  LDS reads count on lgkmcnt and leave the operand stream alone.
+    constexpr bool LST = NW == 8;
+    __shared__ uint64_t qst_cbase[LST ? NQ : 1];
+    __shared__ uint32_t qst_pair[LST ? NQ : 1];
+    __shared__ float qst_qn[LST ? NQ : 1];            // |q|^2; NaN = never skip this query (float operand forms)
+    __shared__ float qst_res[LST ? NQ : 1];           // int8: residual bound (+inf = never skip)
+    __shared__ int qst_n2i[LST ? NQ : 1];             // int8: |qi|^2
+    uint32_t my_qrow[QS];
+    uint64_t my_lkth[QS];
+    [[maybe_unused]] uint32_t my_pair[LST ? 1 : QS];
+    [[maybe_unused]] uint64_t my_cbase[LST ? 1 : QS], my_base[LST ? 1 : QS];
+    [[maybe_unused]] float my_qn[LST ? 1 : QS];
+    [[maybe_unused]] bool my_noskip[LST ? 1 : QS];
     const uint32_t n_part = a.n_part;
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
         const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-        my_pair[s] = a.pairs[p0 + (qi < cnt ? qi : cnt - 1)];
-        my_qrow[s] = my_pair[s] / a.nprobe;
-        my_cbase[s] = a.cand_base[my_pair[s]];
-        my_qn[s] = a.query_norm2[my_qrow[s]];
+        const uint32_t pair = a.pairs[p0 + (qi < cnt ? qi : cnt - 1)];
+        my_qrow[s] = pair / a.nprobe;
         my_lkth[s] = KEY_EMPTY;
-        my_base[s] = ((uint64_t)my_qrow[s] * n_part + (my_pair[s] % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
+        const float qn = a.query_norm2[my_qrow[s]];
         // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
-        my_noskip[s] = F16 && (!(a.query_maxabs[my_qrow[s]] * a.scale <= 32768.0f) || !(my_qn[s] * a.scale2 >= 1.0f) || !(my_qn[s] <= 3.0e38f));
-        if constexpr (I8) {
-            my_qn2i[s] = a.q_n2i[my_qrow[s]];
-            my_qres[s] = a.q_res[my_qrow[s]];
-            my_noskip[s] = !(my_qres[s] <= 3.0e38f);       // a query with non-finite components is never skipped
+        const bool noskip = F16 && (!(a.query_maxabs[my_qrow[s]] * a.scale <= 32768.0f) || !(qn * a.scale2 >= 1.0f) || !(qn <= 3.0e38f));
+        if constexpr (LST) {
+            if (qi < NQ) {
+                qst_pair[qi] = pair;
+                qst_cbase[qi] = a.cand_base[pair];
+                qst_qn[qi] = noskip ? __uint_as_float(0x7FC00000u) : qn;
+                if constexpr (I8) { qst_n2i[qi] = a.q_n2i[my_qrow[s]]; qst_res[qi] = a.q_res[my_qrow[s]]; }   // +inf: non-finite query
+            }
+        } else {
+            my_pair[s] = pair;
+            my_cbase[s] = a.cand_base[pair];
+            my_qn[s] = qn;
+            my_base[s] = ((uint64_t)my_qrow[s] * n_part + (pair % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
+            my_noskip[s] = noskip;
         }
     }
 
@@ -1791,7 +1809,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint32_t npend = 0;
     uint32_t n_exact = 0;
 #ifdef PQV_PROFILE_PHASES
-    uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
+    uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0, ph_top_sum = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
     uint64_t cur_gthr[QS];
@@ -1875,7 +1893,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         uint64_t my_thr[QS];
 #pragma unroll
         for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
-        const uint64_t pos = qsel_u64<QS>(my_cbase, qsl) + roff;
+        uint64_t pos;
+        if constexpr (LST) pos = qst_cbase[qsl] + roff; else pos = qsel_u64<QS>(my_cbase, qsl) + roff;
         const uint64_t mykey_all =
             (have && pos < a.max_pos) ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
         // A pair that beats its query's threshold is APPENDED to the query's candidate buffer: one
@@ -1948,7 +1967,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const uint64_t mykey = mine ? mykey_all : KEY_EMPTY;
             const uint64_t thr = qread_u64<QS>(my_thr, qq);
             if (__ballot(mykey < thr) != 0ull) {
-                const uint64_t base = qread_u64<QS>(my_base, qq);
+                uint64_t base;
+                if constexpr (LST) base = ((uint64_t)qread_u32<QS>(my_qrow, qq) * n_part + (qst_pair[qq] % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
+                else base = qread_u64<QS>(my_base, qq);
                 const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
                                                  a.gthr + qread_u32<QS>(my_qrow, qq),
                                                  qread_u64<QS>(cur_gthr, qq), qread_u64<QS>(my_lkth, qq),
@@ -2007,6 +2028,46 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint64_t gthr_next[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) gthr_next[s] = cur_gthr[s];
+    // B-operand registers of the K loop (two ping-pong stages).  They persist across tiles: the loads of a tile's
+    // first two K steps are issued behind the LAST MFMAs of the previous tile, so they fly during its screen /
+    // expansion / exact evaluations instead of opening the K loop with a full memory round trip.
+#ifndef PQV_NS_WIDE
+#define PQV_NS_WIDE 2
+#endif
+#ifndef PQV_XT
+#define PQV_XT 1
+#endif
+#ifndef PQV_XPF
+#define PQV_XPF 1
+#endif
+    constexpr int NS = (OP != OP_F32 && QLDS && !PF && NG <= 6 && NW == 8) ? PQV_NS_WIDE : 2;      // operand stages in flight
+    constexpr bool XPF = PQV_XPF;          // the next tile's first stages are requested before this tile's screen
+    float4 xs[NS][4];
+    auto tile_desc = [&](uint64_t tn, uint32_t (&so)[4]) {
+        const float4 *b0 = nullptr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint64_t T = blk0 + ((tn + 16 * t) >> 4);
+            if (T > blk_last) T = blk_last;             // tiles past the list's end: masked by the screen
+            const float4 *b = a.mat_blk + T * G * 16;
+            if (t == 0) b0 = b;
+            so[t] = (uint32_t)((b - b0) * 16);
+        }
+        return operand_rsrc(b0);
+    };
+    // (f32 operands keep the per-tile form: their kernels are built for three waves per SIMD and have no registers
+    //  to carry two operand stages through the exact evaluations)
+    constexpr bool XT = PQV_XT && QLDS && !PF && OP != OP_F32;
+    if constexpr (XT && XPF) {
+        if (r0 < r1) {
+            uint32_t so[4];
+            const __amdgpu_buffer_rsrc_t r = tile_desc(r0, so);
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(r, lane_b, so[t] + j * 1024);
+        }
+    }
     [[maybe_unused]] int xn2i_next[4] = {0, 0, 0, 0};
     [[maybe_unused]] float xres_next[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (I8) {
@@ -2022,6 +2083,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
     }
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+#ifdef PQV_PROFILE_PHASES
+        const uint64_t ph_top = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
         // 16-byte column ch, row j of the tile at float4 index (T * G + ch) * 16 + j -- the 64 lanes
@@ -2045,17 +2109,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         if constexpr (I8) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { xn2i[t] = xn2i_next[t]; xres[t] = xres_next[t]; }
-            const uint64_t tn = t0 + 64;
-            if (tn < r1) {
-                const uint32_t nv = (r1 - tn < 64) ? (uint32_t)(r1 - tn) : 64u;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint32_t rr = (uint32_t)(16 * t + l15);
-                    if (rr >= nv) rr = nv - 1;
-                    xn2i_next[t] = a.row_n2i[lbeg + tn + rr];
-                    xres_next[t] = a.row_res[lbeg + tn + rr];
-                }
-            }
         }
         // one descriptor per tile (base = its first 16-row sub-tile); the other sub-tiles and the K steps
         // are scalar byte offsets (< 1 MiB)
@@ -2064,11 +2117,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
         for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
         uint64_t my_thr[QS];
+        if constexpr (!XT) {
 #pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            cur_gthr[s] = gthr_next[s];
-            gthr_next[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+            for (int s = 0; s < QS; ++s) {
+                cur_gthr[s] = gthr_next[s];
+                gthr_next[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+            }
         }
 
         using acc_t = std::conditional_t<I8, i32x4_acc, f32x4_acc>;
@@ -2078,41 +2133,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             // scale, xi / qi the int8 images, |e_x| <= rx and |e_q| <= rq stored upper bounds of the residual norms), so
             //     |q - x| >= |qi - xi| / S - rq - rx        (triangle inequality; |qi - xi|^2 = Nq + Nx - 2 qi.xi EXACTLY)
             // and a pair whose reference distance could still pass the threshold thr has
-            //     |qi - xi| <= S (sqrt(thr (1 + c)) + rq + rx)  =>  Nq + Nx - 2 dot <= Tq2 + bx,
-            //     Tq2 = S^2 tq^2, tq = sqrt(thr (1 + c)) + rq,  bx = S^2 (2 U rx + rx^2), U >= every tq of the quad.
-            // skip  <=>  dot + ceil((bx - Nx) / 2) + ceil((Tq2 - Nq) / 2) < 0: the row term is the accumulator's START
-            // value, the query term one integer add per pair, the sign bit the answer.  All roundings go up (never skip
-            // wrongly); the contraction itself is exact.
-            float tq[QS], U = 0.0f;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
-                const bool open = my_noskip[s] || my_thr[s] == KEY_EMPTY || !(thr_d <= 3.0e38f);
-                tq[s] = open ? -1.0f : sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + my_qres[s];
-                if (qi < cnt && !open) U = fmaxf(U, tq[s]);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) U = fmaxf(U, __shfl_xor(U, off, 64));
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-                int a2 = 1 << 29;                              // never skip
-                if (qi >= cnt) a2 = -(1 << 30);                // not a query of this quad: always "skipped"
-                else if (tq[s] >= 0.0f) {
-                    const float v = a.scale * tq[s];
-                    const float v2 = fminf(v * v * 1.000002f, 1.0e9f);
-                    a2 = ((int)ceilf(v2) + 1 - my_qn2i[s] + 1) >> 1;
-                }
-                if (qi < NQ) reinterpret_cast<int *>(aq)[qi] = a2;
-            }
-            wave_lds_fence();
-            const float s2 = a.scale * a.scale;
+            //     |qi - xi| <= S (sqrt(thr (1 + c)) + rq + R),  R = the largest rx of the tile's rows
+            //     =>  Nq + Nx - 2 dot <= T2 = S^2 (sqrt(thr (1 + c)) + rq + R)^2.
+            // skip  <=>  dot + ceil(-Nx / 2) + ceil((T2 - Nq) / 2) < 0: the row term is the accumulator's START value
+            // (known before the K loop, no threshold in it), the query term one integer add per pair after the loop,
+            // the sign bit the answer.  All roundings go up (never skip wrongly); the contraction itself is exact.
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float bx = s2 * (2.0f * U * xres[t] + xres[t] * xres[t]) * 1.000002f;
-                const int init = ((int)ceilf(fminf(bx, 1.0e9f)) + 1 - xn2i[t] + 1) >> 1;
+                const int init = -(xn2i[t] >> 1);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) acc[g][t] = (i32x4_acc){init, init, init, init};
             }
@@ -2124,15 +2152,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
 
 #ifdef PQV_PROFILE_PHASES
-        const uint64_t ph_a = __builtin_amdgcn_s_memtime();
+        const uint64_t ph_a = __builtin_amdgcn_s_memtime(); ph_top_sum += ph_a - ph_top;
 #endif
         // K loop, two 16-dim steps per iteration with ping-pong operand registers: the loads of the
         // next step are in flight behind the 16 NG MFMAs of the current one.  Full quads (all NG
         // groups active) run a branch-free body, so the compiler's wait counts stay exact (with the
         // per-group branches it falls back to vmcnt(0) in front of every MFMA group, which serialises
         // the prefetch).
-        float4 xa[4], xb[4];
-        const uint32_t nks = G >> 2;          // K steps (4 operand columns = 1 KiB per 16-row sub-tile each)
+        const uint32_t nks = G >> 2;          // K steps (4 operand columns = 1 KiB per 16-row sub-tile each): a multiple of 4
         auto mma = [&](const float4 (&x)[4], uint32_t ks, auto full) {
             const uint32_t chq = ks * 4 + (uint32_t)kk;
 #pragma unroll
@@ -2145,21 +2172,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             }
         };
         auto kloop = [&](auto full) {
+            if constexpr (!(XT && XPF)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t]);
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(xr, lane_b, xso[t] + j * 1024);
+            }
+            // on entry xs[j] holds (or awaits) K step j of this tile; nks is a multiple of 4 >= NS
             uint32_t ks = 0;
-            for (; ks + 2 < nks; ks += 2) {
+            for (; ks + NS < nks; ks += NS) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 1) * 1024);
-                mma(xa, ks, full);
+                for (int j = 0; j < NS; ++j) {
+                    mma(xs[j], ks + j, full);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xa[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 2) * 1024);
-                mma(xb, ks + 1, full);
+                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(xr, lane_b, xso[t] + (ks + j + NS) * 1024);
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xb[t] = buf_ld16(xr, lane_b, xso[t] + (ks + 1) * 1024);
-            mma(xa, ks, full);
-            mma(xb, ks + 1, full);
+            for (int j = 0; j < NS; ++j) mma(xs[j], ks + j, full);
         };
         // !QLDS: both operands stream from global memory through THREE rotating register stages, so the
         // loads of K step s + 2 are issued before the MFMAs of step s (HBM latency is ~2 K steps of a
@@ -2203,6 +2233,42 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
         else if (ng == (uint32_t)NG) kloop(std::true_type{});
         else kloop(std::false_type{});
+        if constexpr (XT) {
+            // Between the K loops NOTHING this wave loads may be consumed while operand prefetches are in flight: loads
+            // return in order, so waiting for a fresh one drains the whole queue (and a register the allocator spills
+            // right after its load does exactly that).  Hence, in this order: (1) the thresholds of this tile's screen
+            // and the next tile's row terms are requested and waited for while the queue is empty anyway -- an L2 round
+            // trip, and the thresholds are as fresh as they can be; (2) only then the next tile's first operand stages
+            // go out, to fly during the screen, the expansion and the exact evaluations.
+#pragma unroll
+            for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t tn = t0 + 64;
+            if constexpr (I8) {
+                if (tn < r1) {
+                    const uint32_t nv = (r1 - tn < 64) ? (uint32_t)(r1 - tn) : 64u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        uint32_t rr = (uint32_t)(16 * t + l15);
+                        if (rr >= nv) rr = nv - 1;
+                        xn2i_next[t] = a.row_n2i[lbeg + tn + rr];
+                        xres_next[t] = a.row_res[lbeg + tn + rr];
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
+            __builtin_amdgcn_sched_barrier(0);
+            if (XPF && tn < r1) {
+                uint32_t nso[4];
+                const __amdgpu_buffer_rsrc_t nxr = tile_desc(tn, nso);
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(nxr, lane_b, nso[t] + j * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a;
@@ -2223,14 +2289,41 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         for (int t = 0; t < 4; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
-        if constexpr (!I8) {
+        if constexpr (I8) {
+            float R = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) R = fmaxf(R, (uint32_t)(16 * t + l15) < nvalid ? xres[t] : 0.0f);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) R = fmaxf(R, __shfl_xor(R, off, 64));
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
+                const float qres = qst_res[qi < NQ ? qi : 0];
+                const bool open = !(qres <= 3.0e38f) || my_thr[s] == KEY_EMPTY || !(thr_d <= 3.0e38f);
+                int a2 = 1 << 29;                              // never skip
+                if (qi >= cnt) a2 = -(1 << 30);                // not a query of this quad: always "skipped"
+                else if (!open) {
+                    const float v = a.scale * (sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + qres + R);
+                    const float v2 = fminf(v * v * 1.000002f, 1.0e9f);
+                    a2 = ((int)ceilf(v2) + 1 - qst_n2i[qi < NQ ? qi : 0] + 1) >> 1;
+                }
+                if (qi < NQ) reinterpret_cast<int *>(aq)[qi] = a2;
+            }
+            wave_lds_fence();
+        } else {
             wave_lds_fence();
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
                 const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
                 // threshold DISTANCE of this lane's query; KEY_EMPTY: "cannot skip"
                 const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
-                if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (my_noskip[s] || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * my_qn[s] - beta * thr_d;
+                float qn;
+                bool noskip;
+                if constexpr (LST) { qn = qst_qn[qi < NQ ? qi : 0]; noskip = !(qn == qn); }
+                else { qn = my_qn[s]; noskip = my_noskip[s]; }
+                if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (noskip || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * qn - beta * thr_d;
             }
             wave_lds_fence();
         }
@@ -2403,7 +2496,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const unsigned long long wid = atomicAdd(&a.stats[6], 1ull);
             if (wid < 65536ull) {
                 unsigned long long *rec = a.stats + 8 + 8 * wid;
-                rec[0] = ph_t0; rec[1] = ph_pro; rec[2] = ph_k; rec[3] = ph_s - ph_e; rec[4] = ph_e;
+                rec[0] = ph_t0; rec[1] = ph_pro | (ph_top_sum << 24); rec[2] = ph_k; rec[3] = ph_s - ph_e; rec[4] = ph_e;
                 rec[5] = __builtin_amdgcn_s_memtime(); rec[6] = ph_em; rec[7] = cnt | ((unsigned long long)n_exact << 32);
             }
         }
@@ -2456,9 +2549,13 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false>
 static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
     auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF>;
-    if (lds > 65536) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
-        if (attr != hipSuccess) return attr;
+    if (lds > 65536) {          // raise the kernel's dynamic-LDS ceiling to what this launch needs (static + dynamic <= 160 KB)
+        static std::atomic<size_t> allowed{65536};
+        if (lds > allowed.load(std::memory_order_relaxed)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+            allowed.store(lds, std::memory_order_relaxed);
+        }
     }
     hipLaunchKernelGGL(kern, dim3(a.grid_x, a.max_quads), dim3(64 * NW), lds, s, a);
     return hipGetLastError();

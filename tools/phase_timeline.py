@@ -1,10 +1,11 @@
 import numpy as np, sys
 r = np.fromfile(sys.argv[1], dtype=np.uint64)
 n = int(min(r[6], 65536)); rec = r[8:8+8*n].reshape(n, 8).astype(np.int64)
+top = rec[:,1] >> 24; rec[:,1] &= (1 << 24) - 1
 t0 = rec[:,0].min(); start = rec[:,0]-t0; end = rec[:,5]-t0
 dur = end-start
 print("waves", n, "span", end.max(), "ticks")
-print("mean dur", dur.mean(), "prologue", rec[:,1].mean(), "kloop", rec[:,2].mean(), "screen", rec[:,3].mean(), "drain", rec[:,4].mean(), "other", (dur-rec[:,1]-rec[:,2]-rec[:,3]-rec[:,4]).mean())
+print("mean dur", dur.mean(), "prologue", rec[:,1].mean(), "kloop", rec[:,2].mean(), "screen", rec[:,3].mean(), "drain", rec[:,4].mean(), "tile-top", top.mean(), "other", (dur-rec[:,1]-rec[:,2]-rec[:,3]-rec[:,4]-top).mean())
 full = (rec[:,7] & 0xffffffff) == 64
 em = rec[:,6] & ((1 << 48) - 1); ne = rec[:,6] >> 48
 print("eval calls/wave", ne.mean(), "eval distance part", em.mean(), "eval tail", (rec[:,4]-em).mean(), "pairs/wave", (rec[:,7]>>32).mean())
