@@ -208,6 +208,15 @@ int pqv_topk_device(const pqv_searcher *searcher, const void *d_queries, uint32_
                     int sqrt_out, void *d_row_idx, void *d_dist, void *d_n_found,
                     void *d_n_candidates, void *hip_stream);
 
+/* The same, plus d_tie_flags (device u32 [nq]): 1 for every query two of whose k results (or the k-th and the
+ * runner-up) have EQUAL output distance -- exactly the queries for which the reference's survivors / order depend on
+ * BinaryHeap history (src/ivf/search.rs:113-140) and pqv_topk_device's (d2, position) order may differ from it.
+ * Everything stays asynchronous; a caller that needs the reference's answer under ties re-submits the flagged
+ * queries to pqv_topk, which replays the heap exactly.  (The kernels then work with k + 1 entries: k <= 1023.) */
+int pqv_topk_device_flags(const pqv_searcher *searcher, const void *d_queries, uint32_t nq, uint32_t k,
+                          uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out, void *d_row_idx,
+                          void *d_dist, void *d_n_found, void *d_n_candidates, void *d_tie_flags, void *hip_stream);
+
 /* Exhaustive top-k of nq queries over EVERY row of the resident column (no index), batched
  * on the matrix cores: what DataFusion's brute-force `ORDER BY array_distance(..) LIMIT k`
  * baseline does row by row (benches/query.rs:76-98), for the metrics above.  Results are
@@ -247,6 +256,21 @@ int pqv_merge_topk_device(int device, const void *d_dist, const void *d_rows, co
 int pqv_merge_topk_packed_device(int device, const void *d_pairs, const void *d_row_base, uint32_t n_lists,
                                  uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream);
 
+/* CandidateCursor (src/df_vector/access.rs:193-243; used at src/df_vector/exec.rs:224-231): when a query over a
+ * multi-file table carries max_candidates, candidates are taken round-robin across the files -- one per file and
+ * turn, each file's own list in probe-rank order -- until the cap; the round-robin position persists between
+ * batches.  Host-side integer logic (no device needed).  A file's share of a batch is always the next PREFIX of its
+ * list, so per_file_taken (optional, [file_count], cumulative) is what to pass as pqv_topk's max_candidates for
+ * that file's searcher.
+ *   add:        replaces file idx's candidate list (rows are copied); idx >= file_count is ignored like the reference
+ *   next_batch: out_file / out_row have room for batch_size entries; *n_out receives the count */
+typedef struct pqv_candidate_cursor pqv_candidate_cursor;
+int  pqv_candidate_cursor_new(uint32_t file_count, pqv_candidate_cursor **out);
+int  pqv_candidate_cursor_add(pqv_candidate_cursor *cursor, uint32_t idx, const uint32_t *rows, uint64_t n_rows);
+int  pqv_candidate_cursor_next_batch(pqv_candidate_cursor *cursor, uint64_t batch_size, uint32_t *out_file,
+                                     uint32_t *out_row, uint64_t *n_out, uint64_t *per_file_taken);
+void pqv_candidate_cursor_free(pqv_candidate_cursor *cursor);
+
 /* Counters mirroring the reference's plan metrics (src/df_vector/index_exec.rs:289-299,
  * src/df_vector/exec.rs:411-427), accumulated per searcher since creation. */
 typedef struct pqv_counters_t {
@@ -259,6 +283,15 @@ typedef struct pqv_counters_t {
     uint64_t screen_survivors;   /* ... of which were evaluated exactly                   */
 } pqv_counters_t;
 int pqv_counters(const pqv_searcher *searcher, pqv_counters_t *out);
+
+/* Diagnostic: the library's own restatement of rand 0.8.5's StdRng (ChaCha12) and seq::index::sample, which draw
+ * every seeded choice of the index build (src/ivf/index.rs:231-232,327,337,340,373,385).  Exposed so that tests can
+ * pin it to rand's published value-stability vectors and cross-check it against the CPU oracle's independent C
+ * restatement.  seed32 != NULL: StdRng::from_seed(seed32), else StdRng::seed_from_u64(seed64).
+ *   mode 0: out[i] = next_u64()            mode 1: out[i] = next_u32()
+ *   mode 2: out[i] = gen_range(0..arg) usize                mode 3: out[i] = bits of gen_range(0.0f32..1.0)
+ *   mode 4: out[0..n) = index::sample(rng, length = arg, amount = n) */
+int pqv_diag_rng(const uint8_t *seed32, uint64_t seed64, int mode, uint64_t arg, uint64_t *out, uint64_t n);
 
 /* Kernel timing for bench.py's roofline line.  While enabled, every pqv_topk /
  * pqv_topk_device call records HIP events on the stream its kernels run on: around the

@@ -309,6 +309,39 @@ class IndexBuilder:
 
 
 # ---------------------------------------------------------------------------------------
+class CandidateCursor:
+    """src/df_vector/access.rs:193-243: round-robin over per-file candidate lists until a cap."""
+
+    def __init__(self, file_count):
+        h = vp()
+        _check(_ffi.lib().pqv_candidate_cursor_new(file_count, C.byref(h)))
+        self._h = h
+        self.file_count = file_count
+
+    def add_candidates(self, idx, rows):
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        _check(_ffi.lib().pqv_candidate_cursor_add(self._h, idx, r.ctypes.data_as(u32p), r.size))
+
+    def next_batch(self, batch_size):
+        """Returns ([(file_idx, row), ...], cumulative rows taken per file)."""
+        of = np.zeros(max(1, batch_size), dtype=np.uint32)
+        orow = np.zeros(max(1, batch_size), dtype=np.uint32)
+        n = C.c_uint64(0)
+        taken = np.zeros(max(1, self.file_count), dtype=np.uint64)
+        _check(_ffi.lib().pqv_candidate_cursor_next_batch(self._h, batch_size, of.ctypes.data_as(u32p), orow.ctypes.data_as(u32p),
+                                                         C.byref(n), taken.ctypes.data_as(u64p)))
+        return list(zip(of[:n.value].tolist(), orow[:n.value].tolist())), taken[:self.file_count].copy()
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().pqv_candidate_cursor_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------
 @dataclass
 class SearchResult:
     """src/ivf/search.rs:41-45"""
@@ -364,8 +397,15 @@ class Searcher:
         return rows, dist, nf, nc
 
     def topk_device(self, d_queries, nq, k, nprobe, d_row_idx, d_dist, d_n_found=0, d_n_candidates=0,
-                    max_candidates=0, metric=_ffi.PQV_L2SQ_REF4, sqrt_out=True, stream=0):
-        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on `stream`."""
+                    max_candidates=0, metric=_ffi.PQV_L2SQ_REF4, sqrt_out=True, stream=0, d_tie_flags=0):
+        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on `stream`.  d_tie_flags (u32 [nq]):
+        also flag the queries whose answer depends on the reference's heap history (re-submit those to topk())."""
+        if d_tie_flags:
+            _check(_ffi.lib().pqv_topk_device_flags(self._h, vp(d_queries), nq, k, nprobe, max_candidates, metric,
+                                                    1 if sqrt_out else 0, vp(d_row_idx), vp(d_dist),
+                                                    vp(d_n_found or None), vp(d_n_candidates or None), vp(d_tie_flags),
+                                                    vp(stream or None)))
+            return
         _check(_ffi.lib().pqv_topk_device(self._h, vp(d_queries), nq, k, nprobe, max_candidates, metric,
                                           1 if sqrt_out else 0, vp(d_row_idx), vp(d_dist),
                                           vp(d_n_found or None), vp(d_n_candidates or None),

@@ -262,6 +262,27 @@ extern "C" int pqv_device_count(void) {
 
 extern "C" int pqv_abi_version(void) { return 101; }
 
+extern "C" int pqv_diag_rng(const uint8_t *seed32, uint64_t seed64, int mode, uint64_t arg, uint64_t *out, uint64_t n) {
+    return guard([&] {
+        if (!out && n) return fail(PQV_ERR_INVALID, "out must not be NULL");
+        pqv::StdRng rng = seed32 ? pqv::StdRng::from_seed(seed32) : pqv::StdRng::seed_from_u64(seed64);
+        if (mode == 4) {
+            if (n > arg) return fail(PQV_ERR_INVALID, "amount exceeds length");
+            const std::vector<uint64_t> s = pqv::index_sample(rng, arg, n);
+            for (uint64_t i = 0; i < n; ++i) out[i] = s[i];
+            return static_cast<int>(PQV_OK);
+        }
+        for (uint64_t i = 0; i < n; ++i) {
+            if (mode == 0) out[i] = rng.next_u64();
+            else if (mode == 1) out[i] = rng.next_u32();
+            else if (mode == 2) out[i] = rng.range_usize(0, arg);
+            else if (mode == 3) { const float f = rng.unit_f32(); uint32_t b; std::memcpy(&b, &f, 4); out[i] = b; }
+            else return fail(PQV_ERR_INVALID, "unknown mode");
+        }
+        return static_cast<int>(PQV_OK);
+    });
+}
+
 // ---------------------------------------------------------------------------------------
 // corpus
 // ---------------------------------------------------------------------------------------
@@ -1616,8 +1637,9 @@ int replay_query_exact(const pqv_searcher *s, Scratch &sc, const float *d_query,
 static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
                                uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                                void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
-                               void *hip_stream) {
+                               void *d_tie_flags, void *hip_stream) {
     if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
+    if (d_tie_flags && k > 1023) return fail(PQV_ERR_UNSUPPORTED, "tie flags need a runner-up entry: k <= 1023");
     if (nq == 0) return PQV_OK;
     if (!d_queries || !d_row_idx || !d_dist) return fail(PQV_ERR_INVALID, "device pointers must not be NULL");
     if (int rc = use_device(s->device)) return rc;
@@ -1625,10 +1647,11 @@ static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, ui
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, stream, &lane)) return rc;
-    const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, k, k, nprobe, max_candidates,
+    // with flags the kernels carry one extra merged entry (the runner-up), exactly as pqv_topk does
+    const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, d_tie_flags ? k + 1 : k, k, nprobe, max_candidates,
                                 metric, sqrt_out, static_cast<uint32_t *>(d_row_idx),
                                 static_cast<float *>(d_dist), static_cast<uint32_t *>(d_n_found),
-                                static_cast<uint64_t *>(d_n_candidates), nullptr, stream, *lane);
+                                static_cast<uint64_t *>(d_n_candidates), static_cast<uint32_t *>(d_tie_flags), stream, *lane);
     if (rc == PQV_OK) s->counters.queries += nq;
     return rc;
 }
@@ -1636,7 +1659,14 @@ extern "C" int pqv_topk_device(const pqv_searcher *s, const void *d_queries, uin
                                uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
                                void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
                                void *hip_stream) {
-    return guard([&] { return pqv_topk_device_impl(s, d_queries, nq, k, nprobe, max_candidates, metric, sqrt_out, d_row_idx, d_dist, d_n_found, d_n_candidates, hip_stream); });
+    return guard([&] { return pqv_topk_device_impl(s, d_queries, nq, k, nprobe, max_candidates, metric, sqrt_out, d_row_idx, d_dist, d_n_found, d_n_candidates, nullptr, hip_stream); });
+}
+extern "C" int pqv_topk_device_flags(const pqv_searcher *s, const void *d_queries, uint32_t nq, uint32_t k,
+                                     uint32_t nprobe, uint64_t max_candidates, int metric, int sqrt_out,
+                                     void *d_row_idx, void *d_dist, void *d_n_found, void *d_n_candidates,
+                                     void *d_tie_flags, void *hip_stream) {
+    if (!d_tie_flags) return fail(PQV_ERR_INVALID, "d_tie_flags must not be NULL");
+    return guard([&] { return pqv_topk_device_impl(s, d_queries, nq, k, nprobe, max_candidates, metric, sqrt_out, d_row_idx, d_dist, d_n_found, d_n_candidates, d_tie_flags, hip_stream); });
 }
 
 static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t nq, uint32_t query_len,
@@ -2165,6 +2195,64 @@ extern "C" int pqv_merge_topk_packed_device(int device, const void *d_pairs, con
     return guard([&] { return pqv_merge_topk_packed_device_impl(device, d_pairs, d_row_base, n_lists, nq, k, d_out_dist,
                                                                 d_out_rows, hip_stream); });
 }
+
+// ---------------------------------------------------------------------------------------
+// CandidateCursor (src/df_vector/access.rs:193-243)
+// ---------------------------------------------------------------------------------------
+struct pqv_candidate_cursor {
+    std::vector<std::vector<uint32_t>> candidates;
+    std::vector<uint64_t> positions;
+    uint64_t round_robin = 0;
+};
+extern "C" int pqv_candidate_cursor_new(uint32_t file_count, pqv_candidate_cursor **out) {
+    return guard([&] {
+        if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+        pqv_candidate_cursor *c = new pqv_candidate_cursor();
+        c->candidates.resize(file_count);                                              // :202-206
+        c->positions.assign(file_count, 0);
+        *out = c;
+        return static_cast<int>(PQV_OK);
+    });
+}
+extern "C" int pqv_candidate_cursor_add(pqv_candidate_cursor *c, uint32_t idx, const uint32_t *rows, uint64_t n_rows) {
+    return guard([&] {
+        if (!c || (n_rows && !rows)) return fail(PQV_ERR_INVALID, "cursor/rows must not be NULL");
+        if (idx < c->candidates.size()) c->candidates[idx].assign(rows, rows + n_rows);  // :209-213 (out of range: ignored)
+        return static_cast<int>(PQV_OK);
+    });
+}
+extern "C" int pqv_candidate_cursor_next_batch(pqv_candidate_cursor *c, uint64_t batch_size, uint32_t *out_file,
+                                               uint32_t *out_row, uint64_t *n_out, uint64_t *per_file_taken) {
+    return guard([&] {
+        if (!c || !n_out || (batch_size && (!out_file || !out_row))) return fail(PQV_ERR_INVALID, "cursor/outputs must not be NULL");
+        *n_out = 0;
+        const uint64_t file_count = c->candidates.size();
+        uint64_t n = 0;
+        if (batch_size != 0 && file_count != 0) {                                      // :216-218
+            uint64_t idx = c->round_robin;
+            while (n < batch_size) {                                                   // :222-238
+                bool progressed = false;
+                for (uint64_t t = 0; t < file_count; ++t) {
+                    const uint64_t f = idx % file_count;
+                    idx += 1;
+                    if (c->positions[f] < c->candidates[f].size()) {
+                        out_file[n] = static_cast<uint32_t>(f);
+                        out_row[n] = c->candidates[f][c->positions[f]++];
+                        ++n;
+                        progressed = true;
+                        if (n >= batch_size) break;
+                    }
+                }
+                if (!progressed) break;
+            }
+            c->round_robin = idx % file_count;                                         // :240
+        }
+        *n_out = n;
+        if (per_file_taken) for (uint64_t f = 0; f < file_count; ++f) per_file_taken[f] = c->positions[f];
+        return static_cast<int>(PQV_OK);
+    });
+}
+extern "C" void pqv_candidate_cursor_free(pqv_candidate_cursor *c) { delete c; }
 
 // ---------------------------------------------------------------------------------------
 // batch-granular re-rank (update_topk_heap, src/df_vector/exec.rs:457-484)

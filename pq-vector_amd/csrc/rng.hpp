@@ -28,6 +28,15 @@ public:
         return r;
     }
 
+    // SeedableRng::from_seed: the 32 bytes are the ChaCha key, little-endian words
+    static StdRng from_seed(const uint8_t seed[32]) {
+        StdRng r;
+        for (int w = 0; w < 8; ++w)
+            r.key_[w] = static_cast<uint32_t>(seed[4 * w]) | (static_cast<uint32_t>(seed[4 * w + 1]) << 8) |
+                        (static_cast<uint32_t>(seed[4 * w + 2]) << 16) | (static_cast<uint32_t>(seed[4 * w + 3]) << 24);
+        return r;
+    }
+
     uint32_t next_u32() {
         if (pos_ >= kBuf) { refill(); pos_ = 0; }
         return buf_[pos_++];

@@ -134,3 +134,45 @@ def test_product_does_not_link_or_import_the_oracle():
     if os.path.exists(so):
         out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
         assert "oracle" not in out
+
+
+def test_candidate_cursor_matches_reference_semantics_and_oracle(oracle):
+    """pqv_candidate_cursor_* (host-side, no device): src/df_vector/access.rs:214-242 -- the reference-derived cases of
+    tests/test_oracle_golden.py plus random lists against the oracle's restatement, including the round-robin position
+    carried across batches (the oracle takes one batch, so successive product batches must concatenate to it)."""
+    import numpy as np
+    import pq_vector_amd as pqv
+    c = pqv.CandidateCursor(3)
+    for i, l in enumerate([[10, 11, 12], [20], [30, 31]]):
+        c.add_candidates(i, l)
+    got, taken = c.next_batch(5)
+    assert got == [(0, 10), (1, 20), (2, 30), (0, 11), (2, 31)] and taken.tolist() == [2, 1, 2]
+    got, taken = c.next_batch(5)
+    assert got == [(0, 12)] and taken.tolist() == [3, 1, 2]
+    assert c.next_batch(0)[0] == [] and pqv.CandidateCursor(0).next_batch(4)[0] == []
+    c = pqv.CandidateCursor(2)
+    c.add_candidates(0, [1]); c.add_candidates(5, [9, 9])          # out-of-range index: ignored (access.rs:210)
+    assert c.next_batch(10)[0] == [(0, 1)]
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        nf = int(rng.integers(1, 7))
+        lists = [rng.integers(0, 1 << 32, size=int(rng.integers(0, 40)), dtype=np.uint64).astype(np.uint32).tolist() for _ in range(nf)]
+        total = sum(len(l) for l in lists)
+        cap = int(rng.integers(0, total + 5))
+        want = oracle.candidate_cursor_take(lists, cap)
+        c = pqv.CandidateCursor(nf)
+        for i, l in enumerate(lists):
+            c.add_candidates(i, l)
+        got, taken = c.next_batch(cap)
+        assert got == want
+        # a file's share is a prefix of its list
+        for f in range(nf):
+            assert [r for (ff, r) in got if ff == f] == lists[f][:int(taken[f])]
+        # split into two batches: same sequence
+        c2 = pqv.CandidateCursor(nf)
+        for i, l in enumerate(lists):
+            c2.add_candidates(i, l)
+        a = int(rng.integers(0, cap + 1))
+        g1, _ = c2.next_batch(a)
+        g2, _ = c2.next_batch(cap - a)
+        assert len(g1) + len(g2) == len(want) and sorted(g1 + g2) == sorted(want)

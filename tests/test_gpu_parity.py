@@ -895,3 +895,45 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, case
     _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
     if case != "constant":
         assert (rows == orows).all()
+
+
+def test_topk_device_flags_mark_every_query_that_needs_the_heap_replay(pqv, oracle):
+    """pqv_topk_device_flags: the asynchronous device path + a per-query tie flag.  On tie-heavy data (a coarse grid,
+    hundreds of equal distances) and on float data: every UNFLAGGED query must equal the reference position by
+    position straight from the device; flagged ones are re-submitted to pqv_topk, whose heap replay must then give the
+    reference's answer -- together: exact under ties without leaving the GPU for the queries that do not need it."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    for style in ("grid", "float"):
+        n, dim, kc, nprobe, nq = 6000, 16, 5, 3, 150
+        data = (rng.integers(0, 3, size=(n, dim)).astype(np.float32) if style == "grid"
+                else rng.random((n, dim), dtype=np.float32))
+        queries = (rng.integers(0, 3, size=(nq, dim)).astype(np.float32) if style == "grid"
+                   else rng.random((nq, dim), dtype=np.float32))
+        oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=4)
+        s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+        q_t = torch.from_numpy(queries).to(dev)
+        for k in (1, 10, 40):
+            r_t = torch.empty((nq, k), dtype=torch.int32, device=dev)
+            d_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            nf_t = torch.empty((nq,), dtype=torch.int32, device=dev)
+            fl_t = torch.full((nq,), 7, dtype=torch.int32, device=dev)
+            s.topk_device(q_t.data_ptr(), nq, k, nprobe, r_t.data_ptr(), d_t.data_ptr(), nf_t.data_ptr(),
+                          stream=torch.cuda.current_stream().cuda_stream, d_tie_flags=fl_t.data_ptr())
+            torch.cuda.synchronize()
+            rows, dist, flags = r_t.cpu().numpy().view(np.uint32), d_t.cpu().numpy(), fl_t.cpu().numpy()
+            orows, odist, onf, _ = oidx.topk_batch(data, queries, k, nprobe)
+            assert set(np.unique(flags).tolist()) <= {0, 1}
+            assert (_bits(dist) == _bits(odist)).all()                  # the distance multiset never depends on ties
+            clean = flags == 0
+            assert (rows[clean] == orows[clean]).all(), f"{style} k={k}: an unflagged query differs from the reference"
+            # the flag is exactly "two adjacent entries among the first k + 1 merged results have equal output distance"
+            o1r, o1d, o1n, _ = oidx.topk_batch(data, queries, k + 1, nprobe)
+            want = np.array([bool((np.diff(o1d[q, :o1n[q]]) == 0).any()) for q in range(nq)])
+            assert (want == ~clean).all(), (style, k, int(want.sum()), int((~clean).sum()))
+            if style == "grid":
+                assert (~clean).any()
+            if (~clean).any():
+                r2, d2, _, _ = s.topk(queries[~clean], k, nprobe)
+                assert (r2 == orows[~clean]).all() and (_bits(d2) == _bits(odist[~clean])).all()
