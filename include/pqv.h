@@ -234,6 +234,13 @@ int pqv_rerank(int device, const float *query, const float *cand, const uint32_t
                const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
                uint32_t *io_rows, float *io_d2, uint32_t *io_count);
 
+/* The same fold for a batch that is ALREADY resident on `device` (e.g. a decoded Arrow values buffer uploaded by the
+ * scan): d_cand [m, dim] f32, d_ids u32[m] or NULL (=> 0..m), the running state d_io_rows u32[k] / d_io_d2 f32[k] /
+ * d_io_count u32[1] lives on the device between batches.  No null mask (compact before the call).  Enqueued on
+ * hip_stream (NULL: a library stream) and completed before the call returns. */
+int pqv_rerank_device(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m, uint32_t dim,
+                      uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count, void *hip_stream);
+
 /* Merge per-shard top-k lists (one list per file/shard, as topk_from_batches does for
  * multi-file tables, src/df_vector/exec.rs:264-267): lists [n_lists, nq, k] of d2 (or
  * distance) and row ids, counts [n_lists, nq]; ties resolve by (value, list index,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pqv_candidate_cursor_next_batch": (C.c_int, [vp, C.c_uint64, u32p, u32p, u64p, u64p]),
     "pqv_candidate_cursor_free": (None, [vp]),
     "pqv_topk_device_flags": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "pqv_rerank_device": (C.c_int, [C.c_int, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]),
     "pqv_diag_rng": (C.c_int, [u8p, C.c_uint64, C.c_int, C.c_uint64, u64p, C.c_uint64]),
     "pqv_searcher_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "pqv_searcher_describe": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]),

@@ -2257,102 +2257,185 @@ extern "C" void pqv_candidate_cursor_free(pqv_candidate_cursor *c) { delete c; }
 // ---------------------------------------------------------------------------------------
 // batch-granular re-rank (update_topk_heap, src/df_vector/exec.rs:457-484)
 // ---------------------------------------------------------------------------------------
+// Scratch of the batch-granular re-rank, pooled per device: steady-state calls allocate nothing (the first version
+// paid ten hipMallocs and six synchronous copies per 2048-row RecordBatch -- the allocation-bound pattern SURVEY D1
+// criticises in row_to_scalar_values).  A context owns a private stream, device buffers grown on demand and pinned
+// staging for the host-buffer entry point.
+namespace {
+struct RerankCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf d_cand, d_q, d_keys, d_vals, d_mvals, d_mdist, d_nf, d_saved, d_base, d_probe0, d_off, d_io_rows, d_io_d2, d_io_cnt, d_ids;
+    PinnedBuf h_stage;
+    uint64_t off_m = ~0ull, base_k = ~0ull;
+    ~RerankCtx() { if (stream) (void)hipStreamDestroy(stream); }
+};
+std::mutex g_rerank_mu;
+std::vector<RerankCtx *> g_rerank_pool;
+
+int rerank_ctx_acquire(int device, RerankCtx **out) {
+    {
+        std::lock_guard<std::mutex> lock(g_rerank_mu);
+        for (size_t i = 0; i < g_rerank_pool.size(); ++i)
+            if (g_rerank_pool[i]->device == device) {
+                *out = g_rerank_pool[i];
+                g_rerank_pool.erase(g_rerank_pool.begin() + static_cast<long>(i));
+                return PQV_OK;
+            }
+    }
+    RerankCtx *c = new RerankCtx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(PQV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = c;
+    return PQV_OK;
+}
+void rerank_ctx_release(RerankCtx *c) {
+    std::lock_guard<std::mutex> lock(g_rerank_mu);
+    if (g_rerank_pool.size() < 16) g_rerank_pool.push_back(c); else delete c;
+}
+
+// The device-resident fold: d_cand [m, dim] and the running state all on the device; enqueued on `stream`.
+int rerank_enqueue(RerankCtx &c, const float *d_query, const float *d_cand, const uint32_t *d_ids, uint64_t m, uint32_t dim,
+                   uint32_t k, int metric, uint32_t *d_io_rows, float *d_io_d2, uint32_t *d_io_count, hipStream_t stream) {
+    using namespace pqv;
+    const uint32_t bpl = static_cast<uint32_t>((m + 255) / 256);
+    const uint32_t n_part = bpl * waves_per_block() + 1;  // +1: the running state
+    HIP_TRY(c.d_keys.ensure(static_cast<size_t>(n_part) * k * sizeof(uint64_t)));
+    HIP_TRY(c.d_vals.ensure(static_cast<size_t>(n_part) * k * sizeof(uint32_t)));
+    HIP_TRY(c.d_mvals.ensure(k * sizeof(uint32_t)));
+    HIP_TRY(c.d_mdist.ensure(k * sizeof(float)));
+    HIP_TRY(c.d_nf.ensure(sizeof(uint32_t)));
+    HIP_TRY(c.d_saved.ensure(k * sizeof(uint32_t)));
+    HIP_TRY(c.d_base.ensure(sizeof(uint64_t))); HIP_TRY(c.d_probe0.ensure(sizeof(uint32_t))); HIP_TRY(c.d_off.ensure(2 * sizeof(uint64_t)));
+    if (c.off_m != m || c.base_k != k) {      // the one-list descriptor of the stream kernel (changes with the batch size only)
+        const uint64_t h_base = k, h_off[2] = {0, m};
+        const uint32_t h_probe0 = 0;
+        HIP_TRY(hipMemcpyAsync(c.d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c.d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c.d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));        // the sources are stack variables
+        c.off_m = m; c.base_k = k;
+    }
+    // running state as the first partial list: positions 0..count-1 (earlier arrivals win ties)
+    HIP_TRY(launch_rerank_state_in(d_io_rows, d_io_d2, d_io_count, k, c.d_keys.as<uint64_t>(), c.d_vals.as<uint32_t>(),
+                                   c.d_saved.as<uint32_t>(), stream));
+    // batch candidates take positions k, k+1, ... via the cand_base entry
+    StreamArgs ra{};
+    ra.mat = d_cand; ra.row_of = nullptr; ra.list_off = c.d_off.as<uint64_t>();
+    ra.probe = c.d_probe0.as<uint32_t>(); ra.cand_base = c.d_base.as<uint64_t>();
+    ra.queries = d_query; ra.nq = 1; ra.nprobe = 1; ra.dim = dim; ra.k = k;
+    ra.rows_per_block = 256; ra.blocks_per_list = bpl; ra.max_pos = ~0ull; ra.metric = metric;
+    ra.part_keys = c.d_keys.as<uint64_t>() + k; ra.part_vals = c.d_vals.as<uint32_t>() + k;
+    HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
+    MergeArgs fm{};
+    fm.part_keys = c.d_keys.as<uint64_t>(); fm.part_vals = c.d_vals.as<uint32_t>();
+    fm.nq = 1; fm.n_part = n_part; fm.k_part = k; fm.k = k; fm.ids = nullptr;
+    fm.row_idx = c.d_mvals.as<uint32_t>(); fm.dist = c.d_mdist.as<float>(); fm.n_found = c.d_nf.as<uint32_t>();
+    fm.sqrt_out = 0;
+    HIP_TRY(launch_merge_final(fm, stream));
+    HIP_TRY(launch_rerank_state_out(c.d_mvals.as<uint32_t>(), c.d_mdist.as<float>(), c.d_nf.as<uint32_t>(), c.d_saved.as<uint32_t>(),
+                                    d_ids, k, d_io_rows, d_io_d2, d_io_count, stream));
+    return PQV_OK;
+}
+
+int rerank_validate(const void *query, const void *io_rows, const void *io_d2, const void *io_count, const void *cand,
+                    uint64_t m, uint32_t dim, uint32_t k, int metric) {
+    if (!query || !io_rows || !io_d2 || !io_count) return fail(PQV_ERR_INVALID, "query/io arrays must not be NULL");
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
+    if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
+    if (m && !cand) return fail(PQV_ERR_INVALID, "cand must not be NULL");
+    if (m > 0x7FFFFFFFull) return fail(PQV_ERR_UNSUPPORTED, "batch larger than 2^31 rows");
+    return PQV_OK;
+}
+}  // namespace
+
+static int pqv_rerank_device_impl(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m,
+                                  uint32_t dim, uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count,
+                                  void *hip_stream) {
+    if (int rc = rerank_validate(d_query, d_io_rows, d_io_d2, d_io_count, d_cand, m, dim, k, metric)) return rc;
+    if (k == 0 || m == 0) return PQV_OK;
+    if (int rc = use_device(device)) return rc;
+    RerankCtx *c = nullptr;
+    if (int rc = rerank_ctx_acquire(device, &c)) return rc;
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    int rc = rerank_enqueue(*c, static_cast<const float *>(d_query), static_cast<const float *>(d_cand),
+                            static_cast<const uint32_t *>(d_ids), m, dim, k, metric, static_cast<uint32_t *>(d_io_rows),
+                            static_cast<float *>(d_io_d2), static_cast<uint32_t *>(d_io_count), stream);
+    // the context's merge scratch is in use until the stream drains: hand it back only then
+    if (rc == PQV_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(PQV_ERR_HIP, "hipStreamSynchronize failed");
+    rerank_ctx_release(c);
+    return rc;
+}
+extern "C" int pqv_rerank_device(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m,
+                                 uint32_t dim, uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count,
+                                 void *hip_stream) {
+    return guard([&] { return pqv_rerank_device_impl(device, d_query, d_cand, d_ids, m, dim, k, metric, d_io_rows, d_io_d2, d_io_count, hip_stream); });
+}
+
 static int pqv_rerank_impl(int device, const float *query, const float *cand, const uint32_t *ids,
                           const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
                           uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
-    using namespace pqv;
-    if (!query || !io_rows || !io_d2 || !io_count) return fail(PQV_ERR_INVALID, "query/io arrays must not be NULL");
-    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (int rc = rerank_validate(query, io_rows, io_d2, io_count, cand, m, dim, k, metric)) return rc;
     if (k == 0) return PQV_OK;  // heap.len() < 0 is never true and peek() is None: nothing is kept
-    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
-    if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
     if (*io_count > k) return fail(PQV_ERR_INVALID, "io_count exceeds k");
     if (m == 0) return PQV_OK;
-    if (!cand) return fail(PQV_ERR_INVALID, "cand must not be NULL");
-    if (m > 0x7FFFFFFFull) return fail(PQV_ERR_UNSUPPORTED, "batch larger than 2^31 rows");
     if (int rc = use_device(device)) return rc;
+    RerankCtx *c = nullptr;
+    if (int rc = rerank_ctx_acquire(device, &c)) return rc;
+    struct Release { RerankCtx *c; ~Release() { rerank_ctx_release(c); } } release{c};
+    hipStream_t stream = c->stream;
 
-    // compact away null / wrong-length rows (exec.rs:496-498,526-528), keep arrival order
-    std::vector<uint32_t> keep;
-    const float *src = cand;
-    std::vector<float> packed;
+    // pinned staging: [query | payload ids | valid rows (compacted: null / wrong-length rows dropped, exec.rs:496-498,
+    // 526-528; arrival order kept)], then ONE async copy per piece on the context's stream
     uint64_t mv = m;
-    if (valid) {
-        keep.reserve(m);
-        for (uint64_t i = 0; i < m; ++i) if (valid[i]) keep.push_back(static_cast<uint32_t>(i));
-        mv = keep.size();
-        if (mv == 0) return PQV_OK;
-        if (mv != m) {
-            packed.resize(mv * dim);
-            for (uint64_t i = 0; i < mv; ++i)
-                std::memcpy(&packed[i * dim], cand + static_cast<uint64_t>(keep[i]) * dim, dim * sizeof(float));
-            src = packed.data();
-        }
+    if (valid) { mv = 0; for (uint64_t i = 0; i < m; ++i) mv += valid[i] != 0; }
+    if (mv == 0) return PQV_OK;
+    const size_t q_bytes = static_cast<size_t>(dim) * sizeof(float), id_bytes = static_cast<size_t>(mv) * sizeof(uint32_t),
+                 c_bytes = static_cast<size_t>(mv) * dim * sizeof(float), st_bytes = static_cast<size_t>(k) * 8 + 4;
+    HIP_TRY(c->h_stage.ensure(q_bytes + id_bytes + c_bytes + st_bytes + 64));
+    uint8_t *hs = c->h_stage.as<uint8_t>();
+    float *h_q = reinterpret_cast<float *>(hs);
+    uint32_t *h_ids = reinterpret_cast<uint32_t *>(hs + q_bytes);
+    float *h_c = reinterpret_cast<float *>(hs + q_bytes + id_bytes);
+    uint8_t *h_st = hs + q_bytes + id_bytes + c_bytes;
+    std::memcpy(h_q, query, q_bytes);
+    if (valid && mv != m) {
+        uint64_t o = 0;
+        for (uint64_t i = 0; i < m; ++i)
+            if (valid[i]) {
+                std::memcpy(h_c + o * dim, cand + i * dim, static_cast<size_t>(dim) * sizeof(float));
+                h_ids[o++] = ids ? ids[i] : static_cast<uint32_t>(i);
+            }
+    } else {
+        std::memcpy(h_c, cand, c_bytes);
+        for (uint64_t i = 0; i < mv; ++i) h_ids[i] = ids ? ids[i] : static_cast<uint32_t>(i);
     }
-    hipStream_t stream = nullptr;  // legacy default stream: this entry is synchronous
-    DevBuf d_cand, d_q, d_keys, d_vals, d_rows, d_dist, d_nf;
     const uint32_t old = *io_count;
-    const uint32_t bpl = static_cast<uint32_t>((mv + 255) / 256);
-    const uint32_t n_part = bpl * waves_per_block() + 1;  // +1: the running state
-    HIP_TRY(d_cand.alloc(mv * dim * sizeof(float)));
-    HIP_TRY(d_q.alloc(dim * sizeof(float)));
-    HIP_TRY(d_keys.alloc(static_cast<size_t>(n_part) * k * sizeof(uint64_t)));
-    HIP_TRY(d_vals.alloc(static_cast<size_t>(n_part) * k * sizeof(uint32_t)));
-    HIP_TRY(d_rows.alloc(k * sizeof(uint32_t)));
-    HIP_TRY(d_dist.alloc(k * sizeof(float)));
-    HIP_TRY(d_nf.alloc(sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(d_cand.p, src, mv * dim * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_q.p, query, dim * sizeof(float), hipMemcpyHostToDevice));
-    // running state as the first partial list: positions 0..old-1 (earlier arrivals win ties);
-    // vals carry a tag bit so the payload can be told from a batch position afterwards
-    std::vector<uint64_t> hk(k, KEY_EMPTY);
-    std::vector<uint32_t> hv(k, 0xFFFFFFFFu);
-    for (uint32_t i = 0; i < old; ++i) {
-        uint32_t bits;
-        std::memcpy(&bits, &io_d2[i], 4);
-        hk[i] = (static_cast<uint64_t>(bits) << 32) | i;
-        hv[i] = 0x80000000u | i;
-    }
-    HIP_TRY(hipMemcpy(d_keys.p, hk.data(), k * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_vals.p, hv.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice));
-
-    // batch candidates take positions k, k+1, ... via a cand_base entry
-    DevBuf d_base, d_probe0, d_off;
-    const uint64_t h_base = k, h_off[2] = {0, mv};
-    const uint32_t h_probe0 = 0;
-    HIP_TRY(d_base.alloc(sizeof(uint64_t))); HIP_TRY(d_probe0.alloc(sizeof(uint32_t))); HIP_TRY(d_off.alloc(2 * sizeof(uint64_t)));
-    HIP_TRY(hipMemcpy(d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice));
-    StreamArgs ra{};
-    ra.mat = d_cand.as<float>(); ra.row_of = nullptr; ra.list_off = d_off.as<uint64_t>();
-    ra.probe = d_probe0.as<uint32_t>(); ra.cand_base = d_base.as<uint64_t>();
-    ra.queries = d_q.as<float>(); ra.nq = 1; ra.nprobe = 1; ra.dim = dim; ra.k = k;
-    ra.rows_per_block = 256; ra.blocks_per_list = bpl; ra.max_pos = ~0ull; ra.metric = metric;
-    ra.part_keys = d_keys.as<uint64_t>() + k; ra.part_vals = d_vals.as<uint32_t>() + k;
-    HIP_TRY(launch_stream(ra, STREAM_TOPK, stream));
-    MergeArgs fm{};
-    fm.part_keys = d_keys.as<uint64_t>(); fm.part_vals = d_vals.as<uint32_t>();
-    fm.nq = 1; fm.n_part = n_part; fm.k_part = k; fm.k = k; fm.ids = nullptr;
-    fm.row_idx = d_rows.as<uint32_t>(); fm.dist = d_dist.as<float>(); fm.n_found = d_nf.as<uint32_t>();
-    fm.sqrt_out = 0;
-    HIP_TRY(launch_merge_final(fm, stream));
-    std::vector<uint32_t> r(k);
-    std::vector<float> d(k);
+    std::memcpy(h_st, io_rows, static_cast<size_t>(old) * 4);
+    std::memcpy(h_st + static_cast<size_t>(k) * 4, io_d2, static_cast<size_t>(old) * 4);
+    std::memcpy(h_st + static_cast<size_t>(k) * 8, &old, 4);
+    HIP_TRY(c->d_q.ensure(q_bytes)); HIP_TRY(c->d_ids.ensure(id_bytes)); HIP_TRY(c->d_cand.ensure(c_bytes));
+    HIP_TRY(c->d_io_rows.ensure(static_cast<size_t>(k) * 4)); HIP_TRY(c->d_io_d2.ensure(static_cast<size_t>(k) * 4)); HIP_TRY(c->d_io_cnt.ensure(4));
+    HIP_TRY(hipMemcpyAsync(c->d_q.p, h_q, q_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_ids.p, h_ids, id_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_cand.p, h_c, c_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_io_rows.p, h_st, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_io_d2.p, h_st + static_cast<size_t>(k) * 4, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_io_cnt.p, h_st + static_cast<size_t>(k) * 8, 4, hipMemcpyHostToDevice, stream));
+    if (int rc = rerank_enqueue(*c, c->d_q.as<float>(), c->d_cand.as<float>(), c->d_ids.as<uint32_t>(), mv, dim, k, metric,
+                                c->d_io_rows.as<uint32_t>(), c->d_io_d2.as<float>(), c->d_io_cnt.as<uint32_t>(), stream))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h_st, c->d_io_rows.p, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_st + static_cast<size_t>(k) * 4, c->d_io_d2.p, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_st + static_cast<size_t>(k) * 8, c->d_io_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     uint32_t nf = 0;
-    HIP_TRY(hipMemcpy(r.data(), d_rows.p, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(d.data(), d_dist.p, k * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&nf, d_nf.p, sizeof nf, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> new_rows(nf);
-    for (uint32_t i = 0; i < nf; ++i) {
-        if (r[i] & 0x80000000u) {
-            new_rows[i] = io_rows[r[i] & 0x7FFFFFFFu];
-        } else {
-            const uint32_t bi = valid && mv != m ? keep[r[i]] : r[i];
-            new_rows[i] = ids ? ids[bi] : bi;
-        }
-    }
-    for (uint32_t i = 0; i < nf; ++i) { io_rows[i] = new_rows[i]; io_d2[i] = d[i]; }
+    std::memcpy(&nf, h_st + static_cast<size_t>(k) * 8, 4);
+    if (nf > k) return fail(PQV_ERR_HIP, "internal error: re-rank count out of range");
+    std::memcpy(io_rows, h_st, static_cast<size_t>(nf) * 4);
+    std::memcpy(io_d2, h_st + static_cast<size_t>(k) * 4, static_cast<size_t>(nf) * 4);
     *io_count = nf;
     return PQV_OK;
 }

@@ -282,6 +282,12 @@ hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads,
 hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s);
 hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s);
 
+// pqv_rerank's running state <-> merge lists (see kernels.hip)
+hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k,
+                                  uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s);
+hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
+                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count, hipStream_t s);
+
 // a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
 hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);
 

@@ -3330,6 +3330,49 @@ hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint6
 }
 
 // ------------------------------------------------------------------------------------
+// pqv_rerank's device-side state handling (update_topk_heap, src/df_vector/exec.rs:457-484): the running top-k of a
+// query is (rows, d2, count), sorted by (d2, arrival).  rerank_state_in turns it into partial list 0 of a merge --
+// keys (d2 bits, position 0..count-1: earlier arrivals win ties), values tagged with bit 31 -- and rerank_state_out
+// maps the merged values back to payloads: a tagged value is an old entry, anything else a position in this batch.
+// One wave each; k <= 1024.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rerank_state_in_kernel(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count,
+                                                            uint32_t k, uint64_t *keys, uint32_t *vals, uint32_t *rows_saved) {
+    const uint32_t cnt = *io_count < k ? *io_count : k;
+    for (uint32_t i = threadIdx.x; i < k; i += 64) {
+        if (i < cnt) {
+            keys[i] = ((uint64_t)__float_as_uint(io_d2[i]) << 32) | i;
+            vals[i] = 0x80000000u | i;
+            rows_saved[i] = io_rows[i];
+        } else {
+            keys[i] = KEY_EMPTY;
+            vals[i] = 0xFFFFFFFFu;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void rerank_state_out_kernel(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found,
+                                                             const uint32_t *rows_saved, const uint32_t *ids, uint32_t k,
+                                                             uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+    const uint32_t nf = *m_found < k ? *m_found : k;
+    for (uint32_t i = threadIdx.x; i < nf; i += 64) {
+        const uint32_t v = m_vals[i];
+        io_rows[i] = (v & 0x80000000u) ? rows_saved[v & 0x7FFFFFFFu] : (ids ? ids[v] : v);
+        io_d2[i] = m_d2[i];
+    }
+    if (threadIdx.x == 0) *io_count = nf;
+}
+hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k,
+                                  uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s) {
+    hipLaunchKernelGGL(rerank_state_in_kernel, dim3(1), dim3(64), 0, s, io_rows, io_d2, io_count, k, keys, vals, rows_saved);
+    return hipGetLastError();
+}
+hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
+                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count, hipStream_t s) {
+    hipLaunchKernelGGL(rerank_state_out_kernel, dim3(1), dim3(64), 0, s, m_vals, m_d2, m_found, rows_saved, ids, k, io_rows, io_d2, io_count);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // fill_ones2_kernel: two buffers set to all-ones bytes in ONE launch (the EMPTY preset of the
 // partial-list keys and values; hipMemsetAsync costs 2-3 launches per buffer).  16 B per lane.
 // ------------------------------------------------------------------------------------

@@ -937,3 +937,44 @@ def test_topk_device_flags_mark_every_query_that_needs_the_heap_replay(pqv, orac
             if (~clean).any():
                 r2, d2, _, _ = s.topk(queries[~clean], k, nprobe)
                 assert (r2 == orows[~clean]).all() and (_bits(d2) == _bits(odist[~clean])).all()
+
+
+@pytest.mark.parametrize("metric_name", ["seq", "ref4"])
+def test_rerank_device_matches_update_topk_heap(pqv, oracle, metric_name):
+    """pqv_rerank_device: RecordBatches already resident on the device, the running top-k state never leaving it;
+    the reference bench's batch shape (2048 rows, benches/query.rs:29) at dim 1024, k = 10 and k = 100, many batches
+    through the pooled context (no allocation in steady state), against one heap over all rows (exec.rs:264-267)."""
+    import torch
+    from pq_vector_amd import _ffi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17)
+    n, dim = 20480, 1024
+    emb = rng.random((n, dim), dtype=np.float32)
+    emb[5000:5040] = emb[100:140]                         # exact duplicates: ties resolve by arrival
+    q = rng.random(dim, dtype=np.float32)
+    order = rng.permutation(n).astype(np.uint32)
+    metric = pqv.PQV_L2SQ_SEQ if metric_name == "seq" else pqv.PQV_L2SQ_REF4
+    emb_t = torch.from_numpy(emb[order]).to(dev)          # arrival order
+    ids_t = torch.from_numpy(order.astype(np.int32)).to(dev)
+    q_t = torch.from_numpy(q).to(dev)
+    for k in (10, 100):
+        io_rows = torch.zeros((k,), dtype=torch.int32, device=dev)
+        io_d2 = torch.zeros((k,), dtype=torch.float32, device=dev)
+        io_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        for b in range(0, n, 2048):
+            rc = _ffi.lib().pqv_rerank_device(0, _ffi.vp(q_t.data_ptr()), _ffi.vp(emb_t[b:b + 2048].data_ptr()),
+                                              _ffi.vp(ids_t[b:b + 2048].data_ptr()), min(2048, n - b), dim, k, metric,
+                                              _ffi.vp(io_rows.data_ptr()), _ffi.vp(io_d2.data_ptr()), _ffi.vp(io_cnt.data_ptr()),
+                                              _ffi.vp(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, _ffi.lib().pqv_last_error()
+        torch.cuda.synchronize()
+        assert int(io_cnt.item()) == k
+        got_r, got_d = io_rows.cpu().numpy().view(np.uint32), io_d2.cpu().numpy()
+        if metric_name == "seq":
+            orow, od2 = oracle.topk_df(emb, order, q, k)
+        else:
+            d2 = np.array([oracle.l2_ref4(q, emb[r]) for r in order], np.float32)
+            sel = np.lexsort((np.arange(n), d2.view(np.uint32)))[:k]
+            orow, od2 = order[sel], d2[sel]
+        assert (_bits(got_d) == _bits(od2)).all()
+        _assert_topk_equal((got_r[None, :], got_d[None, :], np.array([k])), (np.asarray(orow)[None, :], np.asarray(od2)[None, :], np.array([k])), k)
