@@ -160,7 +160,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_part_flags;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -1373,8 +1373,14 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     if (p.tile) {
         pm.hist = pair_u32; pm.hist_stride = kc_pairs; pm.gthr_init = sc.s_gthr.as<unsigned long long>();
         // every partial list of the re-rank starts EMPTY: preset by the probe merge (one wave per query)
-        pm.preset_keys = sc.s_part_keys.as<uint64_t>(); pm.preset_vals = sc.s_part_vals.as<uint32_t>();
-        pm.preset_n = p.n_part_rr * k;
+        if (p.filter && p.quad) {       // wide path: one "written" byte per list (see MergeArgs::preset_flags)
+            const uint32_t nflag = (p.n_part_rr + 3) / 4 * 4;
+            HIP_TRY(sc.s_part_flags.ensure(static_cast<size_t>(nq) * nflag));
+            pm.preset_flags = sc.s_part_flags.as<uint8_t>(); pm.preset_flag_n = nflag;
+        } else {
+            pm.preset_keys = sc.s_part_keys.as<uint64_t>(); pm.preset_vals = sc.s_part_vals.as<uint32_t>();
+            pm.preset_n = p.n_part_rr * k;
+        }
         if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.qmax_out = sc.s_qmax.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
     }
     HIP_TRY(launch_merge_probe(pm, stream));
@@ -1470,6 +1476,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                                        ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
+            ta.part_flags = sc.s_part_flags.as<uint8_t>();
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
@@ -1513,6 +1520,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         fm.cand_keys = sc.s_cand_keys.as<uint64_t>(); fm.cand_vals = sc.s_cand_vals.as<uint32_t>();
         fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->opt.cand_cap, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
+        fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
     }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
@@ -1819,7 +1827,7 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
                                 &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads,
                                 &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
-                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres})
+                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres, &l.s_part_flags})
             other += b->p ? b->bytes : 0;
     if (other_bytes) *other_bytes = other;
     return PQV_OK;

@@ -86,6 +86,13 @@ struct MergeArgs {
     uint64_t       *preset_keys;
     uint32_t       *preset_vals;
     uint32_t        preset_n;
+    // ... or, for the wide screened path (whose waves touch their lists only when a candidate buffer overflows), one
+    // "written" byte per list: probe mode clears preset_flag_n bytes per query, wide_filter_kernel sets a list's byte
+    // with its first fold (which then writes the whole list), and the final merge reads only flagged lists -- 1 byte per
+    // list per step instead of 12 k
+    uint8_t        *preset_flags;
+    uint32_t        preset_flag_n;
+    const uint8_t  *part_flags;  // final mode: [nq][n_part] or nullptr (every list is valid)
     unsigned long long *gthr_init;
     float          *qnorm_out;
     float          *qmax_out;    // max |q_i| per query (f16 screen)
@@ -197,6 +204,7 @@ struct TileArgs {
     unsigned long long *stats;   // [2] optional: += (row, query) pairs screened, += pairs evaluated exactly
     uint64_t       *part_keys;   // [nq][nprobe * slots_per_pair][k]
     uint32_t       *part_vals;
+    uint8_t        *part_flags;  // wide_filter_kernel, optional: [nq][n_part] "this list has been written" (see MergeArgs)
 };
 // PQV_L2SQ_REF4 only, k <= 256.  The caller presets the whole partial-list buffer to EMPTY (0xFF bytes:
 // KEY_EMPTY keys, 0xFFFFFFFF values); a wave touches its slots only when a candidate is admitted.

@@ -461,6 +461,10 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
                 uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
                 for (uint32_t i = threadIdx.x - 64; i < a.preset_n; i += blockDim.x - 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
             }
+            if (a.preset_flags) {
+                uint32_t *pf = reinterpret_cast<uint32_t *>(a.preset_flags + (uint64_t)q * a.preset_flag_n);      // preset_flag_n % 4 == 0
+                for (uint32_t i = threadIdx.x - 64; i < a.preset_flag_n / 4; i += blockDim.x - 64) pf[i] = 0u;
+            }
         }
         return;
     }
@@ -471,6 +475,24 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const uint32_t *pv = a.part_vals + (uint64_t)q * total;
     // with a candidate buffer the partial lists hold something only if the query overflowed it
     const uint64_t scan = (a.cand_keys && a.spilled && a.spilled[q] == 0) ? 0 : total;
+    if (a.part_flags && scan) {
+        // only the lists some wave has written (a handful, and only for a query whose candidate buffer overflowed)
+        const uint8_t *fl = a.part_flags + (uint64_t)q * a.n_part;
+        for (uint32_t l0 = 0; l0 < a.n_part; l0 += 64) {
+            unsigned long long m = __ballot(l0 + lane < a.n_part && fl[l0 + lane] != 0);
+            while (m) {
+                const uint32_t li = l0 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                for (uint32_t e0 = 0; e0 < a.k_part; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    uint64_t key = KEY_EMPTY;
+                    uint32_t val = 0xFFFFFFFFu;
+                    if (e < a.k_part) { key = pk[(uint64_t)li * a.k_part + e]; val = pv[(uint64_t)li * a.k_part + e]; }
+                    tk.offer(key, val, a.k, lane);
+                }
+            }
+        }
+    } else
     for (uint64_t i = 0; i < scan; i += 64) {
         const uint64_t idx = i + lane;
         uint64_t key = KEY_EMPTY;
@@ -596,7 +618,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
 template <bool PROBE>
 static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
-    dim3 grid(a.nq), block(PROBE && a.preset_keys ? 256 : 64);       // probe merge with a preset: three helper waves
+    dim3 grid(a.nq), block(PROBE && (a.preset_keys || a.preset_flags) ? 256 : 64);       // probe merge with a preset: three helper waves
     if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);
@@ -1967,13 +1989,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const uint64_t mykey = mine ? mykey_all : KEY_EMPTY;
             const uint64_t thr = qread_u64<QS>(my_thr, qq);
             if (__ballot(mykey < thr) != 0ull) {
-                uint64_t base;
-                if constexpr (LST) base = ((uint64_t)qread_u32<QS>(my_qrow, qq) * n_part + (qst_pair[qq] % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave) * k;
-                else base = qread_u64<QS>(my_base, qq);
+                uint32_t pr;
+                if constexpr (LST) pr = qst_pair[qq]; else pr = qread_u32<QS>(my_pair, qq);
+                const uint64_t li = (uint64_t)qread_u32<QS>(my_qrow, qq) * n_part + (pr % a.nprobe) * a.slots_per_pair + a.slot_base + bx * NW + wave;
+                const uint64_t base = li * k;
+                // first fold into this list: it still holds whatever an earlier batch left there
+                bool fresh = false;
+                if (a.part_flags) {
+                    fresh = a.part_flags[li] == 0;
+                    if (fresh && lane == 0) a.part_flags[li] = 1;
+                }
                 const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
                                                  a.gthr + qread_u32<QS>(my_qrow, qq),
                                                  qread_u64<QS>(cur_gthr, qq), qread_u64<QS>(my_lkth, qq),
-                                                 mykey, srow, k, lane);
+                                                 mykey, srow, k, lane, fresh);
 #pragma unroll
                 for (int s = 0; s < QS; ++s)
                     if ((uint32_t)(64 * s + lane) == qq) my_lkth[s] = nk;
