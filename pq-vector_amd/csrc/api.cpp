@@ -585,6 +585,10 @@ bool lists_from_assignment(const uint32_t *cluster_of, uint64_t n, uint32_t k,
 struct ScreenedAssign {
     uint32_t dim = 0, kc = 0, width = 0, chunk_q = 0, rpb = 0, bpl = 0, max_quads = 0, ccap = 32;
     const float *d_centroids = nullptr;
+    // f16 operands (PQV_ASSIGN_F16=1; dim % 128 == 0, dim <= 1024): the 8-wave kernel with the chunk's rows staged in LDS
+    bool f16 = false;
+    float f16_scale = 1.0f;
+    DevBuf qmax, dmax;
     DevBuf cblk, cnorm, list_off, blk_off, flag;
     DevBuf qnorm, pairs, quads, nq_u32, cand_base, gthr, part_keys, part_vals, cand_keys, cand_vals, cand_cnt, spilled,
         seed_ub, qblk, dist_out, nfound;
@@ -601,8 +605,11 @@ struct ScreenedAssign {
         dim = d; kc = k; d_centroids = d_c;
         static const uint32_t wide_env = [] { const char *e = std::getenv("PQV_ASSIGN_WIDTH"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
         width = wide_env == 32 && dim > 128 ? 32 : 64;     // 64-row quads halve the re-streaming of the centroids
+        static const bool f16_env = [] { const char *e = std::getenv("PQV_ASSIGN_F16"); return e && *e == '1'; }();
+        f16 = f16_env && (dim % 128) == 0 && dim <= 1024;
+        if (f16) width = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / (static_cast<uint64_t>(dim) * (dim <= 128 ? 6 : 2)) / 32 * 32));
         chunk_q = 65536;
-        rpb = 1024; bpl = (kc + rpb - 1) / rpb;
+        rpb = f16 ? 2048 : 1024; bpl = (kc + rpb - 1) / rpb;
         max_quads = (chunk_q / width + 7) / 8 * 8;
         const uint64_t tiles = (static_cast<uint64_t>(kc) + 15) / 16;
         const uint64_t h_off[2] = {0, kc}, h_blk[2] = {0, tiles};
@@ -612,9 +619,27 @@ struct ScreenedAssign {
         HIP_TRY(hipStreamSynchronize(stream));          // the two host arrays above are stack-allocated
         HIP_TRY(cblk.ensure(tiles * 16 * dim * sizeof(float)));
         HIP_TRY(cnorm.ensure(static_cast<size_t>(kc) * sizeof(float)));
-        HIP_TRY(launch_block_rows(d_c, list_off.as<uint64_t>(), blk_off.as<uint64_t>(), 1, tiles, dim, cblk.p, stream));
         HIP_TRY(launch_row_norms(d_c, kc, dim, 1, cnorm.as<float>(), stream));
-        return check_finite(cnorm.as<float>(), kc, stream, nonfinite);
+        if (int rc = check_finite(cnorm.as<float>(), kc, stream, nonfinite)) return rc;
+        if (f16 && !*nonfinite) {
+            // scale: the centroids' maximum lands below 2^14 (rows beyond the f16 range are never skipped by the kernel)
+            uint32_t bits = 0;
+            HIP_TRY(dmax.ensure(sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(dmax.p, 0, sizeof(uint32_t), stream));
+            HIP_TRY(launch_maxabs(d_c, static_cast<uint64_t>(kc) * dim, dmax.as<uint32_t>(), stream));
+            HIP_TRY(hipMemcpyAsync(&bits, dmax.p, sizeof bits, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            float m; std::memcpy(&m, &bits, sizeof m);
+            int e = 0;
+            if (m > 0.0f) (void)std::frexp(m, &e);
+            const int se = m > 0.0f ? 14 - e : 0;
+            if (se < -60 || se > 60) f16 = false; else f16_scale = std::ldexp(1.0f, se);
+        }
+        if (f16 && !*nonfinite)
+            HIP_TRY(launch_block_rows_f16(d_c, list_off.as<uint64_t>(), blk_off.as<uint64_t>(), 1, tiles, dim, f16_scale, cblk.p, stream));
+        else
+            HIP_TRY(launch_block_rows(d_c, list_off.as<uint64_t>(), blk_off.as<uint64_t>(), 1, tiles, dim, cblk.p, stream));
+        return PQV_OK;
     }
     int check_finite(const float *v, uint64_t n, hipStream_t stream, bool *nonfinite) {
         uint32_t h = 0;
@@ -635,7 +660,7 @@ struct ScreenedAssign {
         if (int rc = check_finite(qnorm.as<float>(), n, stream, &bad)) return rc;
         if (bad) { *fallback = true; return PQV_OK; }
         static const uint32_t seed_env = [] { const char *e = std::getenv("PQV_ASSIGN_SEED"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 256u; }();
-        const uint32_t k = 1, slots = 4 * bpl, seed_rows = std::max<uint32_t>(64, seed_env / 64 * 64), seed_sw = 4;
+        const uint32_t k = 1, slots = (f16 ? 8u : 4u) * bpl, seed_rows = std::max<uint32_t>(64, seed_env / 64 * 64), seed_sw = 4;
         HIP_TRY(pairs.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(quads.ensure(static_cast<size_t>(max_quads) * sizeof(uint4)));
         HIP_TRY(nq_u32.ensure(16)); HIP_TRY(cand_base.ensure(static_cast<size_t>(chunk_q) * 8));
         HIP_TRY(gthr.ensure(static_cast<size_t>(chunk_q) * 8));
@@ -645,8 +670,12 @@ struct ScreenedAssign {
         HIP_TRY(cand_cnt.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(spilled.ensure(static_cast<size_t>(chunk_q) * 4));
         HIP_TRY(seed_ub.ensure(static_cast<size_t>(chunk_q) * seed_sw * 16 * 4));
         HIP_TRY(dist_out.ensure(static_cast<size_t>(chunk_q) * 4)); HIP_TRY(nfound.ensure(static_cast<size_t>(chunk_q) * 4));
-        const bool qlds = static_cast<uint64_t>(width) * dim * sizeof(float) <= 32768;
+        const bool qlds = f16 || static_cast<uint64_t>(width) * dim * sizeof(float) <= 32768;
         if (!qlds) HIP_TRY(qblk.ensure(static_cast<size_t>(max_quads) * width * dim * sizeof(float)));
+        if (f16) {
+            HIP_TRY(qmax.ensure(static_cast<size_t>(n) * sizeof(float)));
+            HIP_TRY(launch_row_norms(d_rows, n, dim, 2, qmax.as<float>(), stream));
+        }
         for (uint64_t r0 = 0; r0 < n; r0 += chunk_q) {
             const uint32_t nq = static_cast<uint32_t>(std::min<uint64_t>(chunk_q, n - r0));
             const float *q = d_rows + r0 * dim;
@@ -668,6 +697,10 @@ struct ScreenedAssign {
             ta.cand_keys = cand_keys.as<uint64_t>(); ta.cand_vals = cand_vals.as<uint32_t>();
             ta.cand_cnt = cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = spilled.as<uint32_t>();
             ta.xcd_swizzle = qlds ? 0 : 1;
+            if (f16) {
+                ta.f16 = 1; ta.scale = f16_scale; ta.scale2 = f16_scale * f16_scale; ta.block_waves = 8;
+                ta.query_maxabs = qmax.as<float>() + r0;
+            }
             if (!qlds) {
                 HIP_TRY(launch_pack_queries(q, ta.pairs, ta.quads, ta.n_quads, max_quads, 1, dim, width / 16, qblk.p, stream));
                 ta.q_blk = static_cast<const float4 *>(qblk.p);

@@ -249,7 +249,7 @@ struct BruteArgs {
     uint32_t     cap;
 };
 hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s);
-// per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2
+// per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2, mode 2 = max |x_i|
 hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s);
 // fold a query's appended candidates to its k best (kept at the front of the buffer), set
 // thr[q] to its k-th key once k candidates exist, report overflow (count > cap) in *overflow

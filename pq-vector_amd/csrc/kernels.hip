@@ -2868,6 +2868,13 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict_
     for (uint64_t r = w; r < n; r += nw) {
         const float *p = rows + r * dim;
         float acc = 0.0f;
+        if (mode == 2) {                 // max |x_i| (NaN propagates as NaN-free max; non-finite rows are caught by their norm)
+            for (uint32_t e = lane; e < dim; e += 64) acc = fmaxf(acc, fabsf(p[e]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc = fmaxf(acc, __shfl_xor(acc, off, 64));
+            if (lane == 0) out[r] = acc;
+            continue;
+        }
         for (uint32_t e = lane; e < dim; e += 64) acc = fmaf(p[e], p[e], acc);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
