@@ -223,15 +223,27 @@ def _footer_kv(meta):
 # ---------------------------------------------------------------------------------------
 def read_index_metadata(path):
     """(offset, embedding_column) from the footer KV, or None (parse_index_metadata :120-143)."""
-    _, meta = _read_footer(path)
-    kv = dict((k, v) for k, v in _footer_kv(meta) if k is not None)
+    try:
+        _, meta = _read_footer(path)
+        kv = dict((k, v) for k, v in _footer_kv(meta) if k is not None)
+    except (IndexError, struct.error, UnicodeDecodeError) as e:      # truncated / corrupt Thrift footer
+        raise PqvError(_ffi.PQV_ERR_FORMAT, f"malformed parquet footer: {e}")
     off, col = kv.get(OFFSET_KEY.encode()), kv.get(COLUMN_KEY.encode())
     if off is None or col is None:
         return None
     col = col.decode()
     if not col.strip():
         raise _err("Embedding column name cannot be empty")
-    return int(off.decode()), col
+    # Rust's `str::parse::<u64>` (parquet.rs:133): ASCII digits only (an optional leading '+'), no blanks, no '_', no sign
+    txt = off.decode("ascii", errors="replace")
+    digits = txt[1:] if txt.startswith("+") else txt
+    if not digits or not all("0" <= ch <= "9" for ch in digits) or int(digits) >= 1 << 64:
+        raise PqvError(_ffi.PQV_ERR_FORMAT, f"invalid pq-vector index offset in parquet footer: {txt!r}")
+    offset = int(digits)
+    import os
+    if offset > os.path.getsize(path):
+        raise PqvError(_ffi.PQV_ERR_FORMAT, "pq-vector index offset lies beyond the end of the file")
+    return offset, col
 
 
 def has_pq_vector_index(path):
@@ -305,11 +317,21 @@ def write_parquet_with_index(source, output, index, embedding_column):
     names = src.schema_arrow.names
     other = [n for n in names if n != embedding_column]
     rg_rows = src.metadata.row_group(0).num_rows if src.metadata.num_row_groups else 1 << 20
-    compression = "NONE"
-    if src.metadata.num_row_groups and src.metadata.row_group(0).num_columns:
-        c = src.metadata.row_group(0).column(0).compression
-        compression = "NONE" if c == "UNCOMPRESSED" else c
+    # per-column codec of the source (collect_column_write_options, parquet.rs:322-336); nested columns report their leaf path
+    compression = {}
+    if src.metadata.num_row_groups:
+        rg0 = src.metadata.row_group(0)
+        for j in range(rg0.num_columns):
+            col = rg0.column(j)
+            top = col.path_in_schema.split(".")[0]
+            compression.setdefault(top, "NONE" if col.compression == "UNCOMPRESSED" else col.compression)
+    for n in names:
+        compression.setdefault(n, "NONE")
+    # The reference closes a data page after ONE row (set_data_page_row_count_limit(1), page size limit = one vector).
+    # parquet-cpp only looks at the page size every `write_batch_size` leaf values, so that must be one vector's worth:
+    # the embedding column then gets exactly one vector per page (page-index reads of single rows stay single-page).
     writer = pq.ParquetWriter(output, src.schema_arrow, data_page_size=max(1, index.dim * 4),
+                              write_batch_size=max(1, index.dim),
                               use_dictionary=other, write_statistics=True, write_page_index=True,
                               compression=compression)
     try:

@@ -182,3 +182,60 @@ def test_thrift_splice_is_byte_stable(pqv, tmp_path):
     pq.write_table(t, path, row_group_size=10)
     _, meta = pio._read_footer(path)
     assert pio._emit_struct(pio._struct_fields(meta)) == meta
+
+
+def _data_pages(path, column_root):
+    """(data pages, rows) of the column's chunk in row group 0, by walking the Thrift PageHeaders of the chunk."""
+    from pq_vector_amd import parquet_io as pio
+    md = pq.ParquetFile(path).metadata
+    rg = md.row_group(0)
+    col = next(rg.column(i) for i in range(rg.num_columns) if rg.column(i).path_in_schema.split(".")[0] == column_root)
+    start = col.dictionary_page_offset if col.has_dictionary_page else col.data_page_offset
+    buf = open(path, "rb").read()[start:start + col.total_compressed_size]
+    pos, pages = 0, 0
+    while pos < len(buf):
+        end = pio._skip(buf, pos, pio.T_STRUCT)                 # the PageHeader struct
+        fields = dict((fid, raw) for fid, _, raw in pio._struct_fields(buf[pos:end]))
+        ptype = pio._zigzag_decode(pio._varint(fields[1], 0)[0])
+        comp = pio._zigzag_decode(pio._varint(fields[3], 0)[0])
+        pages += ptype in (0, 3)                                # DATA_PAGE, DATA_PAGE_V2
+        pos = end + comp
+    return pages, rg.num_rows
+
+
+@pytest.mark.parametrize("codec", ["NONE", "SNAPPY"])
+def test_build_new_writes_one_vector_per_page_and_keeps_column_codecs(pqv, tmp_path, codec):
+    """set_data_page_row_count_limit(1) (src/ivf/parquet.rs:324-326): the embedding column of a build_new copy must
+    hold ONE vector per data page, or the reference's single-row page-index reads degrade to whole-chunk reads; the
+    source's per-column compression is kept (parquet.rs:328-331)."""
+    from pq_vector_amd import parquet_io as pio
+    t, _ = _table(n=300, dim=16)
+    src, out = str(tmp_path / "s.parquet"), str(tmp_path / "o.parquet")
+    pq.write_table(t, src, row_group_size=300, compression={"id": codec, "vec": "NONE", "title": codec})
+    pio.write_parquet_with_index(src, out, _index(pqv, dim=16, n=300), "vec")
+    pages, rows = _data_pages(out, "vec")
+    assert rows == 300 and pages == 300
+    rg = pq.ParquetFile(out).metadata.row_group(0)
+    got = {rg.column(i).path_in_schema.split(".")[0]: rg.column(i).compression for i in range(rg.num_columns)}
+    want = "UNCOMPRESSED" if codec == "NONE" else codec
+    assert got == {"id": want, "vec": "UNCOMPRESSED", "title": want}
+
+
+def test_footer_offset_is_parsed_like_rust_u64_and_corrupt_footers_raise_pqv_errors(pqv, tmp_path):
+    from pq_vector_amd import parquet_io as pio
+    t, _ = _table()
+    for bad in (" 5", "5_0", "-5", "0x10", "", "18446744073709551616", "99999999999"):
+        path = str(tmp_path / "b.parquet")
+        pq.write_table(t.replace_schema_metadata({pio.OFFSET_KEY: bad, pio.COLUMN_KEY: "vec"}), path)
+        with pytest.raises(pqv.PqvError):
+            pqv.read_index_from_parquet(path)
+    path = str(tmp_path / "ok.parquet")
+    pq.write_table(t, path)
+    pio.append_index_inplace(path, _index(pqv), "vec")
+    raw = bytearray(open(path, "rb").read())
+    flen = struct.unpack("<I", raw[-8:-4])[0]
+    cut = str(tmp_path / "cut.parquet")
+    # a footer whose length field points into garbage: the Thrift walk must fail as a PqvError, not an IndexError
+    open(cut, "wb").write(bytes(raw[:len(raw) - 8 - flen]) + b"\x19\xfc\xff\xff" + struct.pack("<I", 4) + b"PAR1")
+    with pytest.raises(pqv.PqvError):
+        pqv.read_index_from_parquet(cut)
