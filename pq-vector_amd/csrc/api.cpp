@@ -186,7 +186,9 @@ struct pqv_searcher {
     mutable std::mutex mu;
     mutable Scratch lanes[PQV_LANES];
     mutable uint32_t lane_rr = 0;
-    mutable DevBuf d_mat_blk, d_blk_off;   // blocked MFMA-operand copy of the lists (built on first use)
+    // blocked MFMA-operand copies of the lists, one per operand form in use (0 f32, 1 f16, 2 int8); built at creation
+    // for the form the dispatch rule picks, a second form only if a later call asks for it (e.g. k > 32 on short lists)
+    mutable DevBuf d_mat_blk_op[3], d_blk_off;
     // f16 operands for the wide screened path: values * f16_scale rounded to f16; possible when the stored rows
     // are finite and the power-of-two scale and its square are representable
     bool f16_ok = false;
@@ -198,7 +200,6 @@ struct pqv_searcher {
     float i8_scale = 1.0f, i8_half = 0.0f;
     DevBuf d_center;
     mutable DevBuf d_row_n2i, d_row_res;
-    mutable int blk_op = -1;               // form of d_mat_blk: 0 f32, 1 f16, 2 int8 (-1: none yet)
     // Tunables.  Defaults are what the dispatch rules below were measured with; every one can be set per
     // searcher through pqv_searcher_set_option (tests and benches use that to force a path) and, for the
     // profiling scripts, through a PQV_<NAME> environment variable read ONCE, when the searcher is created.
@@ -1038,8 +1039,14 @@ void opts_from_env(pqv_searcher::Opts &o) {
 bool wide_path_possible(const pqv_searcher *s) { return (s->dim % 64) == 0 && !s->d_row_of && s->n > 0; }
 
 // Operand form of the screen for this searcher (pqv::ScreenOp numbering: 0 f32, 1 f16, 2 int8)
-int screen_op(const pqv_searcher *s) {
-    if (s->opt.screen_i8 && s->i8_ok && (s->dim % 256) == 0 && s->dim >= 256 && static_cast<uint64_t>(64) * s->dim <= 147456) return 2;
+// int8 images halve the bytes per streamed row but widen the bound (residual norms): where lists are short and k is
+// large the extra exact evaluations cost more than the stream saves -- measured on the reference's bench shape (1 M x
+// 1024, 1000-row lists): K = 100 int8 2.93 against f16 2.31 ms per step, K = 10 equal; C3 (9766-row lists) K = 10
+// 2.44 against 3.85, K = 100 4.21 against 5.10; 1 M x 768 (976-row lists) K = 10 1.07 against 1.16.
+int screen_op(const pqv_searcher *s, uint32_t k = 1) {
+    const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
+    const bool i8_pays = !(k > 32 && mean_len < 4096);
+    if (s->opt.screen_i8 && i8_pays && s->i8_ok && (s->dim % 256) == 0 && s->dim >= 256 && static_cast<uint64_t>(64) * s->dim <= 147456) return 2;
     if (s->opt.screen_f16 && s->f16_ok && (s->dim % 128) == 0 && s->dim <= 1024) return 1;
     return 0;
 }
@@ -1048,33 +1055,33 @@ int screen_op(const pqv_searcher *s) {
 // int8 a quarter)
 int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
     using namespace pqv;
-    if (s->d_mat_blk.p && s->blk_op == op) return PQV_OK;
+    DevBuf &blk = s->d_mat_blk_op[op];
+    if (blk.p) return PQV_OK;
     const uint32_t kc = s->n_clusters;
-    HIP_TRY(hipDeviceSynchronize());           // a form change must not pull the copy from under a running query
-    s->d_mat_blk.release();
     std::vector<uint64_t> boff(static_cast<size_t>(kc) + 1, 0);
     for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
-    HIP_TRY(s->d_blk_off.ensure(boff.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (!s->d_blk_off.p) {
+        HIP_TRY(s->d_blk_off.alloc(boff.size() * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     const uint64_t tiles = std::max<uint64_t>(1, boff[kc]);
     if (op == 2) {
-        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim));
+        HIP_TRY(blk.alloc(tiles * 16 * s->dim));
         HIP_TRY(s->d_row_n2i.ensure(std::max<uint64_t>(1, s->n) * sizeof(int)));
         HIP_TRY(s->d_row_res.ensure(std::max<uint64_t>(1, s->n) * sizeof(float)));
         HIP_TRY(launch_block_rows_i8(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                      (s->max_list_len + 15) / 16, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
-                                     s->d_mat_blk.p, s->d_row_n2i.as<int>(), s->d_row_res.as<float>(), stream));
+                                     blk.p, s->d_row_n2i.as<int>(), s->d_row_res.as<float>(), stream));
     } else if (op == 1) {
-        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim * 2));
+        HIP_TRY(blk.alloc(tiles * 16 * s->dim * 2));
         HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                      (s->max_list_len + 15) / 16, s->dim, s->f16_scale, s->d_mat_blk.p, stream));
+                                      (s->max_list_len + 15) / 16, s->dim, s->f16_scale, blk.p, stream));
     } else {
-        HIP_TRY(s->d_mat_blk.alloc(tiles * 16 * s->dim * sizeof(float)));
+        HIP_TRY(blk.alloc(tiles * 16 * s->dim * sizeof(float)));
         HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                  (s->max_list_len + 15) / 16, s->dim, s->d_mat_blk.p, stream));
+                                  (s->max_list_len + 15) / 16, s->dim, blk.p, stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
-    s->blk_op = op;
+    HIP_TRY(hipStreamSynchronize(stream));      // one-off; calls on other streams may follow at once
     return PQV_OK;
 }
 
@@ -1273,7 +1280,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         if (o.tile_filter == 2) p.filter = max_len > 4ull * p.seed_rows && k <= 256;   // forced
         if (p.filter) {
             p.quad = wide_ok;
-            const int op = p.quad ? screen_op(s) : 0;
+            const int op = p.quad ? screen_op(s, k) : 0;
             p.i8 = op == 2;
             p.f16 = op == 1;
             // Quad width = queries that share one pass over a list.  f32 operands: 64 (dim <= 128) or 32 staged in
@@ -1450,7 +1457,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.xcd_swizzle = 0;
         if (p.filter && p.quad) {
             if (int rc = ensure_blocked_copy(s, p.i8 ? 2 : p.f16 ? 1 : 0, stream)) return rc;     // built at creation; here only after an option change
-            ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk.p);
+            ta.mat_blk = static_cast<const float4 *>(s->d_mat_blk_op[p.i8 ? 2 : p.f16 ? 1 : 0].p);
             ta.blk_off = s->d_blk_off.as<uint64_t>();
             ta.block_waves = p.block_waves;
             if (p.f16) {
@@ -1853,7 +1860,8 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
     std::lock_guard<std::mutex> lock(s->mu);
     if (row_order_bytes) *row_order_bytes = s->corpus && s->corpus->d_rows ? s->corpus->capacity * s->corpus->dim * sizeof(float) : 0;
     if (ivf_rows_bytes) *ivf_rows_bytes = s->d_mat_ivf.p ? s->d_mat_ivf.bytes : 0;
-    if (blocked_bytes) *blocked_bytes = s->d_mat_blk.p ? s->d_mat_blk.bytes : 0;
+    if (blocked_bytes) *blocked_bytes = (s->d_mat_blk_op[0].p ? s->d_mat_blk_op[0].bytes : 0) + (s->d_mat_blk_op[1].p ? s->d_mat_blk_op[1].bytes : 0) +
+                                        (s->d_mat_blk_op[2].p ? s->d_mat_blk_op[2].bytes : 0);
     uint64_t other = s->d_centroids.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes +
                      s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
