@@ -217,6 +217,7 @@ struct pqv_searcher {
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
+        uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
     };
     mutable Opts opt;
     mutable pqv_counters_t counters{};
@@ -1033,6 +1034,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
+    o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
 }
 
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
@@ -1290,11 +1292,16 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             // 32-query form moves 41 GB per step through the fabric at 6.8 TB/s for 15 GB of distinct rows).
             p.block_waves = 4;
             if (p.i8) {             // int8 images: a byte per value -- 128 queries up to 1024 dims, 96 at 1536, 64 at 2048
-                p.block_waves = 8;
+                // Up to 1024 dims a 64-query quad is <= 64 KB, so TWO 4-wave blocks share a CU: the blocks are at
+                // different phases (staging / MFMA screen / exact evaluations) and fill each other's stalls, which one
+                // 8-wave block in lockstep cannot (C3: 2.45 -> 2.35 ms kernel time in the same run, although the lists
+                // are streamed 1.5x as often as with 96-query quads).  Longer rows: one 8-wave block per CU.
+                p.block_waves = (o.wide_waves != 8 && 64ull * s->dim <= 65536) ? 4 : 8;
                 // (the 128-query form keeps 128 accumulator registers per lane and spills inside the K loop: 96 by default)
                 const uint32_t fit = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / s->dim / 32 * 32));
                 p.quad_width = std::min<uint32_t>(96, fit);
                 if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width >= 64 && o.quad_width <= fit) p.quad_width = o.quad_width;
+                if (p.block_waves == 4) p.quad_width = 64;
             } else if (p.f16) {
                 const uint64_t per_q = static_cast<uint64_t>(s->dim) * (s->dim <= 128 ? 6 : 2);     // f16 image (+ f32 original)
                 const uint32_t fit8 = static_cast<uint32_t>(std::min<uint64_t>(128, 147456 / per_q / 32 * 32));
@@ -1314,9 +1321,11 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // about half its time at 1536 rows per 4-wave block, and the lists are cut into equal pieces, so
                 // longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 -> 6.35 ms);
                 // the 8-wave blocks (one per CU) measured best at 3072 on C3 (2.60 -> 2.51 ms against 4608)
-                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256 : (p.block_waves == 8 ? 3072ull : 2304ull);
+                // the two-block int8 form measured best at 1280..1536 (C3: 2.37 ms against 2.51 at 2304, 2.45 at 1024)
+                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256
+                                           : p.block_waves == 8 ? 3072ull : p.i8 ? 1536ull : 2304ull;
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
-                const uint64_t min_blocks = p.block_waves == 8 ? 1024 : 2048;
+                const uint64_t min_blocks = o.min_blocks ? o.min_blocks : (p.block_waves == 8 ? 1024 : 2048);
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
                 while (r > 256 * (p.block_waves / 4) && est_quads * (p.quad_width / 16) * ((max_len + r - 1) / r) < min_blocks) r -= 256;
             }
@@ -1807,6 +1816,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else return fail(PQV_ERR_INVALID, "unknown searcher option: " + n);
     return PQV_OK;
 }

@@ -1679,7 +1679,7 @@ template <int NG, int NW, int S, bool QLDS, int OP, bool PF>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && OP != OP_F32)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
     static_assert(!PF || (QLDS && F16), "whole-tile operand prefetch: f16 rows of <= 128 dims");
-    static_assert(!I8 || (QLDS && NW == 8), "int8 operands: queries staged in LDS, 8-wave blocks");
+    static_assert(!I8 || QLDS, "int8 operands: queries staged in LDS");
     static_assert(TILE_QB == 16 && NG >= 2 && NG <= 8 && (NG % 2) == 0 && (NW == 4 || NW == 8), "16-row MFMA tiles, 2..8 groups, 4 or 8 waves");
     constexpr uint32_t NQ = 16 * NG;
     constexpr int QS = (NQ + 63) / 64;        // state slots per lane
@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // every wave with the same values: in registers they were the first thing the allocator spilled, and a spill
     // reload is a VMEM load -- consuming it drains the wave's whole queue of prefetched operands (vmcnt(0)) at the
     // top of every tile.  LDS reads count on lgkmcnt and leave the operand stream alone.
-    constexpr bool LST = NW == 8;
+    constexpr bool LST = NW == 8 || I8;
     __shared__ uint64_t qst_cbase[LST ? NQ : 1];
     __shared__ uint32_t qst_pair[LST ? NQ : 1];
     __shared__ float qst_qn[LST ? NQ : 1];            // |q|^2; NaN = never skip this query (float operand forms)
@@ -2605,9 +2605,13 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const uint32_t nw = a.block_waves ? a.block_waves : 4;
         if (a.i8) {           // int8 images: 8-wave blocks, up to 128 queries x dim bytes of LDS
-            if ((a.dim % 256) != 0 || nw != 8 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
+            if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
             const size_t lds = (size_t)a.quad_width * a.dim;
             if (lds > 147456) return hipErrorInvalidValue;
+            if (nw == 4) {        // two 4-wave blocks per CU
+                if (a.quad_width == 64 && lds <= 65536) return launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
+                return hipErrorInvalidValue;
+            }
             if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_I8>(a, lds, s);
             if (a.quad_width == 96) return launch_wide<6, 8, S, true, OP_I8>(a, lds, s);
             if (a.quad_width == 64) return launch_wide<4, 8, S, true, OP_I8>(a, lds, s);

@@ -862,8 +862,8 @@ def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier)
 
 
 @pytest.mark.parametrize("case", ["huge_rows", "tiny_values", "constant", "signed_offset"])
-@pytest.mark.parametrize("dim", [256, 512])
-def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, case):
+@pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (512, 8), (1280, 8)])
+def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, waves, case):
     """int8 operands are images of (x - centre) * S with ONE global scale: a few enormous rows squeeze every other row
     into the same few levels (the residual bounds then make the screen useless and everything is evaluated exactly,
     overflowing the candidate buffers), tiny values are scaled up, a constant corpus has no range at all, and data far
@@ -886,8 +886,10 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, case
     oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=3)
     monkeypatch.setenv("PQV_RERANK_MODE", "tile")
     monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    monkeypatch.setenv("PQV_WIDE_WAVES", str(waves))        # two 4-wave blocks per CU (up to 1024 dims) / one 8-wave block
     s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
-    assert "int8 screen operands" in s.describe(nq, k, nprobe)
+    plan = s.describe(nq, k, nprobe)
+    assert "int8 screen operands" in plan and f"{waves} waves per block" in plan, plan
     rows, dist, nf, nc = s.topk(queries, k, nprobe)
     orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
     assert (nc == onc).all() and (nf == onf).all()
