@@ -175,6 +175,8 @@ struct pqv_searcher {
     pqv_corpus *corpus = nullptr;          // borrowed
     std::vector<uint64_t> h_list_off;      // host copy for candidate_rows
     std::vector<uint32_t> h_list_rows;
+    DevBuf d_cent_t;                   // [dim/4][kc_pad] float4 transpose of the centroids (probe_rows_kernel), dim % 4 == 0
+    uint32_t kc_pad = 0;
     DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats, d_row_norm2;   // |x|^2 per storage row (MFMA screen)
     const float *d_mat = nullptr;          // row storage the re-rank reads
     const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout)
@@ -216,6 +218,7 @@ struct pqv_searcher {
         int running_thr = 1;               // running thresholds of the wide kernel
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
+        int probe_rows = 1;                // batched centroid probe (probe_rows_kernel) when dim % 4 == 0; 0 = stream_kernel
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
         uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
     };
@@ -1033,6 +1036,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.running_thr = num("PQV_RUNNING_THR", o.running_thr) != 0;
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
+    o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
 }
@@ -1125,6 +1129,11 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
                          hipMemcpyHostToDevice, s->stream));
     S_TRY(hipMemcpyAsync(s->d_list_off.p, index->list_off.data(), index->list_off.size() * sizeof(uint64_t),
                          hipMemcpyHostToDevice, s->stream));
+    if ((s->dim % 4) == 0 && s->n_clusters) {
+        s->kc_pad = (s->n_clusters + 255) / 256 * 256;
+        S_TRY(s->d_cent_t.alloc(static_cast<size_t>(s->kc_pad) * s->dim * sizeof(float)));
+        S_TRY(pqv::launch_transpose_rows4(s->d_centroids.as<float>(), s->n_clusters, s->kc_pad, s->dim, s->d_cent_t.p, s->stream));
+    }
     if (!index->list_rows.empty())
         S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice, s->stream));
@@ -1222,6 +1231,8 @@ namespace {
 struct TopkPlan {
     uint32_t np;            // effective nprobe
     uint32_t probe_bpl;     // blocks over the centroid matrix
+    uint32_t probe_kpart;   // entries per partial list of the probe pass (np, or 64 unsorted from probe_rows_kernel)
+    bool probe_rows;        // batched probe_rows_kernel instead of the per-query stream_kernel
     uint32_t rr_rows_per_block, rr_bpl;
     uint32_t n_part_probe, n_part_rr;
     bool tile;              // batched cluster-major tiles instead of one stream per (query, list)
@@ -1243,6 +1254,8 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     // probe pass: every block scans 256 centroids (64 per wave)
     p.probe_bpl = (s->n_clusters + 255) / 256;
     p.n_part_probe = p.probe_bpl * pqv::waves_per_block();
+    p.probe_rows = s->opt.probe_rows && s->kc_pad != 0;
+    p.probe_kpart = p.probe_rows ? 64u : p.np;
     // re-rank: enough blocks to fill 256 CUs several times over, few enough partial lists
     const uint64_t max_len = std::max<uint64_t>(1, s->max_list_len);
     const uint64_t max_bpl = (max_len + 255) / 256;
@@ -1371,8 +1384,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     const TopkPlan p = plan_topk(s, nq, nprobe, k, metric);
     const uint64_t max_pos = max_candidates ? max_candidates : ~0ull;
 
-    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint64_t)));
-    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.np * sizeof(uint32_t)));
+    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.probe_kpart * sizeof(uint64_t)));
+    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(nq) * p.n_part_probe * p.probe_kpart * sizeof(uint32_t)));
     HIP_TRY(sc.s_probe.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
     HIP_TRY(sc.s_cand_base.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint64_t)));
     HIP_TRY(sc.s_ncand.ensure(static_cast<size_t>(nq) * sizeof(uint64_t)));
@@ -1409,11 +1422,20 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
         if (p.filter) { HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float))); HIP_TRY(sc.s_qmax.ensure(static_cast<size_t>(nq) * sizeof(float))); }
     }
-    HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
+    if (p.probe_rows) {     // a batch: a lane per centroid, the chains of up to 8 queries in registers
+        pqv::ProbeRowsArgs pr{};
+        pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
+        pr.nq = nq; pr.kc = s->n_clusters; pr.kc_pad = s->kc_pad; pr.dim = s->dim;
+        pr.part_keys = pa.part_keys; pr.part_vals = pa.part_vals;
+        pr.zero_u32 = pa.zero_u32; pr.zero_n = pa.zero_n;
+        HIP_TRY(pqv::launch_probe_rows(pr, stream));
+    } else {
+        HIP_TRY(launch_stream(pa, STREAM_TOPK, stream));
+    }
 
     MergeArgs pm{};
     pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals;
-    pm.nq = nq; pm.n_part = p.n_part_probe; pm.k_part = p.np; pm.k = p.np;
+    pm.nq = nq; pm.n_part = p.n_part_probe; pm.k_part = p.probe_kpart; pm.k = p.np;
     pm.list_off = s->d_list_off.as<uint64_t>();
     pm.probe = sc.s_probe.as<uint32_t>(); pm.cand_base = sc.s_cand_base.as<uint64_t>();
     pm.n_cand = d_n_cand ? d_n_cand : sc.s_ncand.as<uint64_t>();
@@ -1815,6 +1837,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
+    else if (n == "probe_rows") o.probe_rows = value != 0;
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else return fail(PQV_ERR_INVALID, "unknown searcher option: " + n);
@@ -1856,7 +1879,7 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
                       seed_ng, qlds ? "true" : "false", op, S, std::max<uint32_t>(1, nq) * 64);
     }
-    std::snprintf(buf, len, "%s%s", t, kn);
+    std::snprintf(buf, len, "%s; centroid probe: %s%s", t, p.probe_rows ? "probe_rows_kernel (a lane per centroid)" : "stream_kernel", kn);
     return PQV_OK;
 }
 extern "C" int pqv_searcher_describe(const pqv_searcher *s, uint32_t nq, uint32_t k, uint32_t nprobe, int metric,
@@ -1872,7 +1895,7 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
     if (ivf_rows_bytes) *ivf_rows_bytes = s->d_mat_ivf.p ? s->d_mat_ivf.bytes : 0;
     if (blocked_bytes) *blocked_bytes = (s->d_mat_blk_op[0].p ? s->d_mat_blk_op[0].bytes : 0) + (s->d_mat_blk_op[1].p ? s->d_mat_blk_op[1].bytes : 0) +
                                         (s->d_mat_blk_op[2].p ? s->d_mat_blk_op[2].bytes : 0);
-    uint64_t other = s->d_centroids.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes +
+    uint64_t other = s->d_centroids.bytes + s->d_cent_t.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes +
                      s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
@@ -1906,8 +1929,8 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     Scratch &sc = *lane;
     const TopkPlan p = plan_topk(s, 1, nprobe);
     HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
-    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint64_t)));
-    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(p.n_part_probe) * np * sizeof(uint32_t)));
+    HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * p.probe_kpart * sizeof(uint64_t)));
+    HIP_TRY(sc.s_probe_vals.ensure(static_cast<size_t>(p.n_part_probe) * p.probe_kpart * sizeof(uint32_t)));
     HIP_TRY(sc.s_probe.ensure(static_cast<size_t>(np) * sizeof(uint32_t)));
     HIP_TRY(sc.s_cand_base.ensure(static_cast<size_t>(np) * sizeof(uint64_t)));
     HIP_TRY(sc.s_ncand.ensure(sizeof(uint64_t)));
@@ -1918,10 +1941,18 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     pa.queries = sc.s_queries.as<float>(); pa.nq = 1; pa.nprobe = 1; pa.dim = s->dim; pa.k = np;
     pa.rows_per_block = 256; pa.blocks_per_list = p.probe_bpl; pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;
     pa.part_keys = sc.s_probe_keys.as<uint64_t>(); pa.part_vals = sc.s_probe_vals.as<uint32_t>();
-    HIP_TRY(launch_stream(pa, STREAM_TOPK, s->stream));
+    if (p.probe_rows) {
+        pqv::ProbeRowsArgs pr{};
+        pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = pa.queries;
+        pr.nq = 1; pr.kc = s->n_clusters; pr.kc_pad = s->kc_pad; pr.dim = s->dim;
+        pr.part_keys = pa.part_keys; pr.part_vals = pa.part_vals;
+        HIP_TRY(pqv::launch_probe_rows(pr, s->stream));
+    } else {
+        HIP_TRY(launch_stream(pa, STREAM_TOPK, s->stream));
+    }
     MergeArgs pm{};
     pm.part_keys = pa.part_keys; pm.part_vals = pa.part_vals; pm.nq = 1; pm.n_part = p.n_part_probe;
-    pm.k_part = np; pm.k = np; pm.list_off = s->d_list_off.as<uint64_t>();
+    pm.k_part = p.probe_kpart; pm.k = np; pm.list_off = s->d_list_off.as<uint64_t>();
     pm.probe = sc.s_probe.as<uint32_t>(); pm.cand_base = sc.s_cand_base.as<uint64_t>();
     pm.n_cand = sc.s_ncand.as<uint64_t>(); pm.max_pos = ~0ull;
     HIP_TRY(launch_merge_probe(pm, s->stream));

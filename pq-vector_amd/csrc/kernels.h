@@ -45,6 +45,19 @@ struct StreamArgs {
 // Streaming exact-order squared-L2 pass (the re-rank kernel).  Returns hipError_t.
 hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s);
 
+// Batched centroid probe (probe_rows_kernel): every query against every centroid, exact reference order.
+struct ProbeRowsArgs {
+    const float4   *cent_t;      // [dim/4][kc_pad] float4 transpose of the centroid table (launch_transpose_rows4)
+    const float    *queries;     // [nq, dim]
+    uint32_t        nq, kc, kc_pad, dim;
+    uint64_t       *part_keys;   // [nq][4 * ceil(kc/256)][64], unsorted
+    uint32_t       *part_vals;
+    uint32_t       *zero_u32;    // optional scratch to zero (as StreamArgs::zero_u32)
+    uint32_t        zero_n;
+};
+hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s);
+hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
+
 struct MergeArgs {
     const uint64_t *part_keys;   // [nq][n_part][k_part]
     const uint32_t *part_vals;

@@ -445,6 +445,93 @@ hipError_t launch_stream(const StreamArgs &a, StreamMode mode, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
+// probe_rows_kernel: the centroid probe of a BATCH (src/ivf/index.rs:130-149 for every query), dim % 4 == 0.
+//
+// stream_kernel reads the whole centroid table once per query (C3: 1024 queries x 3 MB through L2, 240 us) and
+// re-creates each row's serial chain through an LDS transpose.  Here a LANE owns a centroid and keeps the chains of QB
+// queries in registers: the table is read from a [dim/4][kc_pad] float4 transpose (64 consecutive centroids = one 1 KiB
+// load), the queries are wave-uniform and arrive as scalar operands, so a float4 of a row serves QB queries and the
+// kernel is bound by the 12 VALU operations per (query, centroid, float4) of the reference arithmetic
+//   t = ((d0^2 + d1^2) + d2^2) + d3^2;  sum = sum + t        (index.rs:461-472, no FMA)
+// grid = (ceil(kc / 256), ceil(nq / QB)); the 4 waves of a block take 4 runs of 64 centroids for the same QB queries.
+// Output: UNSORTED partial lists [nq][4 * gridDim.x][64] of (distance bits << 32 | centroid, centroid) for merge_kernel.
+// ------------------------------------------------------------------------------------
+template <int QB>
+__global__ __launch_bounds__(256) void probe_rows_kernel(const ProbeRowsArgs a) {
+    if (a.zero_u32 && blockIdx.x == 0) {
+        for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < a.zero_n; i += gridDim.y * 256) a.zero_u32[i] = 0u;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t part = blockIdx.x * 4 + wave;
+    const uint32_t c = part * 64 + lane;                     // < kc_pad (the transpose is padded with zero rows)
+    const uint32_t q0 = blockIdx.y * QB;
+    const uint32_t G = a.dim >> 2;
+    const float4 *xt = a.cent_t + c;
+    const float *qv[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) qv[u] = a.queries + (uint64_t)(q0 + u < a.nq ? q0 + u : a.nq - 1) * a.dim;
+    float sum[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) sum[u] = 0.0f;
+    if (part * 64 < a.kc_pad) {
+#pragma unroll 2
+        for (uint32_t g = 0; g < G; ++g) {
+            const float4 x = xt[(uint64_t)g * a.kc_pad];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const float4 qq = load4_uniform<true>(qv[u] + g * 4);
+                const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum[u] = sum[u] + t;
+            }
+        }
+    }
+    const uint32_t n_part = gridDim.x * 4;
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        if (q0 + u < a.nq) {
+            const uint64_t o = ((uint64_t)(q0 + u) * n_part + part) * 64 + lane;
+            a.part_keys[o] = c < a.kc ? (((uint64_t)__float_as_uint(sum[u]) << 32) | c) : KEY_EMPTY;
+            a.part_vals[o] = c < a.kc ? c : 0xFFFFFFFFu;
+        }
+    }
+}
+hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s) {
+    if (a.nq == 0 || a.kc == 0) return hipSuccess;
+    if ((a.dim % 4) != 0 || (a.kc_pad % 64) != 0 || a.kc_pad < a.kc) return hipErrorInvalidValue;
+    const uint32_t gx = (a.kc + 255) / 256;
+    // enough blocks for the chip first, then as many queries per row read as the batch allows
+    const int qb = (uint64_t)gx * (a.nq / 8) >= 512 ? 8 : (uint64_t)gx * (a.nq / 4) >= 512 ? 4 : (uint64_t)gx * (a.nq / 2) >= 256 ? 2 : 1;
+    const dim3 grid(gx, (a.nq + qb - 1) / qb);
+    switch (qb) {
+    case 8: hipLaunchKernelGGL(probe_rows_kernel<8>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(probe_rows_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(probe_rows_kernel<2>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(probe_rows_kernel<1>, grid, dim3(256), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+// cent_t[g * kc_pad + c] = float4 g of centroid c (zero rows for c >= kc)
+__global__ __launch_bounds__(256) void transpose_rows4_kernel(const float *__restrict__ rows, uint32_t kc, uint32_t kc_pad, uint32_t dim,
+                                                            float4 *__restrict__ out) {
+    const uint32_t G = dim >> 2;
+    const uint64_t total = (uint64_t)G * kc_pad;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t g = (uint32_t)(i / kc_pad), c = (uint32_t)(i % kc_pad);
+        out[i] = c < kc ? *reinterpret_cast<const float4 *>(rows + (uint64_t)c * dim + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s) {
+    if (kc == 0 || (dim % 4) != 0) return hipErrorInvalidValue;
+    const uint64_t total = (uint64_t)(dim / 4) * kc_pad;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(transpose_rows4_kernel, dim3(blocks), dim3(256), 0, s, rows, kc, kc_pad, dim, static_cast<float4 *>(out));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // merge_kernel: one wave per query folds all partial lists.
 // PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
 // PROBE == true : the k "rows" are centroids; emits the probe order and the candidate

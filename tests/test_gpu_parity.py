@@ -980,3 +980,46 @@ def test_rerank_device_matches_update_topk_heap(pqv, oracle, metric_name):
             orow, od2 = order[sel], d2[sel]
         assert (_bits(got_d) == _bits(od2)).all()
         _assert_topk_equal((got_r[None, :], got_d[None, :], np.array([k])), (np.asarray(orow)[None, :], np.asarray(od2)[None, :], np.array([k])), k)
+
+
+@pytest.mark.parametrize("dim,kc,nprobe", [(8, 5, 3), (64, 70, 70), (128, 316, 20), (96, 1000, 100), (768, 1024, 32), (130, 40, 7)])
+def test_batched_centroid_probe_matches_find_closest_centroids(pqv, oracle, dim, kc, nprobe):
+    """probe_rows_kernel (a lane per centroid, up to 8 queries per row read; dim % 4 == 0) against the oracle's
+    find_closest_centroids (src/ivf/index.rs:130-149): the probe ORDER is pinned through a candidate cap in the middle
+    of a probed list (the cap cuts the concatenation in probe order), the probed SET through n_candidates, and the
+    single-query entry point returns the order itself.  Batch sizes cover every queries-per-lane variant; kc values
+    that are not multiples of 64 / 256 exercise the padded transpose; dim 130 takes the stream_kernel fallback."""
+    rng = np.random.default_rng(dim * 1000 + kc)
+    n = max(4 * kc, 3000)
+    data = rng.random((n, dim), dtype=np.float32)
+    if kc >= 64:
+        data[: kc // 2] = data[kc // 2: 2 * (kc // 2)]                  # duplicate rows: equal centroid distances can occur
+    oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=2)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    plan = s.describe(1024, 5, nprobe)
+    assert ("probe_rows_kernel" in plan) == (dim % 4 == 0), plan
+    s0 = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    s0.set_option("probe_rows", 0)
+    assert "centroid probe: stream_kernel" in s0.describe(1024, 5, nprobe)
+    k = 5
+    for nq in (1, 3, 40, 130, 700, 2100):
+        queries = rng.random((nq, dim), dtype=np.float32)
+        queries[0] = data[0]
+        for q in range(0, nq, max(1, nq // 5)):
+            want = oidx.find_closest_centroids(queries[q], nprobe)
+            got = s.probe(queries[q], nprobe)
+            assert np.array_equal(np.asarray(got, np.uint32), np.asarray(want, np.uint32)), (nq, q)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        r0, d0, nf0, nc0 = s0.topk(queries, k, nprobe)
+        assert np.array_equal(rows, r0) and np.array_equal(_bits(dist), _bits(d0)) and np.array_equal(nc, nc0)
+        cap = int(nc.min()) // 2 + 1
+        rows_c, dist_c, nf_c, nc_c = s.topk(queries, k, nprobe, max_candidates=cap)
+        for q in range(0, nq, max(1, nq // 7)):
+            cand = oidx.candidate_rows(queries[q], nprobe)
+            assert nc[q] == len(cand)
+            cand = cand[:cap]
+            d2 = np.array([oracle.l2_ref4(queries[q], data[r]) for r in cand], np.float32)
+            order = np.lexsort((np.arange(len(cand)), d2.view(np.uint32)))[:k]
+            assert (_bits(dist_c[q, :len(order)]) == _bits(np.sqrt(d2[order]))).all(), (nq, q)
+            if len(set(d2[order].tolist())) == len(order) and (len(d2) <= k or np.sort(d2)[k] != np.sort(d2)[k - 1]):
+                assert (rows_c[q, :len(order)] == cand[order]).all(), (nq, q)
