@@ -1305,16 +1305,20 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             // 32-query form moves 41 GB per step through the fabric at 6.8 TB/s for 15 GB of distinct rows).
             p.block_waves = 4;
             if (p.i8) {             // int8 images: a byte per value -- 128 queries up to 1024 dims, 96 at 1536, 64 at 2048
-                // Up to 1024 dims a 64-query quad is <= 64 KB, so TWO 4-wave blocks share a CU: the blocks are at
-                // different phases (staging / MFMA screen / exact evaluations) and fill each other's stalls, which one
-                // 8-wave block in lockstep cannot (C3: 2.45 -> 2.35 ms kernel time in the same run, although the lists
-                // are streamed 1.5x as often as with 96-query quads).  Longer rows: one 8-wave block per CU.
+                // Up to 1024 dims a 64-query quad is <= 64 KB (96 queries <= 72 KB up to 768 dims), so TWO 4-wave blocks
+                // share a CU: the blocks are at different phases (staging / MFMA screen / exact evaluations) and fill
+                // each other's stalls, which one 8-wave block in lockstep cannot.  C3, kernel time in one run: one
+                // 8-wave block of 96 queries 2.45 ms (12.2 GB through the fabric), two 4-wave blocks of 64 queries 2.36 ms
+                // (15.3 GB at 6.5 TB/s: bandwidth-bound), two of 96 queries 2.21 ms.  Longer rows: one 8-wave block.
                 p.block_waves = (o.wide_waves != 8 && 64ull * s->dim <= 65536) ? 4 : 8;
                 // (the 128-query form keeps 128 accumulator registers per lane and spills inside the K loop: 96 by default)
                 const uint32_t fit = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / s->dim / 32 * 32));
                 p.quad_width = std::min<uint32_t>(96, fit);
                 if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width >= 64 && o.quad_width <= fit) p.quad_width = o.quad_width;
-                if (p.block_waves == 4) p.quad_width = 64;
+                // (a batch that leaves most quads with a few queries -- a single query above all -- takes the 64-query
+                //  form: no spills, 250 against 290 us for one C3 query)
+                if (p.block_waves == 4)
+                    p.quad_width = (o.quad_width != 64 && 96ull * s->dim <= 73728 && (o.quad_width == 96 || pairs >= 16ull * s->n_clusters)) ? 96 : 64;
             } else if (p.f16) {
                 const uint64_t per_q = static_cast<uint64_t>(s->dim) * (s->dim <= 128 ? 6 : 2);     // f16 image (+ f32 original)
                 const uint32_t fit8 = static_cast<uint32_t>(std::min<uint64_t>(128, 147456 / per_q / 32 * 32));
@@ -1334,9 +1338,9 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // about half its time at 1536 rows per 4-wave block, and the lists are cut into equal pieces, so
                 // longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 -> 6.35 ms);
                 // the 8-wave blocks (one per CU) measured best at 3072 on C3 (2.60 -> 2.51 ms against 4608)
-                // the two-block int8 form measured best at 1280..1536 (C3: 2.37 ms against 2.51 at 2304, 2.45 at 1024)
+                // the two-block int8 form is flat between 1280 and 5120 (C3, 96 queries: 2.21 ms at 1792, 2.26 .. 2.29 around)
                 const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256
-                                           : p.block_waves == 8 ? 3072ull : p.i8 ? 1536ull : 2304ull;
+                                           : p.block_waves == 8 ? 3072ull : p.i8 ? 1792ull : 2304ull;
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
                 const uint64_t min_blocks = o.min_blocks ? o.min_blocks : (p.block_waves == 8 ? 1024 : 2048);
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);

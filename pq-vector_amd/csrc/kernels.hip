@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
     // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
     // (<= 256) for the 8-wave blocks, whose LDS belongs to the staged queries
-    constexpr int PASS = NW == 8 ? 256 : 512;
+    constexpr int PASS = NW == 8 ? 256 : (I8 && NG == 6) ? 128 : 512;      // (96 int8 queries, two blocks per CU: 80 KB each)
     constexpr int PEND = PASS + 64;        // one pass + a partial batch
     constexpr int NT = 64 * NW;
 #ifdef PQV_PROFILE_PHASES
@@ -2559,9 +2559,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
         }
-        // slow path: passes of PASS / 64 / 4 = RP of the lane's four queries (r) per group
-        constexpr uint32_t RP = PASS / 256;                  // 2 (half a group per pass) or 1 (a quarter)
-        constexpr uint32_t PPG = 4 / RP;                     // passes per group
+        // slow path: passes of BP = PASS / 64 of a lane's 16 pair bits (cc = 4 r + t) per group: 8 (half a group per
+        // pass), 4 (a quarter) or 2
+        constexpr uint32_t BP = PASS / 64;
+        constexpr uint32_t PPG = 16 / BP;                    // passes per group
         const uint32_t hend = one_pass ? 0u : PPG * ng + (t0 + 64 >= r1 ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t hg = 0; hg < hend; ++hg) {
@@ -2571,8 +2572,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int ww = 1; ww < NG / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? vw[ww] : w;
                 uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
-                // cc = 4 r + t lives in bit 15 - cc: pass ps takes r in [ps RP, ps RP + RP)
-                mm &= (RP == 2 ? 0xFF00u : 0xF000u) >> (4 * RP * ps);
+                // cc = 4 r + t lives in bit 15 - cc: pass ps takes cc in [ps BP, ps BP + BP)
+                mm &= ((((1u << BP) - 1u) << (16 - BP)) & 0xFFFFu) >> (BP * ps);
                 const uint32_t cntl = (uint32_t)__popc(mm);
                 const uint32_t incl = wave_incl_scan_u32(cntl);
                 uint32_t at = npend + incl - cntl;
@@ -2674,7 +2675,11 @@ static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
             allowed.store(lds, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL(kern, dim3(a.grid_x, a.max_quads), dim3(64 * NW), lds, s, a);
+    // Workgroups go to the 8 XCDs round-robin in linear order, and the lists are very unequal (C3: 1 .. 44 k rows around
+    // a mean of 9.8 k), so most quads use only the first few of the grid's row chunks: with an even grid width the
+    // chunk index decides the XCD and some XCDs get most of the work (C4 at 32 chunks: 4.29 ms against 2.76 ms at 19).
+    // An odd width makes consecutive quads start on different XCDs; the extra column exits at once.
+    hipLaunchKernelGGL(kern, dim3(a.grid_x | 1u, a.max_quads), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -2697,6 +2702,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
             if (lds > 147456) return hipErrorInvalidValue;
             if (nw == 4) {        // two 4-wave blocks per CU
                 if (a.quad_width == 64 && lds <= 65536) return launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
+                if (a.quad_width == 96 && lds <= 73728) return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
                 return hipErrorInvalidValue;
             }
             if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_I8>(a, lds, s);

@@ -887,6 +887,8 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, wave
     monkeypatch.setenv("PQV_RERANK_MODE", "tile")
     monkeypatch.setenv("PQV_TILE_FILTER", "2")
     monkeypatch.setenv("PQV_WIDE_WAVES", str(waves))        # two 4-wave blocks per CU (up to 1024 dims) / one 8-wave block
+    if waves == 4 and dim == 512:
+        monkeypatch.setenv("PQV_QUAD_WIDTH", "64")          # (the two-block form takes 96-query quads up to 768 dims)
     s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
     plan = s.describe(nq, k, nprobe)
     assert "int8 screen operands" in plan and f"{waves} waves per block" in plan, plan
