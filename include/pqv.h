@@ -154,6 +154,10 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "quad_xcd"      quad-to-XCD affinity of the wide kernels (-1 by rule)
  *   "wide_waves"    waves per block of the wide kernel: 0 by rule, 4 or 8
  *   "quad_width"    queries per quad of the wide kernel (0 by rule; a multiple of 32)
+ *   "screen_i8"     int8 screen operands for rows of a multiple of 256 dims (default 1)
+ *   "min_blocks"    workgroups the wide kernel's rows-per-block rule aims for on small batches (0 by rule)
+ *   "probe_rows"    batched centroid probe (a lane per centroid): 1 for batches of >= 8 queries (default), 2 always,
+ *                   0 = the per-query stream over the centroid table
  * The same names, upper-cased with a PQV_ prefix, are read from the environment ONCE when a searcher is created
  * (profiling scripts). */
 int pqv_searcher_set_option(pqv_searcher *searcher, const char *name, int64_t value);

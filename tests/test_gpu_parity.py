@@ -862,7 +862,7 @@ def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier)
 
 
 @pytest.mark.parametrize("case", ["huge_rows", "tiny_values", "constant", "signed_offset"])
-@pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (512, 8), (1280, 8)])
+@pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (1024, 4), (512, 8), (1280, 8)])
 def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, waves, case):
     """int8 operands are images of (x - centre) * S with ONE global scale: a few enormous rows squeeze every other row
     into the same few levels (the residual bounds then make the screen useless and everything is evaluated exactly,
@@ -1000,6 +1000,8 @@ def test_batched_centroid_probe_matches_find_closest_centroids(pqv, oracle, dim,
     s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
     plan = s.describe(1024, 5, nprobe)
     assert ("probe_rows_kernel" in plan) == (dim % 4 == 0), plan
+    assert "centroid probe: stream_kernel" in s.describe(1, 5, nprobe)      # a handful of queries keep the per-query stream
+    s.set_option("probe_rows", 2)                                            # ... unless asked: every batch size below
     s0 = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
     s0.set_option("probe_rows", 0)
     assert "centroid probe: stream_kernel" in s0.describe(1024, 5, nprobe)
