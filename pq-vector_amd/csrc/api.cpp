@@ -159,7 +159,7 @@ struct pqv_corpus {
 constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
-        s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
+        s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
         s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_part_flags;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
@@ -217,6 +217,7 @@ struct pqv_searcher {
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
         int running_thr = 1;               // running thresholds of the wide kernel
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
+        int item_grid = 1;                 // wide filter kernel: 1-D grid over (quad, existing row chunk) items
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
         int probe_rows = 1;                // batched centroid probe (probe_rows_kernel) when dim % 4 == 0; 0 = stream_kernel
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
@@ -1036,6 +1037,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.running_thr = num("PQV_RUNNING_THR", o.running_thr) != 0;
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
+    o.item_grid = static_cast<int>(num("PQV_ITEM_GRID", o.item_grid));
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
@@ -1339,9 +1341,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // about half its time at 1536 rows per 4-wave block, and the lists are cut into equal pieces, so
                 // longer blocks pay: measured optimum 2304 on C2 (0.221 -> 0.193 ms) and C3 (6.63 -> 6.35 ms);
                 // the 8-wave blocks (one per CU) measured best at 3072 on C3 (2.60 -> 2.51 ms against 4608)
-                // the two-block int8 form is flat between 1280 and 5120 (C3, 96 queries: 2.21 ms at 1792, 2.26 .. 2.29 around)
+                // the two-block int8 form is flat between 1280 and 5120 on the item grid (C3: 2.19 / 2.20 / 2.16 ms at 1280 /
+                // 1792 / 3072; C4 shard: 2.77 / 2.69 / 2.71)
                 const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256
-                                           : p.block_waves == 8 ? 3072ull : p.i8 ? 1792ull : 2304ull;
+                                           : (p.block_waves == 8 || p.i8) ? 3072ull : 2304ull;
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
                 const uint64_t min_blocks = o.min_blocks ? o.min_blocks : (p.block_waves == 8 ? 1024 : 2048);
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
@@ -1421,7 +1424,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         // u32 scratch: hist[R][kc] cursor[R][kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
         // (R = HIST_REPLICAS partial copies); the probe kernel zeroes hist, the probe merge fills it, the scan sets cursor
         constexpr uint64_t R = pqv::HIST_REPLICAS;
-        HIP_TRY(sc.s_pair_u32.ensure(((2 * R + 3) * kc_pairs + 5) * sizeof(uint32_t)));
+        HIP_TRY(sc.s_pair_u32.ensure(((2 * R + 4) * kc_pairs + 8) * sizeof(uint32_t)));      // + item_off[kc+1] n_items[1]
         pair_u32 = sc.s_pair_u32.as<uint32_t>();
         pa.zero_u32 = pair_u32; pa.zero_n = static_cast<uint32_t>(R * kc_pairs);
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
@@ -1477,6 +1480,16 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ps.n_groups = v + 4ull * kc + 2;
         ps.quad_off = v + 4ull * kc + 3; ps.n_quads = v + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
         ps.pairs = sc.s_pairs.as<uint32_t>(); ps.groups = sc.s_groups.as<uint4>(); ps.quads = sc.s_quads.as<uint4>();
+        // work items of the wide filter kernel (quad x row chunk that exists): its grid then has no holes
+        // (the 8-wave blocks keep the 2-D grid with its quad-to-XCD affinity: C2 7.25 against 7.13 M QPS)
+        const bool items = p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4));
+        const uint32_t max_items = items ? p.max_quads * p.filter_bpl : 0;
+        if (items) {
+            HIP_TRY(sc.s_items.ensure(static_cast<size_t>(max_items) * sizeof(uint32_t)));
+            ps.list_off = s->d_list_off.as<uint64_t>(); ps.item_rows = p.filter_rows_per_block;
+            ps.item_off = v + 5ull * kc + 5; ps.n_items = v + 6ull * kc + 6;
+            ps.item_quad = sc.s_items.as<uint32_t>(); ps.max_items = max_items;
+        }
         HIP_TRY(launch_pair_sort(ps, stream));
         TileArgs ta{};
         ta.mat = s->d_mat; ta.row_of = s->d_row_of; ta.list_off = s->d_list_off.as<uint64_t>();
@@ -1553,6 +1566,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
+            if (items) { ta.item_quad = ps.item_quad; ta.n_items = ps.n_items; ta.max_items = max_items; }
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
@@ -1842,6 +1856,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
+    else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
@@ -1904,7 +1919,7 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
                      s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
-                                &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads,
+                                &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads, &l.s_items,
                                 &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
                                 &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres, &l.s_part_flags})
             other += b->p ? b->bytes : 0;

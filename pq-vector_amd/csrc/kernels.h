@@ -146,6 +146,14 @@ struct PairSortArgs {
     uint32_t       *quad_off;  // [n_clusters + 1]
     uint4          *quads;     // [max_quads] {cluster, first slot, count, 0}
     uint32_t       *n_quads;   // [1]
+    // optional work-item table of the wide filter kernel: one item per (quad, row chunk that exists in the quad's
+    // list), quads in order, so that the kernel's 1-D grid holds no empty workgroups between real ones
+    const uint64_t *list_off;  // [n_clusters + 1]
+    uint32_t        item_rows; // rows per chunk (the kernel's rows_per_block); 0 = no table
+    uint32_t       *item_off;  // [n_clusters + 1] first item of each cluster's first quad
+    uint32_t       *n_items;   // [1]
+    uint32_t       *item_quad; // [max_items] quad of each item; quads[q].w = the quad's first item
+    uint32_t        max_items;
 };
 // hist -> scan -> scatter; three tiny launches
 hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
@@ -199,6 +207,9 @@ struct TileArgs {
     const float    *row_norm2;   // indexed like mat rows
     const float    *query_norm2; // [nq]
     int             xcd_swizzle; // 1: XCD-aware workgroup remap (speed only)
+    const uint32_t *item_quad;   // wide_filter_kernel: work-item table (PairSortArgs::item_quad); nullptr = 2-D grid
+    const uint32_t *n_items;
+    uint32_t        max_items;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates
     uint64_t       *cand_keys;   // [nq][cand_cap]
     uint32_t       *cand_vals;

@@ -728,10 +728,10 @@ __global__ __launch_bounds__(256) void pair_hist_kernel(const PairSortArgs a) {
 
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     // single block: exclusive scans of hist and of ceil(hist / TILE_QB)
-    __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024];
-    __shared__ uint32_t carry_pair, carry_grp, carry_quad;
+    __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024], s_item[1024];
+    __shared__ uint32_t carry_pair, carry_grp, carry_quad, carry_item;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; }
+    if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
         const uint32_t c = base + tid;
@@ -750,22 +750,28 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
         }
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
         const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
-        s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd;
+        uint32_t ni = 0;                     // work items of the cluster: quads x row chunks of its list
+        if (a.item_rows && c < a.n_clusters) {
+            const uint64_t len = a.list_off[c + 1] - a.list_off[c];
+            ni = qd * (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+        }
+        s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd; s_item[tid] = ni;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t vp = 0, vg = 0, vq = 0;
-            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; vq = s_quad[tid - off]; }
+            uint32_t vp = 0, vg = 0, vq = 0, vi = 0;
+            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; vq = s_quad[tid - off]; vi = s_item[tid - off]; }
             __syncthreads();
-            s_pair[tid] += vp; s_grp[tid] += vg; s_quad[tid] += vq;
+            s_pair[tid] += vp; s_grp[tid] += vg; s_quad[tid] += vq; s_item[tid] += vi;
             __syncthreads();
         }
         if (c < a.n_clusters) {
             a.pair_off[c] = carry_pair + s_pair[tid] - h;
             a.group_off[c] = carry_grp + s_grp[tid] - g;
             a.quad_off[c] = carry_quad + s_quad[tid] - qd;
+            if (a.item_rows) a.item_off[c] = carry_item + s_item[tid] - ni;
         }
         __syncthreads();
-        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; carry_quad += s_quad[1023]; }
+        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; carry_quad += s_quad[1023]; carry_item += s_item[1023]; }
         __syncthreads();
     }
     if (tid == 0) {
@@ -774,6 +780,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
         a.quad_off[a.n_clusters] = carry_quad;
         *a.n_groups = carry_grp;
         *a.n_quads = carry_quad;
+        if (a.item_rows) { a.item_off[a.n_clusters] = carry_item; *a.n_items = carry_item < a.max_items ? carry_item : a.max_items; }
     }
 }
 
@@ -791,7 +798,15 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
     }
     if (i % a.quad_width == 0) {
         const uint32_t h = a.hist[c];
-        a.quads[a.quad_off[c] + i / a.quad_width] = make_uint4(c, slot, h - i < a.quad_width ? h - i : a.quad_width, 0u);
+        const uint32_t qi = a.quad_off[c] + i / a.quad_width;
+        uint32_t first = 0;
+        if (a.item_rows) {
+            const uint64_t len = a.list_off[c + 1] - a.list_off[c];
+            const uint32_t nch = (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+            first = a.item_off[c] + (i / a.quad_width) * nch;
+            for (uint32_t t = 0; t < nch && first + t < a.max_items; ++t) a.item_quad[first + t] = qi;
+        }
+        a.quads[qi] = make_uint4(c, slot, h - i < a.quad_width ? h - i : a.quad_width, first);
     }
 }
 
@@ -1780,9 +1795,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
 #endif
     uint32_t bx, by;
-    quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
-    if (by >= *a.n_quads) return;
-    const uint4 quad = a.quads[by];          // {cluster, first pair slot, pair count <= NQ, 0}
+    uint4 quad;                              // {cluster, first pair slot, pair count <= NQ, first work item}
+    if (a.item_quad) {
+        // 1-D grid over the work items (quad, existing row chunk): the lists are very unequal, and a (chunks of the
+        // longest list) x quads grid is mostly workgroups that exit at once, in a pattern that decides which XCD gets
+        // the real ones
+        const uint32_t item = blockIdx.x;
+        if (item >= *a.n_items) return;
+        by = a.item_quad[item];
+        quad = a.quads[by];
+        bx = item - quad.w;
+    } else {
+        quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
+        if (by >= *a.n_quads) return;
+        quad = a.quads[by];
+    }
     const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
     const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
     const int lane = threadIdx.x & 63;
@@ -2679,7 +2706,8 @@ static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
     // a mean of 9.8 k), so most quads use only the first few of the grid's row chunks: with an even grid width the
     // chunk index decides the XCD and some XCDs get most of the work (C4 at 32 chunks: 4.29 ms against 2.76 ms at 19).
     // An odd width makes consecutive quads start on different XCDs; the extra column exits at once.
-    hipLaunchKernelGGL(kern, dim3(a.grid_x | 1u, a.max_quads), dim3(64 * NW), lds, s, a);
+    if (a.item_quad) hipLaunchKernelGGL(kern, dim3(a.max_items), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL(kern, dim3(a.grid_x | 1u, a.max_quads), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 

@@ -889,6 +889,11 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, wave
     monkeypatch.setenv("PQV_WIDE_WAVES", str(waves))        # two 4-wave blocks per CU (up to 1024 dims) / one 8-wave block
     if waves == 4 and dim == 512:
         monkeypatch.setenv("PQV_QUAD_WIDTH", "64")          # (the two-block form takes 96-query quads up to 768 dims)
+    # grid forms: 4-wave blocks default to the work-item grid (quad x existing row chunk), 8-wave blocks to the 2-D grid
+    if waves == 4 and dim == 256:
+        monkeypatch.setenv("PQV_ITEM_GRID", "0")
+    if waves == 8 and dim == 512:
+        monkeypatch.setenv("PQV_ITEM_GRID", "2")
     s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
     plan = s.describe(nq, k, nprobe)
     assert "int8 screen operands" in plan and f"{waves} waves per block" in plan, plan
