@@ -398,7 +398,7 @@ def main():
             "equivalent_GBps": ref_algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
             "note": "SURVEY 8d bytes of the reference loop (every candidate row + id once per query that probes it) / kernel_ms: "
                     "what the per-query streaming kernel would have to sustain for this step time -- the batched screened kernel "
-                    "serves up to 128 queries from one pass over a list and reads 2-byte operand images, so this is a speed-up "
+                    "serves up to 128 queries from one pass over a list and reads 1- or 2-byte operand images, so this is a speed-up "
                     "figure, not a utilisation"},
         "mfma_view": {"flops_per_launch": mf, "achieved_tflops": mf / (k_ms * 1e-3) / 1e12 if k_ms else 0.0,
                       "peak_tflops": 5000.0 if i8 else 2500.0 if f16 else 157.3,
