@@ -77,6 +77,24 @@ def synth(torch, dev, seed, rows, dim):
     return out
 
 
+def synth_mixture(torch, dev, seed, rows, dim, n_centres, sigma=0.1, centre_seed=99):
+    """SURVEY 8(d)'s secondary data set: a Gaussian mixture -- n_centres component centres uniform in [0,1)^dim (the
+    same for corpus and queries), every row a uniformly chosen centre + N(0, sigma^2) noise -- so that the inverted
+    lists follow real structure and IVF recall means something.  Generated on the device in slabs."""
+    gc = torch.Generator(device=dev)
+    gc.manual_seed(centre_seed)
+    centres = torch.rand((n_centres, dim), generator=gc, device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty((rows, dim), dtype=torch.float32, device=dev)
+    step = max(1, (1 << 27) // (dim * 4))
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        comp = torch.randint(0, n_centres, (e - s,), generator=g, device=dev)
+        out[s:e] = centres[comp] + sigma * torch.randn((e - s, dim), generator=g, device=dev, dtype=torch.float32)
+    return out
+
+
 def pmc_traffic(workload, kernels):
     """HBM-side bytes per launch of the dominant kernels from the committed rocprofv3 PMC summaries of THIS
     workload (profiles/<round>_<workload>_pmc_{FETCH,WRITE}_SIZE.txt, written by tools/profile_round.sh from
@@ -124,6 +142,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget per column")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
+    ap.add_argument("--data", default="uniform", choices=["uniform", "mixture"],
+                    help="uniform: the reference's bench recipe (default); mixture: Gaussian mixture with n_clusters "
+                         "components, sigma 0.1 (SURVEY 8d's secondary set: IVF recall is meaningful there)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the shard exchange even with one rank (path check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -186,8 +207,12 @@ def main():
     n_shard = hi - lo
 
     # ---- synthetic data: corpus seed 1234 (+ rank for a shard), query seed 7 ----------------------------
-    corpus_t = synth(torch, dev, 1234 if replica else 1234 + rank, n_shard, dim)
-    queries_t = synth(torch, dev, 7 + rank if replica else 7, nq, dim)          # replicas search different batches
+    if args.data == "mixture":
+        corpus_t = synth_mixture(torch, dev, 1234 if replica else 1234 + rank, n_shard, dim, n_clusters or 1024)
+        queries_t = synth_mixture(torch, dev, 7 + rank if replica else 7, nq, dim, n_clusters or 1024)
+    else:
+        corpus_t = synth(torch, dev, 1234 if replica else 1234 + rank, n_shard, dim)
+        queries_t = synth(torch, dev, 7 + rank if replica else 7, nq, dim)          # replicas search different batches
     torch.cuda.synchronize()
 
     corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n_shard, dim, device=local_rank,
@@ -336,7 +361,8 @@ def main():
                    ["tile_rerank_kernel"] if "tile_rerank_kernel" in plan_text else ["stream_kernel"])
     traffic, traffic_src = (None, None)
     if world == 1 and nq == nq_default and K == 10:
-        traffic, traffic_src = pmc_traffic(args.workload, kernels) if " | kernels: " in plan_text else (None, None)
+        traffic, traffic_src = (pmc_traffic(args.workload, kernels)
+                                if " | kernels: " in plan_text and args.data == "uniform" and nq == nq_default else (None, None))
 
     k_ms = serial_rr_ms if serial_rr_ms else rr_ms          # isolated launches: what rocprofv3 --kernel-trace reports
     achieved = (traffic if traffic else min_bytes) / (k_ms * 1e-3) / 1e9 if k_ms and k_ms > 0 else 0.0
@@ -353,8 +379,8 @@ def main():
         "scaling": "weak" if (weak or replica or world == 1) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {n_total}x{dim} uniform f32, n_clusters {index.n_clusters}"
+        "data": "synthetic" if args.data == "uniform" else "synthetic (gaussian mixture, sigma 0.1)",
+        "config": {"workload": f"{args.workload}: {n_total}x{dim} {'uniform' if args.data == 'uniform' else 'gaussian-mixture'} f32, n_clusters {index.n_clusters}"
                                f"{' per shard' if world > 1 and not replica else ''}, k {K}, nprobe {nprobe}, "
                                f"{nq} queries/step, layout {args.layout}",
                    "rows": n_total, "rows_per_gpu": n_shard, "dim": dim, "n_clusters": int(index.n_clusters), "k": K,

@@ -217,6 +217,7 @@ struct pqv_searcher {
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
         int running_thr = 1;               // running thresholds of the wide kernel
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
+        int seed_refine = 1;               // exact distances behind the k selected seed bounds tighten the first threshold (k <= 16)
         int item_grid = 1;                 // wide filter kernel: 1-D grid over (quad, existing row chunk) items
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
         int probe_rows = 1;                // batched centroid probe (probe_rows_kernel) when dim % 4 == 0; 0 = stream_kernel
@@ -1038,6 +1039,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
     o.item_grid = static_cast<int>(num("PQV_ITEM_GRID", o.item_grid));
+    o.seed_refine = static_cast<int>(num("PQV_SEED_REFINE", o.seed_refine));
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
@@ -1561,8 +1563,14 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(sc.s_thr_bins.ensure(static_cast<size_t>(nq) * sizeof(float4)));
                 ta.thr_hist = sc.s_thr_hist.as<uint32_t>(); ta.thr_bins = static_cast<const float4 *>(sc.s_thr_bins.p);
             }
+            pqv::SeedRefine rf{};
+            if (s->opt.seed_refine && !s->d_row_of) {
+                rf.mat = s->d_mat; rf.queries = d_queries; rf.list_off = s->d_list_off.as<uint64_t>();
+                rf.probe = sc.s_probe.as<uint32_t>(); rf.cand_base = sc.s_cand_base.as<uint64_t>();
+                rf.dim = s->dim; rf.nprobe = p.np; rf.seed_sw = seed.seed_sw; rf.seed_rows = p.seed_rows; rf.max_pos = max_pos;
+            }
             HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream,
-                                       ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p)));
+                                       ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p), &rf));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
@@ -1856,6 +1864,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
+    else if (n == "seed_refine") o.seed_refine = value != 0;
     else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));

@@ -247,9 +247,22 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 // the first rows of every list fills TileArgs::seed_ub, launch_seed_select turns a query's n_vals =
 // nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
+// Optional refinement of the seed threshold (k <= 16, dim % 32 == 0): the k sampled bounds a query selects belong to 4 k
+// rows (a bound is a lane's minimum over the 4 sub-tile rows it saw); their EXACT reference distances are evaluated
+// and the k-th smallest of those -- still k distinct candidates, so still an upper bound of the final k-th distance --
+// replaces the k-th bound: the threshold loses the slack of the operand form (int8: ~1 % of d2) before the screen starts.
+struct SeedRefine {
+    const float    *mat;        // IVF-ordered rows [*, dim] (nullptr = no refinement)
+    const float    *queries;    // [nq, dim]
+    const uint64_t *list_off;
+    const uint32_t *probe;      // [nq, nprobe]
+    const uint64_t *cand_base;  // [nq, nprobe]
+    uint32_t        dim, nprobe, seed_sw, seed_rows;
+    uint64_t        max_pos;
+};
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
                               uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
-                              uint32_t *thr_hist = nullptr, float4 *thr_bins = nullptr);
+                              uint32_t *thr_hist = nullptr, float4 *thr_bins = nullptr, const SeedRefine *refine = nullptr);
 
 // ---- batched brute force as a dense Q.V^T contraction on f32 MFMA (BASELINE config 5) -------
 // score s[i][j] = q_i . v_j over ALL rows j of a row range; distance by `metric`:

@@ -1616,19 +1616,44 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 // gthr[q] = key of the k-th smallest of q's n_vals upper bounds (none if fewer than k are finite); also
 // resets the query's candidate buffer and overflow flag.  One wave per query.
 template <int S>
-__global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
+__global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
                                                         unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                        uint32_t *thr_hist, float4 *thr_bins) {
-    const int lane = threadIdx.x;
+                                                        uint32_t *thr_hist, float4 *thr_bins, const SeedRefine rf) {
+    // one wave selects; with the refinement (256 threads) all four waves share the exact evaluations
+    __shared__ uint64_t s_ent[16];           // the k selected bounds
+    __shared__ uint64_t s_exact[64];         // exact keys of their 4 k rows
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
+    const bool refine = rf.mat && k <= 16u && blockDim.x == 256;
     WaveTopk<S> tk;
     tk.init();
-    // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
-    // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
-    uint64_t cut = KEY_EMPTY;
-    if (k <= 64u) {
-        uint64_t lmin = KEY_EMPTY;
-        for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {          // eight loads in flight per lane
+    if (wave == 0) {
+        // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
+        // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
+        uint64_t cut = KEY_EMPTY;
+        if (k <= 64u) {
+            uint64_t lmin = KEY_EMPTY;
+            for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {          // eight loads in flight per lane
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t idx = i0 + 64 * u + lane;
+                    v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (v[u] < INFINITY) {
+                        const uint64_t key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
+                        lmin = key < lmin ? key : lmin;
+                    }
+                }
+            }
+            uint32_t dummy = 0;
+            bitonic_sort64(lmin, dummy, lane);
+            cut = readlane_u64(lmin, (int)k - 1);
+        }
+        for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {              // eight loads in flight per lane again
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1637,32 +1662,82 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (v[u] < INFINITY) {
-                    const uint64_t key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
-                    lmin = key < lmin ? key : lmin;
+                uint64_t key = KEY_EMPTY;
+                if (v[u] < INFINITY) key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
+                if (key > cut) key = KEY_EMPTY;
+                if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
+            }
+        }
+    }
+    uint64_t kth = tk.kth(k);
+    uint64_t m1key = readlane_u64(tk.key[0], 0);
+    if (refine) {
+        // exact distances of the 4 k rows behind the k selected bounds (SeedRefine): wave w takes entries
+        // [w k / 4 ..) -- pair p = 4 e + t is entry e's sub-tile row t -- and L = 4 or 8 lanes share a pair's chain exactly
+        // as in wide_filter_kernel's evaluation (the reference's order, bit for bit)
+        if (wave == 0 && lane < 16) s_ent[lane] = (uint32_t)lane < k ? tk.key[0] : KEY_EMPTY;
+        __syncthreads();
+        const uint32_t Gx = rf.dim >> 2;
+        uint32_t lg = 0;                       // k pairs per wave
+        while (lg < 3 && (k << (lg + 1)) <= 64u && (Gx % (16u << lg)) == 0u) ++lg;
+        const uint32_t L = 1u << lg;
+        const uint32_t pl = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);      // pair within the wave, lane within the pair
+        const uint32_t pi = (uint32_t)wave * k + pl;                                     // pair of the query: 0 .. 4 k - 1
+        const uint32_t e = pi >> 2, t = pi & 3u;
+        const uint64_t ekey = s_ent[e < 16u ? e : 0u];
+        bool valid = pl < k && ekey != KEY_EMPTY;
+        const uint32_t idx = (uint32_t)ekey;                               // index into the query's n_vals bounds
+        const uint32_t l15 = idx & 15u, slot = (idx >> 4) % rf.seed_sw, j = (idx >> 4) / rf.seed_sw;
+        const uint32_t row = (slot >> 2) * 256u + (slot & 3u) * 64u + 16u * t + l15;      // position in the list (wide_seed_kernel's tiling)
+        uint64_t lbeg = 0, pos = 0;
+        if (valid) {
+            const uint32_t c = rf.probe[(uint64_t)q * rf.nprobe + j];
+            lbeg = rf.list_off[c];
+            pos = rf.cand_base[(uint64_t)q * rf.nprobe + j] + row;
+            valid = row < rf.seed_rows && lbeg + row < rf.list_off[c + 1] && pos < rf.max_pos;
+        }
+        const float *x = rf.mat + (valid ? (lbeg + row) : 0ull) * rf.dim;
+        const float4 *qg = reinterpret_cast<const float4 *>(rf.queries + (uint64_t)q * rf.dim);
+        float sum = 0.0f;
+        constexpr int NB = 8;
+        const uint32_t first = (uint32_t)lane & ~(L - 1u);
+        for (uint32_t g0 = 0; g0 < Gx; g0 += NB * L) {
+            const uint32_t g = g0 + NB * pj;
+            float4 xv[NB], qv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { xv[u] = load4<true>(x + (g + u) * 4); qv[u] = qg[g + u]; }
+            float tt[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y, d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                float w = d0 * d0 + d1 * d1;
+                w = w + d2 * d2;
+                tt[u] = w + d3 * d3;
+            }
+            if (L == 1u) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) sum = sum + tt[u];
+            } else {
+                for (uint32_t sl = 0; sl < L; ++sl) {
+                    float sn = sum;
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) sn = sn + tt[u];
+                    sum = __shfl(pj == sl ? sn : sum, (int)(first + sl), 64);
                 }
             }
         }
-        uint32_t dummy = 0;
-        bitonic_sort64(lmin, dummy, lane);
-        cut = readlane_u64(lmin, (int)k - 1);
+        if (pl < k && pj == 0u && pi < 64u)
+            s_exact[pi] = valid ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
+        __syncthreads();
+        if (wave != 0) return;
+        uint64_t xkey = (uint32_t)lane < 4u * k ? s_exact[lane] : KEY_EMPTY;
+        uint32_t dummy2 = 0;
+        bitonic_sort64(xkey, dummy2, lane);
+        const uint64_t kth2 = readlane_u64(xkey, (int)k - 1);
+        if (kth != KEY_EMPTY && kth2 < kth) { kth = kth2; m1key = readlane_u64(xkey, 0); }
+    } else if (wave != 0) {
+        return;
     }
-    for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {              // eight loads in flight per lane again
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t idx = i0 + 64 * u + lane;
-            v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            uint64_t key = KEY_EMPTY;
-            if (v[u] < INFINITY) key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
-            if (key > cut) key = KEY_EMPTY;
-            if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
-        }
-    }
-    const uint64_t kth = tk.kth(k);
     if (lane == 0) {
         cand_cnt[q] = 0u;
         spilled[q] = 0u;
@@ -1677,7 +1752,7 @@ __global__ __launch_bounds__(64) void seed_select_kernel(const float *seed_ub, u
             float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);            // 1 / w == 0: no running threshold
             if (kth != KEY_EMPTY) {
                 const float thr0 = __uint_as_float((uint32_t)(kth >> 32));
-                const float m1 = __uint_as_float((uint32_t)(readlane_u64(tk.key[0], 0) >> 32));
+                const float m1 = __uint_as_float((uint32_t)(m1key >> 32));
                 float w = (thr0 - m1) * 0.125f;
                 if (!(w > thr0 * 1.0e-6f)) w = thr0 * 0.00390625f;      // degenerate sample: 2^-8 of the bound
                 if (w > 0.0f && w < INFINITY && thr0 < INFINITY)
@@ -1719,10 +1794,13 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
 }
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
                               uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
-                              uint32_t *thr_hist, float4 *thr_bins) {
+                              uint32_t *thr_hist, float4 *thr_bins, const SeedRefine *refine) {
     if (nq == 0) return hipSuccess;
-    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins);
-    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins);
+    SeedRefine rf{};
+    if (refine && refine->mat && (refine->dim % 32) == 0 && k <= 16) rf = *refine;
+    const dim3 block(rf.mat ? 256 : 64);
+    if (k <= 64) hipLaunchKernelGGL(seed_select_kernel<1>, dim3(nq), block, 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins, rf);
+    else if (k <= 256) hipLaunchKernelGGL(seed_select_kernel<4>, dim3(nq), dim3(64), 0, s, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins, rf);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
