@@ -1911,7 +1911,7 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         const bool qlds = p.i8 || p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768;
         const bool pf = p.f16 && s->dim <= 128 && p.block_waves == 4;
         const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
-        const int seed_ng = p.i8 ? 2 : p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
+        const int seed_ng = p.i8 ? (64ull * s->dim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
         std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
                       seed_ng, qlds ? "true" : "false", op, S,

@@ -1769,7 +1769,12 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.i8) {       // int8 images: 32 queries x dim bytes per block
         if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
             32ull * a.dim > 65536) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_I8>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), 32ull * a.dim, s, a);
+        // 64 queries per pass where they fit 48 KB (a 96-query quad is then sampled in two slices instead of three:
+        // the sample rows are re-read once per slice)
+        if (64ull * a.dim <= 49152)
+            hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_I8>), dim3(a.grid_x, a.max_quads, (a.quad_width + 63) / 64), dim3(256), 64ull * a.dim, s, a);
+        else
+            hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_I8>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), 32ull * a.dim, s, a);
         return hipGetLastError();
     }
     if (a.f16) {      // f16 operands: the staged queries take half the LDS; 64 queries per block up to 256 dims, else 32
