@@ -1334,8 +1334,12 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
             } else if (p.f16) {
                 const uint64_t per_q = static_cast<uint64_t>(s->dim) * (s->dim <= 128 ? 6 : 2);     // f16 image (+ f32 original)
                 const uint32_t fit8 = static_cast<uint32_t>(std::min<uint64_t>(128, 147456 / per_q / 32 * 32));
-                const uint32_t fit4 = s->dim <= 256 ? 64 : 32;
-                int waves = o.wide_waves == 4 || o.wide_waves == 8 ? o.wide_waves : 8;       // (C2, 128 dims: 0.224 -> 0.204 ms per serial step with 8)
+                // two 4-wave blocks of 96 queries per CU where 96 queries fit 72 KB (up to 128 dims with the f32 originals,
+                // up to 384 without): C2 7.15 -> 8.02 M QPS against one 8-wave block of 128 (0.151 -> 0.133 ms kernel
+                // time; 5.1f's overlap of two blocks' phases).  Longer rows: one 8-wave block.
+                const bool two96 = 96ull * per_q <= 73728;
+                const uint32_t fit4 = two96 ? 96 : s->dim <= 256 ? 64 : 32;
+                int waves = o.wide_waves == 4 || o.wide_waves == 8 ? o.wide_waves : two96 ? 4 : 8;
                 if (fit8 < 64) waves = 4;
                 p.block_waves = static_cast<uint32_t>(waves);
                 p.quad_width = waves == 8 ? fit8 : fit4;
@@ -1353,7 +1357,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // the two-block int8 form is flat between 1280 and 5120 on the item grid (C3: 2.19 / 2.20 / 2.16 ms at 1280 /
                 // 1792 / 3072; C4 shard: 2.77 / 2.69 / 2.71)
                 const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256
-                                           : (p.block_waves == 8 || p.i8) ? 3072ull : 2304ull;
+                                           : (p.block_waves == 8 || p.i8 || p.quad_width == 96) ? 3072ull : 2304ull;
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
                 const uint64_t min_blocks = o.min_blocks ? o.min_blocks : (p.block_waves == 8 ? 1024 : 2048);
                 r = std::min<uint64_t>(wide_rows, (max_len + 255) / 256 * 256);
@@ -1909,7 +1913,7 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     if (p.tile && p.filter && p.quad) {
         const int S = k <= 64 ? 1 : 4;
         const bool qlds = p.i8 || p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768;
-        const bool pf = p.f16 && s->dim <= 128 && p.block_waves == 4;
+        const bool pf = p.f16 && s->dim <= 128 && p.block_waves == 4 && p.quad_width != 96;
         const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
         const int seed_ng = p.i8 ? (64ull * s->dim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->dim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
         std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",

@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
     // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
     // (<= 256) for the 8-wave blocks, whose LDS belongs to the staged queries
-    constexpr int PASS = NW == 8 ? 256 : (I8 && NG == 6) ? 128 : 512;      // (96 int8 queries, two blocks per CU: 80 KB each)
+    constexpr int PASS = NW == 8 ? 256 : NG == 6 ? 128 : 512;      // (96 int8 queries, two blocks per CU: 80 KB each)
     constexpr int PEND = PASS + 64;        // one pass + a partial batch
     constexpr int NT = 64 * NW;
 #ifdef PQV_PROFILE_PHASES
@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // every wave with the same values: in registers they were the first thing the allocator spilled, and a spill
     // reload is a VMEM load -- consuming it drains the wave's whole queue of prefetched operands (vmcnt(0)) at the
     // top of every tile.  LDS reads count on lgkmcnt and leave the operand stream alone.
-    constexpr bool LST = NW == 8 || I8;
+    constexpr bool LST = NW == 8 || I8 || NG == 6;
     __shared__ uint64_t qst_cbase[LST ? NQ : 1];
     __shared__ uint32_t qst_pair[LST ? NQ : 1];
     __shared__ float qst_qn[LST ? NQ : 1];            // |q|^2; NaN = never skip this query (float operand forms)
@@ -2837,6 +2837,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                 if (a.quad_width == 64) return launch_wide<4, 8, S, true, OP_F16>(b, lds, s);
                 return hipErrorInvalidValue;
             }
+            if (a.quad_width == 96 && lds <= 73728) return launch_wide<6, 4, S, true, OP_F16>(b, lds, s);     // 80 KB per block: two per CU
             if (lds > 65536) return hipErrorInvalidValue;           // + 10 KB of static LDS: two blocks per CU
             if (a.quad_width == 64 && pf) return launch_wide<4, 4, S, true, OP_F16, true>(b, lds, s);
             if (pf) return hipErrorInvalidValue;

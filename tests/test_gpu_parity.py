@@ -835,6 +835,8 @@ def test_fuzz_screened_search_against_oracle(pqv, oracle, monkeypatch, block):
     # exact refinement of the seed thresholds: by rule (rows of >= 256 dims, batches of >= 16 queries) in the even
     # blocks, for every shape in the odd ones (ties, duplicated rows and k up to 16 all pass through it there)
     monkeypatch.setenv("PQV_SEED_REFINE", "2" if block % 2 else "1")
+    if block == 2:
+        monkeypatch.setenv("PQV_WIDE_WAVES", "8")       # one 8-wave block per CU (the default where 96 queries do not fit twice)
     screened = 0
     for seed in range(1000 + 6 * block, 1000 + 6 * block + 6):
         screened += _fuzz_case(pqv, oracle, seed)
