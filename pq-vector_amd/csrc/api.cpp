@@ -1251,12 +1251,12 @@ struct TopkPlan {
     uint32_t slots_per_pair;   // partial lists per (query, probe rank)
 };
 
-// Exact refinement of the seed threshold (SeedRefine): where survivors are expensive (rows of >= 256 dims) and the batch
-// is large enough to repay the select kernel's extra 8 us (C2, 128 dims: 7.18 -> 7.04 M QPS with it; one C3 query
-// 256 -> 263 us)
+// Exact refinement of the seed threshold (SeedRefine): where survivors are expensive (rows of >= 256 dims; C2, 128 dims:
+// 7.18 -> 7.04 M QPS with it).  Any batch size: one uniform C3 query pays 7 us for it (256 -> 263), but one query on the
+// Gaussian-mixture set overflows its candidate buffer without it (282 -> 500 us).
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
-    return s->opt.seed_refine && !s->d_row_of && (s->dim % 32) == 0 && k <= 16 &&
-           (s->opt.seed_refine > 1 || (s->dim >= 256 && nq >= 16));
+    (void)nq;
+    return s->opt.seed_refine && !s->d_row_of && (s->dim % 32) == 0 && k <= 16 && (s->opt.seed_refine > 1 || s->dim >= 256);
 }
 TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
     TopkPlan p{};

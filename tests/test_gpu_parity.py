@@ -832,7 +832,7 @@ def test_fuzz_screened_search_against_oracle(pqv, oracle, monkeypatch, block):
     wherever the lists are long enough: rows, distances and counts must equal the oracle exactly."""
     monkeypatch.setenv("PQV_RERANK_MODE", "tile")
     monkeypatch.setenv("PQV_TILE_FILTER", "2")
-    # exact refinement of the seed thresholds: by rule (rows of >= 256 dims, batches of >= 16 queries) in the even
+    # exact refinement of the seed thresholds: by rule (rows of >= 256 dims) in the even
     # blocks, for every shape in the odd ones (ties, duplicated rows and k up to 16 all pass through it there)
     monkeypatch.setenv("PQV_SEED_REFINE", "2" if block % 2 else "1")
     if block == 2:
