@@ -502,8 +502,12 @@ hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s) {
     if (a.nq == 0 || a.kc == 0) return hipSuccess;
     if ((a.dim % 4) != 0 || (a.kc_pad % 64) != 0 || a.kc_pad < a.kc) return hipErrorInvalidValue;
     const uint32_t gx = (a.kc + 255) / 256;
-    // enough blocks for the chip first, then as many queries per row read as the batch allows
-    const int qb = (uint64_t)gx * (a.nq / 8) >= 512 ? 8 : (uint64_t)gx * (a.nq / 4) >= 512 ? 4 : (uint64_t)gx * (a.nq / 2) >= 256 ? 2 : 1;
+    // enough waves for the chip first (four per SIMD: the loop waits for every row chunk it loads -- C3, 1024 queries:
+    // 83 us with 4 queries per lane and 4096 waves, 106 us with 8 and 2048; an explicit prefetch of the next chunk
+    // measured slower), then as many queries per row read as the batch allows
+    static const int qb_env = [] { const char *e = std::getenv("PQV_PROBE_QB"); return e ? std::atoi(e) : 0; }();
+    int qb = (uint64_t)gx * (a.nq / 8) >= 1024 ? 8 : (uint64_t)gx * (a.nq / 4) >= 512 ? 4 : (uint64_t)gx * (a.nq / 2) >= 256 ? 2 : 1;
+    if (qb_env == 1 || qb_env == 2 || qb_env == 4 || qb_env == 8) qb = qb_env;
     const dim3 grid(gx, (a.nq + qb - 1) / qb);
     switch (qb) {
     case 8: hipLaunchKernelGGL(probe_rows_kernel<8>, grid, dim3(256), 0, s, a); break;
@@ -1628,18 +1632,23 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
     const bool refine = rf.mat && k <= 16u && blockDim.x == 256;
     WaveTopk<S> tk;
     tk.init();
-    if (wave == 0) {
+    // with the refinement the four waves select from a quarter of the bounds each and wave 0 merges the four lists
+    __shared__ uint64_t s_loc[64];
+    const uint32_t quarter = ((n_vals + 3) / 4 + 63) / 64 * 64;
+    const uint32_t v_lo = refine ? (uint32_t)wave * quarter : 0u;
+    const uint32_t v_hi = refine ? (v_lo + quarter < n_vals ? v_lo + quarter : n_vals) : n_vals;
+    if (wave == 0 || refine) {
         // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
         // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
         uint64_t cut = KEY_EMPTY;
         if (k <= 64u) {
             uint64_t lmin = KEY_EMPTY;
-            for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {          // eight loads in flight per lane
+            for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 512) {          // eight loads in flight per lane
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const uint32_t idx = i0 + 64 * u + lane;
-                    v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                    v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -1653,12 +1662,12 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
             bitonic_sort64(lmin, dummy, lane);
             cut = readlane_u64(lmin, (int)k - 1);
         }
-        for (uint32_t i0 = 0; i0 < n_vals; i0 += 512) {              // eight loads in flight per lane again
+        for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 512) {              // eight loads in flight per lane again
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t idx = i0 + 64 * u + lane;
-                v[u] = idx < n_vals ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1667,6 +1676,16 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
                 if (key > cut) key = KEY_EMPTY;
                 if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
             }
+        }
+    }
+    if (refine) {           // merge: 4 x (k <= 16) sorted keys -> one 64-lane sort in wave 0; lanes 0 .. k-1 then hold the k smallest
+        if (lane < 16) s_loc[wave * 16 + lane] = (uint32_t)lane < k ? tk.key[0] : KEY_EMPTY;
+        __syncthreads();
+        if (wave == 0) {
+            uint64_t mk = s_loc[lane];
+            uint32_t dummy = 0;
+            bitonic_sort64(mk, dummy, lane);
+            tk.key[0] = (uint32_t)lane < k ? mk : KEY_EMPTY;
         }
     }
     uint64_t kth = tk.kth(k);
