@@ -217,6 +217,7 @@ struct pqv_searcher {
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
         int running_thr = 1;               // running thresholds of the wide kernel
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
+        int single_bucket = 1;             // one query: the probe merge writes the bucketing, no pair-sort launches
         int seed_refine = 1;               // exact distances behind the k selected seed bounds tighten the first threshold (k <= 16)
         int item_grid = 1;                 // wide filter kernel: 1-D grid over (quad, existing row chunk) items
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
@@ -1040,6 +1041,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
     o.item_grid = static_cast<int>(num("PQV_ITEM_GRID", o.item_grid));
     o.seed_refine = static_cast<int>(num("PQV_SEED_REFINE", o.seed_refine));
+    o.single_bucket = static_cast<int>(num("PQV_SINGLE_BUCKET", o.single_bucket));
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
@@ -1475,15 +1477,38 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         }
         if (p.filter) { pm.qnorm_out = sc.s_qnorm.as<float>(); pm.qmax_out = sc.s_qmax.as<float>(); pm.queries = d_queries; pm.dim = s->dim; }
     }
+    // one query: the probe merge writes the bucketing itself (MergeArgs::sq_*), no pair sort
+    const bool single_bucket = nq == 1 && p.np <= 64 && p.tile && p.filter && p.quad && s->opt.single_bucket;
+    const bool items = p.tile && p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4));
+    const uint32_t max_items = items ? p.max_quads * p.filter_bpl : 0;
+    if (p.tile) {
+        HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
+        HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
+        HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
+        if (items) HIP_TRY(sc.s_items.ensure(static_cast<size_t>(max_items) * sizeof(uint32_t)));
+    }
+    if (single_bucket) {
+        uint32_t *v = pair_u32 + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc_pairs);
+        pm.sq_quads = sc.s_quads.as<uint4>(); pm.sq_pairs = sc.s_pairs.as<uint32_t>(); pm.sq_n_quads = v + 5ull * kc_pairs + 4;
+        if (items) {
+            pm.sq_item_quad = sc.s_items.as<uint32_t>(); pm.sq_n_items = v + 6ull * kc_pairs + 6;
+            pm.sq_item_rows = p.filter_rows_per_block; pm.sq_max_items = max_items;
+        }
+        if (p.i8 && pm.preset_flags) {      // ... and the query's int8 image (the merge's last helper wave)
+            if (int rc = ensure_blocked_copy(s, 2, stream)) return rc;
+            HIP_TRY(sc.s_qi8.ensure(static_cast<size_t>(nq) * s->dim));
+            HIP_TRY(sc.s_qn2i.ensure(static_cast<size_t>(nq) * sizeof(int)));
+            HIP_TRY(sc.s_qres.ensure(static_cast<size_t>(nq) * sizeof(float)));
+            pm.sq_q_i8 = static_cast<int8_t *>(sc.s_qi8.p); pm.sq_q_n2i = sc.s_qn2i.as<int>(); pm.sq_q_res = sc.s_qres.as<float>();
+            pm.sq_center = s->d_center.as<float>(); pm.sq_scale = s->i8_scale; pm.sq_maxabs = s->i8_half;
+        }
+    }
     HIP_TRY(launch_merge_probe(pm, stream));
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
-        HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
-        HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(n_pairs) * sizeof(uint32_t)));
-        HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
         uint32_t *u = pair_u32;
         PairSortArgs ps{};
         ps.probe = sc.s_probe.as<uint32_t>(); ps.n_pairs = n_pairs; ps.n_clusters = kc; ps.hist_done = 1;
@@ -1495,15 +1520,12 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ps.pairs = sc.s_pairs.as<uint32_t>(); ps.groups = sc.s_groups.as<uint4>(); ps.quads = sc.s_quads.as<uint4>();
         // work items of the wide filter kernel (quad x row chunk that exists): its grid then has no holes
         // (the 8-wave blocks keep the 2-D grid with its quad-to-XCD affinity: C2 7.25 against 7.13 M QPS)
-        const bool items = p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4));
-        const uint32_t max_items = items ? p.max_quads * p.filter_bpl : 0;
         if (items) {
-            HIP_TRY(sc.s_items.ensure(static_cast<size_t>(max_items) * sizeof(uint32_t)));
             ps.list_off = s->d_list_off.as<uint64_t>(); ps.item_rows = p.filter_rows_per_block;
             ps.item_off = v + 5ull * kc + 5; ps.n_items = v + 6ull * kc + 6;
             ps.item_quad = sc.s_items.as<uint32_t>(); ps.max_items = max_items;
         }
-        HIP_TRY(launch_pair_sort(ps, stream));
+        if (!single_bucket) HIP_TRY(launch_pair_sort(ps, stream));
         TileArgs ta{};
         ta.mat = s->d_mat; ta.row_of = s->d_row_of; ta.list_off = s->d_list_off.as<uint64_t>();
         ta.queries = d_queries; ta.cand_base = sc.s_cand_base.as<uint64_t>();
@@ -1530,8 +1552,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(sc.s_qi8.ensure(static_cast<size_t>(nq) * s->dim));
                 HIP_TRY(sc.s_qn2i.ensure(static_cast<size_t>(nq) * sizeof(int)));
                 HIP_TRY(sc.s_qres.ensure(static_cast<size_t>(nq) * sizeof(float)));
-                HIP_TRY(launch_quantize_queries_i8(d_queries, nq, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
-                                                   sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), stream));
+                if (!pm.sq_q_i8)
+                    HIP_TRY(launch_quantize_queries_i8(d_queries, nq, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
+                                                       sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), stream));
                 ta.i8 = 1; ta.scale = s->i8_scale; ta.scale2 = s->i8_scale * s->i8_scale;
                 ta.q_i8 = static_cast<const int8_t *>(sc.s_qi8.p); ta.q_n2i = sc.s_qn2i.as<int>(); ta.q_res = sc.s_qres.as<float>();
                 ta.row_n2i = s->d_row_n2i.as<int>(); ta.row_res = s->d_row_res.as<float>();
@@ -1875,6 +1898,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
+    else if (n == "single_bucket") o.single_bucket = value != 0;
     else if (n == "seed_refine") o.seed_refine = static_cast<int>(value);       // 2 = any dim / batch size
     else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size

@@ -92,6 +92,17 @@ struct MergeArgs {
     unsigned long long *stats;
     // probe mode extras for the batched path (all optional): cluster histogram of the (query, probe
     // rank) pairs (zeroed beforehand), reset of the per-query admission thresholds, |q|^2
+    // one query, nprobe <= 64 (probe mode): the wave also writes the bucketing itself -- every probed cluster is one quad
+    // of one pair, in probe-rank order -- and launch_pair_sort is skipped (two launches less per single-query call)
+    uint4          *sq_quads;     // nullptr = off
+    uint32_t       *sq_pairs, *sq_n_quads;
+    uint32_t       *sq_item_quad, *sq_n_items;     // optional work-item table (wide_filter_kernel)
+    uint32_t        sq_item_rows, sq_max_items;
+    int8_t         *sq_q_i8;      // optional (needs the 256-thread form, i.e. preset_flags): the queries' int8 images, as quantize_queries_i8_kernel
+    int            *sq_q_n2i;
+    float          *sq_q_res;
+    const float    *sq_center;
+    float           sq_scale, sq_maxabs;
     uint32_t       *hist;
     uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
     // probe mode, optional: the query's per-wave partial lists of the re-rank start EMPTY (all-ones keys / values);

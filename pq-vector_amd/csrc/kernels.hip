@@ -535,6 +535,49 @@ hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pa
     return hipGetLastError();
 }
 
+__device__ __forceinline__ int quant_i8(float t, float scale) {
+    const float v = rintf(t * scale);
+    return (int)fminf(fmaxf(v, -127.0f), 127.0f);      // NaN -> -127 (callers flag non-finite inputs separately)
+}
+// int8 image of query q by one wave (quantize_queries_i8_kernel; also the probe merge of a single-query call)
+__device__ __forceinline__ void quantize_query_i8_wave(const float *__restrict__ queries, uint32_t q, int lane, uint32_t dim,
+                                                       float scale, const float *__restrict__ center, float maxabs,
+                                                       int8_t *__restrict__ q_i8, int *__restrict__ q_n2i, float *__restrict__ q_res) {
+    const float inv = 1.0f / scale;
+    int n2 = 0;
+    float e2 = 0.0f, big = 0.0f;
+    bool bad = false;
+    for (uint32_t d0 = lane * 4; d0 < dim; d0 += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim + d0);
+        const float4 cx = *reinterpret_cast<const float4 *>(center + d0);
+        const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bad |= !(fabsf(t[e]) < INFINITY);
+            const int v = quant_i8(t[e], scale);
+            const float res = t[e] - (float)v * inv;
+            n2 += v * v;
+            e2 = fmaf(res, res, e2);
+            big = fmaxf(big, fabsf(t[e]));
+            w |= (uint32_t)(v & 0xFF) << (8 * e);
+        }
+        *reinterpret_cast<uint32_t *>(q_i8 + (uint64_t)q * dim + d0) = w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+        big = fmaxf(big, __shfl_xor(big, off, 64));
+    }
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        q_n2i[q] = n2;
+        const float r = sqrtf(e2) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (big + maxabs + 127.0f * inv);
+        q_res[q] = (bad || !(r < INFINITY)) ? INFINITY : r;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // merge_kernel: one wave per query folds all partial lists.
 // PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
@@ -548,6 +591,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     if (threadIdx.x >= 64) {
         // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
         if constexpr (PROBE) {
+            if (a.sq_q_i8 && threadIdx.x >= 192)     // single-query call: the int8 image of the query too (last helper wave)
+                quantize_query_i8_wave(a.queries, q, lane, a.dim, a.sq_scale, a.sq_center, a.sq_maxabs, a.sq_q_i8, a.sq_q_n2i, a.sq_q_res);
             if (a.preset_keys) {
                 uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
                 uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
@@ -675,7 +720,28 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
             if (e < a.k) {
                 a.probe[(uint64_t)q * a.k + e] = c;
                 a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
-                if (a.hist && have) atomicAdd(&a.hist[(uint64_t)(q % HIST_REPLICAS) * a.hist_stride + c], 1u);   // pair bucketing: cluster histogram
+                if (a.hist && have && !a.sq_quads) atomicAdd(&a.hist[(uint64_t)(q % HIST_REPLICAS) * a.hist_stride + c], 1u);   // pair bucketing: cluster histogram
+            }
+            if (a.sq_quads && s == 0) {          // single query (q == 0, a.k <= 64): quad e = pair e = probe rank e
+                const uint32_t nch = (have && a.sq_item_rows) ? (uint32_t)((len + a.sq_item_rows - 1) / a.sq_item_rows) : 0u;
+                uint32_t ii = nch;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)ii, off, 64);
+                    if (lane >= off) ii += o;
+                }
+                const uint32_t first = ii - nch;
+                if (have) {
+                    a.sq_quads[e] = make_uint4(c, e, 1u, first);
+                    a.sq_pairs[e] = e;
+                    for (uint32_t t = 0; t < nch && first + t < a.sq_max_items; ++t) a.sq_item_quad[first + t] = e;
+                }
+                const uint32_t nqd = (uint32_t)__popcll(__ballot(have));
+                const uint32_t nit = readlane_u32(ii, 63);
+                if (lane == 0) {
+                    *a.sq_n_quads = nqd;
+                    if (a.sq_n_items) *a.sq_n_items = nit < a.sq_max_items ? nit : a.sq_max_items;
+                }
             }
             carry += readlane_u64(incl, 63);
         }
@@ -3427,10 +3493,6 @@ hipError_t launch_col_center(const uint32_t *kmin, const uint32_t *kmax, uint32_
     return hipGetLastError();
 }
 
-__device__ __forceinline__ int quant_i8(float t, float scale) {
-    const float v = rintf(t * scale);
-    return (int)fminf(fmaxf(v, -127.0f), 127.0f);      // NaN -> -127 (callers flag non-finite inputs separately)
-}
 
 __global__ __launch_bounds__(256) void block_rows_i8_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
                                                            const uint64_t *__restrict__ blk_off, uint32_t dim, float scale,
@@ -3499,41 +3561,7 @@ __global__ __launch_bounds__(64) void quantize_queries_i8_kernel(const float *__
                                                                 const float *__restrict__ center, float maxabs,
                                                                 int8_t *__restrict__ q_i8, int *__restrict__ q_n2i,
                                                                 float *__restrict__ q_res) {
-    const uint32_t q = blockIdx.x;
-    const int lane = threadIdx.x;
-    const float inv = 1.0f / scale;
-    int n2 = 0;
-    float e2 = 0.0f, big = 0.0f;
-    bool bad = false;
-    for (uint32_t d0 = lane * 4; d0 < dim; d0 += 256) {
-        const float4 x = *reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim + d0);
-        const float4 cx = *reinterpret_cast<const float4 *>(center + d0);
-        const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bad |= !(fabsf(t[e]) < INFINITY);
-            const int v = quant_i8(t[e], scale);
-            const float res = t[e] - (float)v * inv;
-            n2 += v * v;
-            e2 = fmaf(res, res, e2);
-            big = fmaxf(big, fabsf(t[e]));
-            w |= (uint32_t)(v & 0xFF) << (8 * e);
-        }
-        *reinterpret_cast<uint32_t *>(q_i8 + (uint64_t)q * dim + d0) = w;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n2 += __shfl_xor(n2, off, 64);
-        e2 += __shfl_xor(e2, off, 64);
-        big = fmaxf(big, __shfl_xor(big, off, 64));
-    }
-    bad = __ballot(bad) != 0ull;
-    if (lane == 0) {
-        q_n2i[q] = n2;
-        const float r = sqrtf(e2) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (big + maxabs + 127.0f * inv);
-        q_res[q] = (bad || !(r < INFINITY)) ? INFINITY : r;
-    }
+    quantize_query_i8_wave(queries, blockIdx.x, (int)threadIdx.x, dim, scale, center, maxabs, q_i8, q_n2i, q_res);
 }
 hipError_t launch_quantize_queries_i8(const float *queries, uint32_t nq, uint32_t dim, float scale, const float *center,
                                       float maxabs, void *q_i8, int *q_n2i, float *q_res, hipStream_t s) {

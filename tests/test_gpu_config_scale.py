@@ -99,6 +99,14 @@ def test_c3_parameters_natural_dispatch(pqv, oracle, c3_shape):
     for b in (1, 3, 40):
         r3, d3, _, _ = s.topk(queries[100:100 + b], k, nprobe)
         assert np.array_equal(r3, rows_t[100:100 + b]) and np.array_equal(_bits(d3), _bits(dist_t[100:100 + b]))
+    # (a single query is bucketed and quantised by the probe merge itself; the general three-launch form agrees)
+    s1 = pqv.Searcher(index, corpus)
+    s1.set_option("single_bucket", 0)
+    for q in (0, 100, 777):
+        r4, d4, _, nc4 = s1.topk(queries[q:q + 1], k, nprobe)
+        r5, d5, _, nc5 = s.topk(queries[q:q + 1], k, nprobe)
+        assert np.array_equal(r4, r5) and np.array_equal(_bits(d4), _bits(d5)) and np.array_equal(nc4, nc5)
+        assert np.array_equal(r5, rows_t[q:q + 1])
 
 
 @pytest.mark.timeout(1200)
