@@ -1479,7 +1479,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     }
     // one query: the probe merge writes the bucketing itself (MergeArgs::sq_*), no pair sort
     const bool single_bucket = nq == 1 && p.np <= 64 && p.tile && p.filter && p.quad && s->opt.single_bucket;
-    const bool items = p.tile && p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4));
+    // (a work-item table of more than 2^24 entries -- batches of hundreds of thousands of queries -- keeps the 2-D grid)
+    const bool items = p.tile && p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4)) &&
+                       static_cast<uint64_t>(p.max_quads) * p.filter_bpl <= (1ull << 24);
     const uint32_t max_items = items ? p.max_quads * p.filter_bpl : 0;
     if (p.tile) {
         HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
