@@ -578,6 +578,7 @@ __device__ __forceinline__ void quantize_query_i8_wave(const float *__restrict__
     }
 }
 
+__device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int lane);     // (defined below)
 // ------------------------------------------------------------------------------------
 // merge_kernel: one wave per query folds all partial lists.
 // PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
@@ -612,6 +613,21 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const uint32_t *pv = a.part_vals + (uint64_t)q * total;
     // with a candidate buffer the partial lists hold something only if the query overflowed it
     const uint64_t scan = (a.cand_keys && a.spilled && a.spilled[q] == 0) ? 0 : total;
+    // pre-filter (k <= 64, plain scans): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
+    // keys at or below it reach the serial insertion (a few dozen instead of a few hundred); the keys are read twice
+    // (L2) for that
+    uint64_t cut = KEY_EMPTY;
+    uint32_t ncand = 0;
+    if (a.cand_keys) { ncand = a.cand_cnt[q]; if (ncand > a.cand_cap) ncand = a.cand_cap; }
+    if (S == 1 && !(a.part_flags && scan) && scan + ncand > 128) {
+        uint64_t lmin = KEY_EMPTY;
+        for (uint64_t i = lane; i < scan; i += 64) { const uint64_t key = pk[i]; lmin = key < lmin ? key : lmin; }
+        const uint64_t *ck = a.cand_keys + (uint64_t)q * a.cand_cap;
+        for (uint32_t i = lane; i < ncand; i += 64) { const uint64_t key = ck[i]; lmin = key < lmin ? key : lmin; }
+        uint32_t dummy = 0;
+        bitonic_sort64(lmin, dummy, lane);
+        cut = a.k <= 64u ? readlane_u64(lmin, (int)a.k - 1) : KEY_EMPTY;
+    }
     if (a.part_flags && scan) {
         // only the lists some wave has written (a handful, and only for a query whose candidate buffer overflowed)
         const uint8_t *fl = a.part_flags + (uint64_t)q * a.n_part;
@@ -635,7 +651,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
         uint64_t key = KEY_EMPTY;
         uint32_t val = 0xFFFFFFFFu;
         if (idx < scan) { key = pk[idx]; val = pv[idx]; }
-        tk.offer(key, val, a.k, lane);
+        if (key > cut) key = KEY_EMPTY;
+        if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, val, a.k, lane);
     }
     if (a.cand_keys) {
         uint32_t n = a.cand_cnt[q];
@@ -650,10 +667,11 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
                 const uint32_t idx = i0 + 64 * u + lane;
                 kv[u] = idx < n ? ck[idx] : KEY_EMPTY;
                 vv[u] = idx < n ? cv[idx] : 0xFFFFFFFFu;
+                if (kv[u] > cut) kv[u] = KEY_EMPTY;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (i0 + 64 * u < n) tk.offer(kv[u], vv[u], a.k, lane);
+                if (i0 + 64 * u < n && __ballot(kv[u] != KEY_EMPTY) != 0ull) tk.offer(kv[u], vv[u], a.k, lane);
         }
     }
     if constexpr (!PROBE) {
