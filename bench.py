@@ -493,7 +493,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out_d, out_r = step(0)
         torch.cuda.synchronize()
-        result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, qs_host, rows_l[0], dist_l[0], nprobe, nq)
+        result["cpu_baseline"] = cpu_baseline(args, index, corpus_t, qs_host, rows_l[0], dist_l[0], nprobe, nq, searcher)
         par = result["cpu_baseline"]["parity"]
         if not (par["dist_bit_identical"] and par["row_idx_identical_up_to_order_inside_equal_distance_groups"]):
             rc = 3
@@ -600,7 +600,7 @@ def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank,
         sys.exit(rc)
 
 
-def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq):
+def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq, searcher=None):
     """Two columns:
     faithful  -- the CPU oracle (a port of src/ivf/search.rs:83-142, -O3 -march=native -ffp-contract=off on THIS host), ONE
                  thread as the reference's query loop is (search.rs:115), on a bounded sample of the step's queries; the GPU
@@ -618,6 +618,7 @@ def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq):
     gdist = dist_t.cpu().numpy()
     done, spent = 0, 0.0
     ids_ok, dist_ok, ids_tie_ok, tie_groups = True, True, True, 0
+    replayed, replay_ok = 0, True
     chunk = 4
     while done < nq and spent < args.cpu_seconds:
         b = min(chunk, nq - done)
@@ -633,6 +634,10 @@ def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq):
         for i in range(b):
             if (orows[i] == g[i]).all():
                 continue
+            if searcher is not None:        # the host API replays the reference's heap for exactly these queries
+                hr, hd, _, _ = searcher.topk(qs[done + i:done + i + 1], K, nprobe)
+                replayed += 1
+                replay_ok &= bool((hr[0] == orows[i]).all()) and bool((hd.view(np.uint32)[0] == odist.view(np.uint32)[i]).all())
             j = 0
             while j < K:
                 e = j
@@ -651,7 +656,9 @@ def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq):
            "host_cpus": os.cpu_count(),
            "parity": {"queries_checked": done, "row_idx_identical": ids_ok, "dist_bit_identical": dist_ok,
                       "row_idx_identical_up_to_order_inside_equal_distance_groups": ids_tie_ok,
-                      "equal_distance_groups_seen": tie_groups}}
+                      "equal_distance_groups_seen": tie_groups,
+                      "queries_replayed_through_pqv_topk": replayed,
+                      "row_idx_identical_after_replay": bool(ids_ok or (replayed > 0 and replay_ok))}}
     # generous column
     try:
         build_oracle("fast")
