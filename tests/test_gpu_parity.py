@@ -1037,3 +1037,28 @@ def test_batched_centroid_probe_matches_find_closest_centroids(pqv, oracle, dim,
             assert (_bits(dist_c[q, :len(order)]) == _bits(np.sqrt(d2[order]))).all(), (nq, q)
             if len(set(d2[order].tolist())) == len(order) and (len(d2) <= k or np.sort(d2)[k] != np.sort(d2)[k - 1]):
                 assert (rows_c[q, :len(order)] == cand[order]).all(), (nq, q)
+
+
+@pytest.mark.parametrize("dim,waves", [(384, 4), (384, 8), (128, 4), (640, 8)])
+def test_f16_block_forms_match_oracle(pqv, oracle, monkeypatch, dim, waves):
+    """f16 screen operands in both block forms: two 4-wave blocks of 96-query quads per CU (rows up to 128 dims with the
+    f32 originals staged next to the images, up to 384 dims without) and one 8-wave block (longer rows; forced for the
+    short ones).  dim 384 and 640 are multiples of 128 but not of 256, so they never take the int8 form."""
+    rng = np.random.default_rng(dim + waves)
+    n, kc, k, nprobe, nq = 24000, 5, 10, 3, 230
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = (data[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.02).astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=1, max_iters=3)
+    monkeypatch.setenv("PQV_RERANK_MODE", "tile")
+    monkeypatch.setenv("PQV_TILE_FILTER", "2")
+    monkeypatch.setenv("PQV_WIDE_WAVES", str(waves))
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    plan = s.describe(nq, k, nprobe)
+    assert "f16 screen operands" in plan and f"{waves} waves per block" in plan, plan
+    if waves == 4:
+        assert "quads of 96 queries" in plan, plan
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nc == onc).all() and (nf == onf).all()
+    assert (_bits(dist) == _bits(odist)).all()
+    assert (rows == orows).all()
