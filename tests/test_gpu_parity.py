@@ -867,7 +867,7 @@ def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier)
 
 
 @pytest.mark.parametrize("case", ["huge_rows", "tiny_values", "constant", "signed_offset"])
-@pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (1024, 4), (512, 8), (1280, 8)])
+@pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (1024, 4), (512, 8), (1280, 8), (2048, 8)])
 def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, waves, case):
     """int8 operands are images of (x - centre) * S with ONE global scale: a few enormous rows squeeze every other row
     into the same few levels (the residual bounds then make the screen useless and everything is evaluated exactly,
