@@ -156,7 +156,8 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "quad_width"    queries per quad of the wide kernel (0 by rule; a multiple of 32)
  *   "screen_i8"     int8 screen operands for rows of a multiple of 256 dims (default 1)
  *   "min_blocks"    workgroups the wide kernel's rows-per-block rule aims for on small batches (0 by rule)
- *   "single_bucket" a single-query call is bucketed and quantised by the probe merge (three launches less; default 1)
+ *   "single_bucket" a single-query call is bucketed and quantised by the probe merge (three launches less; default 1: and
+ *                   the probe itself joins that block where the centroid table is <= 512 KB; 2 never, 3 always, 0 off)
  *   "seed_refine"   exact distances of the rows behind the k selected seed bounds replace the k-th bound as the first
  *                   threshold (k <= 16; default 1)
  *   "item_grid"     wide kernel grid: 1 = one workgroup per (quad, existing row chunk) for the 4-wave blocks (default),

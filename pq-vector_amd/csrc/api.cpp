@@ -1445,7 +1445,15 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
         if (p.filter) { HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float))); HIP_TRY(sc.s_qmax.ensure(static_cast<size_t>(nq) * sizeof(float))); }
     }
-    if (p.probe_rows) {     // a batch: a lane per centroid, the chains of up to 8 queries in registers
+    // one query on the wide screened path: probe, probe merge, bucketing and quantisation in ONE block (probe_single_kernel)
+    // -- where one CU reads the centroid table fast enough: <= 512 KB (C2: 67 -> 61 us; C3's 3 MB table is no faster
+    // through one block than through the four of stream_kernel + the merge: 243 against 241 us)
+    const bool fused_probe = nq == 1 && p.np <= 64 && p.tile && p.filter && p.quad && s->opt.single_bucket > 0 &&
+                             s->opt.single_bucket != 2 && s->kc_pad != 0 && s->kc_pad <= 1024 &&
+                             (s->opt.single_bucket == 3 || static_cast<uint64_t>(s->kc_pad) * s->dim * 4 <= (512u << 10));
+    if (fused_probe) {
+        // (launched below, once the merge arguments are complete)
+    } else if (p.probe_rows) {     // a batch: a lane per centroid, the chains of up to 8 queries in registers
         pqv::ProbeRowsArgs pr{};
         pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
         pr.nq = nq; pr.kc = s->n_clusters; pr.kc_pad = s->kc_pad; pr.dim = s->dim;
@@ -1505,7 +1513,14 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             pm.sq_center = s->d_center.as<float>(); pm.sq_scale = s->i8_scale; pm.sq_maxabs = s->i8_half;
         }
     }
-    HIP_TRY(launch_merge_probe(pm, stream));
+    if (fused_probe) {
+        pqv::ProbeRowsArgs pr{};
+        pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
+        pr.nq = 1; pr.kc = s->n_clusters; pr.kc_pad = s->kc_pad; pr.dim = s->dim;
+        HIP_TRY(pqv::launch_probe_single(pr, pm, stream));
+    } else {
+        HIP_TRY(launch_merge_probe(pm, stream));
+    }
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
@@ -1900,7 +1915,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
-    else if (n == "single_bucket") o.single_bucket = value != 0;
+    else if (n == "single_bucket") o.single_bucket = static_cast<int>(value);      // 2 = bucketing in the merge, separate probe launch; 3 = fused probe for any table size
     else if (n == "seed_refine") o.seed_refine = static_cast<int>(value);       // 2 = any dim / batch size
     else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size

@@ -56,6 +56,9 @@ struct ProbeRowsArgs {
     uint32_t        zero_n;
 };
 hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s);
+struct MergeArgs;
+// one query: probe + probe merge in one 1024-thread block (kc_pad <= 1024, nprobe <= 64)
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, hipStream_t s);
 hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
 
 struct MergeArgs {

@@ -585,25 +585,103 @@ __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int
 // PROBE == true : the k "rows" are centroids; emits the probe order and the candidate
 //                 position base of each probed list (index.rs:57-63's concatenation).
 // ------------------------------------------------------------------------------------
+// probe merge, waves 1 .. (threads >= 64): the query's partial lists of the re-rank start EMPTY; a single-query call also
+// gets the int8 image of its query (last wave of the block)
+__device__ __forceinline__ void probe_merge_helpers(const MergeArgs &a, uint32_t q) {
+    const int lane = threadIdx.x & 63;
+    if (a.sq_q_i8 && threadIdx.x >= blockDim.x - 64)
+        quantize_query_i8_wave(a.queries, q, lane, a.dim, a.sq_scale, a.sq_center, a.sq_maxabs, a.sq_q_i8, a.sq_q_n2i, a.sq_q_res);
+    if (a.preset_keys) {
+        uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
+        uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
+        for (uint32_t i = threadIdx.x - 64; i < a.preset_n; i += blockDim.x - 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
+    }
+    if (a.preset_flags) {
+        uint32_t *pf = reinterpret_cast<uint32_t *>(a.preset_flags + (uint64_t)q * a.preset_flag_n);      // preset_flag_n % 4 == 0
+        for (uint32_t i = threadIdx.x - 64; i < a.preset_flag_n / 4; i += blockDim.x - 64) pf[i] = 0u;
+    }
+}
+// probe merge, wave 0 after the selection: probe order, candidate bases, histogram / single-query bucketing, norms
+template <int S>
+__device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q, int lane, WaveTopk<S> &tk) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        const bool have = e < a.k && tk.key[s] != KEY_EMPTY;
+        const uint32_t c = have ? tk.val[s] : 0;
+        const uint64_t len = have ? (a.list_off[c + 1] - a.list_off[c]) : 0;
+        // inclusive wave scan of len
+        uint64_t incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+            const uint64_t o = ((uint64_t)hi << 32) | lo;
+            if (lane >= off) incl += o;
+        }
+        if (e < a.k) {
+            a.probe[(uint64_t)q * a.k + e] = c;
+            a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
+            if (a.hist && have && !a.sq_quads) atomicAdd(&a.hist[(uint64_t)(q % HIST_REPLICAS) * a.hist_stride + c], 1u);   // pair bucketing: cluster histogram
+        }
+        if (a.sq_quads && s == 0) {          // single query (q == 0, a.k <= 64): quad e = pair e = probe rank e
+            const uint32_t nch = (have && a.sq_item_rows) ? (uint32_t)((len + a.sq_item_rows - 1) / a.sq_item_rows) : 0u;
+            uint32_t ii = nch;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)ii, off, 64);
+                if (lane >= off) ii += o;
+            }
+            const uint32_t first = ii - nch;
+            if (have) {
+                a.sq_quads[e] = make_uint4(c, e, 1u, first);
+                a.sq_pairs[e] = e;
+                for (uint32_t t = 0; t < nch && first + t < a.sq_max_items; ++t) a.sq_item_quad[first + t] = e;
+            }
+            const uint32_t nqd = (uint32_t)__popcll(__ballot(have));
+            const uint32_t nit = readlane_u32(ii, 63);
+            if (lane == 0) {
+                *a.sq_n_quads = nqd;
+                if (a.sq_n_items) *a.sq_n_items = nit < a.sq_max_items ? nit : a.sq_max_items;
+            }
+        }
+        carry += readlane_u64(incl, 63);
+    }
+    if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
+    if (a.stats && lane == 0) {                       // plan metrics, spread over STATS_SLOTS lines
+#ifdef PQV_PROFILE_PHASES
+        unsigned long long *st = a.stats;
+#else
+        unsigned long long *st = a.stats + 8 + 16 * (q % STATS_SLOTS);
+#endif
+        atomicAdd(&st[2], (unsigned long long)carry);
+        atomicAdd(&st[3], (unsigned long long)(carry < a.max_pos ? carry : a.max_pos));
+    }
+    if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
+    if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
+        float acc = 0.0f;
+        for (uint32_t d = lane; d < a.dim; d += 64) { const float v = a.queries[(uint64_t)q * a.dim + d]; acc += v * v; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) a.qnorm_out[q] = acc;
+    }
+    if (a.qmax_out) {                                              // max |q_i| (f16 operand range check)
+        float m = 0.0f;
+        for (uint32_t d = lane; d < a.dim; d += 64) m = fmaxf(m, fabsf(a.queries[(uint64_t)q * a.dim + d]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        if (lane == 0) a.qmax_out[q] = m;
+    }
+}
+
 template <int S, bool PROBE>
 __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if (threadIdx.x >= 64) {
         // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
-        if constexpr (PROBE) {
-            if (a.sq_q_i8 && threadIdx.x >= 192)     // single-query call: the int8 image of the query too (last helper wave)
-                quantize_query_i8_wave(a.queries, q, lane, a.dim, a.sq_scale, a.sq_center, a.sq_maxabs, a.sq_q_i8, a.sq_q_n2i, a.sq_q_res);
-            if (a.preset_keys) {
-                uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
-                uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
-                for (uint32_t i = threadIdx.x - 64; i < a.preset_n; i += blockDim.x - 64) { pk[i] = KEY_EMPTY; pv[i] = 0xFFFFFFFFu; }
-            }
-            if (a.preset_flags) {
-                uint32_t *pf = reinterpret_cast<uint32_t *>(a.preset_flags + (uint64_t)q * a.preset_flag_n);      // preset_flag_n % 4 == 0
-                for (uint32_t i = threadIdx.x - 64; i < a.preset_flag_n / 4; i += blockDim.x - 64) pf[i] = 0u;
-            }
-        }
+        if constexpr (PROBE) probe_merge_helpers(a, q);
         return;
     }
     WaveTopk<S> tk;
@@ -719,76 +797,77 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
         const bool any_tie = __ballot(tie) != 0ull;
         if (a.tie_flag && lane == 0) a.tie_flag[q] = any_tie ? 1u : 0u;
     } else {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const uint32_t e = s * 64 + lane;
-            const bool have = e < a.k && tk.key[s] != KEY_EMPTY;
-            const uint32_t c = have ? tk.val[s] : 0;
-            const uint64_t len = have ? (a.list_off[c + 1] - a.list_off[c]) : 0;
-            // inclusive wave scan of len
-            uint64_t incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64);
-                const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
-                const uint64_t o = ((uint64_t)hi << 32) | lo;
-                if (lane >= off) incl += o;
-            }
-            if (e < a.k) {
-                a.probe[(uint64_t)q * a.k + e] = c;
-                a.cand_base[(uint64_t)q * a.k + e] = carry + incl - len;
-                if (a.hist && have && !a.sq_quads) atomicAdd(&a.hist[(uint64_t)(q % HIST_REPLICAS) * a.hist_stride + c], 1u);   // pair bucketing: cluster histogram
-            }
-            if (a.sq_quads && s == 0) {          // single query (q == 0, a.k <= 64): quad e = pair e = probe rank e
-                const uint32_t nch = (have && a.sq_item_rows) ? (uint32_t)((len + a.sq_item_rows - 1) / a.sq_item_rows) : 0u;
-                uint32_t ii = nch;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)ii, off, 64);
-                    if (lane >= off) ii += o;
-                }
-                const uint32_t first = ii - nch;
-                if (have) {
-                    a.sq_quads[e] = make_uint4(c, e, 1u, first);
-                    a.sq_pairs[e] = e;
-                    for (uint32_t t = 0; t < nch && first + t < a.sq_max_items; ++t) a.sq_item_quad[first + t] = e;
-                }
-                const uint32_t nqd = (uint32_t)__popcll(__ballot(have));
-                const uint32_t nit = readlane_u32(ii, 63);
-                if (lane == 0) {
-                    *a.sq_n_quads = nqd;
-                    if (a.sq_n_items) *a.sq_n_items = nit < a.sq_max_items ? nit : a.sq_max_items;
-                }
-            }
-            carry += readlane_u64(incl, 63);
-        }
-        if (a.n_cand && lane == 0) a.n_cand[q] = carry;   // uncapped: candidate_rows metric
-        if (a.stats && lane == 0) {                       // plan metrics, spread over STATS_SLOTS lines
-#ifdef PQV_PROFILE_PHASES
-            unsigned long long *st = a.stats;
-#else
-            unsigned long long *st = a.stats + 8 + 16 * (q % STATS_SLOTS);
-#endif
-            atomicAdd(&st[2], (unsigned long long)carry);
-            atomicAdd(&st[3], (unsigned long long)(carry < a.max_pos ? carry : a.max_pos));
-        }
-        if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
-        if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
-            float acc = 0.0f;
-            for (uint32_t d = lane; d < a.dim; d += 64) { const float v = a.queries[(uint64_t)q * a.dim + d]; acc += v * v; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-            if (lane == 0) a.qnorm_out[q] = acc;
-        }
-        if (a.qmax_out) {                                              // max |q_i| (f16 operand range check)
-            float m = 0.0f;
-            for (uint32_t d = lane; d < a.dim; d += 64) m = fmaxf(m, fabsf(a.queries[(uint64_t)q * a.dim + d]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-            if (lane == 0) a.qmax_out[q] = m;
-        }
+        probe_merge_tail<S>(a, q, lane, tk);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// probe_single_kernel: the whole centroid probe of ONE query in one 1024-thread block -- a lane per centroid computes
+// the reference distance exactly as probe_rows_kernel<1> does (kc_pad <= 1024), the keys meet in LDS, wave 0 selects the
+// nprobe nearest and runs the probe merge's tail (probe order, candidate bases, single-query bucketing, norms), the other
+// waves its helper work: one launch instead of stream_kernel + merge_kernel.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a) {
+    __shared__ uint64_t s_keys[1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = threadIdx.x;
+    uint64_t key = KEY_EMPTY;
+    if ((uint32_t)wave * 64u < pr.kc_pad) {
+        const uint32_t G = pr.dim >> 2;
+        const float4 *xt = pr.cent_t + c;
+        const float *qv = pr.queries;
+        float sum = 0.0f;
+        // 16 row chunks in flight per lane (a lane's 768-dim row is 192 dependent adds but independent loads)
+        uint32_t g = 0;
+        for (; g + 16 <= G; g += 16) {
+            float4 x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = xt[(uint64_t)(g + u) * pr.kc_pad];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float4 qq = load4_uniform<true>(qv + (g + u) * 4);
+                const float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                sum = sum + t;
+            }
+        }
+        for (; g < G; ++g) {
+            const float4 x = xt[(uint64_t)g * pr.kc_pad];
+            const float4 qq = load4_uniform<true>(qv + g * 4);
+            const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
+            float t = d0 * d0 + d1 * d1;
+            t = t + d2 * d2;
+            t = t + d3 * d3;
+            sum = sum + t;
+        }
+        if (c < pr.kc) key = ((uint64_t)__float_as_uint(sum) << 32) | c;
+    }
+    s_keys[threadIdx.x] = key;
+    __syncthreads();
+    if (wave != 0) { probe_merge_helpers(a, 0u); return; }
+    WaveTopk<1> tk;
+    tk.init();
+    uint64_t kk[16];
+    uint64_t lmin = KEY_EMPTY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { kk[i] = s_keys[i * 64 + lane]; lmin = kk[i] < lmin ? kk[i] : lmin; }
+    uint32_t dummy = 0;
+    bitonic_sort64(lmin, dummy, lane);
+    const uint64_t cut = readlane_u64(lmin, (int)a.k - 1);       // a.k <= 64
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t k2 = kk[i] > cut ? KEY_EMPTY : kk[i];
+        if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
+    }
+    probe_merge_tail<1>(a, 0u, lane, tk);
+}
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, hipStream_t s) {
+    if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || pr.kc_pad > 1024 || (pr.dim % 4) != 0 || pr.kc == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(probe_single_kernel, dim3(1), dim3(1024), 0, s, pr, a);
+    return hipGetLastError();
 }
 
 template <bool PROBE>

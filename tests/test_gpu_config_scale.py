@@ -100,6 +100,10 @@ def test_c3_parameters_natural_dispatch(pqv, oracle, c3_shape):
         r3, d3, _, _ = s.topk(queries[100:100 + b], k, nprobe)
         assert np.array_equal(r3, rows_t[100:100 + b]) and np.array_equal(_bits(d3), _bits(dist_t[100:100 + b]))
     # (a single query is bucketed and quantised by the probe merge itself; the general three-launch form agrees)
+    s3 = pqv.Searcher(index, corpus)
+    s3.set_option("single_bucket", 3)          # probe + merge + bucketing in one block (the rule keeps that for small tables)
+    r6, d6, _, nc6 = s3.topk(queries[5:6], k, nprobe)
+    assert np.array_equal(r6, rows_t[5:6]) and np.array_equal(_bits(d6), _bits(dist_t[5:6])) and nc6[0] == nc[5]
     s1 = pqv.Searcher(index, corpus)
     s1.set_option("single_bucket", 0)
     for q in (0, 100, 777):
