@@ -159,7 +159,7 @@ struct pqv_corpus {
 constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
-        s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
+        s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_ticket, s_ticket2, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
         s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_part_flags;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
@@ -1446,11 +1446,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         if (p.filter) { HIP_TRY(sc.s_qnorm.ensure(static_cast<size_t>(nq) * sizeof(float))); HIP_TRY(sc.s_qmax.ensure(static_cast<size_t>(nq) * sizeof(float))); }
     }
     // one query on the wide screened path: probe, probe merge, bucketing and quantisation in ONE block (probe_single_kernel)
-    // -- where one CU reads the centroid table fast enough: <= 512 KB (C2: 67 -> 61 us; C3's 3 MB table is no faster
-    // through one block than through the four of stream_kernel + the merge: 243 against 241 us)
     const bool fused_probe = nq == 1 && p.np <= 64 && p.tile && p.filter && p.quad && s->opt.single_bucket > 0 &&
-                             s->opt.single_bucket != 2 && s->kc_pad != 0 && s->kc_pad <= 1024 &&
-                             (s->opt.single_bucket == 3 || static_cast<uint64_t>(s->kc_pad) * s->dim * 4 <= (512u << 10));
+                             s->opt.single_bucket != 2 && s->kc_pad != 0 && s->kc_pad <= 4096;
     if (fused_probe) {
         // (launched below, once the merge arguments are complete)
     } else if (p.probe_rows) {     // a batch: a lane per centroid, the chains of up to 8 queries in registers
@@ -1517,7 +1514,13 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         pqv::ProbeRowsArgs pr{};
         pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
         pr.nq = 1; pr.kc = s->n_clusters; pr.kc_pad = s->kc_pad; pr.dim = s->dim;
-        HIP_TRY(pqv::launch_probe_single(pr, pm, stream));
+        HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(s->kc_pad) * sizeof(uint64_t)));
+        pr.part_keys = sc.s_probe_keys.as<uint64_t>();
+        if (!sc.s_ticket.p) {
+            HIP_TRY(sc.s_ticket.ensure(sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(sc.s_ticket.p, 0, sizeof(uint32_t), stream));
+        }
+        HIP_TRY(pqv::launch_probe_single(pr, pm, sc.s_ticket.as<uint32_t>(), stream));
     } else {
         HIP_TRY(launch_merge_probe(pm, stream));
     }
@@ -1607,7 +1610,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             const uint32_t n_vals = p.np * seed.seed_sw * 16;
             HIP_TRY(sc.s_seed_ub.ensure(static_cast<size_t>(nq) * n_vals * sizeof(float)));
             seed.seed_ub = sc.s_seed_ub.as<float>();
-            HIP_TRY(launch_wide_seed(seed, stream));
             // running thresholds: see TileArgs::thr_hist
             if (s->opt.running_thr && k > 1) {
                 HIP_TRY(sc.s_thr_hist.ensure(static_cast<size_t>(nq) * 16 * sizeof(uint32_t)));
@@ -1620,8 +1622,23 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 rf.probe = sc.s_probe.as<uint32_t>(); rf.cand_base = sc.s_cand_base.as<uint64_t>();
                 rf.dim = s->dim; rf.nprobe = p.np; rf.seed_sw = seed.seed_sw; rf.seed_rows = p.seed_rows; rf.max_pos = max_pos;
             }
-            HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream,
-                                       ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p), &rf));
+            // one query: the seed kernel's last block selects (SeedTail); otherwise a launch of its own
+            const bool seed_tail = nq == 1 && k <= 64 && s->opt.single_bucket > 0;
+            if (seed_tail) {
+                if (!sc.s_ticket2.p) {
+                    HIP_TRY(sc.s_ticket2.ensure(sizeof(uint32_t)));
+                    HIP_TRY(hipMemsetAsync(sc.s_ticket2.p, 0, sizeof(uint32_t), stream));
+                }
+                seed.seed_tail.enable = 1; seed.seed_tail.n_vals = n_vals; seed.seed_tail.k = k;
+                seed.seed_tail.gthr = ta.gthr; seed.seed_tail.cand_cnt = ta.cand_cnt; seed.seed_tail.spilled = ta.spilled;
+                seed.seed_tail.thr_hist = ta.thr_hist; seed.seed_tail.thr_bins = static_cast<float4 *>(sc.s_thr_bins.p);
+                seed.seed_tail.ticket = sc.s_ticket2.as<uint32_t>();
+                seed.seed_tail.rf = rf;
+            }
+            HIP_TRY(launch_wide_seed(seed, stream));
+            if (!seed_tail)
+                HIP_TRY(launch_seed_select(seed.seed_ub, nq, n_vals, k, ta.gthr, ta.cand_cnt, ta.spilled, stream,
+                                           ta.thr_hist, static_cast<float4 *>(sc.s_thr_bins.p), &rf));
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
@@ -1915,7 +1932,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "running_thr") o.running_thr = value != 0;
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
-    else if (n == "single_bucket") o.single_bucket = static_cast<int>(value);      // 2 = bucketing in the merge, separate probe launch; 3 = fused probe for any table size
+    else if (n == "single_bucket") o.single_bucket = static_cast<int>(value);      // 2 = bucketing in the merge, separate probe launch
     else if (n == "seed_refine") o.seed_refine = static_cast<int>(value);       // 2 = any dim / batch size
     else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size
@@ -1982,7 +1999,7 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
                      s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
-                                &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads, &l.s_items,
+                                &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads, &l.s_items, &l.s_ticket, &l.s_ticket2,
                                 &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
                                 &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres, &l.s_part_flags})
             other += b->p ? b->bytes : 0;

@@ -57,8 +57,9 @@ struct ProbeRowsArgs {
 };
 hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s);
 struct MergeArgs;
-// one query: probe + probe merge in one 1024-thread block (kc_pad <= 1024, nprobe <= 64)
-hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, hipStream_t s);
+// one query: probe + probe merge in one launch (kc_pad <= 4096, nprobe <= 64); the last block to finish merges
+// (pr.part_keys: kc_pad keys of scratch; ticket: one zero-initialised u32 that the kernel leaves at zero)
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s);
 hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
 
 struct MergeArgs {
@@ -172,6 +173,29 @@ struct PairSortArgs {
 // hist -> scan -> scatter; three tiny launches
 hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
 
+// Optional refinement of the seed threshold (k <= 16, dim % 32 == 0): the k sampled bounds a query selects belong to 4 k
+// rows (a bound is a lane's minimum over the 4 sub-tile rows it saw); their EXACT reference distances are evaluated
+// and the k-th smallest of those -- still k distinct candidates, so still an upper bound of the final k-th distance --
+// replaces the k-th bound: the threshold loses the slack of the operand form (int8: ~1 % of d2) before the screen starts.
+struct SeedRefine {
+    const float    *mat;        // IVF-ordered rows [*, dim] (nullptr = no refinement)
+    const float    *queries;    // [nq, dim]
+    const uint64_t *list_off;
+    const uint32_t *probe;      // [nq, nprobe]
+    const uint64_t *cand_base;  // [nq, nprobe]
+    uint32_t        dim, nprobe, seed_sw, seed_rows;
+    uint64_t        max_pos;
+};
+// One-query calls: wide_seed_kernel's LAST block to finish (a ticket counter) runs seed_select_kernel's body itself.
+struct SeedTail {
+    int                 enable;
+    uint32_t            n_vals, k;
+    unsigned long long *gthr;
+    uint32_t           *cand_cnt, *spilled, *thr_hist;
+    float4             *thr_bins;
+    uint32_t           *ticket;      // zero-initialised, left at zero
+    SeedRefine          rf;
+};
 struct TileArgs {
     const float    *mat;
     const uint32_t *row_of;
@@ -232,6 +256,7 @@ struct TileArgs {
     uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
     // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
     float          *seed_ub;
+    SeedTail        seed_tail;   // wide_seed_kernel, one query: select + refine in the same launch
     uint32_t        seed_sw;
     // running thresholds (wide_filter_kernel, optional): per query two 64-bit words of 8-bit counters --
     // counter b = appended pairs at distance < thr0 - b w -- and the bin parameters {thr0, w, 1 / w, pad}
@@ -261,19 +286,6 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 // the first rows of every list fills TileArgs::seed_ub, launch_seed_select turns a query's n_vals =
 // nprobe * seed_sw * 16 minima into gthr[q] and resets its candidate buffer / overflow flag.
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s);
-// Optional refinement of the seed threshold (k <= 16, dim % 32 == 0): the k sampled bounds a query selects belong to 4 k
-// rows (a bound is a lane's minimum over the 4 sub-tile rows it saw); their EXACT reference distances are evaluated
-// and the k-th smallest of those -- still k distinct candidates, so still an upper bound of the final k-th distance --
-// replaces the k-th bound: the threshold loses the slack of the operand form (int8: ~1 % of d2) before the screen starts.
-struct SeedRefine {
-    const float    *mat;        // IVF-ordered rows [*, dim] (nullptr = no refinement)
-    const float    *queries;    // [nq, dim]
-    const uint64_t *list_off;
-    const uint32_t *probe;      // [nq, nprobe]
-    const uint64_t *cand_base;  // [nq, nprobe]
-    uint32_t        dim, nprobe, seed_sw, seed_rows;
-    uint64_t        max_pos;
-};
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
                               uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
                               uint32_t *thr_hist = nullptr, float4 *thr_bins = nullptr, const SeedRefine *refine = nullptr);

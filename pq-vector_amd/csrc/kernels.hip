@@ -802,23 +802,23 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// probe_single_kernel: the whole centroid probe of ONE query in one 1024-thread block -- a lane per centroid computes
-// the reference distance exactly as probe_rows_kernel<1> does (kc_pad <= 1024), the keys meet in LDS, wave 0 selects the
-// nprobe nearest and runs the probe merge's tail (probe order, candidate bases, single-query bucketing, norms), the other
-// waves its helper work: one launch instead of stream_kernel + merge_kernel.
+// probe_single_kernel: the whole centroid probe of ONE query in one launch -- a lane per centroid computes the reference
+// distance exactly as probe_rows_kernel<1> does (256 centroids per block, 16 row chunks in flight per lane), the keys go
+// to scratch, and the block that finishes LAST (a ticket counter) selects the nprobe nearest and runs the probe merge's
+// tail (probe order, candidate bases, single-query bucketing, norms) with its other waves doing the merge's helper
+// work: one launch instead of stream_kernel + merge_kernel.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a) {
-    __shared__ uint64_t s_keys[1024];
+__global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a, uint32_t *ticket) {
+    __shared__ uint32_t s_last;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c = threadIdx.x;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;           // < kc_pad (a multiple of 256)
     uint64_t key = KEY_EMPTY;
-    if ((uint32_t)wave * 64u < pr.kc_pad) {
+    {
         const uint32_t G = pr.dim >> 2;
         const float4 *xt = pr.cent_t + c;
         const float *qv = pr.queries;
         float sum = 0.0f;
-        // 16 row chunks in flight per lane (a lane's 768-dim row is 192 dependent adds but independent loads)
         uint32_t g = 0;
         for (; g + 16 <= G; g += 16) {
             float4 x[16];
@@ -845,28 +845,40 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
         }
         if (c < pr.kc) key = ((uint64_t)__float_as_uint(sum) << 32) | c;
     }
-    s_keys[threadIdx.x] = key;
+    __hip_atomic_store(pr.part_keys + c, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
     __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(ticket, 1u);
+        s_last = t == gridDim.x - 1u ? 1u : 0u;
+        if (s_last) *ticket = 0u;                                 // ready for the next call
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     if (wave != 0) { probe_merge_helpers(a, 0u); return; }
     WaveTopk<1> tk;
     tk.init();
-    uint64_t kk[16];
+    // the k-th smallest of the 64 lane minima bounds the k-th smallest key: only keys at or below it are inserted
     uint64_t lmin = KEY_EMPTY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { kk[i] = s_keys[i * 64 + lane]; lmin = kk[i] < lmin ? kk[i] : lmin; }
+    for (uint32_t i = lane; i < pr.kc_pad; i += 64) {
+        const uint64_t k2 = __hip_atomic_load(pr.part_keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lmin = k2 < lmin ? k2 : lmin;
+    }
     uint32_t dummy = 0;
     bitonic_sort64(lmin, dummy, lane);
     const uint64_t cut = readlane_u64(lmin, (int)a.k - 1);       // a.k <= 64
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint64_t k2 = kk[i] > cut ? KEY_EMPTY : kk[i];
+    for (uint32_t i0 = 0; i0 < pr.kc_pad; i0 += 64) {
+        uint64_t k2 = __hip_atomic_load(pr.part_keys + i0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k2 > cut) k2 = KEY_EMPTY;
         if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
     }
     probe_merge_tail<1>(a, 0u, lane, tk);
 }
-hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, hipStream_t s) {
-    if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || pr.kc_pad > 1024 || (pr.dim % 4) != 0 || pr.kc == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(probe_single_kernel, dim3(1), dim3(1024), 0, s, pr, a);
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s) {
+    if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || (pr.kc_pad % 256) != 0 || pr.kc_pad > 4096 || (pr.dim % 4) != 0 ||
+        pr.kc == 0 || !pr.part_keys || !ticket) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(probe_single_kernel, dim3(pr.kc_pad / 256), dim3(256), 0, s, pr, a, ticket);
     return hipGetLastError();
 }
 
@@ -1600,6 +1612,27 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
 // sample.  The sample rows themselves are screened and evaluated by the main pass like all others.
 // Output: seed_ub[((qrow * nprobe + j) * seed_sw + blockIdx.x * 4 + wave) * 16 + (lane & 15)].
 // ------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void seed_select_body(const uint32_t q, const float *seed_ub, uint32_t n_vals, uint32_t k,
+                                                 unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
+                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf);     // (defined below)
+// one-query calls (SeedTail): every block of wide_seed_kernel takes a ticket when it is done -- also the ones with nothing
+// to sample -- and the last one runs the select / refinement for query 0
+__device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
+    __shared__ uint32_t s_seed_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(a.seed_tail.ticket, 1u);
+        s_seed_last = t == gridDim.x * gridDim.y * gridDim.z - 1u ? 1u : 0u;
+        if (s_seed_last) *a.seed_tail.ticket = 0u;
+    }
+    __syncthreads();
+    if (!s_seed_last) return;
+    __threadfence();
+    seed_select_body<1>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
+                        a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf);
+}
 template <int NG, bool QLDS, int OP>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
@@ -1607,12 +1640,12 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr uint32_t NQ = 16 * NG;
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
-    if (by >= *a.n_quads) return;
+    if (by >= *a.n_quads) { if (a.seed_tail.enable) seed_tail_finish(a); return; }
     const uint4 quad = a.quads[by];
     // a quad wider than this kernel's 16 NG queries (the 8-wave filter kernel takes up to 128) is sampled in
     // slices of 16 NG: blockIdx.z
     const uint32_t sub = blockIdx.z * NQ;
-    if (sub >= quad.z) return;
+    if (sub >= quad.z) { if (a.seed_tail.enable) seed_tail_finish(a); return; }
     const uint32_t c = quad.x, p0 = quad.y + sub, cnt = quad.z - sub < NQ ? quad.z - sub : NQ;
     const uint32_t ng = (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
@@ -1778,20 +1811,20 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 a.seed_ub[(((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15] = fmaxf(mins[g][r], 0.0f);
         }
     }
+    if (a.seed_tail.enable) seed_tail_finish(a);
 }
 
 // gthr[q] = key of the k-th smallest of q's n_vals upper bounds (none if fewer than k are finite); also
 // resets the query's candidate buffer and overflow flag.  One wave per query.
 template <int S>
-__global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
-                                                        unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                        uint32_t *thr_hist, float4 *thr_bins, const SeedRefine rf) {
+__device__ __forceinline__ void seed_select_body(const uint32_t q, const float *seed_ub, uint32_t n_vals, uint32_t k,
+                                                 unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
+                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf) {
     // one wave selects; with the refinement (256 threads) all four waves share the exact evaluations
     __shared__ uint64_t s_ent[16];           // the k selected bounds
     __shared__ uint64_t s_exact[64];         // exact keys of their 4 k rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t q = blockIdx.x;
     const bool refine = rf.mat && k <= 16u && blockDim.x == 256;
     WaveTopk<S> tk;
     tk.init();
@@ -1943,6 +1976,12 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
             thr_bins[q] = hb;
         }
     }
+}
+template <int S>
+__global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
+                                                        unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
+                                                        uint32_t *thr_hist, float4 *thr_bins, const SeedRefine rf) {
+    seed_select_body<S>(blockIdx.x, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins, rf);
 }
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
