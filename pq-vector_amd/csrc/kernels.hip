@@ -659,19 +659,30 @@ __device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q,
         atomicAdd(&st[3], (unsigned long long)(carry < a.max_pos ? carry : a.max_pos));
     }
     if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
-    if (a.qnorm_out) {                                             // |q|^2 for the MFMA screen (any order)
-        float acc = 0.0f;
-        for (uint32_t d = lane; d < a.dim; d += 64) { const float v = a.queries[(uint64_t)q * a.dim + d]; acc += v * v; }
+    if (a.qnorm_out || a.qmax_out) {      // |q|^2 for the MFMA screen (any order) and max |q_i| (f16 operand range check):
+        float acc = 0.0f, m = 0.0f;       // one pass, all of a lane's loads in flight together (up to 8 x 16 bytes)
+        const float *qp = a.queries + (uint64_t)q * a.dim;
+        if ((a.dim % 4u) == 0u) {
+            for (uint32_t d0 = (uint32_t)lane * 4u; d0 < a.dim; d0 += 2048u) {
+                float4 v[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) a.qnorm_out[q] = acc;
-    }
-    if (a.qmax_out) {                                              // max |q_i| (f16 operand range check)
-        float m = 0.0f;
-        for (uint32_t d = lane; d < a.dim; d += 64) m = fmaxf(m, fabsf(a.queries[(uint64_t)q * a.dim + d]));
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t d = d0 + 256u * (uint32_t)u;
+                    v[u] = d < a.dim ? *reinterpret_cast<const float4 *>(qp + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-        if (lane == 0) a.qmax_out[q] = m;
+                for (int u = 0; u < 8; ++u) {
+                    acc += v[u].x * v[u].x; acc += v[u].y * v[u].y; acc += v[u].z * v[u].z; acc += v[u].w * v[u].w;
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                }
+            }
+        } else {
+            for (uint32_t d = lane; d < a.dim; d += 64) { const float v = qp[d]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off, 64); m = fmaxf(m, __shfl_down(m, off, 64)); }
+        if (lane == 0 && a.qnorm_out) a.qnorm_out[q] = acc;
+        if (lane == 0 && a.qmax_out) a.qmax_out[q] = m;
     }
 }
 
