@@ -505,9 +505,7 @@ hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s) {
     // enough waves for the chip first (four per SIMD: the loop waits for every row chunk it loads -- C3, 1024 queries:
     // 83 us with 4 queries per lane and 4096 waves, 106 us with 8 and 2048; an explicit prefetch of the next chunk
     // measured slower), then as many queries per row read as the batch allows
-    static const int qb_env = [] { const char *e = std::getenv("PQV_PROBE_QB"); return e ? std::atoi(e) : 0; }();
-    int qb = (uint64_t)gx * (a.nq / 8) >= 1024 ? 8 : (uint64_t)gx * (a.nq / 4) >= 512 ? 4 : (uint64_t)gx * (a.nq / 2) >= 256 ? 2 : 1;
-    if (qb_env == 1 || qb_env == 2 || qb_env == 4 || qb_env == 8) qb = qb_env;
+    const int qb = (uint64_t)gx * (a.nq / 8) >= 1024 ? 8 : (uint64_t)gx * (a.nq / 4) >= 512 ? 4 : (uint64_t)gx * (a.nq / 2) >= 256 ? 2 : 1;
     const dim3 grid(gx, (a.nq + qb - 1) / qb);
     switch (qb) {
     case 8: hipLaunchKernelGGL(probe_rows_kernel<8>, grid, dim3(256), 0, s, a); break;
