@@ -147,7 +147,7 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "rerank_mode"   0 by rule, 1 streaming kernel, 2 batched tile path
  *   "tile_filter"   MFMA lower-bound screen in the batched path: 0 off, 1 by rule, 2 forced
  *   "filter_variant" 1 = one 16-query group per block instead of the wide kernel
- *   "cand_cap"      candidate-buffer entries per query of the wide screened path (default 2048)
+ *   "cand_cap"      candidate-buffer entries per query of the wide screened path (0 = by rule: 2048, 8192 for k > 32)
  *   "screen_f16"    f16 screen operands where the data allows (default 1)
  *   "seed_rows", "wide_rows", "tile_rows"   rows sampled for thresholds / per block (0 = by rule)
  *   "running_thr"   running thresholds of the wide kernel (default 1)

@@ -209,7 +209,7 @@ struct pqv_searcher {
         int rerank_mode = 0;               // 0 auto, 1 stream_kernel, 2 tile path
         int tile_filter = 1;               // MFMA lower-bound screen in the batched path: 0 off, 1 by rule, 2 forced
         int filter_variant = 0;            // 1: one 16-query group per block (tile_filter_kernel)
-        uint32_t cand_cap = 2048;          // candidate-buffer entries per query of the wide screened path
+        uint32_t cand_cap = 0;             // candidate-buffer entries per query of the wide screened path (0 = by rule: 2048, 8192 for k > 32)
         int screen_f16 = 1;                // f16 operands where possible
         int screen_i8 = 1;                 // int8 operands where possible (dim % 256 == 0)
         uint32_t seed_rows = 0;            // rows per list sampled for the thresholds (0 = by rule)
@@ -1030,7 +1030,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     if (const char *m = std::getenv("PQV_RERANK_MODE")) o.rerank_mode = !std::strcmp(m, "stream") ? 1 : !std::strcmp(m, "tile") ? 2 : 0;
     o.tile_filter = static_cast<int>(std::min<long long>(2, std::max<long long>(0, num("PQV_TILE_FILTER", o.tile_filter))));
     o.filter_variant = static_cast<int>(num("PQV_FILTER_VARIANT", o.filter_variant));
-    o.cand_cap = static_cast<uint32_t>(std::max<long long>(1, num("PQV_CAND_CAP", o.cand_cap)));
+    o.cand_cap = static_cast<uint32_t>(std::max<long long>(0, num("PQV_CAND_CAP", o.cand_cap)));
     o.screen_f16 = num("PQV_SCREEN_F16", o.screen_f16) != 0;
     o.screen_i8 = num("PQV_SCREEN_I8", o.screen_i8) != 0;
     o.seed_rows = static_cast<uint32_t>(num("PQV_SEED_ROWS", o.seed_rows));
@@ -1256,6 +1256,11 @@ struct TopkPlan {
 // Exact refinement of the seed threshold (SeedRefine): where survivors are expensive (rows of >= 256 dims; C2, 128 dims:
 // 7.18 -> 7.04 M QPS with it).  Any batch size: one uniform C3 query pays 7 us for it (256 -> 263), but one query on the
 // Gaussian-mixture set overflows its candidate buffer without it (282 -> 500 us).
+// candidate-buffer entries per query: survivors of the screen grow with k (C3: 240 at k 10 with the refined first
+// threshold, 810 at k 32, 2100 at k 100 -- and a query that overflows its buffer falls back to the per-wave sorted lists)
+static uint32_t cand_cap_for(const pqv_searcher *s, uint32_t k) {
+    return std::max<uint32_t>(s->opt.cand_cap ? s->opt.cand_cap : (k > 32 ? 8192u : 2048u), k);
+}
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
     (void)nq;
     return s->opt.seed_refine && !s->d_row_of && (s->dim % 32) == 0 && k <= 16 && (s->opt.seed_refine > 1 || s->dim >= 256);
@@ -1596,7 +1601,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         if (p.filter) ta.query_norm2 = sc.s_qnorm.as<float>();     // filled by the probe merge
         if (timing) HIP_TRY(hipEventRecord(e1, stream));
         if (p.filter && p.quad) {
-            const uint32_t ccap = std::max<uint32_t>(s->opt.cand_cap, k);
+            const uint32_t ccap = cand_cap_for(s, k);
             HIP_TRY(sc.s_cand_keys.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint64_t)));
             HIP_TRY(sc.s_cand_vals.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t)));
             HIP_TRY(sc.s_cand_cnt.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
@@ -1684,7 +1689,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     fm.sqrt_out = sqrt_out; fm.k_out = k_out; fm.tie_flag = d_tie;
     if (use_cand) {
         fm.cand_keys = sc.s_cand_keys.as<uint64_t>(); fm.cand_vals = sc.s_cand_vals.as<uint32_t>();
-        fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = std::max<uint32_t>(s->opt.cand_cap, k);
+        fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = cand_cap_for(s, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
         fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
     }
@@ -1923,7 +1928,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     if (n == "rerank_mode") o.rerank_mode = static_cast<int>(value);
     else if (n == "tile_filter") o.tile_filter = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));
     else if (n == "filter_variant") o.filter_variant = static_cast<int>(value);
-    else if (n == "cand_cap") o.cand_cap = static_cast<uint32_t>(std::max<int64_t>(1, value));
+    else if (n == "cand_cap") o.cand_cap = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "screen_f16") o.screen_f16 = value != 0;
     else if (n == "screen_i8") o.screen_i8 = value != 0;
     else if (n == "seed_rows") o.seed_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
