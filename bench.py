@@ -124,6 +124,23 @@ def pmc_traffic(workload, kernels):
     return total, srcs
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher environment: re-run this command line under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] self-launch:", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     # Libraries (RCCL prints a version banner) may write to fd 1; the contract is ONE JSON line
     # on stdout.  Point fd 1 at stderr for the run and keep the real stdout for the result.
@@ -164,6 +181,13 @@ def main():
     global K
     K = args.k
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called as `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per
+        # GPU, torch.distributed.run on 127.0.0.1 with a free port).  Rank 0 of the children inherits the real
+        # stdout and prints the ONE JSON line; this process only forwards the exit status.
+        os.dup2(real_stdout, 1)
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     import pq_vector_amd as pqv
@@ -172,9 +196,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} devices, {torch.cuda.device_count()} visible "
+                         "(--backend gloo lets ranks share a device: path check only)")
     if not torch.cuda.is_available() or pqv.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: pq_vector_amd has no CPU fallback")
     if args.backend == "gloo":          # test hook: ranks may share a device
