@@ -10,6 +10,7 @@
 //! | `topk()` / `TopkBuilder` / `SearchResult` `src/ivf/search.rs:41-142` | [`TopkBuilder`], [`SearchResult`], [`Searcher::topk`] |
 //! | `update_topk_heap` `src/df_vector/exec.rs:457-484`              | [`RerankState::fold_batch`]            |
 //! | `CandidateCursor` `src/df_vector/access.rs:193-243`             | [`CandidateCursor`]                    |
+//! | one heap over all files `src/df_vector/exec.rs:264-267`         | [`ShardComm::exchange`] (RCCL all-gather + merge) |
 //!
 //! Not compiled in the environment this repository was built in (no Rust toolchain in the image);
 //! `tests/test_rust_binding.py` keeps `sys.rs` in lock-step with `include/pqv.h`, and every `sys::pqv_*` call below is
@@ -19,7 +20,7 @@ pub mod sys;
 
 use std::ffi::CStr;
 use std::num::NonZeroUsize;
-use std::os::raw::c_int;
+use std::os::raw::{c_int, c_void};
 use std::ptr;
 
 pub type Error = Box<dyn std::error::Error + Send + Sync>;
@@ -121,7 +122,7 @@ impl Index {
     pub fn to_bytes(&self) -> Result<Vec<u8>> {
         let (mut buf, mut len) = (ptr::null_mut(), 0usize);
         check(unsafe { sys::pqv_index_to_bytes(self.raw, &mut buf, &mut len) })?;
-        let out = unsafe { std::slice::from_raw_parts(buf, len) }.to_vec();
+        let out = if buf.is_null() || len == 0 { Vec::new() } else { unsafe { std::slice::from_raw_parts(buf, len) }.to_vec() };
         unsafe { sys::pqv_bytes_free(buf) };
         Ok(out)
     }
@@ -239,7 +240,7 @@ impl<'c> Searcher<'c> {
         check(unsafe {
             sys::pqv_candidate_rows(self.raw, query.as_ptr(), query.len() as u32, nprobe.get() as u32, &mut rows, &mut n)
         })?;
-        let out = unsafe { std::slice::from_raw_parts(rows, n as usize) }.to_vec();
+        let out = if rows.is_null() || n == 0 { Vec::new() } else { unsafe { std::slice::from_raw_parts(rows, n as usize) }.to_vec() };
         unsafe { sys::pqv_rows_free(rows) };
         Ok(out)
     }
@@ -304,7 +305,9 @@ impl<'a, 'c> TopkBuilder<'a, 'c> {
 }
 
 /// The running top-k of `VectorTopKExec::topk_from_batches` (`src/df_vector/exec.rs:257-277`): fold one
-/// `RecordBatch` at a time, materialise `ScalarValue`s only for the <= k survivors at the end.
+/// `RecordBatch` at a time, materialise `ScalarValue`s only for the <= k survivors at the end.  `rows` / `d2` hold
+/// the reference `BinaryHeap`'s backing array between batches (the library replays `push` / `peek` / `pop` exactly,
+/// so ties come out as in the reference).
 pub struct RerankState {
     device: usize,
     k: usize,
@@ -318,22 +321,86 @@ impl RerankState {
         Self { device, k, rows: vec![0; k.max(1)], d2: vec![0.0; k.max(1)], count: 0 }
     }
 
+    fn check_lens(m: usize, ids: Option<&[u32]>, valid: Option<&[u8]>) -> Result<()> {
+        if ids.map_or(false, |v| v.len() != m) { return Err("ids length must equal the number of rows".into()); }
+        if valid.map_or(false, |v| v.len() != m) { return Err("valid length must equal the number of rows".into()); }
+        Ok(())
+    }
+
     /// `values`: the batch's list-values buffer `[m, dim]`; `ids`: the payload per row (e.g. batch-global row
-    /// numbers); `valid`: 0 for null rows / wrong-length lists (`exec.rs:496-498,526-528`).  Distances use the
-    /// element-by-element order of `compute_distance_values` (`exec.rs:529-533`).
-    pub fn fold_batch(&mut self, query: &[f32], values: &[f32], ids: &[u32], valid: Option<&[u8]>) -> Result<()> {
+    /// numbers; `None` = 0..m); `valid`: 0 for null rows / wrong-length lists (`exec.rs:496-498,526-528`).
+    /// Distances use the element-by-element order of `compute_distance_values` (`exec.rs:529-533`).
+    pub fn fold_batch(&mut self, query: &[f32], values: &[f32], ids: Option<&[u32]>, valid: Option<&[u8]>) -> Result<()> {
         let dim = query.len();
         let m = if dim == 0 { 0 } else { values.len() / dim };
+        Self::check_lens(m, ids, valid)?;
         check(unsafe {
-            sys::pqv_rerank(self.device as c_int, query.as_ptr(), values.as_ptr(), ids.as_ptr(),
+            sys::pqv_rerank(self.device as c_int, query.as_ptr(), values.as_ptr(), ids.map_or(ptr::null(), |v| v.as_ptr()),
                             valid.map_or(ptr::null(), |v| v.as_ptr()), m as u64, dim as u32, self.k as u32,
                             sys::PQV_L2SQ_SEQ, self.rows.as_mut_ptr(), self.d2.as_mut_ptr(), &mut self.count)
         })
     }
 
-    /// (payload, squared distance), ascending -- `exec.rs:270` sorts by `d2` and emits no distance column.
-    pub fn finish(self) -> Vec<(u32, f32)> {
-        (0..self.count as usize).map(|i| (self.rows[i], self.d2[i])).collect()
+    /// The same for a `Float64Array` values buffer: each value is narrowed `as f32` first (`exec.rs:538-545`).
+    pub fn fold_batch_f64(&mut self, query: &[f32], values: &[f64], ids: Option<&[u32]>, valid: Option<&[u8]>) -> Result<()> {
+        let dim = query.len();
+        let m = if dim == 0 { 0 } else { values.len() / dim };
+        Self::check_lens(m, ids, valid)?;
+        check(unsafe {
+            sys::pqv_rerank_f64(self.device as c_int, query.as_ptr(), values.as_ptr(), ids.map_or(ptr::null(), |v| v.as_ptr()),
+                                valid.map_or(ptr::null(), |v| v.as_ptr()), m as u64, dim as u32, self.k as u32,
+                                sys::PQV_L2SQ_SEQ, self.rows.as_mut_ptr(), self.d2.as_mut_ptr(), &mut self.count)
+        })
+    }
+
+    /// (payload, squared distance) in output order: `heap.into_iter()` + the stable sort of `exec.rs:269-274`
+    /// (no distance column, no sqrt on this path).
+    pub fn finish(self) -> Result<Vec<(u32, f32)>> {
+        let n = self.count as usize;
+        let mut rows = vec![0u32; n.max(1)];
+        let mut d2 = vec![0f32; n.max(1)];
+        check(unsafe { sys::pqv_rerank_finish(self.rows.as_ptr(), self.d2.as_ptr(), self.count, rows.as_mut_ptr(), d2.as_mut_ptr()) })?;
+        Ok((0..n).map(|i| (rows[i], d2[i])).collect())
+    }
+}
+
+/// One rank of the sharded search (`src/df_vector/index_exec.rs:85-164` probes every file's own index;
+/// `src/df_vector/exec.rs:264-267` merges them in one heap): one process per GPU, each holding a row range and its
+/// index; `exchange` is ONE RCCL all-gather of the per-shard top-k + the deterministic merge, no torch involved.
+pub struct ShardComm {
+    raw: *mut sys::PqvShardComm,
+}
+unsafe impl Send for ShardComm {}
+
+impl ShardComm {
+    /// Rank 0 draws the rendezvous id and distributes the 128 bytes over the host's own channel.
+    pub fn unique_id() -> Result<[u8; 128]> {
+        let mut id = [0u8; 128];
+        check(unsafe { sys::pqv_shard_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+    /// Collective over all ranks.
+    pub fn new(device: usize, rank: u32, world: u32, id: &[u8; 128]) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::pqv_shard_comm_create(device as c_int, rank, world, id.as_ptr(), &mut raw) })?;
+        Ok(Self { raw })
+    }
+    pub fn rank(&self) -> u32 { unsafe { sys::pqv_shard_comm_rank(self.raw) } }
+    pub fn world(&self) -> u32 { unsafe { sys::pqv_shard_comm_world(self.raw) } }
+    /// Device pointers: this rank's `pqv_topk_device` outputs `[nq, k]`, the shards' first global rows `i64[world]`,
+    /// outputs `f32 / i64 [nq, k]` -- identical on every rank.  Asynchronous on `hip_stream`.
+    ///
+    /// # Safety
+    /// All pointers must be valid device allocations of the stated sizes on this communicator's GPU.
+    pub unsafe fn exchange(&mut self, d_dist: *const c_void, d_rows: *const c_void, d_row_base: *const c_void, nq: u32, k: u32,
+                           d_out_dist: *mut c_void, d_out_rows: *mut c_void, hip_stream: *mut c_void) -> Result<()> {
+        check(sys::pqv_shard_exchange(self.raw, d_dist, d_rows, d_row_base, nq, k, d_out_dist, d_out_rows, hip_stream))
+    }
+}
+
+impl Drop for ShardComm {
+    fn drop(&mut self) {
+        unsafe { sys::pqv_shard_comm_free(self.raw) }
     }
 }
 

@@ -234,22 +234,41 @@ int pqv_topk_device_flags(const pqv_searcher *searcher, const void *d_queries, u
 int pqv_brute_topk(const pqv_corpus *corpus, const float *queries, uint32_t nq, uint32_t query_len,
                    uint32_t k, int metric, uint32_t *row_idx, float *dist, uint32_t *n_found);
 
-/* update_topk_heap / compute_distance_values (src/df_vector/exec.rs:457-550) for one
- * RecordBatch worth of rows: cand host [m, dim] values buffer, ids[m] the payload to return
- * (e.g. batch row numbers; NULL => 0..m), valid[m] optional bytes (0 = null row or length
- * mismatch => skipped, exec.rs:496-498,526-528).  Folds the batch into the running top-k
- * state (io_rows/io_d2/io_count, caller-owned, capacity k, kept sorted ascending by
- * (d2, arrival)); pass *io_count = 0 for the first batch. */
+/* update_topk_heap / compute_distance_values (src/df_vector/exec.rs:457-550) for one RecordBatch worth of rows:
+ * cand host [m, dim] values buffer, ids[m] the payload to return (e.g. batch row numbers; NULL => 0..m), valid[m]
+ * optional bytes (0 = null row or length mismatch => skipped, exec.rs:496-498,526-528).  The batch's distances are
+ * computed on the GPU in compute_distance_values' order; the rows then pass through the reference's heap policy --
+ * std's BinaryHeap push / peek / pop, restated exactly -- in arrival order, so results equal the reference's in every
+ * non-NaN case, ties included.  The running state io_rows / io_d2 / io_count (caller-owned, capacity k) IS that heap's
+ * backing array between batches (NOT sorted); pass *io_count = 0 for the first batch and call pqv_rerank_finish after
+ * the last.  Any k > 0 (the selection is the heap's; no kernel-side list).
+ * pqv_rerank_f64: the same for a Float64 values buffer, each value narrowed `as f32` first (exec.rs:538-545).
+ * pqv_rerank_finish: heap.into_iter() + the stable sort by distance of exec.rs:269-274 -> out_rows / out_d2 [count]
+ * ascending (host-only; the DataFusion path emits no distance column and takes no sqrt). */
 int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
                const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
                uint32_t *io_rows, float *io_d2, uint32_t *io_count);
+int pqv_rerank_f64(int device, const float *query, const double *cand, const uint32_t *ids,
+                   const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+                   uint32_t *io_rows, float *io_d2, uint32_t *io_count);
+int pqv_rerank_finish(const uint32_t *io_rows, const float *io_d2, uint32_t count, uint32_t *out_rows, float *out_d2);
 
 /* The same fold for a batch that is ALREADY resident on `device` (e.g. a decoded Arrow values buffer uploaded by the
  * scan): d_cand [m, dim] f32, d_ids u32[m] or NULL (=> 0..m), the running state d_io_rows u32[k] / d_io_d2 f32[k] /
- * d_io_count u32[1] lives on the device between batches.  No null mask (compact before the call).  Enqueued on
- * hip_stream (NULL: a library stream) and completed before the call returns. */
+ * d_io_count u32[1] lives on the device between batches, kept SORTED ascending by (d2, arrival) -- a different state
+ * form from pqv_rerank's heap array; do not mix the two on one state (a device count above k is read as k).  No null
+ * mask (compact before the call).  k <= 1024.  Enqueued on hip_stream (NULL: a library stream) and completed before
+ * the call returns.  Everything stays on the GPU, so the heap's sift history is not replayed: the result is the k
+ * smallest by (d2, arrival), equal to the reference's whenever no two of the k results (nor the k-th and the first
+ * excluded row) have the same distance.
+ * pqv_rerank_device_flags also maintains d_tie_flag (device u32[1], zeroed by the caller before the first batch,
+ * sticky): set when such a tie was seen in any fold so far -- then, and only then, the reference's survivors / order
+ * may differ and the caller re-runs those batches through pqv_rerank (k <= 1023: the lists carry a runner-up). */
 int pqv_rerank_device(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m, uint32_t dim,
                       uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count, void *hip_stream);
+int pqv_rerank_device_flags(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m, uint32_t dim,
+                            uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count, void *d_tie_flag,
+                            void *hip_stream);
 
 /* Merge per-shard top-k lists (one list per file/shard, as topk_from_batches does for
  * multi-file tables, src/df_vector/exec.rs:264-267): lists [n_lists, nq, k] of d2 (or
@@ -272,6 +291,34 @@ int pqv_merge_topk_device(int device, const void *d_dist, const void *d_rows, co
  * form in which ONE all-gather delivers every rank's top-k (pq_vector_amd/sharding.py). */
 int pqv_merge_topk_packed_device(int device, const void *d_pairs, const void *d_row_base, uint32_t n_lists,
                                  uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream);
+
+/* ---- the exchange itself, without torch --------------------------------------------------------------------------
+ * Multi-file tables are probed file by file and merged in ONE heap (src/df_vector/index_exec.rs:85-164,
+ * src/df_vector/exec.rs:264-267).  With one shard (file / row-group range) per GPU that heap is one RCCL all-gather of
+ * every rank's k packed {distance, row} results per query over xGMI followed by the merge above on every rank.  These
+ * entry points let the Rust host do that with nothing but this library: librccl is resolved at run time (a copy the
+ * process already loaded -- same SONAME -- else the loader path, else /opt/rocm/lib; PQV_RCCL_LIB overrides) and is
+ * only needed by these calls.
+ *   unique_id     rank 0 draws the 128-byte rendezvous id (ncclGetUniqueId) and hands it to every rank over the host's
+ *                 own channel (a file, a socket, the DataFusion coordinator)
+ *   comm_create   collective over all `world` ranks (ncclCommInitRank), one process per GPU
+ *   comm_adopt    wraps an existing ncclComm_t (passed as void*) of THE SAME librccl (pqv_shard_rccl_path says which
+ *                 one this library bound); the caller keeps ownership of it
+ *   exchange      d_dist f32 / d_rows u32 [nq, k]: this rank's pqv_topk_device outputs (empty slots 0xFFFFFFFF);
+ *                 d_row_base i64[world]: first global row of every shard; writes d_out_dist f32 / d_out_rows i64 [nq, k]
+ *                 ordered by (distance, shard, position) -- identical on every rank.  Asynchronous on hip_stream; calls
+ *                 on one communicator must not overlap (one stream, or the caller's own ordering). */
+#define PQV_SHARD_ID_BYTES 128
+typedef struct pqv_shard_comm pqv_shard_comm;
+const char *pqv_shard_rccl_path(void);
+int  pqv_shard_unique_id(uint8_t *id /* [PQV_SHARD_ID_BYTES] */);
+int  pqv_shard_comm_create(int device, uint32_t rank, uint32_t world, const uint8_t *id, pqv_shard_comm **out);
+int  pqv_shard_comm_adopt(int device, void *nccl_comm, pqv_shard_comm **out);
+uint32_t pqv_shard_comm_rank(const pqv_shard_comm *comm);
+uint32_t pqv_shard_comm_world(const pqv_shard_comm *comm);
+int  pqv_shard_exchange(pqv_shard_comm *comm, const void *d_dist, const void *d_rows, const void *d_row_base,
+                        uint32_t nq, uint32_t k, void *d_out_dist, void *d_out_rows, void *hip_stream);
+void pqv_shard_comm_free(pqv_shard_comm *comm);
 
 /* CandidateCursor (src/df_vector/access.rs:193-243; used at src/df_vector/exec.rs:224-231): when a query over a
  * multi-file table carries max_candidates, candidates are taken round-robin across the files -- one per file and

@@ -48,6 +48,14 @@ SIGNATURES = {
     "pqv_device_count": (C.c_int, []),
     "pqv_abi_version": (C.c_int, []),
     "pqv_merge_topk_packed_device": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "pqv_shard_rccl_path": (C.c_char_p, []),
+    "pqv_shard_unique_id": (C.c_int, [u8p]),
+    "pqv_shard_comm_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, u8p, C.POINTER(vp)]),
+    "pqv_shard_comm_adopt": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "pqv_shard_comm_rank": (C.c_uint32, [vp]),
+    "pqv_shard_comm_world": (C.c_uint32, [vp]),
+    "pqv_shard_exchange": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "pqv_shard_comm_free": (None, [vp]),
     "pqv_candidate_cursor_new": (C.c_int, [C.c_uint32, C.POINTER(vp)]),
     "pqv_candidate_cursor_add": (C.c_int, [vp, C.c_uint32, u32p, C.c_uint64]),
     "pqv_candidate_cursor_next_batch": (C.c_int, [vp, C.c_uint64, u32p, u32p, u64p, u64p]),
@@ -95,6 +103,10 @@ SIGNATURES = {
     "pqv_brute_topk": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, f32p, u32p]),
     "pqv_rerank": (C.c_int, [C.c_int, f32p, f32p, u32p, u8p, C.c_uint64, C.c_uint32, C.c_uint32,
                              C.c_int, u32p, f32p, u32p]),
+    "pqv_rerank_f64": (C.c_int, [C.c_int, f32p, f64p, u32p, u8p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                 C.c_int, u32p, f32p, u32p]),
+    "pqv_rerank_finish": (C.c_int, [u32p, f32p, C.c_uint32, u32p, f32p]),
+    "pqv_rerank_device_flags": (C.c_int, [C.c_int, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp, vp]),
     "pqv_merge_topk": (C.c_int, [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p,
                                  u32p, u32p]),
     "pqv_merge_topk_device": (C.c_int, [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),

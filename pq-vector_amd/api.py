@@ -518,9 +518,13 @@ class TopkBuilder:
 def rerank_batch(query, cand, k, state=None, ids=None, valid=None, metric=_ffi.PQV_L2SQ_SEQ, device=0):
     """update_topk_heap for one RecordBatch (src/df_vector/exec.rs:457-484).
 
-    state = (rows u32[<=k], d2 f32[<=k]) from the previous batch or None; returns the new state."""
+    state = (rows u32[<=k], d2 f32[<=k]): the reference heap's backing array after the previous batch (None for the
+    first); returns the new state.  A float64 `cand` is narrowed `as f32` by the library (exec.rs:538-545).
+    rerank_finish(state) gives the rows in output order."""
     q = _f32(query).reshape(-1)
-    cand = _f32(cand)
+    cand = np.asarray(cand)
+    f64 = cand.dtype == np.float64
+    cand = np.ascontiguousarray(cand, dtype=np.float64 if f64 else np.float32)
     m, dim = cand.shape if cand.ndim == 2 else (0, q.size)
     io_rows = np.zeros(max(k, 1), dtype=np.uint32)
     io_d2 = np.zeros(max(k, 1), dtype=np.float32)
@@ -532,12 +536,24 @@ def rerank_batch(query, cand, k, state=None, ids=None, valid=None, metric=_ffi.P
         io_d2[:len(r)] = d
     ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
     valid_a = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
-    _check(_ffi.lib().pqv_rerank(device, q.ctypes.data_as(f32p), cand.ctypes.data_as(f32p),
-                                 None if ids_a is None else ids_a.ctypes.data_as(u32p),
-                                 None if valid_a is None else valid_a.ctypes.data_as(u8p),
-                                 m, dim, k, metric, io_rows.ctypes.data_as(u32p),
-                                 io_d2.ctypes.data_as(f32p), C.byref(cnt)))
+    fn = _ffi.lib().pqv_rerank_f64 if f64 else _ffi.lib().pqv_rerank
+    _check(fn(device, q.ctypes.data_as(f32p), cand.ctypes.data_as(_ffi.f64p if f64 else f32p),
+              None if ids_a is None else ids_a.ctypes.data_as(u32p),
+              None if valid_a is None else valid_a.ctypes.data_as(u8p),
+              m, dim, k, metric, io_rows.ctypes.data_as(u32p),
+              io_d2.ctypes.data_as(f32p), C.byref(cnt)))
     return io_rows[:cnt.value].copy(), io_d2[:cnt.value].copy()
+
+
+def rerank_finish(state):
+    """heap.into_iter() + the stable sort by distance (src/df_vector/exec.rs:269-274): (rows, d2) ascending."""
+    r = np.ascontiguousarray(state[0], dtype=np.uint32)
+    d = np.ascontiguousarray(state[1], dtype=np.float32)
+    orow = np.empty(max(len(r), 1), dtype=np.uint32)
+    od = np.empty(max(len(r), 1), dtype=np.float32)
+    _check(_ffi.lib().pqv_rerank_finish(r.ctypes.data_as(u32p), d.ctypes.data_as(f32p), len(r),
+                                        orow.ctypes.data_as(u32p), od.ctypes.data_as(f32p)))
+    return orow[:len(r)], od[:len(r)]
 
 
 def merge_topk(dist, rows, counts):

@@ -21,8 +21,10 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
+#include "internal.h"
 #include "kernels.h"
 #include "rng.hpp"
 
@@ -125,6 +127,11 @@ uint32_t host_workers() {
 }
 
 }  // namespace
+
+namespace pqv_internal {
+int fail(int code, const std::string &msg) { return ::fail(code, msg); }
+int use_device(int device) { return ::use_device(device); }
+}  // namespace pqv_internal
 
 // ---------------------------------------------------------------------------------------
 // handles
@@ -1705,10 +1712,12 @@ int validate_topk(const pqv_searcher *s, uint32_t k, uint32_t nprobe, int metric
     if (k == 0) return fail(PQV_ERR_INVALID, "k must be > 0");                         // search.rs:67
     if (nprobe == 0) return fail(PQV_ERR_INVALID, "nprobe must be > 0");               // search.rs:72
     if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
-    if (k > 1024) return fail(PQV_ERR_UNSUPPORTED, "k > 1024 is not supported");
-    if (std::min<uint32_t>(nprobe, s->n_clusters) > 1024)
-        return fail(PQV_ERR_UNSUPPORTED, "nprobe > 1024 is not supported");
     return PQV_OK;
+}
+// the kernels' sorted lists hold up to 1024 entries (k, and the probe's min(nprobe, n_clusters)); pqv_topk goes around
+// that limit (topk_unbounded), the asynchronous device entry points report it
+bool beyond_kernel_lists(const pqv_searcher *s, uint32_t k_lists, uint32_t nprobe) {
+    return k_lists > 1024 || std::min<uint32_t>(nprobe, s->n_clusters) > 1024;
 }
 
 }  // namespace
@@ -1762,35 +1771,36 @@ inline void heap_pop(std::vector<HeapEnt> &h) {
 }
 
 // Recompute one query's candidate distances on the device (STREAM_DIST), then replay them
-// through the heap in candidate order.  qi indexes the current sub-batch's probe scratch.
-int replay_query_exact(const pqv_searcher *s, Scratch &sc, const float *d_query, uint32_t qi, uint32_t np, uint32_t k,
-                       uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
-                       uint32_t *n_found) {
+// through the heap in candidate order.  d_probe / d_cand_base: the query's probe list on the device; `clusters` the
+// same list on the host.  Any k (the selection is the heap's), any nprobe (the grid is cut into slices of probed lists).
+int replay_with_clusters(const pqv_searcher *s, Scratch &sc, const float *d_query, const uint32_t *d_probe,
+                         const uint64_t *d_cand_base, const std::vector<uint32_t> &clusters, uint32_t k,
+                         uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
+                         uint32_t *n_found) {
     using namespace pqv;
-    std::vector<uint32_t> clusters(np);
-    HIP_TRY(hipMemcpyAsync(clusters.data(), sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
-                           np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint32_t np = static_cast<uint32_t>(clusters.size());
     uint64_t total = 0;
     for (uint32_t c : clusters) total += s->h_list_off[c + 1] - s->h_list_off[c];
     const uint64_t use = max_candidates ? std::min<uint64_t>(total, max_candidates) : total;
     std::vector<float> d(std::max<uint64_t>(1, total));
     if (total) {
         HIP_TRY(sc.s_replay.ensure(total * sizeof(float)));
-        StreamArgs ra{};
-        ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
-        ra.probe = sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np;
-        ra.cand_base = sc.s_cand_base.as<uint64_t>() + static_cast<size_t>(qi) * np;
-        ra.queries = d_query; ra.nq = 1; ra.nprobe = np; ra.dim = s->dim; ra.k = 1;
-        ra.rows_per_block = 1024;
-        ra.blocks_per_list = static_cast<uint32_t>((std::max<uint64_t>(1, s->max_list_len) + 1023) / 1024);
-        ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = sc.s_replay.as<float>();
-        HIP_TRY(launch_stream(ra, STREAM_DIST, s->stream));
+        for (uint32_t j0 = 0; j0 < np; j0 += 32768) {                   // gridDim.y <= 65535
+            StreamArgs ra{};
+            ra.mat = s->d_mat; ra.row_of = s->d_row_of; ra.list_off = s->d_list_off.as<uint64_t>();
+            ra.probe = d_probe + j0; ra.cand_base = d_cand_base + j0;
+            ra.queries = d_query; ra.nq = 1; ra.nprobe = std::min<uint32_t>(32768, np - j0); ra.dim = s->dim; ra.k = 1;
+            ra.rows_per_block = 1024;
+            ra.blocks_per_list = static_cast<uint32_t>((std::max<uint64_t>(1, s->max_list_len) + 1023) / 1024);
+            ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = sc.s_replay.as<float>();
+            HIP_TRY(launch_stream(ra, STREAM_DIST, s->stream));
+            s->counters.kernel_launches += 1;
+        }
         HIP_TRY(hipMemcpyAsync(d.data(), sc.s_replay.p, total * sizeof(float), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     std::vector<HeapEnt> heap;
-    heap.reserve(static_cast<size_t>(k) + 1);
+    heap.reserve(static_cast<size_t>(std::min<uint64_t>(k, use)) + 1);
     uint64_t pos = 0;
     for (uint32_t c : clusters) {                                        // candidate_rows order
         const uint64_t b = s->h_list_off[c], e = s->h_list_off[c + 1];
@@ -1807,7 +1817,83 @@ int replay_query_exact(const pqv_searcher *s, Scratch &sc, const float *d_query,
         else { row_idx[i] = 0xFFFFFFFFu; dist[i] = INFINITY; }
     }
     if (n_found) *n_found = static_cast<uint32_t>(heap.size());
+    return PQV_OK;
+}
+
+// qi indexes the current sub-batch's probe scratch (written by the probe merge).
+int replay_query_exact(const pqv_searcher *s, Scratch &sc, const float *d_query, uint32_t qi, uint32_t np, uint32_t k,
+                       uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist,
+                       uint32_t *n_found) {
+    std::vector<uint32_t> clusters(np);
+    HIP_TRY(hipMemcpyAsync(clusters.data(), sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
+                           np * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return replay_with_clusters(s, sc, d_query, sc.s_probe.as<uint32_t>() + static_cast<size_t>(qi) * np,
+                                sc.s_cand_base.as<uint64_t>() + static_cast<size_t>(qi) * np, clusters, k, max_candidates,
+                                metric, sqrt_out, row_idx, dist, n_found);
+}
+
+// topk() beyond the kernels' list capacity (k >= 1024: no runner-up slot left; min(nprobe, n_clusters) > 1024): the
+// reference accepts any NonZeroUsize (search.rs:56-81).  Per query: every centroid distance on the GPU (STREAM_DIST over
+// the centroid table), find_closest_centroids' stable sort + take(nprobe) on the host (index.rs:143-148), every
+// candidate distance on the GPU, the reference's heap on the host.  Correct for any k / nprobe; not a fast path.
+// find_closest_centroids (index.rs:130-149) without the kernels' list limit: every centroid distance on the GPU
+// (STREAM_DIST over the centroid table), the stable sort on the host.  d_query: device [dim]; order: all clusters, nearest first.
+int centroid_order_host(const pqv_searcher *s, Scratch &sc, const float *d_query, std::vector<uint32_t> &order) {
+    using namespace pqv;
+    const uint32_t kc = s->n_clusters;
+    HIP_TRY(sc.s_replay.ensure(std::max<size_t>(1, kc) * sizeof(float)));
+    std::vector<float> cd(kc);
+    StreamArgs pa{};
+    pa.mat = s->d_centroids.as<float>(); pa.row_of = nullptr; pa.list_off = nullptr; pa.probe = nullptr; pa.cand_base = nullptr;
+    pa.single_begin = 0; pa.single_end = kc;
+    pa.queries = d_query; pa.nq = 1; pa.nprobe = 1; pa.dim = s->dim; pa.k = 1;
+    pa.rows_per_block = 256; pa.blocks_per_list = (kc + 255) / 256;
+    pa.max_pos = ~0ull; pa.metric = PQV_L2SQ_REF4;        // find_closest_centroids always uses index.rs:461
+    pa.out_f32 = sc.s_replay.as<float>();
+    HIP_TRY(launch_stream(pa, STREAM_DIST, s->stream));
+    HIP_TRY(hipMemcpyAsync(cd.data(), sc.s_replay.p, static_cast<size_t>(kc) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    order.resize(kc);
+    for (uint32_t c = 0; c < kc; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cd[a] < cd[b]; });   // index.rs:143-147
     s->counters.kernel_launches += 1;
+    return PQV_OK;
+}
+
+int topk_unbounded(const pqv_searcher *s, Scratch &sc, const float *queries, uint32_t nq, uint32_t k, uint32_t nprobe,
+                   uint64_t max_candidates, int metric, int sqrt_out, uint32_t *row_idx, float *dist, uint32_t *n_found,
+                   uint64_t *n_candidates) {
+    using namespace pqv;
+    const uint32_t kc = s->n_clusters, np = std::min<uint32_t>(nprobe, kc);
+    HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
+    HIP_TRY(sc.s_probe.ensure(std::max<size_t>(1, np) * sizeof(uint32_t)));
+    HIP_TRY(sc.s_cand_base.ensure(std::max<size_t>(1, np) * sizeof(uint64_t)));
+    std::vector<uint32_t> order, clusters(np);
+    std::vector<uint64_t> base(np);
+    for (uint32_t q = 0; q < nq; ++q) {
+        HIP_TRY(hipMemcpyAsync(sc.s_queries.p, queries + static_cast<uint64_t>(q) * s->dim, static_cast<size_t>(s->dim) * sizeof(float),
+                               hipMemcpyHostToDevice, s->stream));
+        if (int rc = centroid_order_host(s, sc, sc.s_queries.as<float>(), order)) return rc;
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < np; ++j) {
+            clusters[j] = order[j]; base[j] = total;
+            total += s->h_list_off[order[j] + 1] - s->h_list_off[order[j]];
+        }
+        HIP_TRY(hipMemcpyAsync(sc.s_probe.p, clusters.data(), static_cast<size_t>(np) * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(sc.s_cand_base.p, base.data(), static_cast<size_t>(np) * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+        uint32_t nf = 0;
+        if (int rc = replay_with_clusters(s, sc, sc.s_queries.as<float>(), sc.s_probe.as<uint32_t>(), sc.s_cand_base.as<uint64_t>(),
+                                          clusters, k, max_candidates, metric, sqrt_out, row_idx + static_cast<uint64_t>(q) * k,
+                                          dist + static_cast<uint64_t>(q) * k, &nf))
+            return rc;
+        if (n_found) n_found[q] = nf;
+        if (n_candidates) n_candidates[q] = total;
+        s->counters.candidate_rows += total;                             // index_exec.rs:289-299
+        s->counters.embeddings_fetched += max_candidates ? std::min<uint64_t>(total, max_candidates) : total;   // exec.rs:411-427
+        s->counters.queries += 1;
+        s->counters.exact_replays += 1;
+    }
     return PQV_OK;
 }
 
@@ -1819,6 +1905,8 @@ static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, ui
                                void *d_tie_flags, void *hip_stream) {
     if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
     if (d_tie_flags && k > 1023) return fail(PQV_ERR_UNSUPPORTED, "tie flags need a runner-up entry: k <= 1023");
+    if (beyond_kernel_lists(s, k, nprobe))
+        return fail(PQV_ERR_UNSUPPORTED, "the device entry points take k <= 1024 and min(nprobe, n_clusters) <= 1024 (pqv_topk has no such limit)");
     if (nq == 0) return PQV_OK;
     if (!d_queries || !d_row_idx || !d_dist) return fail(PQV_ERR_INVALID, "device pointers must not be NULL");
     if (int rc = use_device(s->device)) return rc;
@@ -1861,10 +1949,15 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     std::lock_guard<std::mutex> lock(s->mu);
     // One extra merged entry (the runner-up) lets the merge kernel see ties at the k-th
     // distance; queries it flags are replayed through the exact heap (replay_query_exact).
-    const uint32_t k_int = k < 1024 ? k + 1 : k;
+    const uint32_t k_int = k + 1;
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
     Scratch &sc = *lane;
+    if (beyond_kernel_lists(s, k_int, nprobe)) {
+        const int rc = topk_unbounded(s, sc, queries, nq, k, nprobe, max_candidates, metric, sqrt_out, row_idx, dist, n_found, n_candidates);
+        const int rc2 = lane_release(sc, s->stream);
+        return rc ? rc : rc2;
+    }
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
     const TopkPlan p1 = plan_topk(s, 1, nprobe, k_int, metric);
     const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + 1;
@@ -1955,6 +2048,11 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     if (!s || !buf || !len) return fail(PQV_ERR_INVALID, "searcher/buf must not be NULL");
     if (int rc = validate_topk(s, k, nprobe, metric)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
+    if (beyond_kernel_lists(s, k, nprobe)) {
+        std::snprintf(buf, len, "pqv_topk only: stream_kernel (STREAM_DIST) for every centroid and candidate distance, selection by the "
+                                "reference's heap on the host (k > 1024 or min(nprobe, n_clusters) > 1024)");
+        return PQV_OK;
+    }
     const TopkPlan p = plan_topk(s, std::max<uint32_t>(1, nq), nprobe, k, metric);
     char t[512];
     if (p.tile && p.filter && p.quad)
@@ -2025,13 +2123,21 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
                                          ", got " + std::to_string(query_len));
     if (!query || !clusters_out) return fail(PQV_ERR_INVALID, "query/clusters_out must not be NULL");
     const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
-    if (np > 1024) return fail(PQV_ERR_UNSUPPORTED, "nprobe > 1024 is not supported");
     if (int rc = use_device(s->device)) return rc;
     std::lock_guard<std::mutex> lock(s->mu);
     using namespace pqv;
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
     Scratch &sc = *lane;
+    if (np > 1024) {            // beyond the kernels' sorted lists: distances on the GPU, the stable sort on the host
+        HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(sc.s_queries.p, query, static_cast<size_t>(s->dim) * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        std::vector<uint32_t> order;
+        if (int rc = centroid_order_host(s, sc, sc.s_queries.as<float>(), order)) return rc;
+        std::memcpy(clusters_out, order.data(), static_cast<size_t>(np) * sizeof(uint32_t));
+        if (n_out) *n_out = np;
+        return lane_release(sc, s->stream);
+    }
     const TopkPlan p = plan_topk(s, 1, nprobe);
     HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
     HIP_TRY(sc.s_probe_keys.ensure(static_cast<size_t>(p.n_part_probe) * p.probe_kpart * sizeof(uint64_t)));
@@ -2492,28 +2598,31 @@ void rerank_ctx_release(RerankCtx *c) {
 
 // The device-resident fold: d_cand [m, dim] and the running state all on the device; enqueued on `stream`.
 int rerank_enqueue(RerankCtx &c, const float *d_query, const float *d_cand, const uint32_t *d_ids, uint64_t m, uint32_t dim,
-                   uint32_t k, int metric, uint32_t *d_io_rows, float *d_io_d2, uint32_t *d_io_count, hipStream_t stream) {
+                   uint32_t k_out, int metric, uint32_t *d_io_rows, float *d_io_d2, uint32_t *d_io_count, uint32_t *d_tie,
+                   hipStream_t stream) {
     using namespace pqv;
+    // with a tie flag the lists carry one extra entry (the runner-up), as pqv_topk_device_flags does
+    const uint32_t k = d_tie ? k_out + 1 : k_out;
     const uint32_t bpl = static_cast<uint32_t>((m + 255) / 256);
     const uint32_t n_part = bpl * waves_per_block() + 1;  // +1: the running state
     HIP_TRY(c.d_keys.ensure(static_cast<size_t>(n_part) * k * sizeof(uint64_t)));
     HIP_TRY(c.d_vals.ensure(static_cast<size_t>(n_part) * k * sizeof(uint32_t)));
     HIP_TRY(c.d_mvals.ensure(k * sizeof(uint32_t)));
     HIP_TRY(c.d_mdist.ensure(k * sizeof(float)));
-    HIP_TRY(c.d_nf.ensure(sizeof(uint32_t)));
+    HIP_TRY(c.d_nf.ensure(2 * sizeof(uint32_t)));
     HIP_TRY(c.d_saved.ensure(k * sizeof(uint32_t)));
     HIP_TRY(c.d_base.ensure(sizeof(uint64_t))); HIP_TRY(c.d_probe0.ensure(sizeof(uint32_t))); HIP_TRY(c.d_off.ensure(2 * sizeof(uint64_t)));
-    if (c.off_m != m || c.base_k != k) {      // the one-list descriptor of the stream kernel (changes with the batch size only)
-        const uint64_t h_base = k, h_off[2] = {0, m};
+    if (c.off_m != m || c.base_k != k_out) {      // the one-list descriptor of the stream kernel (changes with the batch size only)
+        const uint64_t h_base = k_out, h_off[2] = {0, m};
         const uint32_t h_probe0 = 0;
         HIP_TRY(hipMemcpyAsync(c.d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c.d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c.d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));        // the sources are stack variables
-        c.off_m = m; c.base_k = k;
+        c.off_m = m; c.base_k = k_out;
     }
     // running state as the first partial list: positions 0..count-1 (earlier arrivals win ties)
-    HIP_TRY(launch_rerank_state_in(d_io_rows, d_io_d2, d_io_count, k, c.d_keys.as<uint64_t>(), c.d_vals.as<uint32_t>(),
+    HIP_TRY(launch_rerank_state_in(d_io_rows, d_io_d2, d_io_count, k_out, k, c.d_keys.as<uint64_t>(), c.d_vals.as<uint32_t>(),
                                    c.d_saved.as<uint32_t>(), stream));
     // batch candidates take positions k, k+1, ... via the cand_base entry
     StreamArgs ra{};
@@ -2527,10 +2636,10 @@ int rerank_enqueue(RerankCtx &c, const float *d_query, const float *d_cand, cons
     fm.part_keys = c.d_keys.as<uint64_t>(); fm.part_vals = c.d_vals.as<uint32_t>();
     fm.nq = 1; fm.n_part = n_part; fm.k_part = k; fm.k = k; fm.ids = nullptr;
     fm.row_idx = c.d_mvals.as<uint32_t>(); fm.dist = c.d_mdist.as<float>(); fm.n_found = c.d_nf.as<uint32_t>();
-    fm.sqrt_out = 0;
+    fm.sqrt_out = 0; fm.k_out = k_out; fm.tie_flag = d_tie ? c.d_nf.as<uint32_t>() + 1 : nullptr;
     HIP_TRY(launch_merge_final(fm, stream));
     HIP_TRY(launch_rerank_state_out(c.d_mvals.as<uint32_t>(), c.d_mdist.as<float>(), c.d_nf.as<uint32_t>(), c.d_saved.as<uint32_t>(),
-                                    d_ids, k, d_io_rows, d_io_d2, d_io_count, stream));
+                                    d_ids, k_out, d_io_rows, d_io_d2, d_io_count, d_tie ? c.d_nf.as<uint32_t>() + 1 : nullptr, d_tie, stream));
     return PQV_OK;
 }
 
@@ -2548,8 +2657,9 @@ int rerank_validate(const void *query, const void *io_rows, const void *io_d2, c
 
 static int pqv_rerank_device_impl(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m,
                                   uint32_t dim, uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count,
-                                  void *hip_stream) {
+                                  void *d_tie_flag, void *hip_stream) {
     if (int rc = rerank_validate(d_query, d_io_rows, d_io_d2, d_io_count, d_cand, m, dim, k, metric)) return rc;
+    if (d_tie_flag && k > 1023) return fail(PQV_ERR_UNSUPPORTED, "tie flags need a runner-up entry: k <= 1023");
     if (k == 0 || m == 0) return PQV_OK;
     if (int rc = use_device(device)) return rc;
     RerankCtx *c = nullptr;
@@ -2557,85 +2667,126 @@ static int pqv_rerank_device_impl(int device, const void *d_query, const void *d
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     int rc = rerank_enqueue(*c, static_cast<const float *>(d_query), static_cast<const float *>(d_cand),
                             static_cast<const uint32_t *>(d_ids), m, dim, k, metric, static_cast<uint32_t *>(d_io_rows),
-                            static_cast<float *>(d_io_d2), static_cast<uint32_t *>(d_io_count), stream);
-    // the context's merge scratch is in use until the stream drains: hand it back only then
-    if (rc == PQV_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(PQV_ERR_HIP, "hipStreamSynchronize failed");
+                            static_cast<float *>(d_io_d2), static_cast<uint32_t *>(d_io_count), static_cast<uint32_t *>(d_tie_flag), stream);
+    // the context's merge scratch is in use until the stream drains -- also when the enqueue failed half-way: hand it
+    // back only then
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == PQV_OK) rc = fail(PQV_ERR_HIP, "hipStreamSynchronize failed");
     rerank_ctx_release(c);
     return rc;
 }
 extern "C" int pqv_rerank_device(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m,
                                  uint32_t dim, uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count,
                                  void *hip_stream) {
-    return guard([&] { return pqv_rerank_device_impl(device, d_query, d_cand, d_ids, m, dim, k, metric, d_io_rows, d_io_d2, d_io_count, hip_stream); });
+    return guard([&] { return pqv_rerank_device_impl(device, d_query, d_cand, d_ids, m, dim, k, metric, d_io_rows, d_io_d2, d_io_count, nullptr, hip_stream); });
+}
+extern "C" int pqv_rerank_device_flags(int device, const void *d_query, const void *d_cand, const void *d_ids, uint64_t m,
+                                       uint32_t dim, uint32_t k, int metric, void *d_io_rows, void *d_io_d2, void *d_io_count,
+                                       void *d_tie_flag, void *hip_stream) {
+    if (!d_tie_flag) return fail(PQV_ERR_INVALID, "d_tie_flag must not be NULL");
+    return guard([&] { return pqv_rerank_device_impl(device, d_query, d_cand, d_ids, m, dim, k, metric, d_io_rows, d_io_d2, d_io_count, d_tie_flag, hip_stream); });
 }
 
-static int pqv_rerank_impl(int device, const float *query, const float *cand, const uint32_t *ids,
-                          const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
-                          uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
-    if (int rc = rerank_validate(query, io_rows, io_d2, io_count, cand, m, dim, k, metric)) return rc;
+// Host-buffer fold with the reference's EXACT heap mechanics (exec.rs:457-484): the distances of the batch are
+// computed on the GPU (stream_kernel, STREAM_DIST, in compute_distance_values' order), then the rows walk through
+// std's BinaryHeap push / peek / pop on the host in arrival order -- an O(m) compare loop plus O(log k) per admitted
+// row.  io_rows / io_d2 ARE the heap's backing array between batches, so ties (which make survivors and order depend
+// on sift history) come out as in Rust; pqv_rerank_finish is heap.into_iter() + the stable sort of exec.rs:269-274.
+template <class T>
+static int rerank_host(int device, const float *query, const T *cand, const uint32_t *ids,
+                       const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+                       uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+    if (!query || !io_rows || !io_d2 || !io_count) return fail(PQV_ERR_INVALID, "query/io arrays must not be NULL");
+    if (dim == 0) return fail(PQV_ERR_INVALID, "Embedding dimension must be > 0");
+    if (metric != PQV_L2SQ_REF4 && metric != PQV_L2SQ_SEQ) return fail(PQV_ERR_INVALID, "unknown metric");
+    if (m && !cand) return fail(PQV_ERR_INVALID, "cand must not be NULL");
+    if (m > 0x7FFFFFFFull) return fail(PQV_ERR_UNSUPPORTED, "batch larger than 2^31 rows");
     if (k == 0) return PQV_OK;  // heap.len() < 0 is never true and peek() is None: nothing is kept
     if (*io_count > k) return fail(PQV_ERR_INVALID, "io_count exceeds k");
     if (m == 0) return PQV_OK;
     if (int rc = use_device(device)) return rc;
-    RerankCtx *c = nullptr;
-    if (int rc = rerank_ctx_acquire(device, &c)) return rc;
-    struct Release { RerankCtx *c; ~Release() { rerank_ctx_release(c); } } release{c};
-    hipStream_t stream = c->stream;
-
-    // pinned staging: [query | payload ids | valid rows (compacted: null / wrong-length rows dropped, exec.rs:496-498,
-    // 526-528; arrival order kept)], then ONE async copy per piece on the context's stream
     uint64_t mv = m;
     if (valid) { mv = 0; for (uint64_t i = 0; i < m; ++i) mv += valid[i] != 0; }
     if (mv == 0) return PQV_OK;
-    const size_t q_bytes = static_cast<size_t>(dim) * sizeof(float), id_bytes = static_cast<size_t>(mv) * sizeof(uint32_t),
-                 c_bytes = static_cast<size_t>(mv) * dim * sizeof(float), st_bytes = static_cast<size_t>(k) * 8 + 4;
-    HIP_TRY(c->h_stage.ensure(q_bytes + id_bytes + c_bytes + st_bytes + 64));
+    RerankCtx *c = nullptr;
+    if (int rc = rerank_ctx_acquire(device, &c)) return rc;
+    // the context goes back to the pool only with its stream drained (a failed call may have left work enqueued)
+    struct Release { RerankCtx *c; ~Release() { (void)hipStreamSynchronize(c->stream); rerank_ctx_release(c); } } release{c};
+    hipStream_t stream = c->stream;
+
+    // pinned staging: [query | valid rows compacted in arrival order (null / wrong-length rows dropped, exec.rs:496-498,
+    // 526-528), a Float64 column narrowed `as f32` on the way (exec.rs:542) | distances back]
+    const size_t q_bytes = static_cast<size_t>(dim) * sizeof(float), c_bytes = static_cast<size_t>(mv) * dim * sizeof(float),
+                 d_bytes = static_cast<size_t>(mv) * sizeof(float);
+    HIP_TRY(c->h_stage.ensure(q_bytes + c_bytes + d_bytes + 64));
     uint8_t *hs = c->h_stage.as<uint8_t>();
-    float *h_q = reinterpret_cast<float *>(hs);
-    uint32_t *h_ids = reinterpret_cast<uint32_t *>(hs + q_bytes);
-    float *h_c = reinterpret_cast<float *>(hs + q_bytes + id_bytes);
-    uint8_t *h_st = hs + q_bytes + id_bytes + c_bytes;
+    float *h_q = reinterpret_cast<float *>(hs), *h_c = reinterpret_cast<float *>(hs + q_bytes),
+          *h_d = reinterpret_cast<float *>(hs + q_bytes + c_bytes);
     std::memcpy(h_q, query, q_bytes);
-    if (valid && mv != m) {
+    {
         uint64_t o = 0;
-        for (uint64_t i = 0; i < m; ++i)
-            if (valid[i]) {
-                std::memcpy(h_c + o * dim, cand + i * dim, static_cast<size_t>(dim) * sizeof(float));
-                h_ids[o++] = ids ? ids[i] : static_cast<uint32_t>(i);
-            }
-    } else {
-        std::memcpy(h_c, cand, c_bytes);
-        for (uint64_t i = 0; i < mv; ++i) h_ids[i] = ids ? ids[i] : static_cast<uint32_t>(i);
+        for (uint64_t i = 0; i < m; ++i) {
+            if (valid && !valid[i]) continue;
+            const T *src = cand + i * dim;
+            float *dst = h_c + o * dim;
+            if constexpr (std::is_same<T, float>::value) std::memcpy(dst, src, static_cast<size_t>(dim) * sizeof(float));
+            else for (uint32_t j = 0; j < dim; ++j) dst[j] = static_cast<float>(src[j]);
+            ++o;
+        }
     }
-    const uint32_t old = *io_count;
-    std::memcpy(h_st, io_rows, static_cast<size_t>(old) * 4);
-    std::memcpy(h_st + static_cast<size_t>(k) * 4, io_d2, static_cast<size_t>(old) * 4);
-    std::memcpy(h_st + static_cast<size_t>(k) * 8, &old, 4);
-    HIP_TRY(c->d_q.ensure(q_bytes)); HIP_TRY(c->d_ids.ensure(id_bytes)); HIP_TRY(c->d_cand.ensure(c_bytes));
-    HIP_TRY(c->d_io_rows.ensure(static_cast<size_t>(k) * 4)); HIP_TRY(c->d_io_d2.ensure(static_cast<size_t>(k) * 4)); HIP_TRY(c->d_io_cnt.ensure(4));
+    HIP_TRY(c->d_q.ensure(q_bytes)); HIP_TRY(c->d_cand.ensure(c_bytes)); HIP_TRY(c->d_mdist.ensure(d_bytes));
+    HIP_TRY(c->d_base.ensure(sizeof(uint64_t))); HIP_TRY(c->d_probe0.ensure(sizeof(uint32_t))); HIP_TRY(c->d_off.ensure(2 * sizeof(uint64_t)));
+    if (c->off_m != mv || c->base_k != 0) {       // the one-list descriptor of the stream kernel
+        const uint64_t h_base = 0, h_off[2] = {0, mv};
+        const uint32_t h_probe0 = 0;
+        HIP_TRY(hipMemcpyAsync(c->d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));        // the sources are stack variables
+        c->off_m = mv; c->base_k = 0;
+    }
     HIP_TRY(hipMemcpyAsync(c->d_q.p, h_q, q_bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_ids.p, h_ids, id_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(c->d_cand.p, h_c, c_bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_io_rows.p, h_st, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_io_d2.p, h_st + static_cast<size_t>(k) * 4, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_io_cnt.p, h_st + static_cast<size_t>(k) * 8, 4, hipMemcpyHostToDevice, stream));
-    if (int rc = rerank_enqueue(*c, c->d_q.as<float>(), c->d_cand.as<float>(), c->d_ids.as<uint32_t>(), mv, dim, k, metric,
-                                c->d_io_rows.as<uint32_t>(), c->d_io_d2.as<float>(), c->d_io_cnt.as<uint32_t>(), stream))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(h_st, c->d_io_rows.p, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_st + static_cast<size_t>(k) * 4, c->d_io_d2.p, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(h_st + static_cast<size_t>(k) * 8, c->d_io_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+    pqv::StreamArgs ra{};
+    ra.mat = c->d_cand.as<float>(); ra.row_of = nullptr; ra.list_off = c->d_off.as<uint64_t>();
+    ra.probe = c->d_probe0.as<uint32_t>(); ra.cand_base = c->d_base.as<uint64_t>();
+    ra.queries = c->d_q.as<float>(); ra.nq = 1; ra.nprobe = 1; ra.dim = dim; ra.k = 1;
+    ra.rows_per_block = 256; ra.blocks_per_list = static_cast<uint32_t>((mv + 255) / 256);
+    ra.max_pos = ~0ull; ra.metric = metric; ra.out_f32 = c->d_mdist.as<float>();
+    HIP_TRY(pqv::launch_stream(ra, pqv::STREAM_DIST, stream));
+    HIP_TRY(hipMemcpyAsync(h_d, c->d_mdist.p, d_bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    uint32_t nf = 0;
-    std::memcpy(&nf, h_st + static_cast<size_t>(k) * 8, 4);
-    if (nf > k) return fail(PQV_ERR_HIP, "internal error: re-rank count out of range");
-    std::memcpy(io_rows, h_st, static_cast<size_t>(nf) * 4);
-    std::memcpy(io_d2, h_st + static_cast<size_t>(k) * 4, static_cast<size_t>(nf) * 4);
-    *io_count = nf;
+
+    std::vector<HeapEnt> heap;
+    heap.reserve(static_cast<size_t>(k) + 1);
+    for (uint32_t i = 0; i < *io_count; ++i) heap.push_back(HeapEnt{io_d2[i], io_rows[i]});     // the array IS the heap
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        if (valid && !valid[i]) continue;
+        const HeapEnt ent{h_d[o++], ids ? ids[i] : static_cast<uint32_t>(i)};
+        if (heap.size() < k) heap_push(heap, ent);                                     // exec.rs:474-475
+        else if (ent.d < heap[0].d) { heap_pop(heap); heap_push(heap, ent); }          // :476-481
+    }
+    for (size_t i = 0; i < heap.size(); ++i) { io_rows[i] = heap[i].row; io_d2[i] = heap[i].d; }
+    *io_count = static_cast<uint32_t>(heap.size());
     return PQV_OK;
 }
 extern "C" int pqv_rerank(int device, const float *query, const float *cand, const uint32_t *ids,
                           const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
                           uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
-    return guard([&] { return pqv_rerank_impl(device, query, cand, ids, valid, m, dim, k, metric, io_rows, io_d2, io_count); });
+    return guard([&] { return rerank_host<float>(device, query, cand, ids, valid, m, dim, k, metric, io_rows, io_d2, io_count); });
+}
+extern "C" int pqv_rerank_f64(int device, const float *query, const double *cand, const uint32_t *ids,
+                              const uint8_t *valid, uint64_t m, uint32_t dim, uint32_t k, int metric,
+                              uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+    return guard([&] { return rerank_host<double>(device, query, cand, ids, valid, m, dim, k, metric, io_rows, io_d2, io_count); });
+}
+extern "C" int pqv_rerank_finish(const uint32_t *io_rows, const float *io_d2, uint32_t count, uint32_t *out_rows, float *out_d2) {
+    return guard([&] {
+        if (count && (!io_rows || !io_d2 || !out_rows || !out_d2)) return fail(PQV_ERR_INVALID, "state/output arrays must not be NULL");
+        std::vector<HeapEnt> v(count);
+        for (uint32_t i = 0; i < count; ++i) v[i] = HeapEnt{io_d2[i], io_rows[i]};     // heap.into_iter(): backing-array order
+        std::stable_sort(v.begin(), v.end(), [](const HeapEnt &a, const HeapEnt &b) { return a.d < b.d; });   // exec.rs:270-274
+        for (uint32_t i = 0; i < count; ++i) { out_rows[i] = v[i].row; out_d2[i] = v[i].d; }
+        return static_cast<int>(PQV_OK);
+    });
 }

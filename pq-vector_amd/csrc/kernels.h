@@ -336,6 +336,9 @@ hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const lon
                               uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
                               long long *out_rows, hipStream_t s, uint32_t stride = 1);
 
+// out[i] = {bits of dist[i], rows[i]} (8 bytes per result): the packed form pqv_merge_topk_packed_device reads
+hipError_t launch_pack_pairs(const float *dist, const uint32_t *rows, uint64_t n, void *out, hipStream_t s);
+
 // MFMA-operand copy of the IVF-ordered lists: 16-row tiles, tile T column ch row j at float4 index
 // (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)
 hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
@@ -354,10 +357,11 @@ hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hip
 hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s);
 
 // pqv_rerank's running state <-> merge lists (see kernels.hip)
-hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k,
+hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k, uint32_t k_list,
                                   uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s);
 hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
-                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count, hipStream_t s);
+                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count,
+                                   const uint32_t *m_tie, uint32_t *io_tie, hipStream_t s);
 
 // a[0 .. a_bytes) and b[0 .. b_bytes) = 0xFF bytes in one launch (byte counts: multiples of 16)
 hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s);

@@ -3466,6 +3466,18 @@ hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const lon
     return hipGetLastError();
 }
 
+// {f32 distance, u32 row} of every result as ONE 8-byte element: the send buffer of the shard exchange's single all-gather
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ rows,
+                                                        uint64_t n, uint2 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_uint2(__float_as_uint(dist[i]), rows[i]);
+}
+hipError_t launch_pack_pairs(const float *dist, const uint32_t *rows, uint64_t n, void *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist, rows, n, static_cast<uint2 *>(out));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // block_rows_kernel: the MFMA-operand copy of the IVF-ordered lists.  Every list is cut into
 // 16-row tiles (the last one zero-padded); tile T stores 16-byte column ch of its row j at float4
@@ -3775,9 +3787,9 @@ hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint6
 // One wave each; k <= 1024.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void rerank_state_in_kernel(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count,
-                                                            uint32_t k, uint64_t *keys, uint32_t *vals, uint32_t *rows_saved) {
-    const uint32_t cnt = *io_count < k ? *io_count : k;
-    for (uint32_t i = threadIdx.x; i < k; i += 64) {
+                                                            uint32_t k, uint32_t k_list, uint64_t *keys, uint32_t *vals, uint32_t *rows_saved) {
+    const uint32_t cnt = *io_count < k ? *io_count : k;      // (a count beyond the state's capacity is clamped)
+    for (uint32_t i = threadIdx.x; i < k_list; i += 64) {
         if (i < cnt) {
             keys[i] = ((uint64_t)__float_as_uint(io_d2[i]) << 32) | i;
             vals[i] = 0x80000000u | i;
@@ -3790,23 +3802,28 @@ __global__ __launch_bounds__(64) void rerank_state_in_kernel(const uint32_t *io_
 }
 __global__ __launch_bounds__(64) void rerank_state_out_kernel(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found,
                                                              const uint32_t *rows_saved, const uint32_t *ids, uint32_t k,
-                                                             uint32_t *io_rows, float *io_d2, uint32_t *io_count) {
+                                                             uint32_t *io_rows, float *io_d2, uint32_t *io_count,
+                                                             const uint32_t *m_tie, uint32_t *io_tie) {
     const uint32_t nf = *m_found < k ? *m_found : k;
     for (uint32_t i = threadIdx.x; i < nf; i += 64) {
         const uint32_t v = m_vals[i];
         io_rows[i] = (v & 0x80000000u) ? rows_saved[v & 0x7FFFFFFFu] : (ids ? ids[v] : v);
         io_d2[i] = m_d2[i];
     }
-    if (threadIdx.x == 0) *io_count = nf;
+    if (threadIdx.x == 0) {
+        *io_count = nf;
+        if (io_tie && m_tie && *m_tie) *io_tie = 1u;          // sticky across batches
+    }
 }
-hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k,
+hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k, uint32_t k_list,
                                   uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s) {
-    hipLaunchKernelGGL(rerank_state_in_kernel, dim3(1), dim3(64), 0, s, io_rows, io_d2, io_count, k, keys, vals, rows_saved);
+    hipLaunchKernelGGL(rerank_state_in_kernel, dim3(1), dim3(64), 0, s, io_rows, io_d2, io_count, k, k_list, keys, vals, rows_saved);
     return hipGetLastError();
 }
 hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
-                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count, hipStream_t s) {
-    hipLaunchKernelGGL(rerank_state_out_kernel, dim3(1), dim3(64), 0, s, m_vals, m_d2, m_found, rows_saved, ids, k, io_rows, io_d2, io_count);
+                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count,
+                                   const uint32_t *m_tie, uint32_t *io_tie, hipStream_t s) {
+    hipLaunchKernelGGL(rerank_state_out_kernel, dim3(1), dim3(64), 0, s, m_vals, m_d2, m_found, rows_saved, ids, k, io_rows, io_d2, io_count, m_tie, io_tie);
     return hipGetLastError();
 }
 

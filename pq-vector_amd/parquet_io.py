@@ -317,22 +317,33 @@ def write_parquet_with_index(source, output, index, embedding_column):
     names = src.schema_arrow.names
     other = [n for n in names if n != embedding_column]
     rg_rows = src.metadata.row_group(0).num_rows if src.metadata.num_row_groups else 1 << 20
-    # per-column codec of the source (collect_column_write_options, parquet.rs:322-336); nested columns report their leaf path
-    compression = {}
+    # per-LEAF codec and dictionary use of the source (collect_column_write_options, parquet.rs:322-336).  parquet-cpp
+    # looks column properties up by the full dotted leaf path ("emb.list.element"), so the dicts are keyed by
+    # path_in_schema; a top-level name would silently leave every nested leaf -- the embedding column itself -- uncompressed.
+    compression, dict_cols = {}, []
+    emb_prefix = embedding_column + "."
     if src.metadata.num_row_groups:
         rg0 = src.metadata.row_group(0)
         for j in range(rg0.num_columns):
             col = rg0.column(j)
-            top = col.path_in_schema.split(".")[0]
-            compression.setdefault(top, "NONE" if col.compression == "UNCOMPRESSED" else col.compression)
-    for n in names:
-        compression.setdefault(n, "NONE")
+            path = col.path_in_schema
+            codec = "NONE" if col.compression == "UNCOMPRESSED" else col.compression
+            # (writers name a list's child "element" or "item"; the copy is written with this pyarrow's spelling, so
+            #  both are registered -- the reference pairs source and output leaves by position, parquet.rs:328)
+            for alt in {path, path.replace(".list.item", ".list.element"), path.replace(".list.element", ".list.item")}:
+                compression.setdefault(alt, codec)
+            is_emb = path == embedding_column or path.startswith(emb_prefix)
+            uses_dict = any("DICTIONARY" in str(e) for e in col.encodings)
+            if uses_dict and not is_emb:           # the embedding column is written without a dictionary (parquet.rs:352)
+                dict_cols.append(path)
+    else:
+        dict_cols = list(other)
     # The reference closes a data page after ONE row (set_data_page_row_count_limit(1), page size limit = one vector).
     # parquet-cpp only looks at the page size every `write_batch_size` leaf values, so that must be one vector's worth:
     # the embedding column then gets exactly one vector per page (page-index reads of single rows stay single-page).
     writer = pq.ParquetWriter(output, src.schema_arrow, data_page_size=max(1, index.dim * 4),
                               write_batch_size=max(1, index.dim),
-                              use_dictionary=other, write_statistics=True, write_page_index=True,
+                              use_dictionary=dict_cols, write_statistics=True, write_page_index=True,
                               compression=compression)
     try:
         for i in range(src.metadata.num_row_groups):

@@ -79,3 +79,58 @@ class ShardExchange:
         dist.all_gather_into_tensor(self.gath.view(self.world * self.nq, self.k * 2), packed.view(self.nq, self.k * 2))
         gd = self.gath[..., 0].to(torch.int32).view(torch.float32)
         return merge_gathered(gd, self.gath[..., 1], self.k)
+
+
+class RcclShardComm:
+    """The exchange behind the C ABI (pqv_shard_*, include/pqv.h): RCCL bound by the library itself, so the same calls
+    serve a Rust host.  torch only carries the 128-byte rendezvous id from rank 0 to the others here (any channel
+    would do); the all-gather and the merge run inside libpqv_hip.so on the caller's stream."""
+
+    def __init__(self, rank, world, device_index, id_bytes=None):
+        import ctypes as C
+        from . import _ffi
+        L = _ffi.lib()
+        if id_bytes is None:
+            buf = (C.c_uint8 * 128)()
+            if rank == 0:
+                _rc(L.pqv_shard_unique_id(buf))
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            if world > 1:
+                # the process group may be RCCL-only (device tensors) or gloo (host tensors)
+                if dist.get_backend() == "nccl":
+                    t = t.to(torch.device("cuda", device_index))
+                dist.broadcast(t, src=0)
+            id_bytes = bytes(t.cpu().tolist())
+        idb = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        h = C.c_void_p()
+        _rc(L.pqv_shard_comm_create(device_index, rank, world, idb, C.byref(h)))
+        self._h, self.rank, self.world, self.device_index = h, rank, world, device_index
+
+    def exchange(self, local_dist, local_rows_i32, row_bases_i64, out_d, out_r, stream=None):
+        """local_dist f32 / local_rows_i32 [nq, k] device tensors (raw searcher outputs), row_bases_i64 [world];
+        writes out_d f32 / out_r i64 [nq, k] on `stream` (default: torch's current stream)."""
+        from . import _ffi
+        nq, k = local_dist.shape
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _rc(_ffi.lib().pqv_shard_exchange(self._h, _ffi.vp(local_dist.data_ptr()), _ffi.vp(local_rows_i32.data_ptr()),
+                                          _ffi.vp(row_bases_i64.data_ptr()), nq, k, _ffi.vp(out_d.data_ptr()),
+                                          _ffi.vp(out_r.data_ptr()), _ffi.vp(st)))
+        return out_d, out_r
+
+    def close(self):
+        if self._h:
+            from . import _ffi
+            _ffi.lib().pqv_shard_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _rc(rc):
+    if rc != 0:
+        from . import _ffi
+        raise RuntimeError(_ffi.lib().pqv_last_error().decode())

@@ -1,0 +1,190 @@
+"""Round-3 GPU tests: the shard exchange over RCCL behind the C ABI (one rank: the collective path itself), bench.py's
+self-launched multi-rank run, top-k beyond the kernels' list capacity (any k / nprobe, search.rs:56-81), tie flags of the
+device-resident re-rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _shard_lists(rng, world, nq, k):
+    """per-shard sorted top-k lists with ties across shards and some short lists (empty slots: +inf / 0xFFFFFFFF)"""
+    d = np.sort(rng.integers(0, 40, size=(world, nq, k)).astype(np.float32) * 0.25, axis=2)
+    r = rng.integers(0, 1 << 20, size=(world, nq, k)).astype(np.uint32)
+    for w in range(world):
+        for q in range(0, nq, 5):
+            cut = int(rng.integers(0, k + 1))
+            d[w, q, cut:] = np.inf
+            r[w, q, cut:] = 0xFFFFFFFF
+    return d, r
+
+
+def test_shard_exchange_c_abi_one_rank_rccl(pqv):
+    """pqv_shard_unique_id / comm_create / exchange with world = 1: ncclCommInitRank + ncclAllGather run for real (RCCL
+    bound by the library through dlopen), the merge must equal both the torch stable-sort merge and the host merge."""
+    import torch
+    from pq_vector_amd import _ffi
+    from pq_vector_amd.sharding import RcclShardComm, merge_gathered
+    assert _ffi.lib().pqv_shard_rccl_path().decode().endswith(("librccl.so", "librccl.so.1")) or "rccl" in _ffi.lib().pqv_shard_rccl_path().decode()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    nq, k = 37, 10
+    d, r = _shard_lists(rng, 1, nq, k)
+    comm = RcclShardComm(0, 1, 0)
+    assert _ffi.lib().pqv_shard_comm_world(comm._h) == 1 and _ffi.lib().pqv_shard_comm_rank(comm._h) == 0
+    d_t = torch.from_numpy(d[0]).to(dev)
+    r_t = torch.from_numpy(r[0].view(np.int32)).to(dev)
+    bases = torch.tensor([1000], dtype=torch.int64, device=dev)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_r = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    for _ in range(3):          # steady state: the buffers are reused
+        comm.exchange(d_t, r_t, bases, out_d, out_r)
+    torch.cuda.synchronize()
+    grow = np.where(r[0] == 0xFFFFFFFF, -1, r[0].astype(np.int64) + 1000)
+    md, mr = merge_gathered(torch.from_numpy(d), torch.from_numpy(grow[None]), k)
+    assert (_bits(out_d.cpu().numpy()) == _bits(md.numpy())).all()
+    assert (out_r.cpu().numpy() == mr.numpy()).all()
+    # a larger batch re-allocates the communicator's buffers
+    nq2 = 300
+    d2, r2 = _shard_lists(rng, 1, nq2, k)
+    od2 = torch.empty((nq2, k), dtype=torch.float32, device=dev)
+    or2 = torch.empty((nq2, k), dtype=torch.int64, device=dev)
+    comm.exchange(torch.from_numpy(d2[0]).to(dev), torch.from_numpy(r2[0].view(np.int32)).to(dev), bases, od2, or2)
+    torch.cuda.synchronize()
+    hd, hr, _, _ = pqv.merge_topk(d2, r2, (r2 != 0xFFFFFFFF).sum(axis=2).astype(np.uint32))
+    assert (_bits(od2.cpu().numpy()) == _bits(hd)).all()
+    exp = np.where(hr == 0xFFFFFFFF, -1, hr.astype(np.int64) + 1000)
+    assert (or2.cpu().numpy() == exp).all()
+    comm.close()
+
+
+def test_torch_rccl_exchange_one_rank_matches_merge_gathered(pqv, tmp_path):
+    """The torch.distributed (backend nccl == RCCL) form bench.py cross-checks against: one rank, the collective forced,
+    pqv_merge_topk_packed_device against merge_gathered."""
+    import torch
+    import torch.distributed as dist
+    from pq_vector_amd.sharding import ShardExchange, merge_gathered
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(6)
+        nq, k = 64, 10
+        d, r = _shard_lists(rng, 1, nq, k)
+        x = ShardExchange(1, nq, k, dev, always_collective=True, row_bases=[7])
+        od, orow = x.exchange_u32(torch.from_numpy(d[0]).to(dev), torch.from_numpy(r[0].view(np.int32)).to(dev))
+        torch.cuda.synchronize()
+        grow = np.where(r[0] == 0xFFFFFFFF, -1, r[0].astype(np.int64) + 7)
+        md, mr = merge_gathered(torch.from_numpy(d), torch.from_numpy(grow[None]), k)
+        assert (_bits(od.cpu().numpy()) == _bits(md.numpy())).all() and (orow.cpu().numpy() == mr.numpy()).all()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher environment): it must start its own two
+    ranks, run the sharded path end to end (gloo lets them share this box's one GPU) and print ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["shards"] == 2 and rec["value"] > 0
+
+
+@pytest.mark.parametrize("k,nprobe", [(1024, 4), (1500, 6), (3000, 3), (10, 1500)])
+def test_topk_beyond_the_kernel_list_capacity(pqv, oracle, k, nprobe):
+    """search.rs:56-81 accepts any NonZeroUsize for k and nprobe.  k >= 1024 (no runner-up slot in the kernels' lists) and
+    min(nprobe, n_clusters) > 1024 take pqv_topk's host-replayed path: distances on the GPU, selection by the reference's
+    heap -- ids and distance bits equal to the oracle, tie-heavy data included."""
+    rng = np.random.default_rng(k + nprobe)
+    if nprobe > 1024:
+        n, dim, kc = 6000, 8, 2000
+        data = rng.random((n, dim), dtype=np.float32)
+    else:
+        n, dim, kc = 9000, 16, 6
+        data = rng.integers(0, 4, size=(n, dim)).astype(np.float32)       # massive ties
+    queries = data[:3] + (0.0 if nprobe <= 1024 else 0.01)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.IndexBuilder(corpus).n_clusters(kc).workers(4).max_iters(3).build()
+    oidx = oracle.index_from_bytes(index.to_bytes())
+    s = pqv.Searcher(index, corpus)
+    rows, dist, nf, nc = s.topk(queries, k, nprobe)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    assert (nf == onf).all() and (nc == onc).all()
+    for q in range(len(queries)):
+        m = int(nf[q])
+        assert (_bits(dist[q, :m]) == _bits(odist[q, :m])).all()
+        assert (rows[q, :m] == orows[q, :m]).all()
+    assert (s.probe(queries[0], nprobe) == np.asarray(oidx.find_closest_centroids(queries[0], nprobe))).all()
+    # the asynchronous device entry points report the limit instead of going to the host
+    import torch
+    dev = torch.device("cuda", 0)
+    q_t = torch.from_numpy(queries).to(dev)
+    r_t = torch.empty((len(queries), k), dtype=torch.int32, device=dev)
+    d_t = torch.empty((len(queries), k), dtype=torch.float32, device=dev)
+    if k > 1024 or min(nprobe, kc) > 1024:
+        with pytest.raises(pqv.PqvError):
+            s.topk_device(q_t.data_ptr(), len(queries), k, nprobe, r_t.data_ptr(), d_t.data_ptr())
+
+
+def test_rerank_device_flags_mark_the_folds_that_need_the_heap(pqv, oracle):
+    """pqv_rerank_device_flags: the device-resident fold keeps (d2, arrival) order; its sticky flag must be set exactly
+    when two of the k results, or the k-th and the first excluded row, tie in some fold -- the only case in which the
+    reference's heap (exec.rs:474-481) may answer differently.  Unflagged runs must equal the oracle id for id."""
+    import torch
+    from pq_vector_amd import _ffi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    n, dim, k = 8192, 64, 10
+    for case in ("distinct", "dup_inside", "dup_at_boundary"):
+        emb = rng.random((n, dim), dtype=np.float32)
+        q = rng.random(dim, dtype=np.float32)
+        d2 = ((emb.astype(np.float64) - q) ** 2).sum(axis=1)
+        order = np.argsort(d2, kind="stable")
+        if case == "dup_inside":
+            emb[order[3]] = emb[order[2]]                  # two of the k results tie
+        elif case == "dup_at_boundary":
+            emb[order[k]] = emb[order[k - 1]]              # the k-th and the runner-up tie
+        arrival = rng.permutation(n).astype(np.uint32)
+        emb_t = torch.from_numpy(emb[arrival]).to(dev)
+        ids_t = torch.from_numpy(arrival.astype(np.int32)).to(dev)
+        q_t = torch.from_numpy(q).to(dev)
+        io_r = torch.zeros((k,), dtype=torch.int32, device=dev)
+        io_d = torch.zeros((k,), dtype=torch.float32, device=dev)
+        io_c = torch.zeros((1,), dtype=torch.int32, device=dev)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        for b in range(0, n, 2048):
+            rc = _ffi.lib().pqv_rerank_device_flags(0, _ffi.vp(q_t.data_ptr()), _ffi.vp(emb_t[b:b + 2048].data_ptr()),
+                                                    _ffi.vp(ids_t[b:b + 2048].data_ptr()), 2048, dim, k, pqv.PQV_L2SQ_SEQ,
+                                                    _ffi.vp(io_r.data_ptr()), _ffi.vp(io_d.data_ptr()), _ffi.vp(io_c.data_ptr()),
+                                                    _ffi.vp(flag.data_ptr()), None)
+            assert rc == 0, _ffi.lib().pqv_last_error()
+        torch.cuda.synchronize()
+        orow, od2 = oracle.topk_df(emb, arrival, q, k)
+        got_r, got_d = io_r.cpu().numpy().view(np.uint32), io_d.cpu().numpy()
+        assert (_bits(got_d) == _bits(od2)).all()
+        if case == "distinct":
+            assert int(flag.item()) == 0 and (got_r == orow).all()
+        else:
+            assert int(flag.item()) == 1
+            # the flagged run goes through pqv_rerank, which replays the heap: equal to the reference
+            state = None
+            for b in range(0, n, 2048):
+                state = pqv.rerank_batch(q, emb[arrival[b:b + 2048]], k, state=state, ids=arrival[b:b + 2048])
+            hr, hd = pqv.rerank_finish(state)
+            assert (hr == orow).all() and (_bits(hd) == _bits(od2)).all()

@@ -61,7 +61,7 @@ def test_reference_fixture_ids_5_2(pqv, oracle):
     assert len(cand) == 6                      # candidate_rows: 6 (snapshot)
     fetched = sorted(r for r in cand.tolist() if r >= 2)
     assert len(fetched) == 4                   # embeddings_fetched: 4 (snapshot)
-    rows, d2 = pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched)
+    rows, d2 = pqv.rerank_finish(pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched))
     assert rows.tolist() == [5, 2]
     assert np.allclose(d2, [0.02, 4.0])
 
@@ -75,7 +75,7 @@ def test_reference_fixture_ids_3_4(pqv):
     cand = s.candidate_rows([0, 0], 64)
     fetched = sorted(r for r in cand.tolist() if r >= 3)
     assert len(cand) == 6 and len(fetched) == 3
-    rows, _ = pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched)
+    rows, _ = pqv.rerank_finish(pqv.rerank_batch([0, 0], vecs[fetched], 2, ids=fetched))
     assert rows.tolist() == [3, 4]
 
 
@@ -214,8 +214,50 @@ def test_rerank_batches_match_update_topk_heap(pqv, oracle):
         else:
             kept.append(ids[valid == 1])
     orow, od2 = oracle.topk_df(emb, np.concatenate(kept), q, 10)
-    assert (state[0] == orow).all()
-    assert (_bits(state[1]) == _bits(od2)).all()
+    got = pqv.rerank_finish(state)
+    assert (got[0] == orow).all()
+    assert (_bits(got[1]) == _bits(od2)).all()
+
+
+@pytest.mark.parametrize("k", [1, 3, 10, 37, 100, 1500])
+def test_rerank_replays_the_reference_heap_under_ties(pqv, oracle, k):
+    """exec.rs:474-481 with tied distances: which rows survive at a tied k-th distance and the order inside groups of
+    equal distance are artefacts of BinaryHeap's sift history.  Integer-valued vectors on a coarse grid give hundreds of
+    exact ties; the batch-at-a-time fold must equal one reference heap over all rows, id for id -- for any k (the
+    selection is the heap's own, so k is not bounded by a kernel-side list), with null rows and a Float64 batch
+    (narrowed `as f32`, exec.rs:538-545) in between."""
+    rng = np.random.default_rng(100 + k)
+    n, dim = 6000, 12
+    emb = rng.integers(0, 3, size=(n, dim)).astype(np.float32)
+    q = rng.integers(0, 3, size=dim).astype(np.float32)
+    order = rng.permutation(n).astype(np.uint32)
+    state, kept = None, []
+    for bi, b in enumerate(range(0, n, 1024)):
+        ids = order[b:b + 1024]
+        valid = (rng.random(len(ids)) > 0.05).astype(np.uint8)
+        batch = emb[ids].astype(np.float64) if bi % 2 else emb[ids]
+        state = pqv.rerank_batch(q, batch, k, state=state, ids=ids, valid=valid)
+        kept.append(ids[valid == 1])
+    orow, od2 = oracle.topk_df(emb, np.concatenate(kept), q, k)
+    got = pqv.rerank_finish(state)
+    assert len(got[0]) == len(orow) == min(k, sum(len(x) for x in kept))
+    assert (_bits(got[1]) == _bits(od2)).all()
+    assert (got[0] == orow).all()
+    if k >= 3:
+        assert len(np.unique(od2)) < len(od2)          # the case does hold ties
+
+
+def test_rerank_f64_batches_are_narrowed_like_the_reference(pqv, oracle):
+    """exec.rs:538-545: a Float64 values buffer is narrowed value by value (`as f32`) before the subtraction."""
+    rng = np.random.default_rng(8)
+    emb64 = rng.random((3000, 40)) * 3.0 - 1.0
+    q = rng.random(40, dtype=np.float32)
+    ids = np.arange(3000, dtype=np.uint32)
+    state = pqv.rerank_batch(q, emb64[:2048], 10, ids=ids[:2048])
+    state = pqv.rerank_batch(q, emb64[2048:], 10, state=state, ids=ids[2048:])
+    orow, od2 = oracle.topk_df(emb64.astype(np.float32), ids, q, 10)
+    got = pqv.rerank_finish(state)
+    assert (got[0] == orow).all() and (_bits(got[1]) == _bits(od2)).all()
 
 
 # ---------------------------------------------------------------------------------------

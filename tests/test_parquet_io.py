@@ -221,6 +221,29 @@ def test_build_new_writes_one_vector_per_page_and_keeps_column_codecs(pqv, tmp_p
     assert got == {"id": want, "vec": "UNCOMPRESSED", "title": want}
 
 
+@pytest.mark.parametrize("codec", ["SNAPPY", "ZSTD"])
+def test_build_new_keeps_the_codec_of_the_nested_embedding_leaf(pqv, tmp_path, codec):
+    """parquet.rs:322-336 keeps the codec PER LEAF.  parquet-cpp resolves column properties by the full dotted leaf path
+    (vec.list.element), so a dict keyed by the top-level name leaves the embedding column -- a nested leaf -- uncompressed
+    in the copy; with a compressed source leaf the copy's leaf must carry the same codec (and no dictionary, :352)."""
+    from pq_vector_amd import parquet_io as pio
+    if not pa.Codec.is_available(codec.lower()):
+        pytest.skip(f"{codec} not built into this pyarrow")
+    t, _ = _table(n=200, dim=16)
+    src, out = str(tmp_path / "s.parquet"), str(tmp_path / "o.parquet")
+    pq.write_table(t, src, row_group_size=200, compression={"id": "NONE", "vec.list.element": codec, "title": codec})
+    rg_s = pq.ParquetFile(src).metadata.row_group(0)
+    src_codecs = {rg_s.column(i).path_in_schema: rg_s.column(i).compression for i in range(rg_s.num_columns)}
+    assert src_codecs["vec.list.element"] == codec              # the source really has a compressed nested leaf
+    pio.write_parquet_with_index(src, out, _index(pqv, dim=16, n=200), "vec")
+    rg = pq.ParquetFile(out).metadata.row_group(0)
+    got = {rg.column(i).path_in_schema: rg.column(i).compression for i in range(rg.num_columns)}
+    assert got == src_codecs
+    vec = [rg.column(i) for i in range(rg.num_columns) if rg.column(i).path_in_schema.startswith("vec.")][0]
+    assert not any("DICTIONARY" in str(e) for e in vec.encodings)
+    assert pq.read_table(out).equals(pq.read_table(src))
+
+
 def test_footer_offset_is_parsed_like_rust_u64_and_corrupt_footers_raise_pqv_errors(pqv, tmp_path):
     from pq_vector_amd import parquet_io as pio
     t, _ = _table()
