@@ -167,7 +167,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_ticket, s_ticket2, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_part_flags;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_qresu, s_pair_lb, s_part_flags;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -202,12 +202,12 @@ struct pqv_searcher {
     // are finite and the power-of-two scale and its square are representable
     bool f16_ok = false;
     float f16_scale = 1.0f;
-    // int8 operands (rows of a multiple of 256 dims): images of (x - centre) * i8_scale, centre = per-dimension
-    // mid-range of the stored rows, one global scale mapping the largest |x - centre| to 127; per row |xi|^2 and an
-    // upper bound of the residual norm (see kernels.hip: block_rows_i8_kernel)
+    // int8 operands (rows of a multiple of 256 dims): per LIST the images of (x - centre_c) * S_c -- the IVF residual:
+    // centre_c the per-dimension mid-range of the list's rows, S_c mapping the list's largest |x - centre_c| component
+    // to 127 -- per row |xi|^2 and an upper bound of the residual norm, per list a radius >= |x - centre_c| (see
+    // kernels.hip: block_rows_i8_kernel); built with the blocked copy (ensure_blocked_copy)
     bool i8_ok = false;
-    float i8_scale = 1.0f, i8_half = 0.0f;
-    DevBuf d_center;
+    mutable DevBuf d_center, d_list_scale, d_list_half, d_list_radius;
     mutable DevBuf d_row_n2i, d_row_res;
     // Tunables.  Defaults are what the dispatch rules below were measured with; every one can be set per
     // searcher through pqv_searcher_set_option (tests and benches use that to force a path) and, for the
@@ -231,6 +231,7 @@ struct pqv_searcher {
         int probe_rows = 1;                // batched centroid probe (probe_rows_kernel) when dim % 4 == 0; 0 = stream_kernel
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
         uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
+        int pair_prune = 1;                // int8 path: drop (query, list) pairs whose centre-distance bound exceeds the query's threshold
     };
     mutable Opts opt;
     mutable pqv_counters_t counters{};
@@ -1052,6 +1053,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
+    o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
 }
 
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
@@ -1088,9 +1090,25 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
         HIP_TRY(blk.alloc(tiles * 16 * s->dim));
         HIP_TRY(s->d_row_n2i.ensure(std::max<uint64_t>(1, s->n) * sizeof(int)));
         HIP_TRY(s->d_row_res.ensure(std::max<uint64_t>(1, s->n) * sizeof(float)));
+        // per-list centre (mid-range per dimension), half range, scale; then the images, row terms and list radii
+        const size_t cd = static_cast<size_t>(std::max<uint32_t>(1, kc)) * s->dim;
+        DevBuf d_mm;
+        HIP_TRY(d_mm.alloc(2 * cd * sizeof(uint32_t)));
+        uint32_t *kmin = d_mm.as<uint32_t>(), *kmax = kmin + cd;
+        HIP_TRY(hipMemsetAsync(kmin, 0xFF, cd * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(kmax, 0, cd * sizeof(uint32_t), stream));
+        HIP_TRY(s->d_center.alloc(cd * sizeof(float)));
+        HIP_TRY(s->d_list_scale.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
+        HIP_TRY(s->d_list_half.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
+        HIP_TRY(s->d_list_radius.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
+        HIP_TRY(launch_list_minmax(s->d_mat, s->d_list_off.as<uint64_t>(), kc, s->max_list_len, s->dim, kmin, kmax, stream));
+        HIP_TRY(launch_list_center(kmin, kmax, kc, s->dim, s->d_list_off.as<uint64_t>(), s->d_center.as<float>(), s->d_list_half.as<float>(),
+                                   s->d_list_scale.as<float>(), s->d_list_radius.as<float>(), stream));
         HIP_TRY(launch_block_rows_i8(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                     (s->max_list_len + 15) / 16, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
-                                     blk.p, s->d_row_n2i.as<int>(), s->d_row_res.as<float>(), stream));
+                                     (s->max_list_len + 15) / 16, s->dim, s->d_center.as<float>(), s->d_list_scale.as<float>(),
+                                     s->d_list_half.as<float>(), s->d_list_radius.as<float>(), blk.p, s->d_row_n2i.as<int>(),
+                                     s->d_row_res.as<float>(), stream));
+        HIP_TRY(hipStreamSynchronize(stream));      // d_mm is released at scope exit
     } else if (op == 1) {
         HIP_TRY(blk.alloc(tiles * 16 * s->dim * 2));
         HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
@@ -1195,27 +1213,8 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     }
     // the blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide
     // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
-    if (s->f16_ok && (s->dim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0) {
-        // int8 form: per-dimension mid-range centre and the global scale (finite data only: f16_ok)
-        DevBuf d_mm;
-        S_TRY(d_mm.alloc((2ull * s->dim + 4) * sizeof(uint32_t)));
-        uint32_t *kmin = d_mm.as<uint32_t>(), *kmax = kmin + s->dim, *half = kmax + s->dim;
-        S_TRY(hipMemsetAsync(kmin, 0xFF, s->dim * sizeof(uint32_t), s->stream));
-        S_TRY(hipMemsetAsync(kmax, 0, (s->dim + 4ull) * sizeof(uint32_t), s->stream));
-        S_TRY(s->d_center.alloc(s->dim * sizeof(float)));
-        S_TRY(pqv::launch_col_minmax(s->d_mat, s->n, s->dim, kmin, kmax, s->stream));
-        S_TRY(pqv::launch_col_center(kmin, kmax, s->dim, s->d_center.as<float>(), half, s->stream));
-        uint32_t hb = 0;
-        S_TRY(hipMemcpyAsync(&hb, half, sizeof hb, hipMemcpyDeviceToHost, s->stream));
-        S_TRY(hipStreamSynchronize(s->stream));
-        float h;
-        std::memcpy(&h, &hb, sizeof h);
-        if (hb < 0x7F800000u) {
-            s->i8_half = h;
-            s->i8_scale = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
-            s->i8_ok = std::isfinite(s->i8_scale) && s->i8_scale > 0.0f && std::isfinite(s->i8_scale * s->i8_scale);
-        }
-    }
+    // int8 form of the blocked copy: finite data (f16_ok), rows of a multiple of 256 dims, IVF-ordered rows
+    s->i8_ok = s->f16_ok && (s->dim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0;
     if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 768) {
         if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
     }
@@ -1513,14 +1512,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             pm.sq_item_quad = sc.s_items.as<uint32_t>(); pm.sq_n_items = v + 6ull * kc_pairs + 6;
             pm.sq_item_rows = p.filter_rows_per_block; pm.sq_max_items = max_items;
         }
-        if (p.i8 && pm.preset_flags) {      // ... and the query's int8 image (the merge's last helper wave)
-            if (int rc = ensure_blocked_copy(s, 2, stream)) return rc;
-            HIP_TRY(sc.s_qi8.ensure(static_cast<size_t>(nq) * s->dim));
-            HIP_TRY(sc.s_qn2i.ensure(static_cast<size_t>(nq) * sizeof(int)));
-            HIP_TRY(sc.s_qres.ensure(static_cast<size_t>(nq) * sizeof(float)));
-            pm.sq_q_i8 = static_cast<int8_t *>(sc.s_qi8.p); pm.sq_q_n2i = sc.s_qn2i.as<int>(); pm.sq_q_res = sc.s_qres.as<float>();
-            pm.sq_center = s->d_center.as<float>(); pm.sq_scale = s->i8_scale; pm.sq_maxabs = s->i8_half;
-        }
     }
     if (fused_probe) {
         pqv::ProbeRowsArgs pr{};
@@ -1581,14 +1572,22 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ta.query_maxabs = sc.s_qmax.as<float>();
             }
             if (p.i8) {
-                HIP_TRY(sc.s_qi8.ensure(static_cast<size_t>(nq) * s->dim));
-                HIP_TRY(sc.s_qn2i.ensure(static_cast<size_t>(nq) * sizeof(int)));
-                HIP_TRY(sc.s_qres.ensure(static_cast<size_t>(nq) * sizeof(float)));
-                if (!pm.sq_q_i8)
-                    HIP_TRY(launch_quantize_queries_i8(d_queries, nq, s->dim, s->i8_scale, s->d_center.as<float>(), s->i8_half,
-                                                       sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), stream));
-                ta.i8 = 1; ta.scale = s->i8_scale; ta.scale2 = s->i8_scale * s->i8_scale;
+                // one image per (query, probed list) pair: the query's residual against that list's centre at that list's
+                // scale, + the pair's lower bound from the triangle inequality on the centre (pair_lb)
+                const size_t n_pairs_q = static_cast<size_t>(nq) * p.np;
+                HIP_TRY(sc.s_qi8.ensure(n_pairs_q * s->dim));
+                HIP_TRY(sc.s_qn2i.ensure(n_pairs_q * sizeof(int)));
+                HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
+                HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
+                HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
+                HIP_TRY(launch_quantize_pairs_i8(d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
+                                                 s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q),
+                                                 p.np, s->dim, sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(),
+                                                 sc.s_qresu.as<float>(), sc.s_pair_lb.as<float>(), stream));
+                ta.i8 = 1;
                 ta.q_i8 = static_cast<const int8_t *>(sc.s_qi8.p); ta.q_n2i = sc.s_qn2i.as<int>(); ta.q_res = sc.s_qres.as<float>();
+                ta.q_resu = sc.s_qresu.as<float>(); ta.pair_lb = s->opt.pair_prune ? sc.s_pair_lb.as<float>() : nullptr;
+                ta.list_scale = s->d_list_scale.as<float>();
                 ta.row_n2i = s->d_row_n2i.as<int>(); ta.row_res = s->d_row_res.as<float>();
                 s->counters.kernel_launches += 1;
             }
@@ -2036,6 +2035,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "pair_prune") o.pair_prune = value != 0;
     else return fail(PQV_ERR_INVALID, "unknown searcher option: " + n);
     return PQV_OK;
 }
@@ -2099,7 +2099,7 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
     if (blocked_bytes) *blocked_bytes = (s->d_mat_blk_op[0].p ? s->d_mat_blk_op[0].bytes : 0) + (s->d_mat_blk_op[1].p ? s->d_mat_blk_op[1].bytes : 0) +
                                         (s->d_mat_blk_op[2].p ? s->d_mat_blk_op[2].bytes : 0);
     uint64_t other = s->d_centroids.bytes + s->d_cent_t.bytes + s->d_list_off.bytes + s->d_ids.bytes + s->d_stats.bytes + s->d_row_norm2.bytes + s->d_blk_off.bytes +
-                     s->d_center.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
+                     s->d_center.bytes + s->d_list_scale.bytes + s->d_list_half.bytes + s->d_list_radius.bytes + s->d_row_n2i.bytes + s->d_row_res.bytes;
     for (const Scratch &l : s->lanes)
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
                                 &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads, &l.s_items, &l.s_ticket, &l.s_ticket2,

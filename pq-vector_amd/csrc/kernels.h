@@ -102,11 +102,6 @@ struct MergeArgs {
     uint32_t       *sq_pairs, *sq_n_quads;
     uint32_t       *sq_item_quad, *sq_n_items;     // optional work-item table (wide_filter_kernel)
     uint32_t        sq_item_rows, sq_max_items;
-    int8_t         *sq_q_i8;      // optional (needs the 256-thread form, i.e. preset_flags): the queries' int8 images, as quantize_queries_i8_kernel
-    int            *sq_q_n2i;
-    float          *sq_q_res;
-    const float    *sq_center;
-    float           sq_scale, sq_maxabs;
     uint32_t       *hist;
     uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
     // probe mode, optional: the query's per-wave partial lists of the re-rank start EMPTY (all-ones keys / values);
@@ -233,11 +228,16 @@ struct TileArgs {
     int             q32_lds;      // set by the launcher: the f16 kernel also stages the exact f32 queries in LDS
     float           scale, scale2;
     const float    *query_maxabs;   // [nq] max |q_i| (merge probe)
-    // int8 operands (8-wave wide kernel, dim % 256 == 0): mat_blk is the launch_block_rows_i8 copy; `scale` = S
+    // int8 operands (wide kernels, dim % 256 == 0): mat_blk is the launch_block_rows_i8 copy -- per list the residual
+    // against the list's centre at the list's scale; the query side is one image per (query, probed list) PAIR
+    // (launch_quantize_pairs_i8), indexed by pair = query * nprobe + probe rank
     int             i8;
-    const int8_t   *q_i8;        // [nq][dim] int8 images of the batch's queries (launch_quantize_queries_i8)
-    const int      *q_n2i;       // [nq] |qi|^2
-    const float    *q_res;       // [nq] upper bound of |q - c - qi / S| (+inf: never skip this query)
+    const int8_t   *q_i8;        // [nq * nprobe][dim]
+    const int      *q_n2i;       // [nq * nprobe] |vi|^2
+    const float    *q_res;       // [nq * nprobe] rounding residual of the clamped query residual (lower bounds; +inf: never skip)
+    const float    *q_resu;      // [nq * nprobe] ... plus what the clamp cut off (upper bounds: wide_seed_kernel)
+    const float    *pair_lb;     // [nq * nprobe] or nullptr: lower bound of d2(query, any row of the pair's list)
+    const float    *list_scale;  // [n_clusters] S_c
     const int      *row_n2i;     // per storage row: |xi|^2
     const float    *row_res;     // per storage row: upper bound of |x - c - xi / S|
     const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad
@@ -371,16 +371,19 @@ hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_byte
 hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                                  uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s);
 hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out_bits, hipStream_t s);
-// int8 form (see kernels.hip): per-dimension min / max keys (kmin preset to 0xFF bytes, kmax to 0), the mid-range centre
-// and the largest |x - centre| (float bits, preset 0), the blocked int8 copy + per-row |xi|^2 and residual bound, and
-// the per-batch query images
-hipError_t launch_col_minmax(const float *rows, uint64_t n, uint32_t dim, uint32_t *kmin, uint32_t *kmax, hipStream_t s);
-hipError_t launch_col_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t dim, float *center, uint32_t *half_bits, hipStream_t s);
+// int8 form (see kernels.hip): per-list, per-dimension min / max keys (kmin preset to 0xFF bytes, kmax to 0; [n_clusters, dim]),
+// the per-list mid-range centre, half range, scale and (zeroed) radius, the blocked int8 copy of the residuals + per-row
+// |xi|^2 and residual bound + the per-list radius, and the per-batch images of the (query, probed list) pairs
+hipError_t launch_list_minmax(const float *rows, const uint64_t *list_off, uint32_t n_clusters, uint64_t max_list_len, uint32_t dim,
+                              uint32_t *kmin, uint32_t *kmax, hipStream_t s);
+hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                              float *center, float *half, float *scale, float *radius, hipStream_t s);
 hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
-                                uint64_t max_tiles, uint32_t dim, float scale, const float *center, float maxabs, void *out,
-                                int *row_n2i, float *row_res, hipStream_t s);
-hipError_t launch_quantize_queries_i8(const float *queries, uint32_t nq, uint32_t dim, float scale, const float *center,
-                                      float maxabs, void *q_i8, int *q_n2i, float *q_res, hipStream_t s);
+                                uint64_t max_tiles, uint32_t dim, const float *center, const float *list_scale, const float *list_half,
+                                float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s);
+hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe, const float *center, const float *scale, const float *half,
+                                    const float *radius, uint32_t n_pairs, uint32_t nprobe, uint32_t dim, void *q_i8, int *q_n2i,
+                                    float *q_res, float *q_resu, float *pair_lb, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

@@ -537,43 +537,89 @@ __device__ __forceinline__ int quant_i8(float t, float scale) {
     const float v = rintf(t * scale);
     return (int)fminf(fmaxf(v, -127.0f), 127.0f);      // NaN -> -127 (callers flag non-finite inputs separately)
 }
-// int8 image of query q by one wave (quantize_queries_i8_kernel; also the probe merge of a single-query call)
-__device__ __forceinline__ void quantize_query_i8_wave(const float *__restrict__ queries, uint32_t q, int lane, uint32_t dim,
-                                                       float scale, const float *__restrict__ center, float maxabs,
-                                                       int8_t *__restrict__ q_i8, int *__restrict__ q_n2i, float *__restrict__ q_res) {
-    const float inv = 1.0f / scale;
+// int8 image of one (query, probed list) pair by one wave (quantize_pairs_i8_kernel): the RESIDUAL v = q - centre of the
+// pair's list at that list's scale (see block_rows_i8_kernel for the row side and the bound).
+//   vi      = clamp(rint(v S), -127, 127)
+//   q_res   >= |clamp_box(v) - vi / S|   (box = [-127 / S, 127 / S]^dim, where every row image lives): clamping a query
+//              component towards the box can only SHRINK its distance to a point inside the box, so the LOWER bound
+//              |q - x| >= |vi - xi| / S - q_res - rx stays rigorous with the rounding residual alone -- a far-away query keeps
+//              a tight bound instead of being "never skipped"
+//   q_resu  >= |v - vi / S|               (rounding + what the clamp cut off): the residual of the UPPER bounds (thresholds)
+//   pair_lb <= every reference d2(q, x), x in the list: (|v| - radius)^2 by the triangle inequality on the list's centre,
+//              with the summation margin of the reference order taken off; 0 = no information
+struct PairQuantArgs {
+    const float    *queries;     // [nq, dim]
+    const uint32_t *probe;       // [nq * nprobe] cluster of pair p
+    const float    *center;      // [n_clusters, dim]
+    const float    *scale;       // [n_clusters]
+    const float    *half;        // [n_clusters] largest |x - centre| component of the list
+    const float    *radius;      // [n_clusters] upper bound of |x - centre| over the list's rows
+    uint32_t        n_pairs, nprobe, dim;
+    int8_t         *q_i8;        // [n_pairs, dim]
+    int            *q_n2i;       // [n_pairs]
+    float          *q_res, *q_resu, *pair_lb;
+};
+__device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, int lane) {
+    const uint32_t c = a.probe[p], q = p / a.nprobe;
+    const float scale = a.scale[c], inv = 1.0f / scale, box = 127.0f * inv;
+    const float *qv = a.queries + (uint64_t)q * a.dim, *cv = a.center + (uint64_t)c * a.dim;
     int n2 = 0;
-    float e2 = 0.0f, big = 0.0f;
+    float e2 = 0.0f, u2 = 0.0f, v2 = 0.0f, big = 0.0f;
     bool bad = false;
-    for (uint32_t d0 = lane * 4; d0 < dim; d0 += 256) {
-        const float4 x = *reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim + d0);
-        const float4 cx = *reinterpret_cast<const float4 *>(center + d0);
+    for (uint32_t d0 = lane * 4; d0 < a.dim; d0 += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(qv + d0);
+        const float4 cx = *reinterpret_cast<const float4 *>(cv + d0);
         const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
         uint32_t w = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             bad |= !(fabsf(t[e]) < INFINITY);
             const int v = quant_i8(t[e], scale);
-            const float res = t[e] - (float)v * inv;
+            const float rec = (float)v * inv;
+            const float res = fminf(fmaxf(t[e], -box), box) - rec, resu = t[e] - rec;
             n2 += v * v;
             e2 = fmaf(res, res, e2);
+            u2 = fmaf(resu, resu, u2);
+            v2 = fmaf(t[e], t[e], v2);
             big = fmaxf(big, fabsf(t[e]));
             w |= (uint32_t)(v & 0xFF) << (8 * e);
         }
-        *reinterpret_cast<uint32_t *>(q_i8 + (uint64_t)q * dim + d0) = w;
+        *reinterpret_cast<uint32_t *>(a.q_i8 + (uint64_t)p * a.dim + d0) = w;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         n2 += __shfl_xor(n2, off, 64);
         e2 += __shfl_xor(e2, off, 64);
+        u2 += __shfl_xor(u2, off, 64);
+        v2 += __shfl_xor(v2, off, 64);
         big = fmaxf(big, __shfl_xor(big, off, 64));
     }
     bad = __ballot(bad) != 0ull;
     if (lane == 0) {
-        q_n2i[q] = n2;
-        const float r = sqrtf(e2) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (big + maxabs + 127.0f * inv);
-        q_res[q] = (bad || !(r < INFINITY)) ? INFINITY : r;
+        a.q_n2i[p] = n2;
+        // + the roundings of (q - c) and vi / S inside every residual
+        const float pad = 4.0f * 5.9604645e-08f * sqrtf((float)a.dim) * (big + a.half[c] + box);
+        const float r = sqrtf(e2) * 1.001f + pad, ru = sqrtf(u2) * 1.001f + pad;
+        a.q_res[p] = (bad || !(r < INFINITY)) ? INFINITY : r;
+        a.q_resu[p] = (bad || !(ru < INFINITY)) ? INFINITY : ru;
+        const float cmargin = (float)(a.dim + 16) * 2.384185791015625e-07f;
+        const float lbd = sqrtf(v2) * 0.99998f - a.radius[c];
+        const float lb = lbd > 0.0f ? lbd * lbd * (1.0f - 2.0f * cmargin) * 0.99999f : 0.0f;
+        a.pair_lb[p] = (bad || !(lb < INFINITY)) ? 0.0f : lb;
     }
+}
+__global__ __launch_bounds__(256) void quantize_pairs_i8_kernel(const PairQuantArgs a) {
+    const uint32_t p = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (p < a.n_pairs) quantize_pair_i8_wave(a, p, (int)(threadIdx.x & 63));
+}
+hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe, const float *center, const float *scale, const float *half,
+                                    const float *radius, uint32_t n_pairs, uint32_t nprobe, uint32_t dim, void *q_i8, int *q_n2i,
+                                    float *q_res, float *q_resu, float *pair_lb, hipStream_t s) {
+    if (n_pairs == 0) return hipSuccess;
+    if (dim % 4 || nprobe == 0) return hipErrorInvalidValue;
+    PairQuantArgs a{queries, probe, center, scale, half, radius, n_pairs, nprobe, dim, static_cast<int8_t *>(q_i8), q_n2i, q_res, q_resu, pair_lb};
+    hipLaunchKernelGGL(quantize_pairs_i8_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int lane);     // (defined below)
@@ -586,9 +632,6 @@ __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int
 // probe merge, waves 1 .. (threads >= 64): the query's partial lists of the re-rank start EMPTY; a single-query call also
 // gets the int8 image of its query (last wave of the block)
 __device__ __forceinline__ void probe_merge_helpers(const MergeArgs &a, uint32_t q) {
-    const int lane = threadIdx.x & 63;
-    if (a.sq_q_i8 && threadIdx.x >= blockDim.x - 64)
-        quantize_query_i8_wave(a.queries, q, lane, a.dim, a.sq_scale, a.sq_center, a.sq_maxabs, a.sq_q_i8, a.sq_q_n2i, a.sq_q_res);
     if (a.preset_keys) {
         uint64_t *pk = a.preset_keys + (uint64_t)q * a.preset_n;
         uint32_t *pv = a.preset_vals + (uint64_t)q * a.preset_n;
@@ -1690,7 +1733,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     qnl[lane] = a.query_norm2[my_qrow];
     const float my_qn0 = a.query_norm2[my_qrow];
     bool my_bad16 = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn0 * a.scale2 < 1.0f);   // no valid f16 bound
-    if constexpr (I8) my_bad16 = !(a.q_res[my_qrow] <= 3.0e38f);         // non-finite query: no bound
+    if constexpr (I8) my_bad16 = !(a.q_resu[my_pair] <= 3.0e38f);        // non-finite query: no bound
     liml[lane] = ((uint32_t)lane < cnt && !my_bad16) ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
     if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
@@ -1698,8 +1741,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
-        if constexpr (I8) {
-            const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_qrow, (int)q, 64) * dim);
+        if constexpr (I8) {        // the image of the (query, this list) PAIR: the residual against the list's centre
+            const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_pair, (int)q, 64) * dim);
 #pragma unroll 4
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
         } else if constexpr (F16) {
@@ -1808,11 +1851,13 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
             const uint32_t qrow = (uint32_t)__shfl((int)my_qrow, (int)qi, 64);
             const uint32_t j = (uint32_t)__shfl((int)my_j, (int)qi, 64);
             if constexpr (I8) {
-                // |q - x| <= |qi - xi| / S + rq + rx, |qi - xi|^2 = Nq + Nx - 2 dot <= Nq - 2 (dot - ceil(Nx / 2)); the reference's
-                // computed d2 exceeds the real one by at most the summation margin
+                // |q - x| <= |vi - xi| / S + rq' + rx (rq' includes what the clamp cut off the query residual),
+                // |vi - xi|^2 = Nq + Nx - 2 dot <= Nq - 2 (dot - ceil(Nx / 2)); the reference's computed d2 exceeds the real
+                // one by at most the summation margin
+                const uint32_t pr = (uint32_t)__shfl((int)my_pair, (int)qi, 64);
                 if (qi < cnt && maxs[g][r] > -(1 << 30)) {
-                    const float n_ub = fmaxf((float)(a.q_n2i[qrow] - 2 * maxs[g][r]) * 1.000001f + 2.0f, 0.0f);
-                    const float d = sqrtf(n_ub) * 1.000001f / a.scale + a.q_res[qrow] + rmax;
+                    const float n_ub = fmaxf((float)(a.q_n2i[pr] - 2 * maxs[g][r]) * 1.000001f + 2.0f, 0.0f);
+                    const float d = sqrtf(n_ub) * 1.000001f / a.list_scale[c] + a.q_resu[pr] + rmax;
                     mins[g][r] = d * d * (1.0f + 4.0f * cmargin) * 1.000002f;
                 }
             }
@@ -1997,7 +2042,7 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
     if (a.i8) {       // int8 images: 32 queries x dim bytes per block
-        if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
+        if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_resu || !a.list_scale || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
             32ull * a.dim > 65536) return hipErrorInvalidValue;
         // 64 queries per pass where they fit 48 KB (a 96-query quad is then sampled in two slices instead of three:
         // the sample rows are re-read once per slice)
@@ -2123,11 +2168,42 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         if (by >= *a.n_quads) return;
         quad = a.quads[by];
     }
-    const uint32_t c = quad.x, p0 = quad.y, cnt = quad.z;
-    const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
+    const uint32_t c = quad.x, p0 = quad.y;
+    uint32_t cnt = quad.z;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t k = a.k;
+    // Pairs that cannot contribute: pair_lb[p] is a lower bound of the reference distance between the pair's query and
+    // EVERY row of this list (triangle inequality on the list's centre, quantize_pairs_i8_kernel); once it exceeds the
+    // query's admission threshold none of the list's rows can enter that query's top-k.  Wave 0 compacts the quad's
+    // live pairs to the front (s_perm); a quad without live pairs reads nothing at all.  (The thresholds only ever
+    // tighten, so a pair found dead here stays dead; results do not depend on when a block looks.)
+    __shared__ uint32_t s_perm[NQ];
+    __shared__ uint32_t s_live;
+    const bool prune = I8 && a.pair_lb != nullptr;
+    if (prune) {
+        if (wave == 0) {
+            uint32_t nlive = 0;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
+                bool live = false;
+                if (qi < cnt) {
+                    const uint32_t pair = a.pairs[p0 + qi];
+                    const unsigned long long thr = __hip_atomic_load(a.gthr + pair / a.nprobe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    live = thr == KEY_EMPTY || !(a.pair_lb[pair] > __uint_as_float((uint32_t)(thr >> 32)));
+                }
+                const unsigned long long m = __ballot(live);
+                if (live) s_perm[nlive + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = qi;
+                nlive += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) s_live = nlive;
+        }
+        __syncthreads();
+        cnt = s_live;
+        if (cnt == 0) return;
+    }
+    const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
 
     extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
     __shared__ uint32_t pend_all[NW * PEND];         // (query index << 25) | row offset from the wave's r0
@@ -2165,6 +2241,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // overflows, are never skipped (see aq below).  c16 = 1.25 * 2^-10 carries both with a margin.
     const float c16 = F16 ? 1.25f * 9.765625e-04f : 0.0f;
     const float inv1c = 1.0f / (1.0f - cmargin);
+    [[maybe_unused]] float lscale = 1.0f;            // int8: this list's scale
+    if constexpr (I8) lscale = a.list_scale[c];
     // scores are contracted at scale^2: alpha and beta absorb it (powers of two: exact)
     const float sc2 = F16 ? a.scale2 : 1.0f;
     const float alpha = sc2 * 0.5f * (1.0f - (2.0f * cmargin + c16) * inv1c), beta = sc2 * 0.5f * inv1c;
@@ -2183,6 +2261,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     __shared__ int qst_n2i[LST ? NQ : 1];             // int8: |qi|^2
     uint32_t my_qrow[QS];
     uint64_t my_lkth[QS];
+    [[maybe_unused]] uint32_t my_pairi[I8 ? QS : 1];         // int8: the pair (its image is per (query, list))
     [[maybe_unused]] uint32_t my_pair[LST ? 1 : QS];
     [[maybe_unused]] uint64_t my_cbase[LST ? 1 : QS], my_base[LST ? 1 : QS];
     [[maybe_unused]] float my_qn[LST ? 1 : QS];
@@ -2191,8 +2270,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
         const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-        const uint32_t pair = a.pairs[p0 + (qi < cnt ? qi : cnt - 1)];
+        const uint32_t qic = qi < cnt ? qi : cnt - 1;
+        const uint32_t pair = a.pairs[p0 + (prune ? s_perm[qic] : qic)];
         my_qrow[s] = pair / a.nprobe;
+        if constexpr (I8) my_pairi[s] = pair;
         my_lkth[s] = KEY_EMPTY;
         const float qn = a.query_norm2[my_qrow[s]];
         // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
@@ -2202,7 +2283,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 qst_pair[qi] = pair;
                 qst_cbase[qi] = a.cand_base[pair];
                 qst_qn[qi] = noskip ? __uint_as_float(0x7FC00000u) : qn;
-                if constexpr (I8) { qst_n2i[qi] = a.q_n2i[my_qrow[s]]; qst_res[qi] = a.q_res[my_qrow[s]]; }   // +inf: non-finite query
+                if constexpr (I8) { qst_n2i[qi] = a.q_n2i[pair]; qst_res[qi] = a.q_res[pair]; }   // +inf: non-finite query
             }
         } else {
             my_pair[s] = pair;
@@ -2226,8 +2307,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)q_src * dim);
             float4 *dst = qs + q * G;
             const uint32_t sw = q & 15u;
-            if constexpr (I8) {        // the int8 images were made once per batch (quantize_queries_i8_kernel)
-                const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)q_src * dim);
+            if constexpr (I8) {        // the int8 images were made once per batch and pair (quantize_pairs_i8_kernel)
+                const uint32_t p_src = qsel_u32<QS>(my_pairi, q < NQ ? q : NQ - 1);
+                const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)p_src * dim);
 #pragma unroll 4
                 for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
             } else if constexpr (F16) {
@@ -2762,7 +2844,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 int a2 = 1 << 29;                              // never skip
                 if (qi >= cnt) a2 = -(1 << 30);                // not a query of this quad: always "skipped"
                 else if (!open) {
-                    const float v = a.scale * (sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + qres + R);
+                    const float v = lscale * (sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + qres + R);
                     const float v2 = fminf(v * v * 1.000002f, 1.0e9f);
                     a2 = ((int)ceilf(v2) + 1 - qst_n2i[qi < NQ ? qi : 0] + 1) >> 1;
                 }
@@ -3038,7 +3120,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || a.row_of || !a.cand_keys) return hipErrorInvalidValue;
         const uint32_t nw = a.block_waves ? a.block_waves : 4;
         if (a.i8) {           // int8 images: 8-wave blocks, up to 128 queries x dim bytes of LDS
-            if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
+            if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.list_scale || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
             const size_t lds = (size_t)a.quad_width * a.dim;
             if (lds > 147456) return hipErrorInvalidValue;
             if (nw == 4) {        // two 4-wave blocks per CU
@@ -3614,65 +3696,104 @@ hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out, hipStream_t 
 //   quantize_queries_i8_kernel   the same image of every query of a batch (row-major [nq, dim] int8), |qi|^2 and the
 //                          residual bound; a query with a non-finite component gets +inf (never skipped).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_minmax_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
-                                                        uint32_t *__restrict__ kmin, uint32_t *__restrict__ kmax) {
-    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
-    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (uint64_t r = r0; r < r1; ++r) {
-            const uint32_t kb = sortable_bits(rows[r * dim + d]);
-            lo = kb < lo ? kb : lo;
-            hi = kb > hi ? kb : hi;
+// per-list, per-dimension minimum / maximum of the stored rows: grid (row chunks, lists), a thread per dimension
+__global__ __launch_bounds__(256) void list_minmax_kernel(const float *__restrict__ rows, const uint64_t *__restrict__ list_off,
+                                                         uint32_t dim, uint32_t chunk_rows, uint32_t *__restrict__ kmin,
+                                                         uint32_t *__restrict__ kmax) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], lend = list_off[c + 1];
+    for (uint64_t r0 = lbeg + (uint64_t)blockIdx.x * chunk_rows; r0 < lend; r0 += (uint64_t)gridDim.x * chunk_rows) {
+        const uint64_t r1 = r0 + chunk_rows < lend ? r0 + chunk_rows : lend;
+        for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+            for (uint64_t r = r0; r < r1; ++r) {
+                const uint32_t kb = sortable_bits(rows[r * dim + d]);
+                lo = kb < lo ? kb : lo;
+                hi = kb > hi ? kb : hi;
+            }
+            atomicMin(&kmin[(uint64_t)c * dim + d], lo);
+            atomicMax(&kmax[(uint64_t)c * dim + d], hi);
         }
-        if (r0 < r1) { atomicMin(&kmin[d], lo); atomicMax(&kmax[d], hi); }
     }
 }
-hipError_t launch_col_minmax(const float *rows, uint64_t n, uint32_t dim, uint32_t *kmin, uint32_t *kmax, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    const uint64_t blocks = n < 4096 ? n : 4096;
-    hipLaunchKernelGGL(col_minmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, n, dim, kmin, kmax);
+hipError_t launch_list_minmax(const float *rows, const uint64_t *list_off, uint32_t n_clusters, uint64_t max_list_len, uint32_t dim,
+                              uint32_t *kmin, uint32_t *kmax, hipStream_t s) {
+    if (n_clusters == 0 || max_list_len == 0) return hipSuccess;
+    const uint32_t chunk = 1024;
+    const uint64_t gx = (max_list_len + chunk - 1) / chunk;
+    hipLaunchKernelGGL(list_minmax_kernel, dim3((uint32_t)(gx < 64 ? gx : 64), n_clusters), dim3(256), 0, s, rows, list_off, dim, chunk, kmin, kmax);
     return hipGetLastError();
 }
-// centre[d] = (min + max) / 2, *half_bits = float bits of the largest |x - centre| over all dims (atomicMax); one block
-__global__ __launch_bounds__(256) void col_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
-                                                        uint32_t dim, float *__restrict__ center, uint32_t *half_bits) {
+// centre[c][d] = (min + max) / 2 of list c, half[c] = its largest |x - centre| component, scale[c] = 127 / half (a list
+// whose rows all equal the centre, or an empty one, gets scale 1; the scale is capped so that its square stays finite);
+// radius[c] = 0 (block_rows_i8_kernel raises it).  One block per list.
+__global__ __launch_bounds__(256) void list_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax, uint32_t dim,
+                                                         const uint64_t *__restrict__ list_off, float *__restrict__ center,
+                                                         float *__restrict__ half, float *__restrict__ scale, float *__restrict__ radius) {
+    __shared__ float wm[4];
+    const uint32_t c = blockIdx.x;
+    const bool empty = list_off[c + 1] == list_off[c];
+    float h = 0.0f;
     for (uint32_t d = threadIdx.x; d < dim; d += 256) {
-        const float lo = unsortable_bits(kmin[d]), hi = unsortable_bits(kmax[d]);
-        const float c = 0.5f * lo + 0.5f * hi;
-        center[d] = c;
-        const float h = fmaxf(hi - c, c - lo);
-        atomicMax(half_bits, __float_as_uint(fabsf(h)));
+        float ctr = 0.0f;
+        if (!empty) {
+            const float lo = unsortable_bits(kmin[(uint64_t)c * dim + d]), hi = unsortable_bits(kmax[(uint64_t)c * dim + d]);
+            ctr = 0.5f * lo + 0.5f * hi;
+            h = fmaxf(h, fabsf(fmaxf(hi - ctr, ctr - lo)));
+        }
+        center[(uint64_t)c * dim + d] = ctr;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h = fmaxf(h, __shfl_xor(h, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        half[c] = h;
+        float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+        if (!(sc < 1.0e15f)) sc = 1.0e15f;
+        if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
+        scale[c] = sc;
+        radius[c] = 0.0f;
     }
 }
-hipError_t launch_col_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t dim, float *center, uint32_t *half_bits, hipStream_t s) {
-    hipLaunchKernelGGL(col_center_kernel, dim3(1), dim3(256), 0, s, kmin, kmax, dim, center, half_bits);
+hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                              float *center, float *half, float *scale, float *radius, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(list_center_kernel, dim3(n_clusters), dim3(256), 0, s, kmin, kmax, dim, list_off, center, half, scale, radius);
     return hipGetLastError();
 }
 
-
+// xi = clamp(rint((x - centre_c) S_c), -127, 127) for the rows of list c -- the RESIDUAL against the list's own
+// per-dimension mid-range centre at the list's own scale (the IVF residual: a cluster of tight rows gets a fine grid,
+// wherever in space it sits).  Per row: Nx = |xi|^2 (exact), rx >= |x - centre - xi / S| (f32 sum + 0.1 % + the roundings
+// of the residuals themselves); per list: radius >= |x - centre| of every row (atomic max of non-negative float bits).
 __global__ __launch_bounds__(256) void block_rows_i8_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
-                                                           const uint64_t *__restrict__ blk_off, uint32_t dim, float scale,
-                                                           const float *__restrict__ center, float maxabs, uint4 *__restrict__ out,
-                                                           int *__restrict__ row_n2i, float *__restrict__ row_res) {
+                                                           const uint64_t *__restrict__ blk_off, uint32_t dim,
+                                                           const float *__restrict__ center, const float *__restrict__ list_scale,
+                                                           const float *__restrict__ list_half, float *__restrict__ list_radius,
+                                                           uint4 *__restrict__ out, int *__restrict__ row_n2i, float *__restrict__ row_res) {
     __shared__ int s_n2[16][17];
-    __shared__ float s_e2[16][17];
+    __shared__ float s_e2[16][17], s_v2[16][17];
     const uint32_t c = blockIdx.y;
     const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
     const uint64_t ntile = blk_off[c + 1] - blk_off[c];
     const uint32_t G = dim >> 4;
     const uint32_t j = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const float scale = list_scale[c], maxabs = list_half[c];
     const float inv = 1.0f / scale;
+    const float *ctr = center + (uint64_t)c * dim;
+    float rad = 0.0f;
     for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
         uint4 *dst = out + (blk_off[c] + tl) * G * 16;
         const uint64_t p = tl * 16 + j;
         int n2 = 0;
-        float e2 = 0.0f;
+        float e2 = 0.0f, v2 = 0.0f;
         for (uint32_t cc = cg; cc < G; cc += 16) {
             uint32_t w[4] = {0u, 0u, 0u, 0u};
             if (p < len) {
                 const float4 *r = reinterpret_cast<const float4 *>(src + (lbeg + p) * dim + cc * 16);
-                const float4 *cv = reinterpret_cast<const float4 *>(center + cc * 16);
+                const float4 *cv = reinterpret_cast<const float4 *>(ctr + cc * 16);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float4 x = r[u], cx = cv[u];
@@ -3683,49 +3804,41 @@ __global__ __launch_bounds__(256) void block_rows_i8_kernel(const float *__restr
                         const float res = t[e] - (float)q * inv;
                         n2 += q * q;
                         e2 = fmaf(res, res, e2);
+                        v2 = fmaf(t[e], t[e], v2);
                         w[u] |= (uint32_t)(q & 0xFF) << (8 * e);
                     }
                 }
             }
             dst[cc * 16 + j] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        s_n2[j][cg] = n2; s_e2[j][cg] = e2;
+        s_n2[j][cg] = n2; s_e2[j][cg] = e2; s_v2[j][cg] = v2;
         __syncthreads();
         if (threadIdx.x < 16 && tl * 16 + threadIdx.x < len) {
-            int tn = 0; float te = 0.0f;
+            int tn = 0; float te = 0.0f, tv = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { tn += s_n2[threadIdx.x][g]; te += s_e2[threadIdx.x][g]; }
+            for (int g = 0; g < 16; ++g) { tn += s_n2[threadIdx.x][g]; te += s_e2[threadIdx.x][g]; tv += s_v2[threadIdx.x][g]; }
             row_n2i[lbeg + tl * 16 + threadIdx.x] = tn;
             // upper bound: the f32 sum (+ 0.1 %), plus the roundings of (x - c) and q / S in every residual
-            row_res[lbeg + tl * 16 + threadIdx.x] = sqrtf(te) * 1.001f + 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (maxabs + 127.0f * inv);
+            const float pad = 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (maxabs + 127.0f * inv);
+            row_res[lbeg + tl * 16 + threadIdx.x] = sqrtf(te) * 1.001f + pad;
+            rad = fmaxf(rad, sqrtf(tv) * 1.001f + pad);
         }
         __syncthreads();
     }
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) rad = fmaxf(rad, __shfl_xor(rad, off, 64));
+        if (threadIdx.x == 0 && rad > 0.0f) atomicMax(reinterpret_cast<uint32_t *>(list_radius + c), __float_as_uint(rad));
+    }
 }
 hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
-                                uint64_t max_tiles, uint32_t dim, float scale, const float *center, float maxabs, void *out,
-                                int *row_n2i, float *row_res, hipStream_t s) {
+                                uint64_t max_tiles, uint32_t dim, const float *center, const float *list_scale, const float *list_half,
+                                float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s) {
     if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
     if (dim % 16) return hipErrorInvalidValue;
-    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
-    hipLaunchKernelGGL(block_rows_i8_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, scale, center,
-                       maxabs, static_cast<uint4 *>(out), row_n2i, row_res);
-    return hipGetLastError();
-}
-
-// one wave per query
-__global__ __launch_bounds__(64) void quantize_queries_i8_kernel(const float *__restrict__ queries, uint32_t dim, float scale,
-                                                                const float *__restrict__ center, float maxabs,
-                                                                int8_t *__restrict__ q_i8, int *__restrict__ q_n2i,
-                                                                float *__restrict__ q_res) {
-    quantize_query_i8_wave(queries, blockIdx.x, (int)threadIdx.x, dim, scale, center, maxabs, q_i8, q_n2i, q_res);
-}
-hipError_t launch_quantize_queries_i8(const float *queries, uint32_t nq, uint32_t dim, float scale, const float *center,
-                                      float maxabs, void *q_i8, int *q_n2i, float *q_res, hipStream_t s) {
-    if (nq == 0) return hipSuccess;
-    if (dim % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(quantize_queries_i8_kernel, dim3(nq), dim3(64), 0, s, queries, dim, scale, center, maxabs,
-                       static_cast<int8_t *>(q_i8), q_n2i, q_res);
+    const uint32_t gx = (uint32_t)(max_tiles < 64 ? max_tiles : 64);
+    hipLaunchKernelGGL(block_rows_i8_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, center, list_scale,
+                       list_half, list_radius, static_cast<uint4 *>(out), row_n2i, row_res);
     return hipGetLastError();
 }
 

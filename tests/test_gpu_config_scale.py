@@ -167,3 +167,67 @@ def test_c5_parameters_cosine_batch(pqv):
         tol = 1e-4 * max(abs(kth), 1e-3) + 1e-6
         clearly_in = order[i][od[i] < kth - tol]
         assert set(clearly_in.tolist()) <= set(rows[q].tolist())
+
+
+# ---------------------------------------------------------------------------------------
+# index BUILD parity at configuration scale: blob == oracle.build_index, not only determinism
+# ---------------------------------------------------------------------------------------
+@pytest.mark.timeout(1800)
+def test_c2_full_size_build_blob_equals_oracle(pqv, oracle):
+    """BASELINE configs[1] at full size: 1 M x 128, n_clusters 100, max_iters 20, seed 42 (parquet.rs:37-38), workers 8.
+    sample_size = 50 000 (index.rs:172-174) drawn by index::sample's INPLACE branch, k-means++ over the whole sample,
+    20 Lloyd iterations, final assignment of all 1 M rows -- the blob must equal the CPU oracle's byte for byte."""
+    n, dim, kc = 1_000_000, 128, 100
+    data = _uniform24(np.random.default_rng(1234), n, dim)
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(8).build()
+    rng_state = oracle.rng(42)
+    _, branch = oracle.index_sample(rng_state, n, 50_000)
+    assert branch == 1                                           # inplace
+    oidx = oracle.build_index(data, n_clusters=kc, max_iters=20, seed=42, workers=8)
+    gb, ob = index.to_bytes(), oidx.to_bytes()
+    assert len(gb) == len(ob) == 8 + kc * dim * 4 + kc * 4 + n * 4
+    assert gb[:8 + kc * dim * 4] == ob[:8 + kc * dim * 4], "centroid bits differ"
+    assert gb == ob
+
+
+@pytest.mark.timeout(1800)
+def test_rejection_branch_sample_build_blob_equals_oracle(pqv, oracle):
+    """index::sample's REJECTION branch (index.rs:222-242 -> rand's sample_rejection): taken when the 100 000-row sample
+    is small against n -- C3 / C4 / C5 all build through it.  4.2 M x 4-dim rows keep the oracle build in seconds; the
+    drawn rows decide every centroid, so blob equality pins the branch, its u32 draws and the k-means++ subset after it."""
+    n, dim, kc = 4_200_000, 4, 24
+    rng = np.random.default_rng(77)
+    data = rng.random((n, dim), dtype=np.float32)
+    data[::7] += np.float32(2.0)                                  # two blobs, so the lists are not all alike
+    _, branch = oracle.index_sample(oracle.rng(42), n, 100_000)
+    assert branch == 2                                           # rejection
+    corpus = pqv.Corpus.upload(data)
+    for workers in (8, 3):
+        index = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(workers).build()
+        oidx = oracle.build_index(data, n_clusters=kc, max_iters=20, seed=42, workers=workers)
+        assert index.to_bytes() == oidx.to_bytes(), workers
+
+
+@pytest.mark.timeout(1800)
+def test_c3_shape_screened_final_assignment_matches_oracle_on_a_slice(pqv, oracle, c3_shape):
+    """C3's parameters (dim 768, 1024 centroids): the final assignment of the build runs through the MFMA screen
+    (ScreenedAssign) -- bounds, survivors, exact re-evaluation.  For 100 000 rows spread over the corpus the cluster the
+    GPU put a row into must be the oracle's nearest_centroid (index.rs:244-257: strict '<', lowest index wins) under
+    the GPU-built centroids."""
+    from concurrent.futures import ThreadPoolExecutor
+    data, corpus, index, _ = c3_shape
+    n = data.shape[0]
+    off, rows = index.list_offsets.astype(np.int64), index.list_rows
+    cluster_of = np.empty(n, dtype=np.uint32)
+    for c in range(index.n_clusters):
+        cluster_of[rows[off[c]:off[c + 1]]] = c
+    oidx = oracle.index_from_bytes(index.to_bytes())
+    sel = np.arange(0, n, 10)[:100_000]
+
+    def nearest(lo):
+        return [int(oidx.find_closest_centroids(data[r], 1)[0]) for r in sel[lo:lo + 500]]
+    with ThreadPoolExecutor(max_workers=32) as ex:
+        want = np.array([c for part in ex.map(nearest, range(0, len(sel), 500)) for c in part], dtype=np.uint32)
+    bad = np.nonzero(cluster_of[sel] != want)[0]
+    assert len(bad) == 0, (len(bad), sel[bad[:5]], cluster_of[sel][bad[:5]], want[bad[:5]])
