@@ -1215,7 +1215,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
     // int8 form of the blocked copy: finite data (f16_ok), rows of a multiple of 256 dims, IVF-ordered rows
     s->i8_ok = s->f16_ok && (s->dim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0;
-    if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 768) {
+    if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 192) {
         if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
     }
     S_TRY(hipStreamSynchronize(s->stream));
@@ -1293,8 +1293,9 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     // 123 -> 78 us, on C3 2.0 -> 0.34 ms; 32 queries on C3 15.8 -> 2.2 ms
     const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
     const bool wide_ok = o.filter_variant == 0 && wide_path_possible(s);
-    const bool wide_any_batch = metric == PQV_L2SQ_REF4 && o.tile_filter && k <= 128 && wide_ok &&
-                                mean_len >= 3ull * (mean_len >= 4096 ? 512 : 256);
+    // (round 3: lists down to 192 rows -- the reference's default n_clusters = ceil(sqrt(n)) gives lists of sqrt(n) rows,
+    //  index.rs:161-167 -- with a threshold sample that shrinks with them)
+    const bool wide_any_batch = metric == PQV_L2SQ_REF4 && o.tile_filter && k <= 128 && wide_ok && mean_len >= 192;
     if (wide_any_batch) p.tile = true;
     if (o.rerank_mode == 1) p.tile = false;
     if (o.rerank_mode == 2) p.tile = metric == PQV_L2SQ_REF4 && k <= 256;
@@ -1310,7 +1311,9 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
         p.rr_rows_per_block = static_cast<uint32_t>(rpb);
         // threshold sample: 256 rows per probed list, 512 for lists of >= 4096 rows (survivors per query halve,
         // the sampling pass doubles: C2 0.246 -> 0.226 ms, C3 7.99 -> 7.58 ms)
-        p.seed_rows = o.seed_rows ? std::max<uint32_t>(64, o.seed_rows / 64 * 64) : (mean_len >= 4096 ? 512 : 256);
+        // short lists: a third of the mean list, in 64-row tiles
+        p.seed_rows = o.seed_rows ? std::max<uint32_t>(64, o.seed_rows / 64 * 64)
+                                  : (mean_len >= 4096 ? 512 : mean_len >= 768 ? 256 : static_cast<uint32_t>(std::max<uint64_t>(64, mean_len / 3 / 64 * 64)));
         // k <= 128 (the running-threshold counters are 8 bits wide, the candidate buffers 2048 entries); the wide
         // kernel pays from lists of three seed windows on -- measured on the reference's own bench shape, 1000-row
         // lists at K = 100: 99 k -> 243 k QPS; the one-group kernel (row-order layout, dim % 64 != 0) keeps k <= 32
@@ -1958,8 +1961,10 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
         return rc ? rc : rc2;
     }
     // bound the scratch: sub-batch so the per-wave partial lists stay under ~1 GiB
-    const TopkPlan p1 = plan_topk(s, 1, nprobe, k_int, metric);
-    const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + 1;
+    // (per query: partial lists, probe partial lists, candidate buffer, the int8 images of its probed pairs)
+    const TopkPlan p1 = plan_topk(s, std::min<uint32_t>(nq, 1024), nprobe, k_int, metric);
+    const uint64_t per_query = static_cast<uint64_t>(p1.n_part_rr) * k_int * 12 + static_cast<uint64_t>(p1.n_part_probe) * p1.probe_kpart * 12 +
+                               static_cast<uint64_t>(cand_cap_for(s, k_int)) * 12 + static_cast<uint64_t>(p1.np) * (s->dim + 32) + 1;
     uint32_t batch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / per_query)));
     HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(batch) * s->dim * sizeof(float)));
     HIP_TRY(sc.s_rows.ensure(static_cast<size_t>(batch) * k * sizeof(uint32_t)));

@@ -2303,12 +2303,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         constexpr uint32_t TPQ = NT / NQP2;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
         const uint32_t q_src = qsel_u32<QS>(my_qrow, q < NQ ? q : NQ - 1);
+        // (the shuffles must run with every lane active: a lane that skips the staging still SERVES its state to others)
+        [[maybe_unused]] uint32_t p_src = 0;
+        if constexpr (I8) p_src = qsel_u32<QS>(my_pairi, q < NQ ? q : NQ - 1);
         if (q < 16u * ng) {        // only the active groups are ever read
             const float4 *src = reinterpret_cast<const float4 *>(a.queries + (uint64_t)q_src * dim);
             float4 *dst = qs + q * G;
             const uint32_t sw = q & 15u;
             if constexpr (I8) {        // the int8 images were made once per batch and pair (quantize_pairs_i8_kernel)
-                const uint32_t p_src = qsel_u32<QS>(my_pairi, q < NQ ? q : NQ - 1);
                 const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)p_src * dim);
 #pragma unroll 4
                 for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
