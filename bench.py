@@ -126,6 +126,28 @@ def pmc_traffic(workload, kernels):
     return total, srcs
 
 
+def build_record(n, dim, kc, build_s):
+    """Phases of the last index build (pqv_index_build_stats) and the roofline of its dominant step, the final
+    assignment of every row (src/ivf/index.rs:189-206): a dense n x n_clusters x dim contraction, SURVEY 8(d):
+    2 n k_c dim flops in GEMM form against the f32 MFMA peak (the screen runs on v_mfma_f32_16x16x4_f32)."""
+    import ctypes as C
+    from pq_vector_amd import _ffi
+    st = (C.c_double * 8)()
+    _ffi.lib().pqv_index_build_stats(st, 8)
+    kpp, lloyd, iters, fa, host, fa_screen, lloyd_screen, sample = list(st)
+    flops = 2.0 * n * kc * dim
+    tf = flops / fa / 1e12 if fa > 0 else 0.0
+    return {"seconds": build_s, "vectors_per_s": n / build_s,
+            "phases_s": {"kmeans_pp": kpp, "lloyd": lloyd, "lloyd_iterations": int(iters), "final_assignment": fa,
+                         "host_list_build": host, "sample_rows": int(sample)},
+            "roofline": {"bound": "mfma", "kernel": "final assignment: wide_seed_kernel + seed_select_kernel + wide_filter_kernel<f32 operands> + merge_kernel"
+                                                     if fa_screen else "final assignment: assign_kernel (exact-order VALU)",
+                         "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                         "algo_flops": flops,
+                         "note": "2 n k_c dim flops / the wall time of the whole final-assignment phase (threshold sample, screen, exact "
+                                 "re-evaluation of the survivors, top-1 merge, download of the assignment): a lower bound for the screen kernel"}}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher environment: re-run this command line under
     torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -178,6 +200,8 @@ def main():
                          "and searches its OWN query batch (throughput mode, no data-path collective)")
     ap.add_argument("--single", type=int, default=100,
                     help="also time this many single-query calls (latency mode, p50 / p99); 0 disables")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Gaussian-mixture pass that follows the default C3 run")
+    ap.add_argument("--parity-queries", type=int, default=64, help="queries of the step checked bit for bit against the CPU oracle")
     ap.add_argument("--recall", type=int, default=32, help="queries checked against an exact brute force (0 disables)")
     args = ap.parse_args()
     global K
@@ -254,6 +278,7 @@ def main():
     b = pqv.IndexBuilder(corpus).max_iters(20).seed(42).workers(workers)
     index = b.n_clusters(n_clusters).build() if n_clusters else b.build()
     build_s = time.perf_counter() - t0
+    build_info = build_record(n_shard, dim, int(index.n_clusters), build_s)
     flags = pqv.PQV_LAYOUT_ROW_ORDER if args.layout == "row" else pqv.PQV_LAYOUT_IVF_ORDERED
     t0 = time.perf_counter()
     searcher = pqv.Searcher(index, corpus, flags)
@@ -437,6 +462,7 @@ def main():
         "hot_path_ms_per_step_serial": serial_hot_ms,
         "index_build_vectors_per_s": n_shard / build_s,
         "index_build_s": build_s,
+        "index_build": build_info,
         "searcher_create_s": layout_s,
         "candidates_per_query": cand_rows / nq,
         "corpus_row_scans_per_s": n_total * nq * steps / elapsed if not replica else world * n_total * nq * steps / elapsed,
@@ -488,6 +514,35 @@ def main():
         for _ in range(10):
             xchg_l[0].exchange_u32(dist_l[0], rows_l[0])
         torch.cuda.synchronize()
+        if args.backend == "nccl":
+            # the same exchange through the C ABI (pqv_shard_*: RCCL bound by the library, what a Rust host calls).  A
+            # cross-check only: every rank takes the same collectives whatever fails, and nothing here can cost the line.
+            from pq_vector_amd.sharding import RcclShardComm
+            comm, why = RcclShardComm.create_collective(rank, world, local_rank)
+            if comm is None:
+                result["exchange_c_abi"] = {"error": why[:300]}
+            else:
+                cd = torch.empty((nq, K), dtype=torch.float32, device=dev)
+                cr = torch.empty((nq, K), dtype=torch.int64, device=dev)
+                bases_t = torch.tensor(bases, dtype=torch.int64, device=dev)
+                good, ms_c = 1, None
+                try:
+                    comm.exchange(dist_l[0], rows_l[0], bases_t, cd, cr)
+                    torch.cuda.synchronize()
+                    good = int(torch.equal(cd, ref_d) and torch.equal(cr, ref_r))
+                    t2 = time.perf_counter()
+                    for _ in range(10):
+                        comm.exchange(dist_l[0], rows_l[0], bases_t, cd, cr)
+                    torch.cuda.synchronize()
+                    ms_c = (time.perf_counter() - t2) / 10 * 1e3
+                except Exception as e:
+                    good = 0
+                    result["exchange_c_abi_error"] = str(e)[:300]
+                okc = torch.tensor([good], device=dev)
+                dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+                result["exchange_c_abi"] = {"check": bool(okc.item()), "ms_per_step": ms_c,
+                                            "entry_points": "pqv_shard_unique_id / pqv_shard_comm_create / pqv_shard_exchange"}
+                comm.close()
         result["exchange"] = {"ranks": world, "backend": "RCCL" if args.backend == "nccl" else args.backend,
                               "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
                               "bytes_per_rank_per_step": nq * K * 8,
@@ -529,6 +584,12 @@ def main():
         result["recall_at_k"] = {"queries": m, "recall": hits / float(m * K),
                                  "note": "fraction of the exact top-k (pqv_brute_topk, L2) found by the IVF search at this nprobe; "
                                          "on uniform random data IVF recall is low by nature (benches/query.rs prints the same figure)"}
+    # ---- secondary data set where IVF works: the same shape as a Gaussian mixture ---------------------
+    if rank == 0 and world == 1 and args.workload == "c3" and args.data == "uniform" and not args.no_secondary:
+        try:
+            result["secondary_mixture"] = secondary_mixture(args, pqv, torch, dev, local_rank, n_shard, dim, n_clusters, nprobe, nq)
+        except Exception as e:           # the headline must not depend on it
+            result["secondary_mixture"] = {"error": str(e)[:300]}
     # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled -----------
     rc = 0
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -546,6 +607,54 @@ def main():
     if rc:
         log("[bench] PARITY FAILURE against the CPU oracle")
         sys.exit(rc)
+
+
+def secondary_mixture(args, pqv, torch, dev, local_rank, n, dim, kc, nprobe, nq):
+    """The headline shape on data WITH cluster structure: n_clusters Gaussian components (centres uniform in [0,1)^dim,
+    sigma 0.1), queries from the same mixture.  Uniform random data -- the reference's bench recipe -- has recall@10
+    of ~0.16 at nprobe 32; here the IVF answer is the exact one, which is the regime an IVF index exists for."""
+    corpus_t = synth_mixture(torch, dev, 1234, n, dim, kc)
+    q_t = synth_mixture(torch, dev, 7, nq, dim, kc)
+    corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n, dim, device=local_rank, keepalive=corpus_t)
+    t0 = time.perf_counter()
+    index = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(os.cpu_count() or 1).build()
+    build_s = time.perf_counter() - t0
+    srch = pqv.Searcher(index, corpus)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=dev)]
+    rows = [torch.empty((nq, K), dtype=torch.int32, device=dev) for _ in range(2)]
+    dd = [torch.empty((nq, K), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def mstep(i):
+        st = streams[i % 2]
+        with torch.cuda.stream(st):
+            srch.topk_device(q_t.data_ptr(), nq, K, nprobe, rows[i % 2].data_ptr(), dd[i % 2].data_ptr(), stream=st.cuda_stream)
+
+    for i in range(4):
+        mstep(i)
+    torch.cuda.synchronize()
+    c0 = srch.counters()
+    blocks = []
+    steps = 20
+    while sum(blocks) < 0.5 and len(blocks) < 50:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            mstep(i)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    c1 = srch.counters()
+    el = float(np.median(blocks))
+    m = min(32, nq)
+    got = rows[(steps - 1) % 2][:m].cpu().numpy().view(np.uint32)
+    br, _, _ = corpus.brute_topk(q_t[:m].cpu().numpy(), K, pqv.PQV_L2SQ_MFMA)
+    hits = sum(len(set(got[i].tolist()) & set(br[i].tolist())) for i in range(m))
+    nqs = max(1, c1["queries"] - c0["queries"])
+    return {"value": nq * steps / el, "unit": "queries/s", "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": len(blocks),
+            "data": f"synthetic gaussian mixture: {kc} components, sigma 0.1, {n}x{dim}, k {K}, nprobe {nprobe}, {nq} queries/step",
+            "recall_at_k": hits / float(m * K), "index_build_s": build_s,
+            "screen_survivors_per_query": (c1["screen_survivors"] - c0["screen_survivors"]) / nqs,
+            "screened_rows_per_query": (c1["screened_pairs"] - c0["screened_pairs"]) / nqs,
+            "candidates_per_query": (c1["candidate_rows"] - c0["candidate_rows"]) / nqs,
+            "dispatch": srch.describe(nq, K, nprobe)}
 
 
 def replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps):
@@ -658,17 +767,13 @@ def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq, searcher
     grows = rows_t.cpu().numpy().view(np.uint32)
     gdist = dist_t.cpu().numpy()
     done, spent = 0, 0.0
-    ids_ok, dist_ok, ids_tie_ok, tie_groups = True, True, True, 0
-    replayed, replay_ok = 0, True
-    chunk = 4
-    while done < nq and spent < args.cpu_seconds:
-        b = min(chunk, nq - done)
-        t0 = time.perf_counter()
-        orows, odist, onf, _ = oidx.topk_batch(host, qs[done:done + b], K, nprobe)
-        spent += time.perf_counter() - t0
-        g = grows[done:done + b]
-        ids_ok &= bool((orows == g).all())
-        dist_ok &= bool((odist.view(np.uint32) == gdist[done:done + b].view(np.uint32)).all())
+    st = {"ids": True, "dist": True, "tie": True, "groups": 0, "replayed": 0, "replay_ok": True}
+
+    def check(q0, orows, odist):
+        b = len(orows)
+        g = grows[q0:q0 + b]
+        st["ids"] &= bool((orows == g).all())
+        st["dist"] &= bool((odist.view(np.uint32) == gdist[q0:q0 + b].view(np.uint32)).all())
         # pqv_topk_device orders equal output distances by (d2, position); Rust orders them by heap
         # history (the host API pqv_topk replays that exactly).  Inside a group of equal distance the
         # id SETS must still agree.
@@ -676,24 +781,44 @@ def cpu_baseline(args, index, corpus_t, qs, rows_t, dist_t, nprobe, nq, searcher
             if (orows[i] == g[i]).all():
                 continue
             if searcher is not None:        # the host API replays the reference's heap for exactly these queries
-                hr, hd, _, _ = searcher.topk(qs[done + i:done + i + 1], K, nprobe)
-                replayed += 1
-                replay_ok &= bool((hr[0] == orows[i]).all()) and bool((hd.view(np.uint32)[0] == odist.view(np.uint32)[i]).all())
+                hr, hd, _, _ = searcher.topk(qs[q0 + i:q0 + i + 1], K, nprobe)
+                st["replayed"] += 1
+                st["replay_ok"] &= bool((hr[0] == orows[i]).all()) and bool((hd.view(np.uint32)[0] == odist.view(np.uint32)[i]).all())
             j = 0
             while j < K:
                 e = j
                 while e + 1 < K and odist[i, e + 1] == odist[i, j]:
                     e += 1
                 if e > j:
-                    tie_groups += 1
-                ids_tie_ok &= sorted(orows[i, j:e + 1].tolist()) == sorted(g[i, j:e + 1].tolist())
+                    st["groups"] += 1
+                st["tie"] &= sorted(orows[i, j:e + 1].tolist()) == sorted(g[i, j:e + 1].tolist())
                 j = e + 1
+
+    # faithful column: ONE thread, timed
+    chunk = 4
+    while done < nq and spent < args.cpu_seconds:
+        b = min(chunk, nq - done)
+        t0 = time.perf_counter()
+        orows, odist, onf, _ = oidx.topk_batch(host, qs[done:done + b], K, nprobe)
+        spent += time.perf_counter() - t0
+        check(done, orows, odist)
         done += b
         chunk = min(64, chunk * 2)
-    out = {"value": done / spent, "unit": "queries/s", "cores": 1, "kind": "port",
+    timed = done
+    # parity only (not timed): the sample is widened to >= 64 queries spread over the batch, one query per host thread
+    # (results are independent per query)
+    extra = [q for q in range(nq - 1, timed - 1, -max(1, (nq - timed) // 64))][:max(0, min(args.parity_queries, nq) - timed)]
+    if extra:
+        nthr_p = max(1, min(len(extra), os.cpu_count() or 1, 64))
+        with ThreadPoolExecutor(max_workers=nthr_p) as ex:
+            for q, (orows, odist, _, _) in zip(extra, ex.map(lambda q: oidx.topk_batch(host, qs[q:q + 1], K, nprobe), extra)):
+                check(q, orows, odist)
+        done += len(extra)
+    ids_ok, dist_ok, ids_tie_ok, tie_groups, replayed, replay_ok = st["ids"], st["dist"], st["tie"], st["groups"], st["replayed"], st["replay_ok"]
+    out = {"value": timed / spent, "unit": "queries/s", "cores": 1, "kind": "port",
            "threads_note": "one thread, as the reference's query loop (search.rs:115)",
-           "sample": f"first {done} of the step's {nq} queries, in-memory corpus, oracle -O3 -march=native "
-                     f"-ffp-contract=off, {spent:.1f} s",
+           "sample": f"first {timed} of the step's {nq} queries, in-memory corpus, oracle -O3 -march=native "
+                     f"-ffp-contract=off, {spent:.1f} s (+ {done - timed} more queries checked for parity only, one per host thread)",
            "host_cpus": os.cpu_count(),
            "parity": {"queries_checked": done, "row_idx_identical": ids_ok, "dist_bit_identical": dist_ok,
                       "row_idx_identical_up_to_order_inside_equal_distance_groups": ids_tie_ok,

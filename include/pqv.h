@@ -106,6 +106,11 @@ void pqv_corpus_free(pqv_corpus *corpus);
  *                       0 => this host's online CPU count. */
 int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
                     uint64_t seed, uint32_t workers, pqv_index **out);
+/* Phase wall times of the calling thread's last pqv_index_build / pqv_index_build_host / pqv_kmeans (bench records):
+ * out[0] k-means++ seconds, [1] Lloyd seconds, [2] Lloyd iterations run, [3] final assignment seconds (device work +
+ * download), [4] host inverted-list build seconds, [5] 1 if the final assignment ran through the MFMA screen, [6] same for
+ * the Lloyd assignments, [7] sample rows; entries beyond n are not written. */
+int pqv_index_build_stats(double *out, uint32_t n);
 /* Host-pointer form with the reference's exact argument shape: uploads, builds, frees. */
 int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
                          uint32_t n_clusters, uint32_t max_iters, uint64_t seed,

@@ -110,6 +110,9 @@ struct PinnedBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// phase wall times of this thread's last index build (pqv_index_build_stats)
+thread_local double g_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // PQV_VERBOSE=1: phase timings of the build on stderr
 bool verbose() {
     static const bool v = [] { const char *e = std::getenv("PQV_VERBOSE"); return e && *e && *e != '0'; }();
@@ -830,6 +833,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     d_min.release(); d_init_own.release(); d_idx.release();
     HIP_TRY(hipStreamSynchronize(stream));
     const double t_pp1 = now_s();
+    g_build_stats[0] = t_pp1 - t_pp0;
     if (verbose()) std::fprintf(stderr, "[pqv] k-means++: %u rounds over %llu rows in %.3f s\n", k,
                                 (unsigned long long)init_n, t_pp1 - t_pp0);
 
@@ -879,6 +883,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
                                     k, d_centroids, stream));                          // :436-453
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    g_build_stats[1] = now_s() - t_pp1; g_build_stats[2] = iters; g_build_stats[6] = use_screen ? 1.0 : 0.0;
     if (verbose()) std::fprintf(stderr, "[pqv] Lloyd: %u iterations over %llu rows in %.3f s\n", iters,
                                 (unsigned long long)n, now_s() - t_pp1);
     if (iters_run) *iters_run = iters;
@@ -960,6 +965,8 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         delete idx;
         return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
     }
+    g_build_stats[3] = t_fa1 - t_fa0; g_build_stats[4] = now_s() - t_fa1; g_build_stats[5] = exact_assign ? 0.0 : 1.0;
+    g_build_stats[7] = static_cast<double>(sample_size);
     if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
                                 (unsigned long long)n, t_fa1 - t_fa0, now_s() - t_fa1);
     *out = idx;
@@ -978,6 +985,12 @@ static int pqv_index_build_impl(const pqv_corpus *corpus, uint32_t n_clusters, u
 extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
                                uint64_t seed, uint32_t workers, pqv_index **out) {
     return guard([&] { return pqv_index_build_impl(corpus, n_clusters, max_iters, seed, workers, out); });
+}
+
+extern "C" int pqv_index_build_stats(double *out, uint32_t n) {
+    if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 8 ? g_build_stats[i] : 0.0;
+    return PQV_OK;
 }
 
 static int pqv_index_build_host_impl(int device, const float *data, uint64_t data_len, uint32_t dim,

@@ -106,6 +106,44 @@ class RcclShardComm:
         _rc(L.pqv_shard_comm_create(device_index, rank, world, idb, C.byref(h)))
         self._h, self.rank, self.world, self.device_index = h, rank, world, device_index
 
+    @classmethod
+    def create_collective(cls, rank, world, device_index):
+        """Every rank of the torch process group calls this together.  Returns (comm or None, reason): whatever fails
+        on whichever rank, every rank takes the same number of collectives, so a failure never leaves ranks waiting
+        for each other."""
+        import ctypes as C
+        from . import _ffi
+        dev = torch.device("cuda", device_index)
+        on_gpu = world > 1 and dist.get_backend() == "nccl"
+        msg = torch.zeros(129, dtype=torch.uint8)
+        reason = ""
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if _ffi.lib().pqv_shard_unique_id(buf) == 0:
+                msg[0] = 1
+                msg[1:] = torch.tensor(list(buf), dtype=torch.uint8)
+            else:
+                reason = _ffi.lib().pqv_last_error().decode()
+        if world > 1:
+            t = msg.to(dev) if on_gpu else msg
+            dist.broadcast(t, src=0)
+            msg = t.cpu()
+        if int(msg[0]) != 1:
+            return None, reason or "rank 0 could not draw a rendezvous id"
+        comm = None
+        try:
+            comm = cls(rank, world, device_index, id_bytes=bytes(msg[1:].tolist()))
+        except Exception as e:
+            reason = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            if comm is not None:
+                comm.close()
+            return None, reason or "communicator creation failed on another rank"
+        return comm, ""
+
     def exchange(self, local_dist, local_rows_i32, row_bases_i64, out_d, out_r, stream=None):
         """local_dist f32 / local_rows_i32 [nq, k] device tensors (raw searcher outputs), row_bases_i64 [world];
         writes out_d f32 / out_r i64 [nq, k] on `stream` (default: torch's current stream)."""
