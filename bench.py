@@ -514,6 +514,10 @@ def main():
         for _ in range(10):
             xchg_l[0].exchange_u32(dist_l[0], rows_l[0])
         torch.cuda.synchronize()
+        result["exchange"] = {"ranks": world, "backend": "RCCL" if args.backend == "nccl" else args.backend,
+                              "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
+                              "bytes_per_rank_per_step": nq * K * 8,
+                              "collective": "one all_gather_into_tensor of packed {f32 distance, u32 row} pairs + shard_merge_kernel"}
         if args.backend == "nccl":
             # the same exchange through the C ABI (pqv_shard_*: RCCL bound by the library, what a Rust host calls).  A
             # cross-check only: every rank takes the same collectives whatever fails, and nothing here can cost the line.
@@ -543,10 +547,6 @@ def main():
                 result["exchange_c_abi"] = {"check": bool(okc.item()), "ms_per_step": ms_c,
                                             "entry_points": "pqv_shard_unique_id / pqv_shard_comm_create / pqv_shard_exchange"}
                 comm.close()
-        result["exchange"] = {"ranks": world, "backend": "RCCL" if args.backend == "nccl" else args.backend,
-                              "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
-                              "bytes_per_rank_per_step": nq * K * 8,
-                              "collective": "one all_gather_into_tensor of packed {f32 distance, u32 row} pairs + shard_merge_kernel"}
 
     # ---- N > 1: the other multi-GPU mode on the same hardware, as a secondary object -------------------------
     if world > 1 and not replica and not args.force_dist and args.multi == "auto":
