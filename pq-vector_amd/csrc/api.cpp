@@ -157,8 +157,8 @@ struct pqv_corpus {
     hipStream_t stream = nullptr;
     // lazily computed per-row auxiliaries of pqv_brute_topk: 1/|v| and |v|^2
     mutable std::mutex aux_mu;
-    mutable DevBuf aux_rnorm, aux_norm2;
-    mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0;
+    mutable DevBuf aux_rnorm, aux_norm2, aux_v16;      // aux_v16: L2-normalised f16 images [n, dim_p] (the f16 screen of pqv_brute_topk)
+    mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0, aux_v16_rows = 0;
     ~pqv_corpus() {
         if (d_rows && owned) (void)hipFree(d_rows);
         if (stream) (void)hipStreamDestroy(stream);
@@ -2337,6 +2337,31 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         }
         d_row_aux = buf.as<float>();
     }
+    // Round 3: beyond the first row range the contraction runs on the f16 matrix pipe as a screen (kernels.hip:
+    // brute_f16_kernel) and only what it lets through is scored in f32.  Needs the normalised f16 image of the
+    // corpus (+ 1 / |v| whatever the metric); PQV_BRUTE_F16=0 keeps the f32 contraction everywhere.
+    static const bool f16_env = [] { const char *e = std::getenv("PQV_BRUTE_F16"); return !(e && *e == '0'); }();
+    const uint32_t dim_p = (dim + 31) / 32 * 32;
+    const bool use_f16 = f16_env && n >= 32768 && static_cast<uint64_t>(dim_p) * 2 * 320 < 0x7FFFFFFFull;
+    const uint16_t *d_v16 = nullptr;
+    const float *d_vn2 = nullptr;
+    if (use_f16) {
+        std::lock_guard<std::mutex> lock(c->aux_mu);
+        if (c->aux_rnorm_rows != n || !c->aux_rnorm.p) {
+            HIP_TRY(c->aux_rnorm.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
+            HIP_TRY(launch_row_norms(c->d_rows, n, dim, 0, c->aux_rnorm.as<float>(), stream));
+            c->aux_rnorm_rows = n;
+        }
+        if (mode == 1) d_vn2 = d_row_aux;
+        if (c->aux_v16_rows != n || !c->aux_v16.p) {
+            HIP_TRY(c->aux_v16.alloc(std::max<uint64_t>(1, n) * dim_p * sizeof(uint16_t)));
+            HIP_TRY(launch_normalize_f16(c->d_rows, c->aux_rnorm.as<float>(), n, dim, dim_p, c->aux_v16.p, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            c->aux_v16_rows = n;
+        }
+        d_v16 = c->aux_v16.as<uint16_t>();
+    }
+    const float f16_eps = 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
 
     const uint32_t cap = std::max<uint32_t>(16384, 4 * k);
     const uint32_t qbatch = std::min<uint32_t>(nq, 4096);
@@ -2351,12 +2376,21 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
     HIP_TRY(d_rows_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(uint32_t)));
     HIP_TRY(d_dist_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(float)));
     HIP_TRY(d_nf.alloc(static_cast<size_t>(qbatch) * sizeof(uint32_t)));
+    DevBuf d_q16, d_qrn;
+    if (use_f16) {
+        HIP_TRY(d_q16.alloc(static_cast<size_t>(qbatch) * dim_p * sizeof(uint16_t)));
+        HIP_TRY(d_qrn.alloc(static_cast<size_t>(qbatch) * sizeof(float)));
+    }
 
     for (uint32_t q0 = 0; q0 < nq; q0 += qbatch) {
         const uint32_t b = std::min<uint32_t>(qbatch, nq - q0);
         HIP_TRY(hipMemcpyAsync(d_q.p, queries + static_cast<uint64_t>(q0) * dim, static_cast<size_t>(b) * dim * sizeof(float),
                                hipMemcpyHostToDevice, stream));
         HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, mode, d_qaux.as<float>(), stream));
+        if (use_f16) {
+            HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, 0, d_qrn.as<float>(), stream));
+            HIP_TRY(launch_normalize_f16(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, stream));
+        }
         HIP_TRY(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(b) * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_thr.p, 0xFF, static_cast<size_t>(b) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), stream));
@@ -2388,7 +2422,18 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
             ba.metric = mode == 0 ? BRUTE_COSINE : BRUTE_L2SQ;
             ba.thr = d_thr.as<unsigned long long>(); ba.cand = d_cand.as<unsigned long long>();
             ba.cand_cnt = d_cnt.as<uint32_t>(); ba.cap = cap;
-            HIP_TRY(launch_brute_mfma(ba, stream));
+            // the first range seeds the thresholds exactly; every later one is screened on the f16 pipe
+            const bool screen = use_f16 && range.first > 0;
+            if (screen) {
+                BruteF16Args fa{};
+                fa.v16 = d_v16; fa.q16 = d_q16.as<uint16_t>(); fa.row_aux = d_vn2; fa.query_aux = d_qaux.as<float>();
+                fa.row_begin = range.first; fa.row_end = range.second; fa.nq = b; fa.dim_p = dim_p;
+                fa.metric = ba.metric; fa.eps = f16_eps;
+                fa.thr = ba.thr; fa.cand = ba.cand; fa.cand_cnt = ba.cand_cnt; fa.cap = cap;
+                HIP_TRY(launch_brute_f16(fa, stream));
+            } else {
+                HIP_TRY(launch_brute_mfma(ba, stream));
+            }
             // overflow is checked BEFORE the select pass touches the buffer fronts, so a
             // rollback only has to restore the counts
             HIP_TRY(launch_brute_overflow_check(d_cnt.as<uint32_t>(), b, cap, d_flag.as<uint32_t>(), stream));
@@ -2407,6 +2452,7 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
                 todo.emplace_back(range.first, mid);
                 continue;
             }
+            if (screen) HIP_TRY(launch_brute_rescore(ba, d_cnt_saved.as<uint32_t>(), stream));     // exact f32 keys for what the screen let through
             HIP_TRY(launch_brute_select(d_cand.as<unsigned long long>(), d_cnt.as<uint32_t>(), cap, b, k,
                                         d_thr.as<unsigned long long>(), d_flag.as<uint32_t>(), stream));
         }

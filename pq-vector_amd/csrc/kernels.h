@@ -312,6 +312,26 @@ struct BruteArgs {
     uint32_t     cap;
 };
 hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s);
+// The f16 screen of the same search (kernels.hip: brute_f16_kernel): L2-normalised f16 images x 2^8 of rows / queries
+// ([*, dim_p], dim_p a multiple of 32, launch_normalize_f16), lower-bound keys against the exact thresholds; appended
+// entries are then rewritten with their exact f32 keys by launch_brute_rescore (entries [first[q], cand_cnt[q]) of query q).
+struct BruteF16Args {
+    const uint16_t *v16;       // [n, dim_p]
+    const uint16_t *q16;       // [nq, dim_p]
+    const float *row_aux;      // [n]  |v|^2 (l2 only)
+    const float *query_aux;    // [nq] |q|^2 (l2 only)
+    uint64_t     row_begin, row_end;
+    uint32_t     nq, dim_p;
+    int          metric;
+    float        eps;          // bound of |s~ - s^| on the cosine scale
+    const unsigned long long *thr;
+    unsigned long long *cand;
+    uint32_t    *cand_cnt;
+    uint32_t     cap;
+};
+hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s);
+hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s);
+hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipStream_t s);
 // per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2, mode 2 = max |x_i|
 hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s);
 // fold a query's appended candidates to its k best (kept at the front of the buffer), set

@@ -3383,6 +3383,218 @@ hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Round 3: the same batched brute force on the f16 matrix pipe (16x the f32 rate) as a SCREEN, exact f32 re-scoring
+// of what it lets through -- the design of the IVF path applied to BASELINE config 5.
+//
+// Images: every row and query is L2-normalised, scaled by 2^8 and rounded to f16 (unit vectors: components <= 1, so
+// nothing overflows and sub-normals are below 2^-22 of the vector), rows padded with zeros to a multiple of 32 dims.
+// With s~ = (image dot product) / 2^16 and s^ the true cosine:
+//     |s~ - s^| <= (2^-10 + 2^-22) sum |q^_i v^_i| + (accumulation) <= eps = 1.01 * 2^-10 + 2 dim 2^-24 + 2e-6
+// (relative 2^-11 per f16 operand, Cauchy-Schwarz on unit vectors; f32 accumulation of dim exact products; the
+// roundings of the normalisation itself).  brute_f16_kernel appends every (query, row) whose LOWER bound
+//     cosine:  (1 - s~) - eps            l2:  (|q|^2 + |v|^2 - 2 |q||v| s~) - 2 |q||v| eps
+// does not exceed the query's threshold (the k-th smallest EXACT distance so far), brute_rescore_kernel replaces each
+// appended entry by its exact f32 key (the arithmetic of the f32 path's epilogue), and the select pass goes on as before:
+// no candidate of the final top-k can be lost, and every returned distance is an f32 one.
+//
+// Block tile 128 queries x 256 rows, 4 waves as 2 x 2, each a 64 x 128 sub-tile = 2 x 4 tiles of
+// v_mfma_f32_32x32x16_f16; K in 32-value stages through double-buffered LDS (64 bytes per row and stage, 16-byte chunks
+// XOR-swizzled like the f32 kernel's).  An LDS operand read feeds 2 (row side) or 4 (query side) MFMAs: 6 reads per 8
+// MFMAs, 96 B/clk/CU at the full matrix rate.  The grid is 1-D and XCD-aware: the 8 query tiles of one row tile run
+// back to back on ONE XCD, so a row tile leaves HBM once and serves the other seven from that XCD's L2.
+// ------------------------------------------------------------------------------------
+constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;
+
+__global__ __launch_bounds__(256, 2) void brute_f16_kernel(const BruteF16Args a) {
+    __shared__ float4 As4[2][BH_BM * 4];
+    __shared__ float4 Bs4[2][BH_BN * 4];
+    __shared__ unsigned long long thr_s[BH_BM];
+    __shared__ float qaux_s[BH_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // id -> (XCD, slot): XCD x takes the row tiles = x (mod 8), each followed by all of its query tiles
+    const uint32_t ny = (a.nq + BH_BM - 1) / BH_BM;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint64_t vt = (uint64_t)(slot / ny) * 8u + xcd;
+    const uint32_t qt = slot % ny;
+    const uint64_t n0 = a.row_begin + vt * BH_BN;
+    if (n0 >= a.row_end) return;
+    const uint32_t m0 = qt * BH_BM;
+    const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32); 2 bytes each
+
+    const int ld_r = tid >> 2, ld_ch = tid & 3;      // staging: row ld_r (+ 64 h), 16-byte chunk ld_ch of the stage
+    float4 ra[2], rb[4];
+    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * dp * 2 : 0, vleft = (a.row_end - n0) * dp * 2;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(a.q16 + (uint64_t)m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(a.v16 + n0 * dp), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, r64_b = 64u * dp * 2;
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * r64_b);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * r64_b);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int r = ld_r + 64 * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { const int r = ld_r + 64 * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
+    };
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (tid < BH_BM) {
+        const uint32_t qi = m0 + tid;
+        thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
+        qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
+    }
+
+    const uint32_t nk = dp / BH_BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    // operand roles of v_mfma_f32_32x32x16_f16: lane (l31, lk) owns row l31 of a 32-row tile and the 8 consecutive k
+    // values 8 lk .. 8 lk + 7 of the instruction's 16; MFMA j of a stage takes chunk 2 j + lk (term order is free)
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[2], rowb[4], swa[2], swb[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { rowb[t] = wn * 128 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1u);
+        if (kt + 1 < nk) fetch((kt + 1) * BH_BK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8_t av[2], bv[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const float inv = 1.52587890625e-05f;            // 2^-16: the two images carry 2^8 each
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t vj = n0 + wn * 128 + j * 32 + l31;
+        const bool jv = vj < a.row_end;
+        const float vaux = (jv && a.metric != BRUTE_COSINE) ? a.row_aux[vj] : 0.0f;          // l2: |v|^2 (cosine: no row term)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const uint32_t qi = m0 + ml;
+                const float sc = acc[i][j][r] * inv;
+                float lb;
+                if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - a.eps;
+                else {
+                    const float qv = sqrtf(qaux_s[ml] * vaux) * 1.000001f;     // |q| |v|
+                    lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * a.eps - 1.0e-6f * (qaux_s[ml] + vaux);
+                    lb = lb < 0.0f ? 0.0f : lb;
+                }
+                // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
+                const bool keep = !((unsigned long long)sortable_bits(lb) > (thr_s[ml] >> 32));
+                if (jv && qi < a.nq && keep) {
+                    const uint32_t slot2 = atomicAdd(&a.cand_cnt[qi], 1u);
+                    if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vj;
+                }
+            }
+        }
+    }
+}
+hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
+    if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
+    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 320 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t nb = (a.row_end - a.row_begin + BH_BN - 1) / BH_BN, ny = (a.nq + BH_BM - 1) / BH_BM;
+    const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(brute_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// L2-normalised f16 images (x 2^8), zero-padded to dim_p: one wave per row.  rnorm: 1 / |row| (0 for a zero row).
+__global__ __launch_bounds__(256) void normalize_f16_kernel(const float *__restrict__ rows, const float *__restrict__ rnorm,
+                                                           uint64_t n, uint32_t dim, uint32_t dim_p, uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        const float sc = rnorm[r] * 256.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            float v = e < dim ? p[e] * sc : 0.0f;
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);          // (a non-finite row: the exact pass decides)
+            const _Float16 h = (_Float16)v;
+            out[r * dim_p + e] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(normalize_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<uint16_t *>(out));
+    return hipGetLastError();
+}
+
+// exact f32 keys for the entries the f16 screen appended to the candidate buffers: entry slots [first[q], min(cnt[q], cap)),
+// one wave per entry (the row id sits in the entry's low word).  Same arithmetic as brute_mfma_kernel's epilogue on an
+// f32 dot product.
+__global__ __launch_bounds__(256) void brute_rescore_kernel(const BruteArgs a, const uint32_t *__restrict__ first) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.y;
+    uint32_t cnt = a.cand_cnt[q];
+    if (cnt > a.cap) cnt = a.cap;
+    const float *qp = a.queries + (uint64_t)q * a.dim;
+    const float qaux = a.query_aux[q];
+    for (uint32_t e = first[q] + blockIdx.x * 4u + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4u) {
+        unsigned long long *ent = a.cand + (uint64_t)q * a.cap + e;
+        const uint32_t row = (uint32_t)*ent;
+        const float *vp = a.rows + (uint64_t)row * a.dim;
+        float s = 0.0f;
+        if ((a.dim & 3u) == 0) {
+            for (uint32_t d = lane * 4; d < a.dim; d += 256) {
+                const float4 x = *reinterpret_cast<const float4 *>(qp + d), y = *reinterpret_cast<const float4 *>(vp + d);
+                s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+            }
+        } else {
+            for (uint32_t d = lane; d < a.dim; d += 64) s = fmaf(qp[d], vp[d], s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        float d;
+        const float vaux = a.row_aux[row];
+        if (a.metric == BRUTE_COSINE) d = 1.0f - s * qaux * vaux;
+        else { d = qaux + vaux - 2.0f * s; d = d < 0.0f ? 0.0f : d; }
+        if (lane == 0) *ent = ((unsigned long long)sortable_bits(d) << 32) | row;
+    }
+}
+hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(brute_rescore_kernel, dim3(32, a.nq), dim3(256), 0, s, a, first);
+    return hipGetLastError();
+}
+
 // one wave per row; f32 partial sums, wave-reduced
 __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ rows, uint64_t n,
                                                        uint32_t dim, int mode, float *__restrict__ out) {
