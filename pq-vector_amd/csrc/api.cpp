@@ -627,7 +627,8 @@ struct ScreenedAssign {
         static const bool f16_env = [] { const char *e = std::getenv("PQV_ASSIGN_F16"); return e && *e == '1'; }();
         f16 = f16_env && (dim % 128) == 0 && dim <= 1024;
         if (f16) width = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / (static_cast<uint64_t>(dim) * (dim <= 128 ? 6 : 2)) / 32 * 32));
-        chunk_q = 65536;
+        static const uint32_t chunk_env = [] { const char *e = std::getenv("PQV_ASSIGN_CHUNK"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
+        chunk_q = chunk_env >= 4096 ? chunk_env / 4096 * 4096 : 65536;
         rpb = f16 ? 2048 : 1024; bpl = (kc + rpb - 1) / rpb;
         max_quads = (chunk_q / width + 7) / 8 * 8;
         const uint64_t tiles = (static_cast<uint64_t>(kc) + 15) / 16;
@@ -1529,6 +1530,22 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             pm.sq_item_rows = p.filter_rows_per_block; pm.sq_max_items = max_items;
         }
     }
+    bool pairs_quantized = false;
+    if (fused_probe && p.i8) {
+        // ... and the int8 images of the query's probed pairs (one launch less per single-query call)
+        if (int rc = ensure_blocked_copy(s, 2, stream)) return rc;
+        const size_t n_pairs_q = static_cast<size_t>(nq) * p.np;
+        HIP_TRY(sc.s_qi8.ensure(n_pairs_q * s->dim));
+        HIP_TRY(sc.s_qn2i.ensure(n_pairs_q * sizeof(int)));
+        HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
+        HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
+        HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
+        pm.sq_pq = pqv::PairQuantArgs{d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
+                                      s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q), p.np, s->dim,
+                                      static_cast<int8_t *>(sc.s_qi8.p), sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), sc.s_qresu.as<float>(),
+                                      sc.s_pair_lb.as<float>()};
+        pairs_quantized = true;
+    }
     if (fused_probe) {
         pqv::ProbeRowsArgs pr{};
         pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
@@ -1596,6 +1613,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
                 HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
                 HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
+                if (!pairs_quantized)
                 HIP_TRY(launch_quantize_pairs_i8(d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
                                                  s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q),
                                                  p.np, s->dim, sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(),
@@ -2402,7 +2420,9 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         std::vector<std::pair<uint64_t, uint64_t>> todo;
         {
             std::vector<std::pair<uint64_t, uint64_t>> fwd;
-            uint64_t lo = 0, len = std::min<uint64_t>(n, std::max<uint64_t>(8192, 8ull * k));
+            // (the first range has no threshold yet, so EVERY pair of it is appended -- one atomic each: 8192 rows cost 3.8 ms on
+            //  C5, a tenth of the step; 2048 rows seed thresholds that the next range tightens anyway)
+            uint64_t lo = 0, len = std::min<uint64_t>(n, std::max<uint64_t>(use_f16 ? 2048 : 8192, 8ull * k));
             while (lo < n) {
                 const uint64_t hi = std::min<uint64_t>(n, lo + len);
                 fwd.emplace_back(lo, hi);

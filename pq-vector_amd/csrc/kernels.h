@@ -62,6 +62,20 @@ struct MergeArgs;
 hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s);
 hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
 
+// int8 images of (query, probed list) pairs (kernels.hip: quantize_pair_i8_wave)
+struct PairQuantArgs {
+    const float    *queries;     // [nq, dim]
+    const uint32_t *probe;       // [nq * nprobe] cluster of pair p
+    const float    *center;      // [n_clusters, dim]
+    const float    *scale;       // [n_clusters]
+    const float    *half;        // [n_clusters] largest |x - centre| component of the list
+    const float    *radius;      // [n_clusters] upper bound of |x - centre| over the list's rows
+    uint32_t        n_pairs, nprobe, dim;
+    int8_t         *q_i8;        // [n_pairs, dim]
+    int            *q_n2i;       // [n_pairs]
+    float          *q_res, *q_resu, *pair_lb;
+};
+
 struct MergeArgs {
     const uint64_t *part_keys;   // [nq][n_part][k_part]
     const uint32_t *part_vals;
@@ -102,6 +116,7 @@ struct MergeArgs {
     uint32_t       *sq_pairs, *sq_n_quads;
     uint32_t       *sq_item_quad, *sq_n_items;     // optional work-item table (wide_filter_kernel)
     uint32_t        sq_item_rows, sq_max_items;
+    PairQuantArgs   sq_pq;        // launch_probe_single only, optional (q_i8 != nullptr): the int8 images of the query's pairs too
     uint32_t       *hist;
     uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
     // probe mode, optional: the query's per-wave partial lists of the re-rank start EMPTY (all-ones keys / values);

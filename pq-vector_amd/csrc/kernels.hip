@@ -547,18 +547,6 @@ __device__ __forceinline__ int quant_i8(float t, float scale) {
 //   q_resu  >= |v - vi / S|               (rounding + what the clamp cut off): the residual of the UPPER bounds (thresholds)
 //   pair_lb <= every reference d2(q, x), x in the list: (|v| - radius)^2 by the triangle inequality on the list's centre,
 //              with the summation margin of the reference order taken off; 0 = no information
-struct PairQuantArgs {
-    const float    *queries;     // [nq, dim]
-    const uint32_t *probe;       // [nq * nprobe] cluster of pair p
-    const float    *center;      // [n_clusters, dim]
-    const float    *scale;       // [n_clusters]
-    const float    *half;        // [n_clusters] largest |x - centre| component of the list
-    const float    *radius;      // [n_clusters] upper bound of |x - centre| over the list's rows
-    uint32_t        n_pairs, nprobe, dim;
-    int8_t         *q_i8;        // [n_pairs, dim]
-    int            *q_n2i;       // [n_pairs]
-    float          *q_res, *q_resu, *pair_lb;
-};
 __device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, int lane) {
     const uint32_t c = a.probe[p], q = p / a.nprobe;
     const float scale = a.scale[c], inv = 1.0f / scale, box = 127.0f * inv;
@@ -908,7 +896,14 @@ __global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs p
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (wave != 0) { probe_merge_helpers(a, 0u); return; }
+    if (wave != 0) {
+        probe_merge_helpers(a, 0u);
+        if (a.sq_pq.q_i8) {        // ... then the int8 images of the query's probed pairs, once wave 0 has written the probe order
+            __syncthreads();
+            for (uint32_t p = (uint32_t)wave - 1u; p < a.sq_pq.n_pairs; p += 3u) quantize_pair_i8_wave(a.sq_pq, p, lane);
+        }
+        return;
+    }
     WaveTopk<1> tk;
     tk.init();
     // the k-th smallest of the 64 lane minima bounds the k-th smallest key: only keys at or below it are inserted
@@ -926,6 +921,10 @@ __global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs p
         if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
     }
     probe_merge_tail<1>(a, 0u, lane, tk);
+    if (a.sq_pq.q_i8) {
+        __threadfence();
+        __syncthreads();           // the probe order is in memory: the helper waves quantise the pairs
+    }
 }
 hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s) {
     if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || (pr.kc_pad % 256) != 0 || pr.kc_pad > 4096 || (pr.dim % 4) != 0 ||
