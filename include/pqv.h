@@ -146,7 +146,7 @@ int  pqv_searcher_create(const pqv_index *index, pqv_corpus *corpus, uint32_t fl
                          pqv_searcher **out);
 void pqv_searcher_free(pqv_searcher *searcher);
 
-/* Tunables of one searcher (all optional; the defaults are the measured dispatch rules of DESIGN.md 5.1c).
+/* Tunables of one searcher (all optional; the defaults are the measured dispatch rules of DESIGN.md 5 / DESIGN_HISTORY.md 5.1c-f).
  * The reference has no such knobs -- its topk() is one fixed loop (src/ivf/search.rs:112-127) -- so nothing here
  * changes results, only which kernels produce them; tests use it to force every path through the same oracle.
  *   "rerank_mode"   0 by rule, 1 streaming kernel, 2 batched tile path
@@ -161,8 +161,11 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "quad_width"    queries per quad of the wide kernel (0 by rule; a multiple of 32)
  *   "screen_i8"     int8 screen operands for rows of a multiple of 256 dims (default 1)
  *   "min_blocks"    workgroups the wide kernel's rows-per-block rule aims for on small batches (0 by rule)
- *   "single_bucket" a single-query call is bucketed and quantised by the probe merge (three launches less; default 1: and
- *                   the probe itself joins that block where the centroid table is <= 512 KB; 2 never, 3 always, 0 off)
+ *   "pair_prune"    int8 path: skip (query, list) pairs whose centre-distance bound already exceeds the query's threshold
+ *                   (default 1)
+ *   "single_bucket" a single-query call is bucketed by the probe merge itself (two launches less).  1 (default) and 3: the
+ *                   probe joins that launch too wherever there are at most 4096 centroids (probe_single_kernel); 2: the
+ *                   bucketing only, the probe keeps its own launch; 0: the general three-launch pair sort
  *   "seed_refine"   exact distances of the rows behind the k selected seed bounds replace the k-th bound as the first
  *                   threshold (k <= 16; default 1)
  *   "item_grid"     wide kernel grid: 1 = one workgroup per (quad, existing row chunk) for the 4-wave blocks (default),

@@ -627,8 +627,7 @@ struct ScreenedAssign {
         static const bool f16_env = [] { const char *e = std::getenv("PQV_ASSIGN_F16"); return e && *e == '1'; }();
         f16 = f16_env && (dim % 128) == 0 && dim <= 1024;
         if (f16) width = static_cast<uint32_t>(std::min<uint64_t>(128, 147456ull / (static_cast<uint64_t>(dim) * (dim <= 128 ? 6 : 2)) / 32 * 32));
-        static const uint32_t chunk_env = [] { const char *e = std::getenv("PQV_ASSIGN_CHUNK"); return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0u; }();
-        chunk_q = chunk_env >= 4096 ? chunk_env / 4096 * 4096 : 65536;
+        chunk_q = 65536;          // (131072 / 262144 rows per chunk measured the same build time: the per-chunk launches are not what bounds it)
         rpb = f16 ? 2048 : 1024; bpl = (kc + rpb - 1) / rpb;
         max_quads = (chunk_q / width + 7) / 8 * 8;
         const uint64_t tiles = (static_cast<uint64_t>(kc) + 15) / 16;
@@ -1293,7 +1292,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
     p.probe_bpl = (s->n_clusters + 255) / 256;
     p.n_part_probe = p.probe_bpl * pqv::waves_per_block();
     // (a handful of queries: the per-query stream over the table is the shorter chain -- 26 against 31 us for one query)
-    p.probe_rows = s->opt.probe_rows && s->kc_pad != 0 && (nq >= 8 || s->opt.probe_rows > 1);
+    // (it writes every centroid key of every query: beyond 2 GiB of that scratch -- hundreds of thousands of centroids
+    //  times tens of thousands of queries in one device call -- the per-query stream probe takes over)
+    p.probe_rows = s->opt.probe_rows && s->kc_pad != 0 && (nq >= 8 || s->opt.probe_rows > 1) &&
+                   static_cast<uint64_t>(nq) * s->kc_pad * 12 <= (2ull << 30);
     p.probe_kpart = p.probe_rows ? 64u : p.np;
     // re-rank: enough blocks to fill 256 CUs several times over, few enough partial lists
     const uint64_t max_len = std::max<uint64_t>(1, s->max_list_len);
@@ -1373,7 +1375,11 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 if (fit8 < 64) waves = 4;
                 p.block_waves = static_cast<uint32_t>(waves);
                 p.quad_width = waves == 8 ? fit8 : fit4;
-                if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width <= p.quad_width && (waves == 4 || o.quad_width >= 64))
+                // (a requested width the chosen form has no instantiation for is ignored, never an error at launch: the
+                //  whole-tile-prefetch form of rows <= 128 dims exists for 64 and 96 queries only)
+                const bool pf_form = waves == 4 && s->dim <= 128;
+                if (o.quad_width && (o.quad_width % 32) == 0 && o.quad_width <= p.quad_width && (waves == 4 || o.quad_width >= 64) &&
+                    !(pf_form && o.quad_width == 32))
                     p.quad_width = o.quad_width;
             } else {
                 p.quad_width = s->dim <= 128 ? 64 : 32;
@@ -1530,22 +1536,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             pm.sq_item_rows = p.filter_rows_per_block; pm.sq_max_items = max_items;
         }
     }
-    bool pairs_quantized = false;
-    if (fused_probe && p.i8) {
-        // ... and the int8 images of the query's probed pairs (one launch less per single-query call)
-        if (int rc = ensure_blocked_copy(s, 2, stream)) return rc;
-        const size_t n_pairs_q = static_cast<size_t>(nq) * p.np;
-        HIP_TRY(sc.s_qi8.ensure(n_pairs_q * s->dim));
-        HIP_TRY(sc.s_qn2i.ensure(n_pairs_q * sizeof(int)));
-        HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
-        HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
-        HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
-        pm.sq_pq = pqv::PairQuantArgs{d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
-                                      s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q), p.np, s->dim,
-                                      static_cast<int8_t *>(sc.s_qi8.p), sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), sc.s_qresu.as<float>(),
-                                      sc.s_pair_lb.as<float>()};
-        pairs_quantized = true;
-    }
     if (fused_probe) {
         pqv::ProbeRowsArgs pr{};
         pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
@@ -1613,7 +1603,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
                 HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
                 HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
-                if (!pairs_quantized)
                 HIP_TRY(launch_quantize_pairs_i8(d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
                                                  s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q),
                                                  p.np, s->dim, sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(),

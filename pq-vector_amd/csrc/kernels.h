@@ -116,7 +116,6 @@ struct MergeArgs {
     uint32_t       *sq_pairs, *sq_n_quads;
     uint32_t       *sq_item_quad, *sq_n_items;     // optional work-item table (wide_filter_kernel)
     uint32_t        sq_item_rows, sq_max_items;
-    PairQuantArgs   sq_pq;        // launch_probe_single only, optional (q_i8 != nullptr): the int8 images of the query's pairs too
     uint32_t       *hist;
     uint32_t        hist_stride;  // > 0: HIST_REPLICAS copies hist[r * hist_stride + c], query q adds to copy q % HIST_REPLICAS
     // probe mode, optional: the query's per-wave partial lists of the re-rank start EMPTY (all-ones keys / values);

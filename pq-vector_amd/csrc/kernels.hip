@@ -896,14 +896,7 @@ __global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs p
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (wave != 0) {
-        probe_merge_helpers(a, 0u);
-        if (a.sq_pq.q_i8) {        // ... then the int8 images of the query's probed pairs, once wave 0 has written the probe order
-            __syncthreads();
-            for (uint32_t p = (uint32_t)wave - 1u; p < a.sq_pq.n_pairs; p += 3u) quantize_pair_i8_wave(a.sq_pq, p, lane);
-        }
-        return;
-    }
+    if (wave != 0) { probe_merge_helpers(a, 0u); return; }
     WaveTopk<1> tk;
     tk.init();
     // the k-th smallest of the 64 lane minima bounds the k-th smallest key: only keys at or below it are inserted
@@ -921,10 +914,6 @@ __global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs p
         if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
     }
     probe_merge_tail<1>(a, 0u, lane, tk);
-    if (a.sq_pq.q_i8) {
-        __threadfence();
-        __syncthreads();           // the probe order is in memory: the helper waves quantise the pairs
-    }
 }
 hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s) {
     if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || (pr.kc_pad % 256) != 0 || pr.kc_pad > 4096 || (pr.dim % 4) != 0 ||

@@ -911,11 +911,12 @@ def test_f16_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, outlier)
 @pytest.mark.parametrize("case", ["huge_rows", "tiny_values", "constant", "signed_offset"])
 @pytest.mark.parametrize("dim,waves", [(256, 4), (512, 4), (1024, 4), (512, 8), (1280, 8), (2048, 8)])
 def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, waves, case):
-    """int8 operands are images of (x - centre) * S with ONE global scale: a few enormous rows squeeze every other row
-    into the same few levels (the residual bounds then make the screen useless and everything is evaluated exactly,
-    overflowing the candidate buffers), tiny values are scaled up, a constant corpus has no range at all, and data far
-    from the origin relies on the centring.  Queries far outside the corpus range are clamped images with large
-    residuals.  Results must stay those of the oracle bit for bit."""
+    """int8 operands are per-LIST images of (x - centre_c) * S_c (the list's mid-range centre and scale): a few enormous
+    rows squeeze every other row of their list into the same few levels (the residual bounds then make the screen useless
+    there and everything is evaluated exactly, overflowing the candidate buffers), tiny values are scaled up, a constant
+    corpus has no range at all, and data far from the origin relies on the centring.  Queries far outside the corpus range
+    are clamped images (the clamp is monotone: the lower bound stays valid with the rounding residual alone).  Results
+    must stay those of the oracle bit for bit."""
     rng = np.random.default_rng(77 + dim)
     n, kc, k, nprobe, nq = 14000, 5, 10, 3, 100
     data = rng.random((n, dim), dtype=np.float32)
@@ -951,6 +952,55 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, wave
     _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
     if case != "constant":
         assert (rows == orows).all()
+
+
+@pytest.mark.parametrize("dim", [256, 768])
+def test_i8_residual_images_clamped_queries_and_pair_pruning(pqv, oracle, dim):
+    """Round 3: the int8 screen works on the IVF residual -- per list the image of x - centre_c at the list's own scale, per
+    (query, probed list) pair the image of q - centre_c CLAMPED into the list's box -- and drops whole (query, list) pairs
+    whose centre-distance bound (|q - centre_c| - radius_c)^2 exceeds the query's threshold.  Tight, well separated
+    clusters of very different spreads make all of it bite: most probed pairs are pruned, every query is clamped in
+    every list but its own; degenerate lists (one row; identical rows: half range 0) sit among them.  Queries inside a
+    cluster, exactly on a row, on a centre, half way between two clusters and 100x outside everything: ids and distance
+    bits must equal the oracle's with the pruning on and off, and the pruning must really remove work."""
+    rng = np.random.default_rng(5 + dim)
+    kc, per, k, nprobe = 12, 1500, 10, 6
+    cen = (rng.standard_normal((kc, dim)) * 4.0).astype(np.float32)
+    spread = rng.choice([0.02, 0.1, 0.5], size=kc).astype(np.float32)
+    parts = [cen[c] + spread[c] * rng.standard_normal((per, dim)).astype(np.float32) for c in range(kc - 2)]
+    parts.append(cen[kc - 2][None, :].repeat(40, axis=0))                       # identical rows: a list without any range
+    parts.append((cen[kc - 1] + 50.0)[None, :].astype(np.float32))             # a single far row: a list of one
+    data = np.ascontiguousarray(np.concatenate(parts).astype(np.float32))
+    data = data[rng.permutation(len(data))]
+    n = len(data)
+    nq = 160
+    queries = (cen[rng.integers(0, kc - 2, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+    queries[0:8] = data[rng.integers(0, n, 8)]                                  # exact hits
+    queries[8:16] = cen[:8]                                                     # on a centre
+    queries[16:24] = 0.5 * (cen[:8] + cen[1:9])                                 # between two clusters
+    queries[24:28] = queries[24:28] * np.float32(100.0)                         # far outside everything
+    queries[28] = cen[kc - 2]                                                   # the constant list's own point
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=10)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    corpus = pqv.Corpus.upload(data)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    screened = {}
+    for prune in (1, 0):
+        for width in (0, 64):
+            s = pqv.Searcher(index, corpus)
+            s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2); s.set_option("pair_prune", prune)
+            if width:
+                s.set_option("quad_width", width)
+            assert "int8 screen operands" in s.describe(nq, k, nprobe)
+            rows, dist, nf, nc = s.topk(queries, k, nprobe)
+            assert (nc == onc).all() and (nf == onf).all()
+            assert (_bits(dist) == _bits(odist)).all(), (prune, width)
+            _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+            # single queries take the fused probe + their own bucketing: same answers
+            r1, d1, _, _ = s.topk(queries[17:18], k, nprobe)
+            assert (_bits(d1) == _bits(odist[17:18])).all()
+            screened[(prune, width)] = s.counters()["screened_pairs"]
+    assert screened[(1, 0)] < 0.6 * screened[(0, 0)], screened        # the pruning removes most of the far pairs' rows
 
 
 def test_topk_device_flags_mark_every_query_that_needs_the_heap_replay(pqv, oracle):

@@ -1,5 +1,5 @@
 # One-off fuzz of the screened search against the oracle on the GPU box: FZ_LO / FZ_HI = seed range (tests/test_gpu_parity.py::_fuzz_case).
-# Variants used this round: default; PQV_SEED_ROWS=64 PQV_WIDE_ROWS=256 (loose seeds, many small blocks); PQV_CAND_CAP=8 (spills).
+# Variants used: default; PQV_SEED_ROWS=64 PQV_WIDE_ROWS=256 (loose seeds, many small blocks); PQV_CAND_CAP=8 (spills); PQV_PAIR_PRUNE=0; PQV_QUAD_WIDTH=64.
 python - <<'PY'
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
