@@ -163,6 +163,9 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "min_blocks"    workgroups the wide kernel's rows-per-block rule aims for on small batches (0 by rule)
  *   "pair_prune"    int8 path: skip (query, list) pairs whose centre-distance bound already exceeds the query's threshold
  *                   (default 1)
+ *   "i8_form"       int8 images: 0 by rule -- the per-list residual (one query image per probed pair) where the lists' own
+ *                   scales are >= 1.3x the scale one centre for the whole corpus would get, else the one-centre form (one
+ *                   image per query) --, 1 one centre, 2 residual; the int8 copy is rebuilt on the next call
  *   "single_bucket" a single-query call is bucketed by the probe merge itself (two launches less).  1 (default) and 3: the
  *                   probe joins that launch too wherever there are at most 4096 centroids (probe_single_kernel); 2: the
  *                   bucketing only, the probe keeps its own launch; 0: the general three-launch pair sort

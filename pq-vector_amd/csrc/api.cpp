@@ -210,6 +210,11 @@ struct pqv_searcher {
     // to 127 -- per row |xi|^2 and an upper bound of the residual norm, per list a radius >= |x - centre_c| (see
     // kernels.hip: block_rows_i8_kernel); built with the blocked copy (ensure_blocked_copy)
     bool i8_ok = false;
+    // i8_residual: the per-list (residual) form pays where the lists are much tighter than the corpus (clustered data:
+    // a per-list scale twice the global one halves the bound's slack); where they are not (uniform data) the one-centre
+    // form gives the same bound with ONE image per query instead of one per probed pair -- 0.45 GB less traffic per
+    // C3 step and an L2-hot staging source.  Decided when the int8 copy is built (ensure_blocked_copy).
+    mutable bool i8_residual = true;
     mutable DevBuf d_center, d_list_scale, d_list_half, d_list_radius;
     mutable DevBuf d_row_n2i, d_row_res;
     // Tunables.  Defaults are what the dispatch rules below were measured with; every one can be set per
@@ -235,6 +240,7 @@ struct pqv_searcher {
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
         uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
         int pair_prune = 1;                // int8 path: drop (query, list) pairs whose centre-distance bound exceeds the query's threshold
+        int i8_form = 0;                   // int8 images: 0 by rule (per-list residual where the lists are tight), 1 one centre, 2 residual
     };
     mutable Opts opt;
     mutable pqv_counters_t counters{};
@@ -1067,6 +1073,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
     o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
+    o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
 }
 
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
@@ -1117,6 +1124,36 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
         HIP_TRY(launch_list_minmax(s->d_mat, s->d_list_off.as<uint64_t>(), kc, s->max_list_len, s->dim, kmin, kmax, stream));
         HIP_TRY(launch_list_center(kmin, kmax, kc, s->dim, s->d_list_off.as<uint64_t>(), s->d_center.as<float>(), s->d_list_half.as<float>(),
                                    s->d_list_scale.as<float>(), s->d_list_radius.as<float>(), stream));
+        {   // residual or one-centre form: compare the lists' scales with the scale ONE centre for the whole corpus would get
+            DevBuf d_g;
+            HIP_TRY(d_g.alloc((static_cast<size_t>(s->dim) + 2) * sizeof(float)));
+            float *g_center = d_g.as<float>(), *g_hs = g_center + s->dim;
+            HIP_TRY(launch_global_center(kmin, kmax, kc, s->dim, s->d_list_off.as<uint64_t>(), g_center, g_hs, stream));
+            std::vector<float> h_scale(std::max<uint32_t>(1, kc));
+            float h_g[2] = {0.0f, 1.0f};
+            HIP_TRY(hipMemcpyAsync(h_scale.data(), s->d_list_scale.p, static_cast<size_t>(kc) * sizeof(float), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(h_g, g_hs, sizeof h_g, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            // row-weighted median of the list scales (an empty or one-point list says nothing about the data)
+            std::vector<std::pair<float, uint64_t>> sc;
+            uint64_t rows_total = 0;
+            for (uint32_t c = 0; c < kc; ++c) {
+                const uint64_t len = s->h_list_off[c + 1] - s->h_list_off[c];
+                if (len >= 2) { sc.emplace_back(h_scale[c], len); rows_total += len; }
+            }
+            std::sort(sc.begin(), sc.end());
+            float med = h_g[1];
+            uint64_t acc = 0;
+            for (const auto &e : sc) { acc += e.second; if (2 * acc >= rows_total) { med = e.first; break; } }
+            const int form = s->opt.i8_form;
+            s->i8_residual = form == 2 || (form != 1 && med >= 1.3f * h_g[1]);
+            if (!s->i8_residual)
+                HIP_TRY(launch_broadcast_center(g_center, g_hs, kc, s->dim, s->d_center.as<float>(), s->d_list_half.as<float>(),
+                                                s->d_list_scale.as<float>(), stream));
+            if (verbose()) std::fprintf(stderr, "[pqv] int8 images: median list scale %.4g, one-centre scale %.4g -> %s form\n", med, h_g[1],
+                                        s->i8_residual ? "per-list residual" : "one-centre");
+            HIP_TRY(hipStreamSynchronize(stream));      // d_g is released at scope exit
+        }
         HIP_TRY(launch_block_rows_i8(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                      (s->max_list_len + 15) / 16, s->dim, s->d_center.as<float>(), s->d_list_scale.as<float>(),
                                      s->d_list_half.as<float>(), s->d_list_radius.as<float>(), blk.p, s->d_row_n2i.as<int>(),
@@ -1595,21 +1632,23 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ta.query_maxabs = sc.s_qmax.as<float>();
             }
             if (p.i8) {
-                // one image per (query, probed list) pair: the query's residual against that list's centre at that list's
-                // scale, + the pair's lower bound from the triangle inequality on the centre (pair_lb)
-                const size_t n_pairs_q = static_cast<size_t>(nq) * p.np;
-                HIP_TRY(sc.s_qi8.ensure(n_pairs_q * s->dim));
-                HIP_TRY(sc.s_qn2i.ensure(n_pairs_q * sizeof(int)));
-                HIP_TRY(sc.s_qres.ensure(n_pairs_q * sizeof(float)));
-                HIP_TRY(sc.s_qresu.ensure(n_pairs_q * sizeof(float)));
-                HIP_TRY(sc.s_pair_lb.ensure(n_pairs_q * sizeof(float)));
-                HIP_TRY(launch_quantize_pairs_i8(d_queries, sc.s_probe.as<uint32_t>(), s->d_center.as<float>(), s->d_list_scale.as<float>(),
-                                                 s->d_list_half.as<float>(), s->d_list_radius.as<float>(), static_cast<uint32_t>(n_pairs_q),
-                                                 p.np, s->dim, sc.s_qi8.p, sc.s_qn2i.as<int>(), sc.s_qres.as<float>(),
-                                                 sc.s_qresu.as<float>(), sc.s_pair_lb.as<float>(), stream));
-                ta.i8 = 1;
+                // residual form: one image per (query, probed list) pair -- the query's residual against that list's centre at
+                // that list's scale -- + the pair's lower bound from the triangle inequality on the centre (pair_lb);
+                // one-centre form: one image per query (every list shares centre and scale)
+                const bool per_pair = s->i8_residual;
+                const size_t n_img = per_pair ? static_cast<size_t>(nq) * p.np : nq;
+                HIP_TRY(sc.s_qi8.ensure(n_img * s->dim));
+                HIP_TRY(sc.s_qn2i.ensure(n_img * sizeof(int)));
+                HIP_TRY(sc.s_qres.ensure(n_img * sizeof(float)));
+                HIP_TRY(sc.s_qresu.ensure(n_img * sizeof(float)));
+                HIP_TRY(sc.s_pair_lb.ensure(n_img * sizeof(float)));
+                HIP_TRY(launch_quantize_pairs_i8(d_queries, per_pair ? sc.s_probe.as<uint32_t>() : nullptr, s->d_center.as<float>(),
+                                                 s->d_list_scale.as<float>(), s->d_list_half.as<float>(), s->d_list_radius.as<float>(),
+                                                 static_cast<uint32_t>(n_img), per_pair ? p.np : 1u, s->dim, sc.s_qi8.p, sc.s_qn2i.as<int>(),
+                                                 sc.s_qres.as<float>(), sc.s_qresu.as<float>(), sc.s_pair_lb.as<float>(), stream));
+                ta.i8 = 1; ta.i8_pair_images = per_pair ? 1 : 0;
                 ta.q_i8 = static_cast<const int8_t *>(sc.s_qi8.p); ta.q_n2i = sc.s_qn2i.as<int>(); ta.q_res = sc.s_qres.as<float>();
-                ta.q_resu = sc.s_qresu.as<float>(); ta.pair_lb = s->opt.pair_prune ? sc.s_pair_lb.as<float>() : nullptr;
+                ta.q_resu = sc.s_qresu.as<float>(); ta.pair_lb = (per_pair && s->opt.pair_prune) ? sc.s_pair_lb.as<float>() : nullptr;
                 ta.list_scale = s->d_list_scale.as<float>();
                 ta.row_n2i = s->d_row_n2i.as<int>(); ta.row_res = s->d_row_res.as<float>();
                 s->counters.kernel_launches += 1;
@@ -2061,6 +2100,12 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "pair_prune") o.pair_prune = value != 0;
+    else if (n == "i8_form") {        // takes effect when the int8 copy is (re)built
+        o.i8_form = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();          // nothing in flight may still read the copy
+        s->d_mat_blk_op[2].release();
+    }
     else return fail(PQV_ERR_INVALID, "unknown searcher option: " + n);
     return PQV_OK;
 }
@@ -2082,11 +2127,12 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     char t[512];
     if (p.tile && p.filter && p.quad)
         std::snprintf(t, sizeof t, "wide_seed_kernel + seed_select_kernel + wide_filter_kernel: %s screen operands, quads of %u queries "
-                      "staged %s, %u waves per block, %u rows per block, threshold sample %u rows per list%s",
+                      "staged %s, %u waves per block, %u rows per block, threshold sample %u rows per list%s%s",
                       p.i8 ? "int8" : p.f16 ? "f16" : "f32", p.quad_width,
                       (p.i8 || p.f16 || static_cast<uint64_t>(p.quad_width) * s->dim * 4 <= 32768) ? "in LDS" : "as a blocked copy in global memory",
                       p.block_waves, p.filter_rows_per_block, p.seed_rows,
-                      seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? " + exact refinement" : "");
+                      seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? " + exact refinement" : "",
+                      !p.i8 ? "" : !s->d_mat_blk_op[2].p ? "" : s->i8_residual ? "; int8 images of the per-list residual (one per probed pair)" : "; int8 images about one centre (one per query)");
     else if (p.tile && p.filter)
         std::snprintf(t, sizeof t, "tile_rerank_kernel (exact seed window of %u rows) + tile_filter_kernel: 16-query groups, f32 screen operands, "
                       "%u rows per block", p.seed_rows, p.filter_rows_per_block);

@@ -249,6 +249,8 @@ struct TileArgs {
     const int8_t   *q_i8;        // [nq * nprobe][dim]
     const int      *q_n2i;       // [nq * nprobe] |vi|^2
     const float    *q_res;       // [nq * nprobe] rounding residual of the clamped query residual (lower bounds; +inf: never skip)
+    int             i8_pair_images;   // 1: images per pair (the residual form); 0: ONE image per query, indexed by query (every
+                                      // list shares centre and scale: the tables hold the same values for all lists)
     const float    *q_resu;      // [nq * nprobe] ... plus what the clamp cut off (upper bounds: wide_seed_kernel)
     const float    *pair_lb;     // [nq * nprobe] or nullptr: lower bound of d2(query, any row of the pair's list)
     const float    *list_scale;  // [n_clusters] S_c
@@ -412,6 +414,10 @@ hipError_t launch_list_minmax(const float *rows, const uint64_t *list_off, uint3
                               uint32_t *kmin, uint32_t *kmax, hipStream_t s);
 hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
                               float *center, float *half, float *scale, float *radius, hipStream_t s);
+hipError_t launch_global_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                                float *g_center, float *g_half_scale, hipStream_t s);
+hipError_t launch_broadcast_center(const float *g_center, const float *g_half_scale, uint32_t n_clusters, uint32_t dim, float *center,
+                                   float *half, float *scale, hipStream_t s);
 hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                                 uint64_t max_tiles, uint32_t dim, const float *center, const float *list_scale, const float *list_half,
                                 float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s);

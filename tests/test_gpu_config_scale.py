@@ -80,7 +80,8 @@ def test_c3_parameters_natural_dispatch(pqv, oracle, c3_shape):
     assert after["embeddings_fetched"] - before["embeddings_fetched"] == int(nc.sum())
     # the other paths agree bit for bit: int8 with 64-query quads, int8 in one 8-wave block per CU (96- and 128-query quads), f16 operands (8-wave 96-query and 4-wave 32-query quads),
     # f32 operands, the exact tile kernel, the stream kernel
-    for opts in ({"quad_width": 64}, {"item_grid": 0}, {"seed_refine": 0}, {"wide_waves": 8}, {"wide_waves": 8, "item_grid": 2}, {"wide_waves": 8, "quad_width": 128}, {"screen_i8": 0}, {"screen_i8": 0, "wide_waves": 4}, {"screen_i8": 0, "screen_f16": 0},
+    assert "about one centre" in plan, plan              # uniform data: per-list scales buy nothing, one image per query
+    for opts in ({"i8_form": 2}, {"i8_form": 2, "pair_prune": 0}, {"quad_width": 64}, {"item_grid": 0}, {"seed_refine": 0}, {"wide_waves": 8}, {"wide_waves": 8, "item_grid": 2}, {"wide_waves": 8, "quad_width": 128}, {"screen_i8": 0}, {"screen_i8": 0, "wide_waves": 4}, {"screen_i8": 0, "screen_f16": 0},
                  {"tile_filter": 0, "rerank_mode": 2}, {"rerank_mode": 1}):
         s2 = pqv.Searcher(index, corpus)
         for name, v in opts.items():

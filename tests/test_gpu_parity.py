@@ -935,6 +935,7 @@ def test_i8_screen_with_extreme_value_ranges(pqv, oracle, monkeypatch, dim, wave
     monkeypatch.setenv("PQV_RERANK_MODE", "tile")
     monkeypatch.setenv("PQV_TILE_FILTER", "2")
     monkeypatch.setenv("PQV_WIDE_WAVES", str(waves))        # two 4-wave blocks per CU (up to 1024 dims) / one 8-wave block
+    monkeypatch.setenv("PQV_I8_FORM", "2" if waves == 8 or dim == 1024 else "1")      # per-list residual images / one centre: both forms see every case
     if waves == 4 and dim == 512:
         monkeypatch.setenv("PQV_QUAD_WIDTH", "64")          # (the two-block form takes 96-query quads up to 768 dims)
     # grid forms: 4-wave blocks default to the work-item grid (quad x existing row chunk), 8-wave blocks to the 2-D grid
@@ -989,10 +990,13 @@ def test_i8_residual_images_clamped_queries_and_pair_pruning(pqv, oracle, dim):
         for width in (0, 64):
             s = pqv.Searcher(index, corpus)
             s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2); s.set_option("pair_prune", prune)
+            if width == 64 and prune == 0:
+                s.set_option("i8_form", 1)                # the one-centre form on the same data (by rule: residual here)
             if width:
                 s.set_option("quad_width", width)
             assert "int8 screen operands" in s.describe(nq, k, nprobe)
             rows, dist, nf, nc = s.topk(queries, k, nprobe)
+            assert ("about one centre" if (width == 64 and prune == 0) else "per-list residual") in s.describe(nq, k, nprobe)
             assert (nc == onc).all() and (nf == onf).all()
             assert (_bits(dist) == _bits(odist)).all(), (prune, width)
             _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
