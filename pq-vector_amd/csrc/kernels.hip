@@ -548,7 +548,8 @@ __device__ __forceinline__ int quant_i8(float t, float scale) {
 //   pair_lb <= every reference d2(q, x), x in the list: (|v| - radius)^2 by the triangle inequality on the list's centre,
 //              with the summation margin of the reference order taken off; 0 = no information
 __device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, int lane) {
-    const uint32_t c = a.probe[p], q = p / a.nprobe;
+    // (probe == nullptr: ONE image per query -- every list then shares centre and scale, entry 0 of the tables)
+    const uint32_t c = a.probe ? a.probe[p] : 0u, q = a.probe ? p / a.nprobe : p;
     const float scale = a.scale[c], inv = 1.0f / scale, box = 127.0f * inv;
     const float *qv = a.queries + (uint64_t)q * a.dim, *cv = a.center + (uint64_t)c * a.dim;
     int n2 = 0;
@@ -591,9 +592,11 @@ __device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, ui
         a.q_res[p] = (bad || !(r < INFINITY)) ? INFINITY : r;
         a.q_resu[p] = (bad || !(ru < INFINITY)) ? INFINITY : ru;
         const float cmargin = (float)(a.dim + 16) * 2.384185791015625e-07f;
-        const float lbd = sqrtf(v2) * 0.99998f - a.radius[c];
-        const float lb = lbd > 0.0f ? lbd * lbd * (1.0f - 2.0f * cmargin) * 0.99999f : 0.0f;
-        a.pair_lb[p] = (bad || !(lb < INFINITY)) ? 0.0f : lb;
+        if (a.probe) {
+            const float lbd = sqrtf(v2) * 0.99998f - a.radius[c];
+            const float lb = lbd > 0.0f ? lbd * lbd * (1.0f - 2.0f * cmargin) * 0.99999f : 0.0f;
+            a.pair_lb[p] = (bad || !(lb < INFINITY)) ? 0.0f : lb;
+        }
     }
 }
 __global__ __launch_bounds__(256) void quantize_pairs_i8_kernel(const PairQuantArgs a) {
@@ -604,7 +607,7 @@ hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe,
                                     const float *radius, uint32_t n_pairs, uint32_t nprobe, uint32_t dim, void *q_i8, int *q_n2i,
                                     float *q_res, float *q_resu, float *pair_lb, hipStream_t s) {
     if (n_pairs == 0) return hipSuccess;
-    if (dim % 4 || nprobe == 0) return hipErrorInvalidValue;
+    if (dim % 4 || nprobe == 0 || (probe && !pair_lb)) return hipErrorInvalidValue;
     PairQuantArgs a{queries, probe, center, scale, half, radius, n_pairs, nprobe, dim, static_cast<int8_t *>(q_i8), q_n2i, q_res, q_resu, pair_lb};
     hipLaunchKernelGGL(quantize_pairs_i8_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -1721,7 +1724,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     qnl[lane] = a.query_norm2[my_qrow];
     const float my_qn0 = a.query_norm2[my_qrow];
     bool my_bad16 = F16 && (a.query_maxabs[my_qrow] * a.scale > 32768.0f || my_qn0 * a.scale2 < 1.0f);   // no valid f16 bound
-    if constexpr (I8) my_bad16 = !(a.q_resu[my_pair] <= 3.0e38f);        // non-finite query: no bound
+    [[maybe_unused]] const uint32_t my_img = a.i8_pair_images ? my_pair : my_qrow;     // int8: image per pair or per query
+    if constexpr (I8) my_bad16 = !(a.q_resu[my_img] <= 3.0e38f);         // non-finite query: no bound
     liml[lane] = ((uint32_t)lane < cnt && !my_bad16) ? (room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room) : 0u;
     if constexpr (QLDS) {
         constexpr uint32_t TPQ = 256 / NQ;
@@ -1730,7 +1734,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         float4 *dst = qs + q * G;
         const uint32_t sw = q & 15u;
         if constexpr (I8) {        // the image of the (query, this list) PAIR: the residual against the list's centre
-            const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_pair, (int)q, 64) * dim);
+            const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_img, (int)q, 64) * dim);
 #pragma unroll 4
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
         } else if constexpr (F16) {
@@ -1842,7 +1846,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 // |q - x| <= |vi - xi| / S + rq' + rx (rq' includes what the clamp cut off the query residual),
                 // |vi - xi|^2 = Nq + Nx - 2 dot <= Nq - 2 (dot - ceil(Nx / 2)); the reference's computed d2 exceeds the real
                 // one by at most the summation margin
-                const uint32_t pr = (uint32_t)__shfl((int)my_pair, (int)qi, 64);
+                const uint32_t pr = (uint32_t)__shfl((int)my_img, (int)qi, 64);
                 if (qi < cnt && maxs[g][r] > -(1 << 30)) {
                     const float n_ub = fmaxf((float)(a.q_n2i[pr] - 2 * maxs[g][r]) * 1.000001f + 2.0f, 0.0f);
                     const float d = sqrtf(n_ub) * 1.000001f / a.list_scale[c] + a.q_resu[pr] + rmax;
@@ -2261,7 +2265,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const uint32_t qic = qi < cnt ? qi : cnt - 1;
         const uint32_t pair = a.pairs[p0 + (prune ? s_perm[qic] : qic)];
         my_qrow[s] = pair / a.nprobe;
-        if constexpr (I8) my_pairi[s] = pair;
+        if constexpr (I8) my_pairi[s] = a.i8_pair_images ? pair : my_qrow[s];      // the image: per pair or per query
         my_lkth[s] = KEY_EMPTY;
         const float qn = a.query_norm2[my_qrow[s]];
         // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
@@ -2271,7 +2275,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 qst_pair[qi] = pair;
                 qst_cbase[qi] = a.cand_base[pair];
                 qst_qn[qi] = noskip ? __uint_as_float(0x7FC00000u) : qn;
-                if constexpr (I8) { qst_n2i[qi] = a.q_n2i[pair]; qst_res[qi] = a.q_res[pair]; }   // +inf: non-finite query
+                if constexpr (I8) { qst_n2i[qi] = a.q_n2i[my_pairi[s]]; qst_res[qi] = a.q_res[my_pairi[s]]; }   // +inf: non-finite query
             }
         } else {
             my_pair[s] = pair;
@@ -3963,6 +3967,60 @@ hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32
                               float *center, float *half, float *scale, float *radius, hipStream_t s) {
     if (n_clusters == 0) return hipSuccess;
     hipLaunchKernelGGL(list_center_kernel, dim3(n_clusters), dim3(256), 0, s, kmin, kmax, dim, list_off, center, half, scale, radius);
+    return hipGetLastError();
+}
+
+// The one-centre form (round 2's): per-dimension min / max over ALL lists -> centre and scale in entry 0 of scratch
+// tables (global_center_kernel), and, if that form is chosen, every list's entry overwritten with them
+// (broadcast_center_kernel) -- block_rows_i8_kernel and the screen kernels then need no second code path.
+__global__ __launch_bounds__(256) void global_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
+                                                           uint32_t n_clusters, uint32_t dim, const uint64_t *__restrict__ list_off,
+                                                           float *__restrict__ g_center, float *__restrict__ g_half_scale) {
+    __shared__ float wm[4];
+    float h = 0.0f;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (list_off[c + 1] == list_off[c]) continue;
+            const uint32_t a = kmin[(uint64_t)c * dim + d], b = kmax[(uint64_t)c * dim + d];
+            lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+        }
+        float ctr = 0.0f;
+        if (lo <= hi) {
+            const float flo = unsortable_bits(lo), fhi = unsortable_bits(hi);
+            ctr = 0.5f * flo + 0.5f * fhi;
+            h = fmaxf(h, fabsf(fmaxf(fhi - ctr, ctr - flo)));
+        }
+        g_center[d] = ctr;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h = fmaxf(h, __shfl_xor(h, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+        if (!(sc < 1.0e15f)) sc = 1.0e15f;
+        if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
+        g_half_scale[0] = h; g_half_scale[1] = sc;
+    }
+}
+__global__ __launch_bounds__(256) void broadcast_center_kernel(const float *__restrict__ g_center, const float *__restrict__ g_half_scale,
+                                                              uint32_t dim, float *__restrict__ center, float *__restrict__ half,
+                                                              float *__restrict__ scale) {
+    const uint32_t c = blockIdx.x;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) center[(uint64_t)c * dim + d] = g_center[d];
+    if (threadIdx.x == 0) { half[c] = g_half_scale[0]; scale[c] = g_half_scale[1]; }
+}
+hipError_t launch_global_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                                float *g_center, float *g_half_scale, hipStream_t s) {
+    hipLaunchKernelGGL(global_center_kernel, dim3(1), dim3(256), 0, s, kmin, kmax, n_clusters, dim, list_off, g_center, g_half_scale);
+    return hipGetLastError();
+}
+hipError_t launch_broadcast_center(const float *g_center, const float *g_half_scale, uint32_t n_clusters, uint32_t dim, float *center,
+                                   float *half, float *scale, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(broadcast_center_kernel, dim3(n_clusters), dim3(256), 0, s, g_center, g_half_scale, dim, center, half, scale);
     return hipGetLastError();
 }
 
