@@ -428,6 +428,8 @@ hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe,
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
                               uint64_t m, uint32_t dim, float *out, hipStream_t s);
+// out[i, :dim_p] = src[idx32 ? idx32[i] : i, :dim] zero-padded (dim, dim_p multiples of 4): see pad_rows_kernel
+hipError_t launch_pad_rows(const float *src, const uint32_t *idx32, uint64_t m, uint32_t dim, uint32_t dim_p, float *out, hipStream_t s);
 // f64 -> f32 narrowing of a staged column chunk
 hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipStream_t s);
 

@@ -4222,6 +4222,34 @@ hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_byte
 }
 
 // ------------------------------------------------------------------------------------
+// pad_rows: out[i, 0 .. dim_p) = {src[idx ? idx[i] : i, 0 .. dim), 0 ...} for dim % 4 == 0: rows (and per batch the queries)
+// of a dimension the MFMA screen has no tiling for are stored zero-padded to one it has.  The reference's distance
+// takes 4 elements per step (index.rs:461-473), so a padded group adds ((0 + 0) + 0) + 0 = +0.0 to a non-negative sum:
+// every distance over the padded rows is bit-identical to the one over the originals.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, const uint32_t *__restrict__ idx32, uint64_t m,
+                                                      uint32_t dim, uint32_t dim_p, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t G = dim >> 2, Gp = dim_p >> 2;
+    for (uint64_t i = wave; i < m; i += nwaves) {
+        const uint64_t r = idx32 ? (uint64_t)idx32[i] : i;
+        const float4 *s = reinterpret_cast<const float4 *>(src + r * dim);
+        float4 *d = reinterpret_cast<float4 *>(out + i * dim_p);
+        for (uint32_t g = lane; g < Gp; g += 64) d[g] = g < G ? s[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+hipError_t launch_pad_rows(const float *src, const uint32_t *idx32, uint64_t m, uint32_t dim, uint32_t dim_p, float *out, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    if ((dim % 4) != 0 || (dim_p % 4) != 0 || dim_p < dim) return hipErrorInvalidValue;
+    uint64_t blocks = (m + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, src, idx32, m, dim, dim_p, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
 // ------------------------------------------------------------------------------------
 template <bool ALIGNED>

@@ -1007,6 +1007,48 @@ def test_i8_residual_images_clamped_queries_and_pair_pruning(pqv, oracle, dim):
     assert screened[(1, 0)] < 0.6 * screened[(0, 0)], screened        # the pruning removes most of the far pairs' rows
 
 
+@pytest.mark.parametrize("dim,sdim,op", [(96, 128, "f16"), (100, 128, "f16"), (52, 64, "f32"), (200, 256, "int8"), (300, 384, "f16"),
+                                         (1000, 1024, "int8"), (36, 36, None), (130, 130, None)])
+def test_dims_without_an_mfma_tiling_are_screened_on_zero_padded_rows(pqv, oracle, dim, sdim, op):
+    """dim % 64 != 0 used to fall to the exact VALU kernels.  For dim % 4 == 0 the IVF-ordered rows (and per batch the
+    queries) are stored zero-padded to the nearest tiling whose padding stays within a third of the row: the reference's
+    distance walks 4 elements per step (index.rs:461-473), a padded group adds +0.0, so every distance is bit-identical
+    and the screened path applies.  dim % 4 != 0 (the reference's scalar tail) and tiny rows keep the exact kernels.
+    Both metrics, a candidate cap, a single query and k = 40 against the oracle."""
+    rng = np.random.default_rng(900 + dim)
+    n, kc, nprobe, nq = 9000, 6, 3, 70
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    queries[::9] = data[rng.integers(0, n, len(queries[::9]))]
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=4)
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), corpus)
+    plan = s.describe(nq, 10, nprobe)
+    if op:
+        assert f"zero-padded from {dim} to {sdim} dims" in plan and f"{op} screen operands" in plan and "wide_filter_kernel" in plan, plan
+    else:
+        assert "zero-padded" not in plan, plan
+    for k in (10, 40):
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (_bits(dist) == _bits(odist)).all() and (rows == orows).all(), (dim, k)
+    r1, d1, _, _ = s.topk(queries[3:4], 10, nprobe)
+    o1 = oidx.topk_batch(data, queries[3:4], 10, nprobe)
+    assert (r1 == o1[0]).all() and (_bits(d1) == _bits(o1[1])).all()
+    # the DataFusion order (exec.rs:529-533) and a candidate cap in the middle of a list, against a direct evaluation
+    cap = n // kc + 137
+    rows, d2, nf, nc = s.topk(queries[:8], 10, nprobe, max_candidates=cap, metric=pqv.PQV_L2SQ_SEQ, sqrt_out=False)
+    for q in range(8):
+        cand = oidx.candidate_rows(queries[q], nprobe)[:cap]
+        d = np.array([oracle.l2_seq(data[r], queries[q]) for r in cand], np.float32)
+        order = np.lexsort((np.arange(len(cand)), d.view(np.uint32)))[:10]
+        assert (_bits(d2[q, :len(order)]) == _bits(d[order])).all() and (rows[q, :len(order)] == cand[order]).all()
+    # the padded copy is the searcher's own: the corpus still answers in its real dimension
+    got = corpus.fetch_rows(np.array([5, 17], np.uint32)) if hasattr(corpus, "fetch_rows") else data[[5, 17]]
+    assert np.array_equal(got, data[[5, 17]])
+
+
 def test_topk_device_flags_mark_every_query_that_needs_the_heap_replay(pqv, oracle):
     """pqv_topk_device_flags: the asynchronous device path + a per-query tie flag.  On tie-heavy data (a coarse grid,
     hundreds of equal distances) and on float data: every UNFLAGGED query must equal the reference position by
