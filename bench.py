@@ -200,6 +200,10 @@ def main():
                          "and searches its OWN query batch (throughput mode, no data-path collective)")
     ap.add_argument("--single", type=int, default=100,
                     help="also time this many single-query calls (latency mode, p50 / p99); 0 disables")
+    ap.add_argument("--cabi-check", action="store_true",
+                    help="multi-rank runs: also run the exchange through the C ABI (pqv_shard_*: RCCL bound by the library) and compare; "
+                         "always on for --force-dist with one rank, opt-in beyond (a second communicator that has never met real "
+                         "multi-GPU hardware must not be able to cost a scaling run its line)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Gaussian-mixture pass that follows the default C3 run")
     ap.add_argument("--parity-queries", type=int, default=64, help="queries of the step checked bit for bit against the CPU oracle")
     ap.add_argument("--recall", type=int, default=32, help="queries checked against an exact brute force (0 disables)")
@@ -518,7 +522,7 @@ def main():
                               "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
                               "bytes_per_rank_per_step": nq * K * 8,
                               "collective": "one all_gather_into_tensor of packed {f32 distance, u32 row} pairs + shard_merge_kernel"}
-        if args.backend == "nccl":
+        if args.backend == "nccl" and (args.cabi_check or world == 1):
             # the same exchange through the C ABI (pqv_shard_*: RCCL bound by the library, what a Rust host calls).  A
             # cross-check only: every rank takes the same collectives whatever fails, and nothing here can cost the line.
             from pq_vector_amd.sharding import RcclShardComm
