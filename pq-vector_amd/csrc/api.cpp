@@ -755,6 +755,75 @@ struct ScreenedAssign {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// Round 3: the assignment as a dense f16 contraction + exact re-scoring (kernels.hip: assign_f16_kernel,
+// assign_rescore_kernel).  Rows and centroids are imaged as unit vectors about a common centre mu (the column mean of
+// the centroids: the distance is translation invariant, and |x - mu| |c - mu| is what scales the bound's slack); the
+// screen leaves a handful of candidate centroids per row, the exact pass evaluates those in the reference's order and
+// takes the argmin by (distance bits, index) -- index.rs:408-415's strict '<' in ascending order.  Needs dim % 4 == 0
+// and finite norms (NaN ordering is the reference's `<`, not the key order): otherwise the callers keep their old path.
+// ---------------------------------------------------------------------------------------
+struct GemmAssign {
+    uint32_t dim = 0, dim_p = 0, kc = 0, kc_pad = 0, cap = 32;
+    uint64_t chunk = 1u << 20;
+    const float *d_centroids = nullptr;
+    DevBuf mu, c16, cn2, x16, xn2, cand, cnt, flag;
+
+    static bool applicable(uint32_t dim, uint32_t kc) {
+        const char *e = std::getenv("PQV_ASSIGN_GEMM");          // 0 = off, n > 1 = smallest centroid count that takes this path
+        const long v = e ? std::strtol(e, nullptr, 10) : 128L;
+        return v != 0 && (dim % 4) == 0 && kc >= static_cast<uint32_t>(v > 1 ? v : 128) && static_cast<uint64_t>((dim + 31) / 32 * 32) * 2 * 320 < 0x7FFFFFFFull;
+    }
+    int finite(const float *v, uint64_t n, hipStream_t stream, bool *bad) {
+        uint32_t h = 0;
+        HIP_TRY(flag.ensure(sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), stream));
+        HIP_TRY(pqv::launch_nonfinite_flag(v, n, flag.as<uint32_t>(), stream));
+        HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *bad = h != 0;
+        return PQV_OK;
+    }
+    int set_centroids(const float *d_c, uint32_t k, uint32_t d, hipStream_t stream, bool *nonfinite) {
+        using namespace pqv;
+        dim = d; dim_p = (d + 31) / 32 * 32; kc = k; kc_pad = (k + 255) / 256 * 256; d_centroids = d_c;
+        HIP_TRY(mu.ensure(static_cast<size_t>(dim) * sizeof(float)));
+        HIP_TRY(c16.ensure(static_cast<size_t>(kc_pad) * dim_p * sizeof(uint16_t)));
+        HIP_TRY(cn2.ensure(static_cast<size_t>(kc_pad) * sizeof(float)));
+        HIP_TRY(launch_col_mean(d_c, kc, dim, mu.as<float>(), stream));
+        HIP_TRY(launch_center_normalize_f16(d_c, mu.as<float>(), kc, kc_pad, dim, dim_p, cn2.as<float>(), c16.p, stream));
+        return finite(cn2.as<float>(), kc, stream, nonfinite);
+    }
+    // cluster[0 .. n) for rows d_rows[0 .. n); *fallback = true if a row norm is not finite (the caller re-runs its old path)
+    int run(const float *d_rows, uint64_t n, uint32_t *d_cluster, hipStream_t stream, bool *fallback) {
+        using namespace pqv;
+        *fallback = false;
+        const uint64_t ch = std::min<uint64_t>(chunk, std::max<uint64_t>(1, n));
+        HIP_TRY(x16.ensure(ch * dim_p * sizeof(uint16_t)));
+        HIP_TRY(xn2.ensure(ch * sizeof(float)));
+        HIP_TRY(cand.ensure(ch * cap * sizeof(uint32_t)));
+        HIP_TRY(cnt.ensure(ch * sizeof(uint32_t)));
+        const float eps = 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
+        const float cm = static_cast<float>(dim + 16) * 2.384185791015625e-07f;
+        for (uint64_t r0 = 0; r0 < n; r0 += ch) {
+            const uint64_t m = std::min<uint64_t>(ch, n - r0);
+            const float *rows = d_rows + r0 * dim;
+            HIP_TRY(launch_center_normalize_f16(rows, mu.as<float>(), m, m, dim, dim_p, xn2.as<float>(), x16.p, stream));
+            bool bad = false;
+            if (int rc = finite(xn2.as<float>(), m, stream, &bad)) return rc;
+            if (bad) { *fallback = true; return PQV_OK; }
+            HIP_TRY(hipMemsetAsync(cnt.p, 0, m * sizeof(uint32_t), stream));
+            AssignF16Args a{};
+            a.x16 = x16.as<uint16_t>(); a.c16 = c16.as<uint16_t>(); a.xn2 = xn2.as<float>(); a.cn2 = cn2.as<float>();
+            a.m = m; a.kc = kc; a.kc_pad = kc_pad; a.dim_p = dim_p; a.eps = eps; a.cm = cm;
+            a.cand = cand.as<uint32_t>(); a.cand_cnt = cnt.as<uint32_t>(); a.cap = cap;
+            HIP_TRY(launch_assign_f16(a, stream));
+            HIP_TRY(launch_assign_rescore(rows, d_centroids, m, dim, kc, cand.as<uint32_t>(), cnt.as<uint32_t>(), cap, d_cluster + r0, stream));
+        }
+        return PQV_OK;
+    }
+};
+
 // d_data [n, dim] resident; writes d_centroids [k, dim] (device) and optionally the final
 // assignment (host).
 int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uint32_t max_iters,
@@ -863,11 +932,22 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     std::vector<uint32_t> rows;
     uint32_t iters = 0;
     ScreenedAssign screen;
-    const bool use_screen = ScreenedAssign::applicable(dim, k);
+    GemmAssign gemm;
+    const bool use_gemm = GemmAssign::applicable(dim, k);
+    const bool use_screen = !use_gemm && ScreenedAssign::applicable(dim, k);
     for (uint32_t iter = 0; iter < max_iters; ++iter) {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, (static_cast<size_t>(k) + 1) * sizeof(unsigned long long), stream));
         unsigned long long *d_changed = d_counts.as<unsigned long long>() + k;
         bool exact_assign = !use_screen;
+        if (use_gemm) {
+            bool bad_c = false, bad_r = false;
+            if (int rc = gemm.set_centroids(d_centroids, k, dim, stream, &bad_c)) return rc;
+            if (!bad_c) {
+                if (int rc = gemm.run(d_data, n, d_cur, stream, &bad_r)) return rc;
+                if (!bad_r) HIP_TRY(launch_count_changed(d_cur, d_prev, n, d_changed, stream));
+            }
+            exact_assign = bad_c || bad_r;
+        }
         if (use_screen) {
             bool bad_c = false, bad_r = false;
             if (int rc = screen.set_centroids(d_centroids, k, dim, stream, &bad_c)) return rc;
@@ -894,7 +974,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
                                     k, d_centroids, stream));                          // :436-453
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    g_build_stats[1] = now_s() - t_pp1; g_build_stats[2] = iters; g_build_stats[6] = use_screen ? 1.0 : 0.0;
+    g_build_stats[1] = now_s() - t_pp1; g_build_stats[2] = iters; g_build_stats[6] = use_gemm ? 2.0 : use_screen ? 1.0 : 0.0;
     if (verbose()) std::fprintf(stderr, "[pqv] Lloyd: %u iterations over %llu rows in %.3f s\n", iters,
                                 (unsigned long long)n, now_s() - t_pp1);
     if (iters_run) *iters_run = iters;
@@ -945,7 +1025,19 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     DevBuf d_cluster;
     HIP_TRY(d_cluster.alloc(n * sizeof(uint32_t)));
     bool exact_assign = true;
-    if (ScreenedAssign::applicable(dim, static_cast<uint32_t>(k))) {
+    double assign_form = 0.0;
+    if (GemmAssign::applicable(dim, static_cast<uint32_t>(k))) {
+        GemmAssign gemm;
+        bool bad_c = false, bad_r = false;
+        if (int rc = gemm.set_centroids(d_centroids.as<float>(), static_cast<uint32_t>(k), dim, stream, &bad_c)) return rc;
+        if (!bad_c) {
+            if (int rc = gemm.run(corpus->d_rows, n, d_cluster.as<uint32_t>(), stream, &bad_r)) return rc;
+            exact_assign = bad_r;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));     // the context's buffers are released at scope exit
+        if (!exact_assign) assign_form = 2.0;
+    }
+    if (exact_assign && ScreenedAssign::applicable(dim, static_cast<uint32_t>(k))) {
         ScreenedAssign screen;
         bool bad_c = false, bad_r = false;
         if (int rc = screen.set_centroids(d_centroids.as<float>(), static_cast<uint32_t>(k), dim, stream, &bad_c)) return rc;
@@ -976,7 +1068,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         delete idx;
         return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
     }
-    g_build_stats[3] = t_fa1 - t_fa0; g_build_stats[4] = now_s() - t_fa1; g_build_stats[5] = exact_assign ? 0.0 : 1.0;
+    g_build_stats[3] = t_fa1 - t_fa0; g_build_stats[4] = now_s() - t_fa1; g_build_stats[5] = assign_form > 0.0 ? assign_form : exact_assign ? 0.0 : 1.0;
     g_build_stats[7] = static_cast<double>(sample_size);
     if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
                                 (unsigned long long)n, t_fa1 - t_fa0, now_s() - t_fa1);

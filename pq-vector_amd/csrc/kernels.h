@@ -346,6 +346,27 @@ struct BruteF16Args {
     uint32_t     cap;
 };
 hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s);
+// The k-means assignment on the f16 matrix pipe (kernels.hip: assign_f16_kernel): images of (row - mu) / |row - mu| * 2^8
+// for rows and centroids (launch_center_normalize_f16; the centroid table padded to kc_pad rows, a multiple of 256),
+// candidate lists per row, then launch_assign_rescore picks the exact argmin among them.
+struct AssignF16Args {
+    const uint16_t *x16;     // [m, dim_p]
+    const uint16_t *c16;     // [kc_pad, dim_p]
+    const float    *xn2;     // [m]  |row - mu|^2
+    const float    *cn2;     // [kc] |centroid - mu|^2
+    uint64_t        m;
+    uint32_t        kc, kc_pad, dim_p;
+    float           eps, cm;  // image dot-product bound (cosine scale); the reference summation margin
+    uint32_t       *cand;     // [m][cap] candidate centroid ids
+    uint32_t       *cand_cnt; // [m] (zeroed by the caller; may exceed cap: the row is then compared with every centroid)
+    uint32_t        cap;
+};
+hipError_t launch_assign_f16(const AssignF16Args &a, hipStream_t s);
+hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint64_t m, uint32_t dim, uint32_t kc, const uint32_t *cand,
+                                 const uint32_t *cand_cnt, uint32_t cap, uint32_t *cluster, hipStream_t s);
+hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint64_t n, uint64_t n_pad, uint32_t dim, uint32_t dim_p,
+                                       float *out_n2, void *out, hipStream_t s);
+hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s);
 hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s);
 hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipStream_t s);
 // per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2, mode 2 = max |x_i|

@@ -3587,6 +3587,281 @@ hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipSt
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Round 3: the k-means assignment (index.rs:395-430 Lloyd, :189-206 + :244-257 final) as a dense contraction on the f16
+// matrix pipe + exact re-scoring -- the brute-force design with the roles swapped: every ROW keeps a threshold and a
+// candidate list, the CENTROIDS are the streamed side.
+//
+//   images      x^ = (x - mu) / |x - mu| * 2^8 in f16 for rows and centroids alike (mu: any fixed vector -- the distance is
+//               translation invariant; centring shrinks |x - mu| |c - mu| and with it the bound's slack)
+//   assign_f16_kernel   one block = 128 rows against ALL centroids, 256 at a time (4 waves as 2 x 2, 64 rows x 128
+//               centroids each, v_mfma_f32_32x32x16_f16, K in 32-value stages through double-buffered LDS).  With s~ the image
+//               dot product / 2^16:  d~ = |a|^2 + |b|^2 - 2 |a||b| s~,  |d~ - d| <= err = 2 |a||b| eps + 4e-6 (|a|^2 + |b|^2)
+//               (eps as in brute_f16_kernel), and the reference's computed distance lies within (1 +- cm) of d.  Per row the
+//               smallest UPPER bound seen so far is a running threshold (LDS); every centroid whose LOWER bound does not
+//               exceed it is appended to the row's candidate list.  The true argmin is never dropped: its lower bound is
+//               below its own upper bound, which is below every threshold the row ever had.
+//   assign_rescore_kernel   exact reference-order distances (index.rs:461-480) of a row's candidates, four lanes per row,
+//               argmin by (distance bits, centroid index) = strict '<' in ascending index order; a row whose list
+//               overflowed is compared with every centroid.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void assign_f16_kernel(const AssignF16Args a) {
+    __shared__ float4 As4[2][BH_BM * 4];
+    __shared__ float4 Bs4[2][BH_BN * 4];
+    __shared__ uint32_t thr_s[BH_BM];        // running threshold per row: bits of a non-negative float
+    __shared__ float xn2_s[BH_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint64_t m0 = (uint64_t)blockIdx.x * BH_BM;
+    const uint32_t dp = a.dim_p;
+    const int ld_r = tid >> 2, ld_ch = tid & 3;
+    float4 ra[2], rb[4];
+    const uint64_t qleft = (a.m - m0) * dp * 2;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(a.x16 + m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, r64_b = 64u * dp * 2;
+    if (tid < BH_BM) {
+        thr_s[tid] = 0x7F800000u;            // +inf
+        xn2_s[tid] = m0 + tid < a.m ? a.xn2[m0 + tid] : 0.0f;
+    }
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[2], rowb[4], swa[2], swb[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { rowb[t] = wn * 128 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
+    const uint32_t nk = dp / BH_BK;
+    const float inv = 1.52587890625e-05f;    // 2^-16
+
+    for (uint32_t c0 = 0; c0 < a.kc; c0 += BH_BN) {
+        const uint64_t vleft = (uint64_t)(a.kc_pad - c0) * dp * 2;
+        const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(a.c16 + (uint64_t)c0 * dp), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+        auto fetch = [&](uint32_t k0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * r64_b);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * r64_b);
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int r = ld_r + 64 * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { const int r = ld_r + 64 * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
+        };
+        f32x16_t acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (uint32_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1u);
+            if (kt + 1 < nk) fetch((kt + 1) * BH_BK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x8_t av[2], bv[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+            }
+            if (kt + 1 < nk) stash(buf ^ 1);
+            __syncthreads();
+        }
+        // ---- bounds of this centroid tile.  C/D layout: col = lane & 31 (centroid), row = (r & 3) + 8 (r >> 2) + 4 lk
+        float cn2[4];
+        bool cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t vj = c0 + wn * 128 + j * 32 + l31;
+            cv[j] = vj < a.kc;
+            cn2[j] = cv[j] ? a.cn2[vj] : 0.0f;
+        }
+        auto bounds = [&](int i, int j, int r, float &lb, float &ub) {
+            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float xn = xn2_s[ml], nn = xn + cn2[j];
+            const float qv = sqrtf(xn * cn2[j]) * 1.000001f;
+            const float dt = nn - 2.0f * qv * (acc[i][j][r] * inv);
+            const float err = 2.0f * qv * a.eps + 4.0e-6f * nn;
+            ub = fmaxf(dt + err, 0.0f) * (1.0f + a.cm) + 1.0e-30f;
+            lb = fmaxf(dt - err, 0.0f) * (1.0f - a.cm);
+        };
+        // (1) the rows' running thresholds: smallest upper bound of this tile, reduced over the 32 centroid lanes
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lb, ub;
+                    bounds(i, j, r, lb, ub);
+                    if (cv[j] && ub < mn) mn = ub;                  // (a NaN bound never lowers a threshold)
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+                if (l31 == 0 && mn < INFINITY)
+                    atomicMin(&thr_s[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk], __float_as_uint(mn));
+            }
+        }
+        __syncthreads();
+        // (2) candidates: every centroid whose lower bound does not exceed its row's threshold (NaN bounds are kept)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float thr = __uint_as_float(thr_s[ml]);
+                const uint64_t row = m0 + ml;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lb, ub;
+                    bounds(i, j, r, lb, ub);
+                    if (cv[j] && row < a.m && !(lb > thr)) {
+                        const uint32_t slot = atomicAdd(&a.cand_cnt[row], 1u);
+                        if (slot < a.cap) a.cand[row * a.cap + slot] = c0 + wn * 128 + j * 32 + l31;
+                    }
+                }
+            }
+        }
+        __syncthreads();          // the LDS stages are reused by the next centroid tile
+    }
+}
+hipError_t launch_assign_f16(const AssignF16Args &a, hipStream_t s) {
+    if (a.m == 0 || a.kc == 0) return hipSuccess;
+    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 320 >= 0x7FFFFFFFull || (a.kc_pad % BH_BN) != 0 || a.kc_pad < a.kc)
+        return hipErrorInvalidValue;
+    const uint64_t blocks = (a.m + BH_BM - 1) / BH_BM;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assign_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// exact pass: four lanes per row, each walking candidates 4 t + (lane & 3) of its row in the reference's order
+__global__ __launch_bounds__(256) void assign_rescore_kernel(const float *__restrict__ rows, const float *__restrict__ centroids, uint64_t m,
+                                                            uint32_t dim, uint32_t kc, const uint32_t *__restrict__ cand,
+                                                            const uint32_t *__restrict__ cand_cnt, uint32_t cap, uint32_t *__restrict__ cluster) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (uint32_t)(lane >> 2);
+    const uint32_t cl = (uint32_t)lane & 3u;
+    const bool live = row < m;
+    uint32_t cnt = live ? cand_cnt[row] : 0u;
+    const bool all = cnt > cap;                       // list overflowed: every centroid is a candidate
+    if (all) cnt = kc;
+    const float *x = rows + (live ? row : 0) * dim;
+    const uint32_t G = dim >> 2;
+    uint64_t best = KEY_EMPTY;
+    uint32_t rounds = (cnt + 3) >> 2;
+    // (the loop count differs per lane: no cross-lane operation inside)
+    for (uint32_t t = 0; t < rounds; ++t) {
+        const uint32_t ci = 4 * t + cl;
+        if (ci >= cnt) break;
+        const uint32_t j = all ? ci : cand[row * cap + ci];
+        const float *c = centroids + (uint64_t)j * dim;
+        float sum = 0.0f;
+        uint32_t g = 0;
+        for (; g + 8 <= G; g += 8) {
+            float4 xv[8], cvv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = load4<true>(x + (g + u) * 4); cvv[u] = load4<true>(c + (g + u) * 4); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d0 = xv[u].x - cvv[u].x, d1 = xv[u].y - cvv[u].y, d2 = xv[u].z - cvv[u].z, d3 = xv[u].w - cvv[u].w;
+                float tt = d0 * d0 + d1 * d1;
+                tt = tt + d2 * d2;
+                sum = sum + (tt + d3 * d3);
+            }
+        }
+        for (; g < G; ++g) {
+            const float4 xv = load4<true>(x + g * 4), cv = load4<true>(c + g * 4);
+            const float d0 = xv.x - cv.x, d1 = xv.y - cv.y, d2 = xv.z - cv.z, d3 = xv.w - cv.w;
+            float tt = d0 * d0 + d1 * d1;
+            tt = tt + d2 * d2;
+            sum = sum + (tt + d3 * d3);
+        }
+        const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | j;
+        best = key < best ? key : best;
+    }
+    // the row's four lanes: smallest (distance bits, index) = strict '<' in ascending centroid order (index.rs:408-415)
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint64_t o = shfl_u64(best, lane ^ off);
+        best = o < best ? o : best;
+    }
+    if (live && cl == 0) cluster[row] = best == KEY_EMPTY ? 0u : (uint32_t)best;
+}
+hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint64_t m, uint32_t dim, uint32_t kc, const uint32_t *cand,
+                                 const uint32_t *cand_cnt, uint32_t cap, uint32_t *cluster, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    if ((dim % 4) != 0) return hipErrorInvalidValue;
+    const uint64_t blocks = (m + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assign_rescore_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, centroids, m, dim, kc, cand, cand_cnt, cap, cluster);
+    return hipGetLastError();
+}
+
+// |row - mu|^2 and 1 / |row - mu| per row, and the f16 image of (row - mu) / |row - mu| * 2^8 zero-padded to dim_p:
+// one wave per row (mu == nullptr: no centring).  pad_to rows beyond n are written as zero rows (the centroid table is
+// padded to a multiple of 256 rows).
+__global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *__restrict__ rows, const float *__restrict__ mu, uint64_t n,
+                                                                  uint64_t n_pad, uint32_t dim, uint32_t dim_p, float *__restrict__ out_n2,
+                                                                  uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n_pad; r += nw) {
+        if (r >= n) {
+            for (uint32_t e = lane; e < dim_p; e += 64) out[r * dim_p + e] = 0;
+            continue;
+        }
+        const float *p = rows + r * dim;
+        float acc = 0.0f;
+        for (uint32_t e = lane; e < dim; e += 64) { const float v = p[e] - (mu ? mu[e] : 0.0f); acc = fmaf(v, v, acc); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out_n2[r] = acc;
+        const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            float v = e < dim ? (p[e] - (mu ? mu[e] : 0.0f)) * sc : 0.0f;
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            const _Float16 h = (_Float16)v;
+            out[r * dim_p + e] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint64_t n, uint64_t n_pad, uint32_t dim, uint32_t dim_p,
+                                       float *out_n2, void *out, hipStream_t s) {
+    if (n_pad == 0) return hipSuccess;
+    uint64_t blocks = (n_pad + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(center_normalize_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, mu, n, n_pad, dim, dim_p, out_n2,
+                       static_cast<uint16_t *>(out));
+    return hipGetLastError();
+}
+// mu[d] = mean over the k rows of m[., d] (one block)
+__global__ __launch_bounds__(256) void col_mean_kernel(const float *__restrict__ m, uint32_t k, uint32_t dim, float *__restrict__ mu) {
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        float acc = 0.0f;
+        for (uint32_t r = 0; r < k; ++r) acc += m[(uint64_t)r * dim + d];
+        mu[d] = k ? acc / (float)k : 0.0f;
+    }
+}
+hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s) {
+    hipLaunchKernelGGL(col_mean_kernel, dim3(1), dim3(256), 0, s, m, k, dim, mu);
+    return hipGetLastError();
+}
+
 // one wave per row; f32 partial sums, wave-reduced
 __global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ rows, uint64_t n,
                                                        uint32_t dim, int mode, float *__restrict__ out) {

@@ -816,21 +816,47 @@ def test_running_thresholds_with_hundreds_of_tied_candidates(pqv, oracle, monkey
     (9000, 128, 96, 2),          # forced at a small centroid count: fewer seeds than the seed window
     (6000, 320, 70, 2),          # long rows: blocked global query copy
     (5000, 768, 520, None),      # C3-shaped rows
+    (7000, 100, 300, 2),         # dim % 32 != 0: the f16 images are zero-padded (the f32 screen does not apply: exact kernel)
+    (40000, 16, 257, 2),         # one centroid past a 256-tile; short rows
 ])
 def test_screened_assignment_builds_identical_index(pqv, oracle, monkeypatch, n, dim, kc, min_k):
-    """Index build with the MFMA-screened assignment (Lloyd iterations and final assignment) must produce
-    the oracle's blob byte for byte, and the same blob as the exact VALU assignment."""
+    """Index build with the f16 contraction + exact re-scoring (round 3: assign_f16_kernel), with the f32 MFMA-screened
+    assignment and with the exact VALU assignment (Lloyd iterations and final assignment alike) must produce the
+    oracle's blob byte for byte."""
     rng = np.random.default_rng(n + dim + kc)
     data = rng.random((n, dim), dtype=np.float32)
     data[::5] = np.round(data[::5] * 4) / 4          # coarse values: exact distance ties between centroids occur
+    data[7::11] = data[3::11][:len(data[7::11])]      # duplicated rows
     want = oracle.build_index(data, n_clusters=kc, workers=3, max_iters=4, seed=11).to_bytes()
     corpus = pqv.Corpus.upload(data)
     blobs = {}
-    for mode in ("screen", "exact"):
+    for mode in ("gemm", "screen", "exact"):
+        monkeypatch.setenv("PQV_ASSIGN_GEMM", (str(min_k) if min_k else "1") if mode == "gemm" else "0")
         monkeypatch.setenv("PQV_ASSIGN_SCREEN", "0" if mode == "exact" else (str(min_k) if min_k else "1"))
         blobs[mode] = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(4).seed(11).workers(3).build().to_bytes()
     assert blobs["exact"] == want
     assert blobs["screen"] == want
+    assert blobs["gemm"] == want
+
+
+def test_gemm_assignment_with_hostile_geometry(pqv, oracle, monkeypatch):
+    """The f16 screen of the assignment images rows and centroids as unit vectors about the centroids' mean.  Data far
+    from the origin with a tiny spread (the centring carries it), centroids that coincide (k-means++ on duplicated rows:
+    exact ties, lowest index must win), one cluster 10^4 times wider than the others (every candidate list of its rows
+    overflows: those rows are compared with every centroid) and rows equal to the mean (zero image): the blob must stay
+    the oracle's."""
+    rng = np.random.default_rng(404)
+    dim, kc = 64, 200
+    tight = (rng.random((6000, dim), dtype=np.float32) * np.float32(0.01) + np.float32(500.0)).astype(np.float32)
+    dup = np.repeat(tight[:50], 20, axis=0)
+    wide = (rng.standard_normal((3000, dim)) * 100.0 + 500.0).astype(np.float32)
+    data = np.ascontiguousarray(np.concatenate([tight, dup, wide]).astype(np.float32))
+    data = data[rng.permutation(len(data))]
+    monkeypatch.setenv("PQV_ASSIGN_GEMM", "2")
+    for seed in (1, 2):
+        want = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=5, seed=seed).to_bytes()
+        got = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).max_iters(5).seed(seed).workers(2).build().to_bytes()
+        assert got == want, seed
 
 
 def _fuzz_case(pqv, oracle, seed):
