@@ -805,13 +805,14 @@ struct GemmAssign {
         HIP_TRY(cnt.ensure(ch * sizeof(uint32_t)));
         const float eps = 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
         const float cm = static_cast<float>(dim + 16) * 2.384185791015625e-07f;
+        // (one host check of the row norms after all chunks: a non-finite one sends the whole call to the caller's old path)
+        HIP_TRY(flag.ensure(sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), stream));
         for (uint64_t r0 = 0; r0 < n; r0 += ch) {
             const uint64_t m = std::min<uint64_t>(ch, n - r0);
             const float *rows = d_rows + r0 * dim;
             HIP_TRY(launch_center_normalize_f16(rows, mu.as<float>(), m, m, dim, dim_p, xn2.as<float>(), x16.p, stream));
-            bool bad = false;
-            if (int rc = finite(xn2.as<float>(), m, stream, &bad)) return rc;
-            if (bad) { *fallback = true; return PQV_OK; }
+            HIP_TRY(launch_nonfinite_flag(xn2.as<float>(), m, flag.as<uint32_t>(), stream));
             HIP_TRY(hipMemsetAsync(cnt.p, 0, m * sizeof(uint32_t), stream));
             AssignF16Args a{};
             a.x16 = x16.as<uint16_t>(); a.c16 = c16.as<uint16_t>(); a.xn2 = xn2.as<float>(); a.cn2 = cn2.as<float>();
@@ -820,6 +821,10 @@ struct GemmAssign {
             HIP_TRY(launch_assign_f16(a, stream));
             HIP_TRY(launch_assign_rescore(rows, d_centroids, m, dim, kc, cand.as<uint32_t>(), cnt.as<uint32_t>(), cap, d_cluster + r0, stream));
         }
+        uint32_t h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *fallback = h != 0;
         return PQV_OK;
     }
 };

@@ -3827,6 +3827,45 @@ __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *
         }
         const float *p = rows + r * dim;
         float acc = 0.0f;
+        if ((dim & 7u) == 0 && dim <= 2048) {
+            // 8 values (two 16-byte loads) per lane and step, kept in registers between the norm and the scaling pass
+            float4 v[4][2];
+            const uint32_t G8 = dim >> 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t g = (uint32_t)lane + 64u * (uint32_t)u;
+                if (g < G8) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(p + g * 8);
+                    float4 a0 = pp[0], a1 = pp[1];
+                    if (mu) {
+                        const float4 *mm = reinterpret_cast<const float4 *>(mu + g * 8);
+                        const float4 m0 = mm[0], m1 = mm[1];
+                        a0.x -= m0.x; a0.y -= m0.y; a0.z -= m0.z; a0.w -= m0.w; a1.x -= m1.x; a1.y -= m1.y; a1.z -= m1.z; a1.w -= m1.w;
+                    }
+                    v[u][0] = a0; v[u][1] = a1;
+                    acc = fmaf(a0.x, a0.x, acc); acc = fmaf(a0.y, a0.y, acc); acc = fmaf(a0.z, a0.z, acc); acc = fmaf(a0.w, a0.w, acc);
+                    acc = fmaf(a1.x, a1.x, acc); acc = fmaf(a1.y, a1.y, acc); acc = fmaf(a1.z, a1.z, acc); acc = fmaf(a1.w, a1.w, acc);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) out_n2[r] = acc;
+            const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+            auto cl = [&](float x) { return fminf(fmaxf(x * sc, -65504.0f), 65504.0f); };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t g = (uint32_t)lane + 64u * (uint32_t)u;
+                if (g < (dim_p >> 3)) {
+                    f16x8_t h = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (g < G8) {
+                        h[0] = (_Float16)cl(v[u][0].x); h[1] = (_Float16)cl(v[u][0].y); h[2] = (_Float16)cl(v[u][0].z); h[3] = (_Float16)cl(v[u][0].w);
+                        h[4] = (_Float16)cl(v[u][1].x); h[5] = (_Float16)cl(v[u][1].y); h[6] = (_Float16)cl(v[u][1].z); h[7] = (_Float16)cl(v[u][1].w);
+                    }
+                    *reinterpret_cast<float4 *>(out + r * dim_p + g * 8) = __builtin_bit_cast(float4, h);
+                }
+            }
+            continue;
+        }
         for (uint32_t e = lane; e < dim; e += 64) { const float v = p[e] - (mu ? mu[e] : 0.0f); acc = fmaf(v, v, acc); }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -3849,16 +3888,23 @@ hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint6
                        static_cast<uint16_t *>(out));
     return hipGetLastError();
 }
-// mu[d] = mean over the k rows of m[., d] (one block)
+// mu[d] = mean over the k rows of m[., d]: one block per 64 columns, four row slices per column reduced through LDS
 __global__ __launch_bounds__(256) void col_mean_kernel(const float *__restrict__ m, uint32_t k, uint32_t dim, float *__restrict__ mu) {
-    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
-        float acc = 0.0f;
-        for (uint32_t r = 0; r < k; ++r) acc += m[(uint64_t)r * dim + d];
-        mu[d] = k ? acc / (float)k : 0.0f;
+    __shared__ float part[4][64];
+    const uint32_t d = blockIdx.x * 64u + (threadIdx.x & 63u), sl = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (d < dim)
+        for (uint32_t r = sl; r < k; r += 4) acc += m[(uint64_t)r * dim + d];
+    part[sl][threadIdx.x & 63u] = acc;
+    __syncthreads();
+    if (sl == 0 && d < dim) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        mu[d] = k ? t / (float)k : 0.0f;
     }
 }
 hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s) {
-    hipLaunchKernelGGL(col_mean_kernel, dim3(1), dim3(256), 0, s, m, k, dim, mu);
+    if (dim == 0) return hipSuccess;
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, m, k, dim, mu);
     return hipGetLastError();
 }
 
