@@ -137,15 +137,22 @@ def build_record(n, dim, kc, build_s):
     kpp, lloyd, iters, fa, host, fa_screen, lloyd_screen, sample = list(st)
     flops = 2.0 * n * kc * dim
     tf = flops / fa / 1e12 if fa > 0 else 0.0
+    gemm = fa_screen >= 2
+    peak = 2500.0 if gemm else 157.3
     return {"seconds": build_s, "vectors_per_s": n / build_s,
             "phases_s": {"kmeans_pp": kpp, "lloyd": lloyd, "lloyd_iterations": int(iters), "final_assignment": fa,
                          "host_list_build": host, "sample_rows": int(sample)},
-            "roofline": {"bound": "mfma", "kernel": "final assignment: wide_seed_kernel + seed_select_kernel + wide_filter_kernel<f32 operands> + merge_kernel"
-                                                     if fa_screen else "final assignment: assign_kernel (exact-order VALU)",
-                         "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("final assignment: center_normalize_f16_kernel + assign_f16_kernel (f16 contraction against all centroids) + "
+                                    "assign_rescore_kernel (exact order)") if gemm else
+                                   "final assignment: wide_seed_kernel + seed_select_kernel + wide_filter_kernel<f32 operands> + merge_kernel"
+                                   if fa_screen else "final assignment: assign_kernel (exact-order VALU)",
+                         "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                         "frac_of_f32_mfma_peak": tf / 157.3,
                          "algo_flops": flops,
-                         "note": "2 n k_c dim flops / the wall time of the whole final-assignment phase (threshold sample, screen, exact "
-                                 "re-evaluation of the survivors, top-1 merge, download of the assignment): a lower bound for the screen kernel"}}
+                         "note": "2 n k_c dim flops / the wall time of the whole final-assignment phase (images, contraction, exact "
+                                 "re-scoring of the candidates, download of the assignment): a lower bound for the contraction kernel; "
+                                 "peak = dense f16 MFMA for the f16 contraction, f32 MFMA for the f32 screen"}}
 
 
 def self_launch(n):

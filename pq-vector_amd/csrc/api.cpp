@@ -820,6 +820,15 @@ struct GemmAssign {
             a.cand = cand.as<uint32_t>(); a.cand_cnt = cnt.as<uint32_t>(); a.cap = cap;
             HIP_TRY(launch_assign_f16(a, stream));
             HIP_TRY(launch_assign_rescore(rows, d_centroids, m, dim, kc, cand.as<uint32_t>(), cnt.as<uint32_t>(), cap, d_cluster + r0, stream));
+            if (verbose() && r0 == 0 && n >= 65536) {      // candidates the screen left per row (first chunk)
+                std::vector<uint32_t> hc(m);
+                HIP_TRY(hipMemcpyAsync(hc.data(), cnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                uint64_t sum = 0, over = 0; uint32_t mx = 0;
+                for (uint32_t c : hc) { sum += c; mx = std::max(mx, c); over += c > cap; }
+                std::fprintf(stderr, "[pqv] f16 assignment: %.2f candidates per row (max %u, %llu rows over the %u-entry list) of %u centroids\n",
+                             static_cast<double>(sum) / static_cast<double>(m), mx, (unsigned long long)over, cap, kc);
+            }
         }
         uint32_t h = 0;
         HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, stream));

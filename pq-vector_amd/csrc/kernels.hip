@@ -3621,9 +3621,12 @@ __global__ __launch_bounds__(256, 2) void assign_f16_kernel(const AssignF16Args 
     const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t *>(a.x16 + m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
     const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, r64_b = 64u * dp * 2;
+    __shared__ float xs_s[BH_BM];            // |row - mu| (the square roots are taken once per row / centroid, not per pair)
     if (tid < BH_BM) {
         thr_s[tid] = 0x7F800000u;            // +inf
-        xn2_s[tid] = m0 + tid < a.m ? a.xn2[m0 + tid] : 0.0f;
+        const float xn = m0 + tid < a.m ? a.xn2[m0 + tid] : 0.0f;
+        xn2_s[tid] = xn;
+        xs_s[tid] = sqrtf(xn) * 1.000001f;
     }
     const int l31 = lane & 31, lk = lane >> 5;
     int rowa[2], rowb[4], swa[2], swb[4];
@@ -3680,18 +3683,19 @@ __global__ __launch_bounds__(256, 2) void assign_f16_kernel(const AssignF16Args 
             __syncthreads();
         }
         // ---- bounds of this centroid tile.  C/D layout: col = lane & 31 (centroid), row = (r & 3) + 8 (r >> 2) + 4 lk
-        float cn2[4];
+        float cn2[4], cs[4];
         bool cv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t vj = c0 + wn * 128 + j * 32 + l31;
             cv[j] = vj < a.kc;
             cn2[j] = cv[j] ? a.cn2[vj] : 0.0f;
+            cs[j] = sqrtf(cn2[j]) * 1.000001f;
         }
         auto bounds = [&](int i, int j, int r, float &lb, float &ub) {
             const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             const float xn = xn2_s[ml], nn = xn + cn2[j];
-            const float qv = sqrtf(xn * cn2[j]) * 1.000001f;
+            const float qv = xs_s[ml] * cs[j];                      // >= |a| |b|
             const float dt = nn - 2.0f * qv * (acc[i][j][r] * inv);
             const float err = 2.0f * qv * a.eps + 4.0e-6f * nn;
             ub = fmaxf(dt + err, 0.0f) * (1.0f + a.cm) + 1.0e-30f;
