@@ -3396,56 +3396,66 @@ hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
 // MFMAs, 96 B/clk/CU at the full matrix rate.  The grid is 1-D and XCD-aware: the 8 query tiles of one row tile run
 // back to back on ONE XCD, so a row tile leaves HBM once and serves the other seven from that XCD's L2.
 // ------------------------------------------------------------------------------------
-constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;
+constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;       // assign_f16_kernel's tile (and the 4-wave form of brute_f16_kernel)
 
-__global__ __launch_bounds__(256, 2) void brute_f16_kernel(const BruteF16Args a) {
-    __shared__ float4 As4[2][BH_BM * 4];
-    __shared__ float4 Bs4[2][BH_BN * 4];
-    __shared__ unsigned long long thr_s[BH_BM];
-    __shared__ float qaux_s[BH_BM];
+// NWM x NWN waves, each a (32 TM) x (32 TN) sub-tile: block tile BM = 32 TM NWM queries x BN = 32 TN NWN rows.
+//   <2, 2, 2, 4>: 128 x 256, 256 threads, two blocks per CU (round 3's first form: 0.29 of the f16 peak on C5 -- PMC: the
+//                 matrix pipe busy 29 % of the time, 8.4 TB/s of L2 reads with 92 % hits: bound by the L2 -> LDS traffic
+//                 of a tile that does 85 flops per staged byte)
+//   <2, 4, 4, 2>: 256 x 256, 512 threads, one block per CU: 128 flops per staged byte
+template <int NWM, int NWN, int TM, int TN>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
+    constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
+    constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;          // 16-byte chunks a thread stages per K stage
+    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "staging split");
+    __shared__ float4 As4[2][BM * 4];
+    __shared__ float4 Bs4[2][BN * 4];
+    __shared__ unsigned long long thr_s[BM];
+    __shared__ float qaux_s[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     // id -> (XCD, slot): XCD x takes the row tiles = x (mod 8), each followed by all of its query tiles
-    const uint32_t ny = (a.nq + BH_BM - 1) / BH_BM;
+    const uint32_t ny = (a.nq + BM - 1) / BM;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint64_t vt = (uint64_t)(slot / ny) * 8u + xcd;
     const uint32_t qt = slot % ny;
-    const uint64_t n0 = a.row_begin + vt * BH_BN;
+    const uint64_t n0 = a.row_begin + vt * BN;
     if (n0 >= a.row_end) return;
-    const uint32_t m0 = qt * BH_BM;
+    const uint32_t m0 = qt * BM;
     const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32); 2 bytes each
 
-    const int ld_r = tid >> 2, ld_ch = tid & 3;      // staging: row ld_r (+ 64 h), 16-byte chunk ld_ch of the stage
-    float4 ra[2], rb[4];
+    constexpr int RPS = NT / 4;                      // rows one staging step of the block covers
+    const int ld_r = tid >> 2, ld_ch = tid & 3;      // staging: row ld_r (+ RPS h), 16-byte chunk ld_ch of the stage
+    float4 ra[CA], rb[CB];
     const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * dp * 2 : 0, vleft = (a.row_end - n0) * dp * 2;
     const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t *>(a.q16 + (uint64_t)m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
     const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t *>(a.v16 + n0 * dp), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
-    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, r64_b = 64u * dp * 2;
+    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, step_b = (uint32_t)RPS * dp * 2;
     auto fetch = [&](uint32_t k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * r64_b);
+        for (int h = 0; h < CA; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * step_b);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * r64_b);
+        for (int h = 0; h < CB; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * step_b);
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int r = ld_r + 64 * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
+        for (int h = 0; h < CA; ++h) { const int r = ld_r + RPS * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) { const int r = ld_r + 64 * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
+        for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
     };
 
-    f32x16_t acc[2][4];
+    f32x16_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if (tid < BH_BM) {
+    if (tid < BM) {
         const uint32_t qi = m0 + tid;
         thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
         qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
@@ -3458,25 +3468,25 @@ __global__ __launch_bounds__(256, 2) void brute_f16_kernel(const BruteF16Args a)
     // operand roles of v_mfma_f32_32x32x16_f16: lane (l31, lk) owns row l31 of a 32-row tile and the 8 consecutive k
     // values 8 lk .. 8 lk + 7 of the instruction's 16; MFMA j of a stage takes chunk 2 j + lk (term order is free)
     const int l31 = lane & 31, lk = lane >> 5;
-    int rowa[2], rowb[4], swa[2], swb[4];
+    int rowa[TM], rowb[TN], swa[TM], swb[TN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
+    for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { rowb[t] = wn * 128 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
+    for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
     for (uint32_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1u);
         if (kt + 1 < nk) fetch((kt + 1) * BH_BK);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f16x8_t av[2], bv[4];
+            f16x8_t av[TM], bv[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
+            for (int t = 0; t < TM; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
+            for (int t = 0; t < TN; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
+                for (int jj = 0; jj < TN; ++jj)
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[jj], acc[i][jj], 0, 0, 0);
         }
         if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
@@ -3486,15 +3496,15 @@ __global__ __launch_bounds__(256, 2) void brute_f16_kernel(const BruteF16Args a)
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const float inv = 1.52587890625e-05f;            // 2^-16: the two images carry 2^8 each
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t vj = n0 + wn * 128 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+        const uint64_t vj = n0 + wn * 32 * TN + j * 32 + l31;
         const bool jv = vj < a.row_end;
         const float vaux = (jv && a.metric != BRUTE_COSINE) ? a.row_aux[vj] : 0.0f;          // l2: |v|^2 (cosine: no row term)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const uint32_t qi = m0 + ml;
                 const float sc = acc[i][j][r] * inv;
                 float lb;
@@ -3516,11 +3526,16 @@ __global__ __launch_bounds__(256, 2) void brute_f16_kernel(const BruteF16Args a)
 }
 hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
-    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 320 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const uint64_t nb = (a.row_end - a.row_begin + BH_BN - 1) / BH_BN, ny = (a.nq + BH_BM - 1) / BH_BM;
+    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // 256 x 256 tiles from 256 queries on (PQV_BRUTE_TILE=128 keeps the 128 x 256 form for comparison)
+    static const int tile_env = [] { const char *e = std::getenv("PQV_BRUTE_TILE"); return e ? std::atoi(e) : 0; }();
+    const bool big = tile_env == 256 || (tile_env != 128 && a.nq > 128);
+    const uint64_t bm = big ? 256 : 128, bn = 256;
+    const uint64_t nb = (a.row_end - a.row_begin + bn - 1) / bn, ny = (a.nq + bm - 1) / bm;
     const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(brute_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
