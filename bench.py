@@ -571,15 +571,32 @@ def main():
         nc1 = torch.empty((1,), dtype=torch.int64, device=dev)
         st0 = lane_streams[0].cuda_stream
         lat = []
+        # diagnostic build only (make -C pq-vector_amd/csrc stamps; PQV_LIB_PATH): device wall-clock stamps inside the kernels
+        import ctypes
+        from pq_vector_amd import _ffi
+        stamps_fn = getattr(_ffi.lib(), "pqv_debug_stamps", None) if os.environ.get("PQV_LIB_PATH") else None
+        stamp_rows = []
         for i in range(args.single + 5):
             q1 = queries_t[i % nq:i % nq + 1]
             torch.cuda.synchronize()
+            if stamps_fn is not None:
+                stamps_fn(None, 1)
             t1 = time.perf_counter()
             searcher.topk_device(q1.data_ptr(), 1, K, nprobe, rows1.data_ptr(), dist1.data_ptr(),
                                  nf1.data_ptr(), nc1.data_ptr(), stream=st0)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
+            if stamps_fn is not None:
+                buf = (ctypes.c_ulonglong * 64)()
+                stamps_fn(buf, 0)
+                stamp_rows.append(np.array(buf[:], dtype=np.uint64))
         lat = np.array(lat[5:]) * 1e6
+        if stamp_rows:
+            st = np.stack(stamp_rows[5:]).astype(np.int64)
+            rel = (st - st[:, :1]) * 0.01            # 100 MHz ticks -> microseconds after the probe kernel's first block started
+            med = np.median(rel, axis=0)
+            sys.stderr.write("stamps (us after probe start, median): " + " ".join(
+                f"[{j}]={med[j]:.1f}" for j in range(64) if (st[:, j] != 0).all() and (st[:, j] != -1).all()) + "\n")
         result["single_query"] = {"calls": int(lat.size), "p50_us": float(np.percentile(lat, 50)),
                                   "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()),
                                   "qps": float(1e6 / lat.mean()), "dispatch": searcher.describe(1, K, nprobe),

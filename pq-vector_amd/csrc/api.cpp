@@ -1704,6 +1704,23 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             pm.sq_item_rows = p.filter_rows_per_block; pm.sq_max_items = max_items;
         }
     }
+    // int8 screen: the query images (one per query, or one per probed pair in the residual form) -- see step 2
+    pqv::PairQuantArgs pq_args{};
+    bool quant_done = false;
+    if (p.tile && p.filter && p.quad && p.i8) {
+        if (int rc = ensure_blocked_copy(s, 2, stream)) return rc;     // centres and scales (built at creation; here only after an option change)
+        const bool per_pair = s->i8_residual;
+        const size_t n_img = per_pair ? static_cast<size_t>(nq) * p.np : nq;
+        HIP_TRY(sc.s_qi8.ensure(n_img * s->sdim));
+        HIP_TRY(sc.s_qn2i.ensure(n_img * sizeof(int)));
+        HIP_TRY(sc.s_qres.ensure(n_img * sizeof(float)));
+        HIP_TRY(sc.s_qresu.ensure(n_img * sizeof(float)));
+        HIP_TRY(sc.s_pair_lb.ensure(n_img * sizeof(float)));
+        pq_args = pqv::PairQuantArgs{d_queries_s, per_pair ? sc.s_probe.as<uint32_t>() : nullptr, s->d_center.as<float>(),
+                                     s->d_list_scale.as<float>(), s->d_list_half.as<float>(), s->d_list_radius.as<float>(),
+                                     static_cast<uint32_t>(n_img), per_pair ? p.np : 1u, s->sdim, static_cast<int8_t *>(sc.s_qi8.p),
+                                     sc.s_qn2i.as<int>(), sc.s_qres.as<float>(), sc.s_qresu.as<float>(), sc.s_pair_lb.as<float>()};
+    }
     if (fused_probe) {
         pqv::ProbeRowsArgs pr{};
         pr.cent_t = s->d_cent_t.as<float4>(); pr.queries = d_queries;
@@ -1714,7 +1731,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(sc.s_ticket.ensure(sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(sc.s_ticket.p, 0, sizeof(uint32_t), stream));
         }
-        HIP_TRY(pqv::launch_probe_single(pr, pm, sc.s_ticket.as<uint32_t>(), stream));
+        // (the image(s) of a one-query call are made inside the probe launch)
+        quant_done = pq_args.n_pairs != 0;
+        HIP_TRY(pqv::launch_probe_single(pr, pm, sc.s_ticket.as<uint32_t>(), quant_done ? &pq_args : nullptr, stream));
     } else {
         HIP_TRY(launch_merge_probe(pm, stream));
     }
@@ -1767,22 +1786,17 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 // that list's scale -- + the pair's lower bound from the triangle inequality on the centre (pair_lb);
                 // one-centre form: one image per query (every list shares centre and scale)
                 const bool per_pair = s->i8_residual;
-                const size_t n_img = per_pair ? static_cast<size_t>(nq) * p.np : nq;
-                HIP_TRY(sc.s_qi8.ensure(n_img * s->sdim));
-                HIP_TRY(sc.s_qn2i.ensure(n_img * sizeof(int)));
-                HIP_TRY(sc.s_qres.ensure(n_img * sizeof(float)));
-                HIP_TRY(sc.s_qresu.ensure(n_img * sizeof(float)));
-                HIP_TRY(sc.s_pair_lb.ensure(n_img * sizeof(float)));
-                HIP_TRY(launch_quantize_pairs_i8(d_queries_s, per_pair ? sc.s_probe.as<uint32_t>() : nullptr, s->d_center.as<float>(),
-                                                 s->d_list_scale.as<float>(), s->d_list_half.as<float>(), s->d_list_radius.as<float>(),
-                                                 static_cast<uint32_t>(n_img), per_pair ? p.np : 1u, s->sdim, sc.s_qi8.p, sc.s_qn2i.as<int>(),
-                                                 sc.s_qres.as<float>(), sc.s_qresu.as<float>(), sc.s_pair_lb.as<float>(), stream));
+                if (!quant_done) {
+                    HIP_TRY(launch_quantize_pairs_i8(pq_args.queries, pq_args.probe, pq_args.center, pq_args.scale, pq_args.half, pq_args.radius,
+                                                     pq_args.n_pairs, pq_args.nprobe, pq_args.dim, pq_args.q_i8, pq_args.q_n2i, pq_args.q_res,
+                                                     pq_args.q_resu, pq_args.pair_lb, stream));
+                    s->counters.kernel_launches += 1;
+                }
                 ta.i8 = 1; ta.i8_pair_images = per_pair ? 1 : 0;
                 ta.q_i8 = static_cast<const int8_t *>(sc.s_qi8.p); ta.q_n2i = sc.s_qn2i.as<int>(); ta.q_res = sc.s_qres.as<float>();
                 ta.q_resu = sc.s_qresu.as<float>(); ta.pair_lb = (per_pair && s->opt.pair_prune) ? sc.s_pair_lb.as<float>() : nullptr;
                 ta.list_scale = s->d_list_scale.as<float>();
                 ta.row_n2i = s->d_row_n2i.as<int>(); ta.row_res = s->d_row_res.as<float>();
-                s->counters.kernel_launches += 1;
             }
             // quad-to-XCD affinity: on by default for the global-query variant, whose per-quad operand copies
             // must stay L2-resident
@@ -3052,3 +3066,10 @@ extern "C" int pqv_rerank_finish(const uint32_t *io_rows, const float *io_d2, ui
         return static_cast<int>(PQV_OK);
     });
 }
+
+#ifdef PQV_STAMPS
+// diagnostic build only (make stamps): device wall-clock stamps of the one-query launch sequence
+extern "C" int pqv_debug_stamps(unsigned long long *out, int reset) {
+    return pqv::stamps_io(out, reset) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -59,7 +59,8 @@ hipError_t launch_probe_rows(const ProbeRowsArgs &a, hipStream_t s);
 struct MergeArgs;
 // one query: probe + probe merge in one launch (kc_pad <= 4096, nprobe <= 64); the last block to finish merges
 // (pr.part_keys: kc_pad keys of scratch; ticket: one zero-initialised u32 that the kernel leaves at zero)
-hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s);
+struct PairQuantArgs;
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, const PairQuantArgs *quant, hipStream_t s);
 hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
 
 // int8 images of (query, probed list) pairs (kernels.hip: quantize_pair_i8_wave)
@@ -203,6 +204,7 @@ struct SeedTail {
     uint32_t           *cand_cnt, *spilled, *thr_hist;
     float4             *thr_bins;
     uint32_t           *ticket;      // zero-initialised, left at zero
+    uint32_t            lds_floats;  // dynamic LDS of the launch, in floats (set by launch_wide_seed): the refinement's term table
     SeedRefine          rf;
 };
 struct TileArgs {
@@ -471,4 +473,7 @@ hipError_t launch_lloyd_update(const float *rows, uint32_t dim, const uint32_t *
 // number of per-wave partial lists per (query, probed list)
 inline uint32_t waves_per_block() { return 4; }
 
+#ifdef PQV_STAMPS
+hipError_t stamps_io(unsigned long long *out, int reset);
+#endif
 }  // namespace pqv

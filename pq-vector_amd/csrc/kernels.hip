@@ -25,6 +25,25 @@
 
 namespace pqv {
 
+// diagnostic build (make stamps): wall-clock stamps (100 MHz) of the one-query launch sequence, read by tools/stamps_single.py
+#ifdef PQV_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define PQV_STAMP_MAX(i) do { if (threadIdx.x == 0) atomicMax(&g_stamps[i], (unsigned long long)wall_clock64()); } while (0)
+#define PQV_STAMP_MIN(i) do { if (threadIdx.x == 0) atomicMin(&g_stamps[i], (unsigned long long)wall_clock64()); } while (0)
+hipError_t stamps_io(unsigned long long *out, int reset) {
+    if (out) { hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64); if (e != hipSuccess) return e; }
+    if (reset) {
+        unsigned long long init[64];
+        for (int k = 0; k < 64; ++k) init[k] = (k % 8 == 0) ? ~0ull : 0ull;       // slots 0, 8, 16, ...: earliest start
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), init, sizeof init);
+    }
+    return hipSuccess;
+}
+#else
+#define PQV_STAMP_MAX(i) do { } while (0)
+#define PQV_STAMP_MIN(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------
 // small wave64 helpers
 // ------------------------------------------------------------------------------------
@@ -547,9 +566,12 @@ __device__ __forceinline__ int quant_i8(float t, float scale) {
 //   q_resu  >= |v - vi / S|               (rounding + what the clamp cut off): the residual of the UPPER bounds (thresholds)
 //   pair_lb <= every reference d2(q, x), x in the list: (|v| - radius)^2 by the triangle inequality on the list's centre,
 //              with the summation margin of the reference order taken off; 0 = no information
+__device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, uint32_t c, uint32_t q, int lane);
 __device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, int lane) {
     // (probe == nullptr: ONE image per query -- every list then shares centre and scale, entry 0 of the tables)
-    const uint32_t c = a.probe ? a.probe[p] : 0u, q = a.probe ? p / a.nprobe : p;
+    quantize_pair_i8_wave(a, p, a.probe ? a.probe[p] : 0u, a.probe ? p / a.nprobe : p, lane);
+}
+__device__ __forceinline__ void quantize_pair_i8_wave(const PairQuantArgs &a, uint32_t p, uint32_t c, uint32_t q, int lane) {
     const float scale = a.scale[c], inv = 1.0f / scale, box = 127.0f * inv;
     const float *qv = a.queries + (uint64_t)q * a.dim, *cv = a.center + (uint64_t)c * a.dim;
     int n2 = 0;
@@ -614,6 +636,33 @@ hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe,
 }
 
 __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int lane);     // (defined below)
+// The k smallest of a wave's NK keys per lane, given a cut that at least k of them do not exceed (the k-th smallest of
+// the lane minima): when at most 64 keys pass the cut -- the usual case, k .. a few dozen -- they are compacted through
+// `buf` (64 entries of this wave's LDS) and ONE bitonic sort replaces their serial insertion (0.1 us each in a tail that
+// runs alone on the chip).  Returns false, leaving `sorted` alone, when more than 64 pass (the caller inserts them).
+template <int NK>
+__device__ __forceinline__ bool wave_select_by_sort(const uint64_t (&keys)[NK], uint64_t cut, int lane, uint64_t *buf, uint64_t &sorted) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < NK; ++u) mine += (keys[u] != KEY_EMPTY && keys[u] <= cut) ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = readlane_u32(incl, 63);
+    if (total > 64u) return false;
+    uint32_t at = incl - mine;
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+        if (keys[u] != KEY_EMPTY && keys[u] <= cut) buf[at++] = keys[u];
+    wave_lds_fence();
+    sorted = (uint32_t)lane < total ? buf[lane] : KEY_EMPTY;
+    uint32_t dummy = 0;
+    bitonic_sort64(sorted, dummy, lane);
+    return true;
+}
 // ------------------------------------------------------------------------------------
 // merge_kernel: one wave per query folds all partial lists.
 // PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
@@ -722,6 +771,7 @@ template <int S, bool PROBE>
 __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
+    if constexpr (!PROBE) PQV_STAMP_MIN(24);
     if (threadIdx.x >= 64) {
         // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
         if constexpr (PROBE) probe_merge_helpers(a, q);
@@ -839,55 +889,84 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
         if (a.n_found && lane == 0) a.n_found[q] = found;
         const bool any_tie = __ballot(tie) != 0ull;
         if (a.tie_flag && lane == 0) a.tie_flag[q] = any_tie ? 1u : 0u;
+        PQV_STAMP_MAX(25);
     } else {
         probe_merge_tail<S>(a, q, lane, tk);
     }
 }
 
 // ------------------------------------------------------------------------------------
-// probe_single_kernel: the whole centroid probe of ONE query in one launch -- a lane per centroid computes the reference
-// distance exactly as probe_rows_kernel<1> does (256 centroids per block, 16 row chunks in flight per lane), the keys go
-// to scratch, and the block that finishes LAST (a ticket counter) selects the nprobe nearest and runs the probe merge's
-// tail (probe order, candidate bases, single-query bucketing, norms) with its other waves doing the merge's helper
-// work: one launch instead of stream_kernel + merge_kernel.
+// probe_single_kernel: the whole centroid probe of ONE query in one launch.  A block takes 64 centroids (a lane each);
+// its 16 waves split the row's 4-value groups, compute the reference's per-group terms ((d0^2 + d1^2) + d2^2) + d3^2 with
+// all of their loads in flight at once and leave them in LDS; wave 0 then adds the terms in the reference's order
+// (index.rs:461-480: one running sum over the groups) -- the same bits as probe_rows_kernel<1>, but the 3 MB centroid
+// table is read by kc / 64 blocks x 16 waves instead of kc / 256 blocks walking it 16 groups at a time (round 3: 43 -> 
+// µs on C3).  The keys go to scratch, and the block that finishes LAST (a ticket counter) selects the nprobe nearest and
+// runs the probe merge's tail (probe order, candidate bases, single-query bucketing, norms) with its other waves doing
+// the merge's helper work: one launch instead of stream_kernel + merge_kernel.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a, uint32_t *ticket) {
+constexpr uint32_t PS_SLAB = 192;      // groups per LDS slab (48 KB of terms)
+__global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a, uint32_t *ticket, const PairQuantArgs qa) {
     __shared__ uint32_t s_last;
+    __shared__ float ts[PS_SLAB * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;           // < kc_pad (a multiple of 256)
+    const uint32_t c = blockIdx.x * 64u + (uint32_t)lane;         // < kc_pad (a multiple of 256)
     uint64_t key = KEY_EMPTY;
-    {
+    PQV_STAMP_MIN(0);
+    // the int8 image of the query (wide screened path) rides along.  One-centre form: it does not depend on the probe -- an
+    // extra block makes it while the others read the centroids.  Residual form (one image per probed list): the last
+    // block's helper waves make them once wave 0 has the probe order (below).
+    const bool extra = blockIdx.x * 64u >= pr.kc_pad;
+    if (extra) {
+        if (wave == 0 && qa.n_pairs && !qa.probe) quantize_pair_i8_wave(qa, 0u, 0u, 0u, lane);
+    } else {
         const uint32_t G = pr.dim >> 2;
         const float4 *xt = pr.cent_t + c;
         const float *qv = pr.queries;
         float sum = 0.0f;
-        uint32_t g = 0;
-        for (; g + 16 <= G; g += 16) {
-            float4 x[16];
+        for (uint32_t s0 = 0; s0 < G; s0 += PS_SLAB) {
+            const uint32_t sl = G - s0 < PS_SLAB ? G - s0 : PS_SLAB;
+            // wave w: groups w, w + 16, ... of the slab, 12 in flight (a 768-dim row: all of them at once)
+            for (uint32_t gb = (uint32_t)wave; gb < sl; gb += 192) {
+                float4 x[12];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = xt[(uint64_t)(g + u) * pr.kc_pad];
+                for (int u = 0; u < 12; ++u) {
+                    const uint32_t g = gb + 16u * (uint32_t)u;
+                    x[u] = xt[(uint64_t)(s0 + (g < sl ? g : gb)) * pr.kc_pad];
+                }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const float4 qq = load4_uniform<true>(qv + (g + u) * 4);
-                const float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
-                float t = d0 * d0 + d1 * d1;
-                t = t + d2 * d2;
-                t = t + d3 * d3;
-                sum = sum + t;
+                for (int u = 0; u < 12; ++u) {
+                    const uint32_t g = gb + 16u * (uint32_t)u;
+                    if (g < sl) {
+                        const float4 qq = load4_uniform<true>(qv + (s0 + g) * 4);
+                        const float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
+                        float t = d0 * d0 + d1 * d1;
+                        t = t + d2 * d2;
+                        t = t + d3 * d3;
+                        ts[g * 64u + (uint32_t)lane] = t;
+                    }
+                }
             }
-        }
-        for (; g < G; ++g) {
-            const float4 x = xt[(uint64_t)g * pr.kc_pad];
-            const float4 qq = load4_uniform<true>(qv + g * 4);
-            const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
-            float t = d0 * d0 + d1 * d1;
-            t = t + d2 * d2;
-            t = t + d3 * d3;
-            sum = sum + t;
+            PQV_STAMP_MAX(1);
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t g = 0;
+                for (; g + 16 <= sl; g += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = ts[(g + u) * 64u + (uint32_t)lane];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum = sum + t[u];
+                }
+                for (; g < sl; ++g) sum = sum + ts[g * 64u + (uint32_t)lane];
+            }
+            __syncthreads();
         }
         if (c < pr.kc) key = ((uint64_t)__float_as_uint(sum) << 32) | c;
     }
+    PQV_STAMP_MAX(2);
+    if (wave == 0 && !extra)
     __hip_atomic_store(pr.part_keys + c, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     __syncthreads();
@@ -899,29 +978,78 @@ __global__ __launch_bounds__(256) void probe_single_kernel(const ProbeRowsArgs p
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (wave != 0) { probe_merge_helpers(a, 0u); return; }
+    PQV_STAMP_MAX(3);
+    __shared__ uint32_t s_probe_c[64];
+    if (wave != 0) {
+        probe_merge_helpers(a, 0u);
+        if (qa.n_pairs && qa.probe) {
+            __syncthreads();                   // wave 0 has the probe order
+            const uint32_t nw = blockDim.x / 64u - 1u;
+            for (uint32_t p = (uint32_t)wave - 1u; p < qa.n_pairs; p += nw) {
+                const uint32_t c = s_probe_c[p];
+                if (c != 0xFFFFFFFFu) quantize_pair_i8_wave(qa, p, c, 0u, lane);
+            }
+        }
+        return;
+    }
     WaveTopk<1> tk;
     tk.init();
-    // the k-th smallest of the 64 lane minima bounds the k-th smallest key: only keys at or below it are inserted
+    // the k-th smallest of the 64 lane minima bounds the k-th smallest key: only keys at or below it are inserted.
+    // (16 key loads in flight per lane: the tail runs alone on the chip, every dependent round trip is its full latency)
     uint64_t lmin = KEY_EMPTY;
-    for (uint32_t i = lane; i < pr.kc_pad; i += 64) {
-        const uint64_t k2 = __hip_atomic_load(pr.part_keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lmin = k2 < lmin ? k2 : lmin;
+    uint64_t kreg[16];
+    for (uint32_t i0 = 0; i0 < pr.kc_pad; i0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
+            kreg[u] = i < pr.kc_pad ? __hip_atomic_load(pr.part_keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lmin = kreg[u] < lmin ? kreg[u] : lmin;
     }
     uint32_t dummy = 0;
     bitonic_sort64(lmin, dummy, lane);
     const uint64_t cut = readlane_u64(lmin, (int)a.k - 1);       // a.k <= 64
-    for (uint32_t i0 = 0; i0 < pr.kc_pad; i0 += 64) {
-        uint64_t k2 = __hip_atomic_load(pr.part_keys + i0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k2 > cut) k2 = KEY_EMPTY;
-        if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
+    PQV_STAMP_MAX(4);
+    __shared__ uint64_t s_sel[64];
+    uint64_t sorted = KEY_EMPTY;
+    if (pr.kc_pad <= 1024 && wave_select_by_sort<16>(kreg, cut, lane, s_sel, sorted)) {
+        tk.key[0] = (uint32_t)lane < a.k ? sorted : KEY_EMPTY;
+        tk.val[0] = (uint32_t)tk.key[0];
+    } else
+    for (uint32_t i0 = 0; i0 < pr.kc_pad; i0 += 1024) {
+        if (pr.kc_pad > 1024) {        // (up to 1024 centroids the keys are still in registers)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
+                kreg[u] = i < pr.kc_pad ? __hip_atomic_load(pr.part_keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_EMPTY;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            uint64_t k2 = kreg[u];
+            if (k2 > cut) k2 = KEY_EMPTY;
+            if (__ballot(k2 != KEY_EMPTY) != 0ull) tk.offer(k2, (uint32_t)k2, a.k, lane);
+        }
+    }
+    PQV_STAMP_MAX(5);
+    if (qa.n_pairs && qa.probe) {
+        s_probe_c[lane] = ((uint32_t)lane < a.k && tk.key[0] != KEY_EMPTY) ? tk.val[0] : 0xFFFFFFFFu;
+        __syncthreads();
     }
     probe_merge_tail<1>(a, 0u, lane, tk);
+    PQV_STAMP_MAX(6);
 }
-hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, hipStream_t s) {
+hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, const PairQuantArgs *quant, hipStream_t s) {
     if (pr.nq != 1 || a.nq != 1 || a.k == 0 || a.k > 64 || (pr.kc_pad % 256) != 0 || pr.kc_pad > 4096 || (pr.dim % 4) != 0 ||
         pr.kc == 0 || !pr.part_keys || !ticket) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(probe_single_kernel, dim3(pr.kc_pad / 256), dim3(256), 0, s, pr, a, ticket);
+    PairQuantArgs qa{};
+    if (quant) {
+        qa = *quant;
+        if (qa.dim % 4 || qa.nprobe == 0 || (qa.probe ? (qa.n_pairs != a.k || !qa.pair_lb) : qa.n_pairs != 1)) return hipErrorInvalidValue;
+    }
+    const uint32_t extra = (qa.n_pairs && !qa.probe) ? 1u : 0u;
+    hipLaunchKernelGGL(probe_single_kernel, dim3(pr.kc_pad / 64 + extra), dim3(1024), 0, s, pr, a, ticket, qa);
     return hipGetLastError();
 }
 
@@ -1658,7 +1786,8 @@ __global__ __launch_bounds__(256) void tile_filter_kernel(const TileArgs a) {
 template <int S>
 __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *seed_ub, uint32_t n_vals, uint32_t k,
                                                  unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf);     // (defined below)
+                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf,
+                                                 float *lds_terms = nullptr, uint32_t lds_floats = 0);     // (defined below)
 // one-query calls (SeedTail): every block of wide_seed_kernel takes a ticket when it is done -- also the ones with nothing
 // to sample -- and the last one runs the select / refinement for query 0
 __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
@@ -1673,22 +1802,29 @@ __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
     __syncthreads();
     if (!s_seed_last) return;
     __threadfence();
+    PQV_STAMP_MAX(12);
+    extern __shared__ float4 qs_tail[];       // the staged queries are no longer needed: the refinement's term table
     seed_select_body<1>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
-                        a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf);
+                        a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf, reinterpret_cast<float *>(qs_tail), a.seed_tail.lds_floats);
 }
-template <int NG, bool QLDS, int OP>
+// U: operand stages a wave keeps in flight.  1 for batches (other waves fill the stalls); a one-query call has ONE 64-row
+// tile per wave and nothing else on the CU, so its 48 KB are requested 6 stages at a time.  Only the U > 1 instances
+// carry the one-query tail (select + refinement by the last block): its register needs (16 row chunks + 16 query chunks
+// in flight per lane) would otherwise set the allocation -- and halve the occupancy -- of the batched instances.
+template <int NG, bool QLDS, int OP, int U = 1>
 __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
     static_assert(!I8 || QLDS, "int8 operands: queries staged in LDS");
     constexpr uint32_t NQ = 16 * NG;
+    PQV_STAMP_MIN(8);
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
-    if (by >= *a.n_quads) { if (a.seed_tail.enable) seed_tail_finish(a); return; }
+    if (by >= *a.n_quads) { if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); } return; }
     const uint4 quad = a.quads[by];
     // a quad wider than this kernel's 16 NG queries (the 8-wave filter kernel takes up to 128) is sampled in
     // slices of 16 NG: blockIdx.z
     const uint32_t sub = blockIdx.z * NQ;
-    if (sub >= quad.z) { if (a.seed_tail.enable) seed_tail_finish(a); return; }
+    if (sub >= quad.z) { if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); } return; }
     const uint32_t c = quad.x, p0 = quad.y + sub, cnt = quad.z - sub < NQ ? quad.z - sub : NQ;
     const uint32_t ng = (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
@@ -1746,6 +1882,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         }
     }
     __syncthreads();      // also orders the qnl / liml writes above
+    PQV_STAMP_MAX(9);
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
@@ -1793,19 +1930,29 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 if constexpr (I8) { const int init = -((xn2i[t] + 1) >> 1); acc[g][t] = (i32x4_acc){init, init, init, init}; }
                 else acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
             }
-        for (uint32_t ks = 0; ks < (G >> 2); ++ks) {
-            float4 x[4];
+        const uint32_t nks = G >> 2;
+        for (uint32_t ks0 = 0; ks0 < nks; ks0 += U) {
+            float4 x[U][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = buf_ld16(xr, lane_off * 16u, xso[t] + ks * 1024);
-            const uint32_t chq = ks * 4 + (uint32_t)kk;
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ks = ks0 + u < nks ? ks0 + u : nks - 1;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if ((uint32_t)g < ng) {
-                    float4 qc;
-                    if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
-                    else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + ks * 1024);
+                for (int t = 0; t < 4; ++t) x[u][t] = buf_ld16(xr, lane_off * 16u, xso[t] + ks * 1024);
+            }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ks = ks0 + u;
+                if (U > 1 && ks >= nks) break;
+                const uint32_t chq = ks * 4 + (uint32_t)kk;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if ((uint32_t)g < ng) {
+                        float4 qc;
+                        if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+                        else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + ks * 1024);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[u][t]);
+                    }
                 }
             }
         }
@@ -1833,6 +1980,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
             }
         }
     }
+    PQV_STAMP_MAX(10);
     // publish: one value per (query, this wave, lane & 15)
     const uint32_t my_j = my_pair % a.nprobe;
 #pragma unroll
@@ -1857,7 +2005,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 a.seed_ub[(((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15] = fmaxf(mins[g][r], 0.0f);
         }
     }
-    if (a.seed_tail.enable) seed_tail_finish(a);
+    PQV_STAMP_MAX(11);
+    if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); }
 }
 
 // gthr[q] = key of the k-th smallest of q's n_vals upper bounds (none if fewer than k are finite); also
@@ -1865,7 +2014,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 template <int S>
 __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *seed_ub, uint32_t n_vals, uint32_t k,
                                                  unsigned long long *gthr, uint32_t *cand_cnt, uint32_t *spilled,
-                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf) {
+                                                 uint32_t *thr_hist, float4 *thr_bins, const SeedRefine &rf,
+                                                 float *lds_terms, uint32_t lds_floats) {
     // one wave selects; with the refinement (256 threads) all four waves share the exact evaluations
     __shared__ uint64_t s_ent[16];           // the k selected bounds
     __shared__ uint64_t s_exact[64];         // exact keys of their 4 k rows
@@ -1883,17 +2033,51 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
         // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
         // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
         uint64_t cut = KEY_EMPTY;
+        bool done = false;
+        if constexpr (S == 1) {
+            if (k <= 64u && v_hi <= v_lo + 1024u) {
+                // the wave's bounds fit 16 per lane: one round trip, kept in registers for both passes, and the few that pass the
+                // cut are sorted instead of inserted one by one
+                uint64_t kreg[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t idx = v_lo + 64 * u + lane;
+                    const float v = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                    kreg[u] = v < INFINITY ? (((uint64_t)__float_as_uint(v) << 32) | idx) : KEY_EMPTY;
+                }
+                uint64_t lmin = KEY_EMPTY;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) lmin = kreg[u] < lmin ? kreg[u] : lmin;
+                uint32_t dummy = 0;
+                bitonic_sort64(lmin, dummy, lane);
+                cut = readlane_u64(lmin, (int)k - 1);
+                __shared__ uint64_t s_sel[4 * 64];
+                uint64_t sorted = KEY_EMPTY;
+                if (wave < 4 && wave_select_by_sort<16>(kreg, cut, lane, s_sel + wave * 64, sorted)) {
+                    tk.key[0] = (uint32_t)lane < k ? sorted : KEY_EMPTY;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        uint64_t key = kreg[u];
+                        if (key > cut) key = KEY_EMPTY;
+                        if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
+                    }
+                }
+                done = true;
+            }
+        }
+        if (!done) {
         if (k <= 64u) {
             uint64_t lmin = KEY_EMPTY;
-            for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 512) {          // eight loads in flight per lane
-                float v[8];
+            for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 1024) {         // sixteen loads in flight per lane
+                float v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const uint32_t idx = i0 + 64 * u + lane;
                     v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     if (v[u] < INFINITY) {
                         const uint64_t key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
                         lmin = key < lmin ? key : lmin;
@@ -1904,20 +2088,21 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
             bitonic_sort64(lmin, dummy, lane);
             cut = readlane_u64(lmin, (int)k - 1);
         }
-        for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 512) {              // eight loads in flight per lane again
-            float v[8];
+        for (uint32_t i0 = v_lo; i0 < v_hi; i0 += 1024) {             // sixteen loads in flight per lane again
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const uint32_t idx = i0 + 64 * u + lane;
                 v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 uint64_t key = KEY_EMPTY;
                 if (v[u] < INFINITY) key = ((uint64_t)__float_as_uint(v[u]) << 32) | (i0 + 64 * u + lane);
                 if (key > cut) key = KEY_EMPTY;
                 if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, 0u, k, lane);
             }
+        }
         }
     }
     if (refine) {           // merge: 4 x (k <= 16) sorted keys -> one 64-lane sort in wave 0; lanes 0 .. k-1 then hold the k smallest
@@ -1932,6 +2117,7 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
     }
     uint64_t kth = tk.kth(k);
     uint64_t m1key = readlane_u64(tk.key[0], 0);
+    PQV_STAMP_MAX(13);
     if (refine) {
         // exact distances of the 4 k rows behind the k selected bounds (SeedRefine): wave w takes entries
         // [w k / 4 ..) -- pair p = 4 e + t is entry e's sub-tile row t -- and L = 4 or 8 lanes share a pair's chain exactly
@@ -1939,8 +2125,107 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
         if (wave == 0 && lane < 16) s_ent[lane] = (uint32_t)lane < k ? tk.key[0] : KEY_EMPTY;
         __syncthreads();
         const uint32_t Gx = rf.dim >> 2;
+        const uint32_t NP = 4u * k + 1u <= 64u ? 4u * k + 1u : 64u;        // row stride of the term table (odd: no bank conflicts)
+        if (lds_terms && (uint64_t)Gx * NP <= lds_floats) {
+            // The tail of a one-query call runs alone on the chip: every dependent round trip costs its full latency, and the
+            // 4 k rows sit on 4 k cold pages.  All 256 threads fetch the rows' 16-byte chunks at once (coalesced along a row),
+            // leave the per-chunk terms ((d0^2 + d1^2) + d2^2) + d3^2 in LDS, and lane p of wave 0 then adds row p's terms in
+            // the reference's order -- the same bits as the lane chains below, in one round trip instead of three.
+            __shared__ uint64_t s_rowoff[64];
+            const uint32_t np = 4u * k;                                    // <= 64
+            bool valid = false;
+            uint64_t pos = 0;
+            if (wave == 0) {
+                const uint32_t pi = (uint32_t)lane;
+                const uint32_t e = pi >> 2, t = pi & 3u;
+                const uint64_t ekey = s_ent[e < 16u ? e : 0u];
+                valid = pi < np && ekey != KEY_EMPTY;
+                const uint32_t idx = (uint32_t)ekey;
+                const uint32_t l15 = idx & 15u, slot = (idx >> 4) % rf.seed_sw, j = (idx >> 4) / rf.seed_sw;
+                const uint32_t row = (slot >> 2) * 256u + (slot & 3u) * 64u + 16u * t + l15;
+                uint64_t lbeg = 0;
+                if (valid) {
+                    const uint32_t c = rf.probe[(uint64_t)q * rf.nprobe + j];
+                    lbeg = rf.list_off[c];
+                    pos = rf.cand_base[(uint64_t)q * rf.nprobe + j] + row;
+                    valid = row < rf.seed_rows && lbeg + row < rf.list_off[c + 1] && pos < rf.max_pos;
+                }
+                s_rowoff[lane] = valid ? (lbeg + row) * rf.dim : 0ull;
+            }
+            __syncthreads();
+            const float4 *qg4 = reinterpret_cast<const float4 *>(rf.queries + (uint64_t)q * rf.dim);
+            if (Gx <= 256u) {
+                // thread (rg, g): chunk g of rows rg, rg + RG, ... -- one query chunk per thread, up to 40 row chunks in flight
+                // (k = 10 on a 768-dim row: every byte of the 40 rows is requested in ONE round trip)
+                const uint32_t RG = 256u / Gx, rg = threadIdx.x / Gx, g = threadIdx.x - rg * Gx;
+                if (rg < RG) {
+                    const float4 qc = qg4[g];
+                    constexpr int B = 40;
+                    for (uint32_t p0 = rg; p0 < np; p0 += RG * B) {
+                        float4 xv[B];
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            const uint32_t pr2 = p0 + RG * (uint32_t)u;
+                            xv[u] = load4<true>(rf.mat + s_rowoff[pr2 < np ? pr2 : p0] + g * 4u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            const uint32_t pr2 = p0 + RG * (uint32_t)u;
+                            if (pr2 < np) {
+                                const float d0 = qc.x - xv[u].x, d1 = qc.y - xv[u].y, d2 = qc.z - xv[u].z, d3 = qc.w - xv[u].w;
+                                float w = d0 * d0 + d1 * d1;
+                                w = w + d2 * d2;
+                                lds_terms[g * NP + pr2] = w + d3 * d3;
+                            }
+                        }
+                    }
+                }
+            } else {
+            const uint32_t items = np * Gx;
+            for (uint32_t i0 = 0; i0 < items; i0 += 256u * 16u) {
+                float4 xv[16], qv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    uint32_t i = i0 + 256u * (uint32_t)u + threadIdx.x;
+                    i = i < items ? i : items - 1u;
+                    const uint32_t pr2 = i / Gx, g = i - pr2 * Gx;
+                    xv[u] = load4<true>(rf.mat + s_rowoff[pr2] + g * 4u);
+                    qv[u] = qg4[g];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t i = i0 + 256u * (uint32_t)u + threadIdx.x;
+                    if (i < items) {
+                        const uint32_t pr2 = i / Gx, g = i - pr2 * Gx;
+                        const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y, d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                        float w = d0 * d0 + d1 * d1;
+                        w = w + d2 * d2;
+                        lds_terms[g * NP + pr2] = w + d3 * d3;
+                    }
+                }
+            }
+            }
+            __syncthreads();
+            PQV_STAMP_MAX(14);
+            if (wave != 0) return;
+            float sum = 0.0f;
+            const uint32_t pcol = (uint32_t)lane < np ? (uint32_t)lane : 0u;
+            for (uint32_t g = 0; g < Gx; g += 16) {                        // Gx % 16 == 0 (dim % 64 == 0 on this path)
+                float t16[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t16[u] = lds_terms[(g + u) * NP + pcol];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum = sum + t16[u];
+            }
+            uint64_t xkey = valid ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
+            uint32_t dummy2 = 0;
+            bitonic_sort64(xkey, dummy2, lane);
+            const uint64_t kth2 = readlane_u64(xkey, (int)k - 1);
+            if (kth != KEY_EMPTY && kth2 < kth) { kth = kth2; m1key = readlane_u64(xkey, 0); }
+        } else {
+        constexpr int NB = 16;                 // row chunks a lane has in flight (the tail of a one-query call runs alone)
         uint32_t lg = 0;                       // k pairs per wave
-        while (lg < 3 && (k << (lg + 1)) <= 64u && (Gx % (16u << lg)) == 0u) ++lg;
+        while (lg < 3 && (k << (lg + 1)) <= 64u && (Gx % ((uint32_t)(2 * NB) << lg)) == 0u) ++lg;
         const uint32_t L = 1u << lg;
         const uint32_t pl = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);      // pair within the wave, lane within the pair
         const uint32_t pi = (uint32_t)wave * k + pl;                                     // pair of the query: 0 .. 4 k - 1
@@ -1960,13 +2245,15 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
         const float *x = rf.mat + (valid ? (lbeg + row) : 0ull) * rf.dim;
         const float4 *qg = reinterpret_cast<const float4 *>(rf.queries + (uint64_t)q * rf.dim);
         float sum = 0.0f;
-        constexpr int NB = 8;
         const uint32_t first = (uint32_t)lane & ~(L - 1u);
         for (uint32_t g0 = 0; g0 < Gx; g0 += NB * L) {
             const uint32_t g = g0 + NB * pj;
             float4 xv[NB], qv[NB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) { xv[u] = load4<true>(x + (g + u) * 4); qv[u] = qg[g + u]; }
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t gu = g + u < Gx ? g + u : Gx - 1;          // (L == 1: Gx need not be a multiple of NB)
+                xv[u] = load4<true>(x + gu * 4); qv[u] = qg[gu];
+            }
             float tt[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
@@ -1990,12 +2277,14 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
         if (pl < k && pj == 0u && pi < 64u)
             s_exact[pi] = valid ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
         __syncthreads();
+        PQV_STAMP_MAX(14);
         if (wave != 0) return;
         uint64_t xkey = (uint32_t)lane < 4u * k ? s_exact[lane] : KEY_EMPTY;
         uint32_t dummy2 = 0;
         bitonic_sort64(xkey, dummy2, lane);
         const uint64_t kth2 = readlane_u64(xkey, (int)k - 1);
         if (kth != KEY_EMPTY && kth2 < kth) { kth = kth2; m1key = readlane_u64(xkey, 0); }
+        }
     } else if (wave != 0) {
         return;
     }
@@ -2022,6 +2311,7 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
             thr_bins[q] = hb;
         }
     }
+    PQV_STAMP_MAX(15);
 }
 template <int S>
 __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, uint32_t n_vals, uint32_t k,
@@ -2029,41 +2319,54 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
                                                         uint32_t *thr_hist, float4 *thr_bins, const SeedRefine rf) {
     seed_select_body<S>(blockIdx.x, seed_ub, n_vals, k, gthr, cand_cnt, spilled, thr_hist, thr_bins, rf);
 }
+// QLDS forms: a one-query call (seed_tail) takes the deep-prefetch instance and tells the tail how much dynamic LDS it has
+#define SEED_LAUNCH(NG_, OP_, GRID_, LDS_)                                                                              \
+    {                                                                                                                   \
+        TileArgs b = a;                                                                                                 \
+        b.seed_tail.lds_floats = (uint32_t)((size_t)(LDS_) / 4);                                                        \
+        if (deep) hipLaunchKernelGGL((wide_seed_kernel<NG_, true, OP_, 6>), GRID_, dim3(256), (LDS_), s, b);            \
+        else hipLaunchKernelGGL((wide_seed_kernel<NG_, true, OP_>), GRID_, dim3(256), (LDS_), s, b);                    \
+    }
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
+    const bool deep = a.seed_tail.enable != 0;       // a one-query call: six operand stages in flight per wave
     if (a.i8) {       // int8 images: 32 queries x dim bytes per block
         if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_resu || !a.list_scale || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
             32ull * a.dim > 65536) return hipErrorInvalidValue;
         // 64 queries per pass where they fit 48 KB (a 96-query quad is then sampled in two slices instead of three:
         // the sample rows are re-read once per slice)
         if (64ull * a.dim <= 49152)
-            hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_I8>), dim3(a.grid_x, a.max_quads, (a.quad_width + 63) / 64), dim3(256), 64ull * a.dim, s, a);
+            SEED_LAUNCH(4, OP_I8, dim3(a.grid_x, a.max_quads, (a.quad_width + 63) / 64), 64ull * a.dim)
         else
-            hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_I8>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), 32ull * a.dim, s, a);
+            SEED_LAUNCH(2, OP_I8, dim3(a.grid_x, a.max_quads, a.quad_width / 32), 32ull * a.dim)
         return hipGetLastError();
     }
     if (a.f16) {      // f16 operands: the staged queries take half the LDS; 64 queries per block up to 256 dims, else 32
         if ((a.dim % 128) != 0 || !a.query_maxabs || a.dim > 1024) return hipErrorInvalidValue;
         if (lds4 / 2 <= 32768 && (a.quad_width % 64) == 0)
-            hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_F16>), dim3(a.grid_x, a.max_quads, a.quad_width / 64), dim3(256), lds4 / 2, s, a);
+            SEED_LAUNCH(4, OP_F16, dim3(a.grid_x, a.max_quads, a.quad_width / 64), lds4 / 2)
         else if ((a.quad_width % 32) == 0)
-            hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_F16>), dim3(a.grid_x, a.max_quads, a.quad_width / 32), dim3(256), lds2 / 2, s, a);
+            SEED_LAUNCH(2, OP_F16, dim3(a.grid_x, a.max_quads, a.quad_width / 32), lds2 / 2)
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (a.quad_width == 64 && lds4 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<4, true, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), lds4, s, a);
+        SEED_LAUNCH(4, OP_F32, dim3(a.grid_x, a.max_quads), lds4)
     else if (a.quad_width == 32 && lds2 <= 32768)
-        hipLaunchKernelGGL((wide_seed_kernel<2, true, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), lds2, s, a);
-    else if (a.quad_width == 32 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
-    else if (a.quad_width == 64 && a.q_blk)
-        hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        SEED_LAUNCH(2, OP_F32, dim3(a.grid_x, a.max_quads), lds2)
+    else if (a.quad_width == 32 && a.q_blk) {
+        if (deep) hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32, 6>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+    } else if (a.quad_width == 64 && a.q_blk) {
+        if (deep) hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32, 6>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+    }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+#undef SEED_LAUNCH
 hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals, uint32_t k, unsigned long long *gthr,
                               uint32_t *cand_cnt, uint32_t *spilled, hipStream_t s,
                               uint32_t *thr_hist, float4 *thr_bins, const SeedRefine *refine) {
@@ -2144,6 +2447,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifdef PQV_PROFILE_PHASES
     const uint64_t ph_t0 = __builtin_amdgcn_s_memtime();
 #endif
+    PQV_STAMP_MIN(16);
     uint32_t bx, by;
     uint4 quad;                              // {cluster, first pair slot, pair count <= NQ, first work item}
     if (a.item_quad) {
@@ -3036,6 +3340,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
 #endif
     }
+    PQV_STAMP_MAX(17);
 }
 
 template <int S>
@@ -3115,11 +3420,14 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
         const uint32_t nw = a.block_waves ? a.block_waves : 4;
         if (a.i8) {           // int8 images: 8-wave blocks, up to 128 queries x dim bytes of LDS
             if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_res || !a.list_scale || !a.row_n2i || !a.row_res) return hipErrorInvalidValue;
-            const size_t lds = (size_t)a.quad_width * a.dim;
-            if (lds > 147456) return hipErrorInvalidValue;
+            // (only the groups of 16 queries a quad really has are staged or read -- a batch of <= 16 queries asks for a
+            // quarter of the LDS and twice as many blocks fit a CU: a one-query call streams its lists with 16 waves per CU)
+            const uint32_t live_w = a.nq < a.quad_width ? (a.nq + 15u) / 16u * 16u : a.quad_width;
+            const size_t lds = (size_t)live_w * a.dim;
+            if ((size_t)a.quad_width * a.dim > 147456) return hipErrorInvalidValue;
             if (nw == 4) {        // two 4-wave blocks per CU
-                if (a.quad_width == 64 && lds <= 65536) return launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
-                if (a.quad_width == 96 && lds <= 73728) return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
+                if (a.quad_width == 64 && 64ull * a.dim <= 65536) return launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
+                if (a.quad_width == 96 && 96ull * a.dim <= 73728) return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
                 return hipErrorInvalidValue;
             }
             if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_I8>(a, lds, s);
