@@ -640,8 +640,34 @@ __device__ __forceinline__ void bitonic_sort64(uint64_t &key, uint32_t &val, int
 // the lane minima): when at most 64 keys pass the cut -- the usual case, k .. a few dozen -- they are compacted through
 // `buf` (64 entries of this wave's LDS) and ONE bitonic sort replaces their serial insertion (0.1 us each in a tail that
 // runs alone on the chip).  Returns false, leaving `sorted` alone, when more than 64 pass (the caller inserts them).
+// k-th smallest (k >= 1) of the wave's 64 keys by rank counting: every lane compares its key with all 64 (broadcast LDS
+// reads, ~0.2 us) -- a third of a bitonic sort.  Keys other than KEY_EMPTY are distinct.  `buf`: 64 entries.
+__device__ __forceinline__ uint64_t wave_kth_by_rank(uint64_t key, uint32_t k, int lane, uint64_t *buf) {
+    buf[lane] = key;
+    wave_lds_fence();
+    uint32_t rank = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) rank += buf[j] < key ? 1u : 0u;
+    const unsigned long long m = __ballot(key != KEY_EMPTY && rank == k - 1u);
+    wave_lds_fence();
+    return m ? readlane_u64(key, __builtin_ctzll(m)) : KEY_EMPTY;
+}
+// ascending order of the wave's distinct keys (KEY_EMPTY = none; only lanes < span hold keys) by rank counting
+__device__ __forceinline__ uint64_t wave_sort_by_rank(uint64_t key, uint32_t span, int lane, uint64_t *buf /* 128 entries */) {
+    buf[lane] = key;
+    wave_lds_fence();
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < span; ++j) rank += buf[j] < key ? 1u : 0u;
+    const bool have = key != KEY_EMPTY;
+    const uint32_t total = (uint32_t)__popcll(__ballot(have));
+    if (have) buf[64 + rank] = key;
+    wave_lds_fence();
+    const uint64_t r = (uint32_t)lane < total ? buf[64 + lane] : KEY_EMPTY;
+    wave_lds_fence();
+    return r;
+}
 template <int NK>
-__device__ __forceinline__ bool wave_select_by_sort(const uint64_t (&keys)[NK], uint64_t cut, int lane, uint64_t *buf, uint64_t &sorted) {
+__device__ __forceinline__ bool wave_select_by_sort(const uint64_t (&keys)[NK], uint64_t cut, int lane, uint64_t *buf /* 128 entries */, uint64_t &sorted) {
     uint32_t mine = 0;
 #pragma unroll
     for (int u = 0; u < NK; ++u) mine += (keys[u] != KEY_EMPTY && keys[u] <= cut) ? 1u : 0u;
@@ -656,11 +682,11 @@ __device__ __forceinline__ bool wave_select_by_sort(const uint64_t (&keys)[NK], 
     uint32_t at = incl - mine;
 #pragma unroll
     for (int u = 0; u < NK; ++u)
-        if (keys[u] != KEY_EMPTY && keys[u] <= cut) buf[at++] = keys[u];
+        if (keys[u] != KEY_EMPTY && keys[u] <= cut) buf[64 + at++] = keys[u];
     wave_lds_fence();
-    sorted = (uint32_t)lane < total ? buf[lane] : KEY_EMPTY;
-    uint32_t dummy = 0;
-    bitonic_sort64(sorted, dummy, lane);
+    const uint64_t mykey = (uint32_t)lane < total ? buf[64 + lane] : KEY_EMPTY;
+    wave_lds_fence();
+    sorted = wave_sort_by_rank(mykey, total, lane, buf);
     return true;
 }
 // ------------------------------------------------------------------------------------
@@ -968,7 +994,10 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
     PQV_STAMP_MAX(2);
     if (wave == 0 && !extra)
     __hip_atomic_store(pr.part_keys + c, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    // The keys are published by agent-scope atomic stores (write-through to the memory side) and read back by agent-scope
+    // atomic loads: all the ticket needs is that the stores have completed -- a release fence would also write the L2 back,
+    // and the matching acquire would invalidate it under the tail's other loads (~1.5 us each way in a tail that runs alone).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(ticket, 1u);
@@ -977,7 +1006,6 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     PQV_STAMP_MAX(3);
     __shared__ uint32_t s_probe_c[64];
     if (wave != 0) {
@@ -1007,11 +1035,9 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
 #pragma unroll
         for (int u = 0; u < 16; ++u) lmin = kreg[u] < lmin ? kreg[u] : lmin;
     }
-    uint32_t dummy = 0;
-    bitonic_sort64(lmin, dummy, lane);
-    const uint64_t cut = readlane_u64(lmin, (int)a.k - 1);       // a.k <= 64
+    __shared__ uint64_t s_sel[128];
+    const uint64_t cut = wave_kth_by_rank(lmin, a.k, lane, s_sel);       // a.k <= 64
     PQV_STAMP_MAX(4);
-    __shared__ uint64_t s_sel[64];
     uint64_t sorted = KEY_EMPTY;
     if (pr.kc_pad <= 1024 && wave_select_by_sort<16>(kreg, cut, lane, s_sel, sorted)) {
         tk.key[0] = (uint32_t)lane < a.k ? sorted : KEY_EMPTY;
@@ -1792,7 +1818,7 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
 // to sample -- and the last one runs the select / refinement for query 0
 __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
     __shared__ uint32_t s_seed_last;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the bounds went out as agent-scope atomic stores (see probe_single_kernel)
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(a.seed_tail.ticket, 1u);
@@ -1801,7 +1827,6 @@ __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
     }
     __syncthreads();
     if (!s_seed_last) return;
-    __threadfence();
     PQV_STAMP_MAX(12);
     extern __shared__ float4 qs_tail[];       // the staged queries are no longer needed: the refinement's term table
     seed_select_body<1>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
@@ -2001,8 +2026,11 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                     mins[g][r] = d * d * (1.0f + 4.0f * cmargin) * 1.000002f;
                 }
             }
-            if (qi < cnt)
-                a.seed_ub[(((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15] = fmaxf(mins[g][r], 0.0f);
+            if (qi < cnt) {
+                float *dst = a.seed_ub + (((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15;
+                if constexpr (U > 1) __hip_atomic_store(dst, fmaxf(mins[g][r], 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = fmaxf(mins[g][r], 0.0f);
+            }
         }
     }
     PQV_STAMP_MAX(11);
@@ -2029,6 +2057,12 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
     const uint32_t quarter = ((n_vals + 3) / 4 + 63) / 64 * 64;
     const uint32_t v_lo = refine ? (uint32_t)wave * quarter : 0u;
     const uint32_t v_hi = refine ? (v_lo + quarter < n_vals ? v_lo + quarter : n_vals) : n_vals;
+    // (the one-query tail -- the only caller with LDS for the terms -- reads bounds this very launch published: agent-scope loads)
+    const bool same_launch = lds_terms != nullptr;
+    auto ld_ub = [&](uint32_t idx) {
+        const float *p = seed_ub + (uint64_t)q * n_vals + idx;
+        return same_launch ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    };
     if (wave == 0 || refine) {
         // pre-filter (k <= 64): the k-th smallest of the 64 lane minima bounds the k-th smallest overall, so only
         // values at or below it are offered to the serial insertion (a few dozen instead of all n_vals)
@@ -2042,18 +2076,16 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t idx = v_lo + 64 * u + lane;
-                    const float v = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                    const float v = idx < v_hi ? ld_ub(idx) : INFINITY;
                     kreg[u] = v < INFINITY ? (((uint64_t)__float_as_uint(v) << 32) | idx) : KEY_EMPTY;
                 }
                 uint64_t lmin = KEY_EMPTY;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) lmin = kreg[u] < lmin ? kreg[u] : lmin;
-                uint32_t dummy = 0;
-                bitonic_sort64(lmin, dummy, lane);
-                cut = readlane_u64(lmin, (int)k - 1);
-                __shared__ uint64_t s_sel[4 * 64];
+                __shared__ uint64_t s_sel[4 * 128];
+                cut = wave_kth_by_rank(lmin, k, lane, s_sel + (wave & 3) * 128);
                 uint64_t sorted = KEY_EMPTY;
-                if (wave < 4 && wave_select_by_sort<16>(kreg, cut, lane, s_sel + wave * 64, sorted)) {
+                if (wave < 4 && wave_select_by_sort<16>(kreg, cut, lane, s_sel + wave * 128, sorted)) {
                     tk.key[0] = (uint32_t)lane < k ? sorted : KEY_EMPTY;
                 } else {
 #pragma unroll
@@ -2074,7 +2106,7 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t idx = i0 + 64 * u + lane;
-                    v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                    v[u] = idx < v_hi ? ld_ub(idx) : INFINITY;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
@@ -2093,7 +2125,7 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const uint32_t idx = i0 + 64 * u + lane;
-                v[u] = idx < v_hi ? seed_ub[(uint64_t)q * n_vals + idx] : INFINITY;
+                v[u] = idx < v_hi ? ld_ub(idx) : INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -2109,9 +2141,8 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
         if (lane < 16) s_loc[wave * 16 + lane] = (uint32_t)lane < k ? tk.key[0] : KEY_EMPTY;
         __syncthreads();
         if (wave == 0) {
-            uint64_t mk = s_loc[lane];
-            uint32_t dummy = 0;
-            bitonic_sort64(mk, dummy, lane);
+            __shared__ uint64_t s_mrg[128];
+            const uint64_t mk = wave_sort_by_rank(s_loc[lane], 64u, lane, s_mrg);
             tk.key[0] = (uint32_t)lane < k ? mk : KEY_EMPTY;
         }
     }
@@ -2218,10 +2249,9 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
                 for (int u = 0; u < 16; ++u) sum = sum + t16[u];
             }
             uint64_t xkey = valid ? (((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)pos) : KEY_EMPTY;
-            uint32_t dummy2 = 0;
-            bitonic_sort64(xkey, dummy2, lane);
-            const uint64_t kth2 = readlane_u64(xkey, (int)k - 1);
-            if (kth != KEY_EMPTY && kth2 < kth) { kth = kth2; m1key = readlane_u64(xkey, 0); }
+            __shared__ uint64_t s_fin[64];
+            const uint64_t kth2 = wave_kth_by_rank(xkey, k, lane, s_fin);
+            if (kth != KEY_EMPTY && kth2 < kth) { kth = kth2; m1key = wave_kth_by_rank(xkey, 1u, lane, s_fin); }
         } else {
         constexpr int NB = 16;                 // row chunks a lane has in flight (the tail of a one-query call runs alone)
         uint32_t lg = 0;                       // k pairs per wave
