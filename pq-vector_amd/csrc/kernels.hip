@@ -689,6 +689,38 @@ __device__ __forceinline__ bool wave_select_by_sort(const uint64_t (&keys)[NK], 
     sorted = wave_sort_by_rank(mykey, total, lane, buf);
     return true;
 }
+// the same with a 32-bit payload per key
+template <int NK>
+__device__ __forceinline__ bool wave_select_by_sort_kv(const uint64_t (&keys)[NK], const uint32_t (&vals)[NK], uint64_t cut, int lane,
+                                                       uint64_t *buf /* 128 */, uint32_t *vbuf /* 128 */, uint64_t &sorted, uint32_t &sval) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < NK; ++u) mine += (keys[u] != KEY_EMPTY && keys[u] <= cut) ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = readlane_u32(incl, 63);
+    if (total > 64u) return false;
+    uint32_t at = incl - mine;
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+        if (keys[u] != KEY_EMPTY && keys[u] <= cut) { buf[at] = keys[u]; vbuf[at] = vals[u]; ++at; }
+    wave_lds_fence();
+    const bool have = (uint32_t)lane < total;
+    const uint64_t key = have ? buf[lane] : KEY_EMPTY;
+    const uint32_t val = have ? vbuf[lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < total; ++j) rank += buf[j] < key ? 1u : 0u;
+    if (have) { buf[64 + rank] = key; vbuf[64 + rank] = val; }
+    wave_lds_fence();
+    sorted = have ? buf[64 + lane] : KEY_EMPTY;
+    sval = have ? vbuf[64 + lane] : 0xFFFFFFFFu;
+    wave_lds_fence();
+    return true;
+}
 // ------------------------------------------------------------------------------------
 // merge_kernel: one wave per query folds all partial lists.
 // PROBE == false: final results (row ids via ids[], sqrt optional, search.rs:129-141).
@@ -708,9 +740,37 @@ __device__ __forceinline__ void probe_merge_helpers(const MergeArgs &a, uint32_t
         for (uint32_t i = threadIdx.x - 64; i < a.preset_flag_n / 4; i += blockDim.x - 64) pf[i] = 0u;
     }
 }
+// |q|^2 for the MFMA screen (any order) and max |q_i| (f16 operand range check): one wave
+__device__ __forceinline__ void probe_query_norms(const MergeArgs &a, uint32_t q, int lane) {
+    if (a.qnorm_out || a.qmax_out) {      // |q|^2 for the MFMA screen (any order) and max |q_i| (f16 operand range check):
+        float acc = 0.0f, m = 0.0f;       // one pass, all of a lane's loads in flight together (up to 8 x 16 bytes)
+        const float *qp = a.queries + (uint64_t)q * a.dim;
+        if ((a.dim % 4u) == 0u) {
+            for (uint32_t d0 = (uint32_t)lane * 4u; d0 < a.dim; d0 += 2048u) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t d = d0 + 256u * (uint32_t)u;
+                    v[u] = d < a.dim ? *reinterpret_cast<const float4 *>(qp + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc += v[u].x * v[u].x; acc += v[u].y * v[u].y; acc += v[u].z * v[u].z; acc += v[u].w * v[u].w;
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                }
+            }
+        } else {
+            for (uint32_t d = lane; d < a.dim; d += 64) { const float v = qp[d]; acc += v * v; m = fmaxf(m, fabsf(v)); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off, 64); m = fmaxf(m, __shfl_down(m, off, 64)); }
+        if (lane == 0 && a.qnorm_out) a.qnorm_out[q] = acc;
+        if (lane == 0 && a.qmax_out) a.qmax_out[q] = m;
+    }
+}
 // probe merge, wave 0 after the selection: probe order, candidate bases, histogram / single-query bucketing, norms
 template <int S>
-__device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q, int lane, WaveTopk<S> &tk) {
+__device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q, int lane, WaveTopk<S> &tk, bool norms = true) {
     uint64_t carry = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -766,31 +826,7 @@ __device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q,
         atomicAdd(&st[3], (unsigned long long)(carry < a.max_pos ? carry : a.max_pos));
     }
     if (a.gthr_init && lane == 0) a.gthr_init[q] = ~0ull;          // per-query admission threshold: none yet
-    if (a.qnorm_out || a.qmax_out) {      // |q|^2 for the MFMA screen (any order) and max |q_i| (f16 operand range check):
-        float acc = 0.0f, m = 0.0f;       // one pass, all of a lane's loads in flight together (up to 8 x 16 bytes)
-        const float *qp = a.queries + (uint64_t)q * a.dim;
-        if ((a.dim % 4u) == 0u) {
-            for (uint32_t d0 = (uint32_t)lane * 4u; d0 < a.dim; d0 += 2048u) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t d = d0 + 256u * (uint32_t)u;
-                    v[u] = d < a.dim ? *reinterpret_cast<const float4 *>(qp + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc += v[u].x * v[u].x; acc += v[u].y * v[u].y; acc += v[u].z * v[u].z; acc += v[u].w * v[u].w;
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
-                }
-            }
-        } else {
-            for (uint32_t d = lane; d < a.dim; d += 64) { const float v = qp[d]; acc += v * v; m = fmaxf(m, fabsf(v)); }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off, 64); m = fmaxf(m, __shfl_down(m, off, 64)); }
-        if (lane == 0 && a.qnorm_out) a.qnorm_out[q] = acc;
-        if (lane == 0 && a.qmax_out) a.qmax_out[q] = m;
-    }
+    if (norms) probe_query_norms(a, q, lane);
 }
 
 template <int S, bool PROBE>
@@ -816,6 +852,46 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     uint64_t cut = KEY_EMPTY;
     uint32_t ncand = 0;
     if (a.cand_keys) { ncand = a.cand_cnt[q]; if (ncand > a.cand_cap) ncand = a.cand_cap; }
+    bool folded = false;
+    if constexpr (S == 1 && !PROBE) {
+        // the usual final merge of the wide screened path: nothing spilled, up to 1024 candidates, k <= 64 -- keys and values
+        // in ONE round trip (16 per lane), the k-th lane minimum as a cut, and the handful that pass it ordered by rank
+        // counting instead of being inserted one by one
+        if (a.cand_keys && scan == 0 && ncand <= 1024u && a.k <= 64u) {
+            __shared__ uint64_t s_mk[128];
+            __shared__ uint32_t s_mv[128];
+            const uint64_t *ck = a.cand_keys + (uint64_t)q * a.cand_cap;
+            const uint32_t *cv = a.cand_vals + (uint64_t)q * a.cand_cap;
+            uint64_t kreg[16];
+            uint32_t vreg[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+                kreg[u] = idx < ncand ? ck[idx] : KEY_EMPTY;
+                vreg[u] = idx < ncand ? cv[idx] : 0xFFFFFFFFu;
+            }
+            uint64_t lmin = KEY_EMPTY;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) lmin = kreg[u] < lmin ? kreg[u] : lmin;
+            const uint64_t cut2 = wave_kth_by_rank(lmin, a.k, lane, s_mk);
+            uint64_t sk = KEY_EMPTY;
+            uint32_t sv = 0xFFFFFFFFu;
+            if (wave_select_by_sort_kv<16>(kreg, vreg, cut2, lane, s_mk, s_mv, sk, sv)) {
+                tk.key[0] = (uint32_t)lane < a.k ? sk : KEY_EMPTY;
+                tk.val[0] = (uint32_t)lane < a.k ? sv : 0xFFFFFFFFu;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    uint64_t key = kreg[u];
+                    if (key > cut2) key = KEY_EMPTY;
+                    if (__ballot(key != KEY_EMPTY) != 0ull) tk.offer(key, vreg[u], a.k, lane);
+                }
+            }
+            folded = true;
+        }
+    }
+    if (folded) {
+    } else {
     if (S == 1 && !(a.part_flags && scan) && scan + ncand > 128) {
         uint64_t lmin = KEY_EMPTY;
         for (uint64_t i = lane; i < scan; i += 64) { const uint64_t key = pk[i]; lmin = key < lmin ? key : lmin; }
@@ -871,6 +947,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
                 if (i0 + 64 * u < n && __ballot(kv[u] != KEY_EMPTY) != 0ull) tk.offer(kv[u], vv[u], a.k, lane);
         }
     }
+    }
     if constexpr (!PROBE) {
         const uint32_t k_out = a.k_out ? a.k_out : a.k;
         uint32_t found = 0;
@@ -922,8 +999,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// probe_single_kernel: the whole centroid probe of ONE query in one launch.  A block takes 64 centroids (a lane each);
-// its 16 waves split the row's 4-value groups, compute the reference's per-group terms ((d0^2 + d1^2) + d2^2) + d3^2 with
+// probe_single_kernel: the whole centroid probe of ONE query in one launch.  A block takes 16 centroids (kc / 16 blocks:
+// a CU takes in ~40 GB/s, so the 3 MB table wants 64+ of them); its 16 waves split the row's 4-value groups, compute the reference's per-group terms ((d0^2 + d1^2) + d2^2) + d3^2 with
 // all of their loads in flight at once and leave them in LDS; wave 0 then adds the terms in the reference's order
 // (index.rs:461-480: one running sum over the groups) -- the same bits as probe_rows_kernel<1>, but the 3 MB centroid
 // table is read by kc / 64 blocks x 16 waves instead of kc / 256 blocks walking it 16 groups at a time (round 3: 43 -> 
@@ -931,68 +1008,70 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
 // runs the probe merge's tail (probe order, candidate bases, single-query bucketing, norms) with its other waves doing
 // the merge's helper work: one launch instead of stream_kernel + merge_kernel.
 // ------------------------------------------------------------------------------------
-constexpr uint32_t PS_SLAB = 192;      // groups per LDS slab (48 KB of terms)
+constexpr uint32_t PS_SLAB = 768;      // groups per LDS slab (48 KB of terms)
+constexpr uint32_t PS_CPB = 16;        // centroids per block
 __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs pr, const MergeArgs a, uint32_t *ticket, const PairQuantArgs qa) {
     __shared__ uint32_t s_last;
-    __shared__ float ts[PS_SLAB * 64];
+    __shared__ float ts[PS_SLAB * PS_CPB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c = blockIdx.x * 64u + (uint32_t)lane;         // < kc_pad (a multiple of 256)
+    const uint32_t cl = (uint32_t)lane & 15u, gs = (uint32_t)lane >> 4;
+    const uint32_t c = blockIdx.x * PS_CPB + cl;                  // < kc_pad (a multiple of 256)
     uint64_t key = KEY_EMPTY;
     PQV_STAMP_MIN(0);
     // the int8 image of the query (wide screened path) rides along.  One-centre form: it does not depend on the probe -- an
     // extra block makes it while the others read the centroids.  Residual form (one image per probed list): the last
     // block's helper waves make them once wave 0 has the probe order (below).
-    const bool extra = blockIdx.x * 64u >= pr.kc_pad;
+    const bool extra = blockIdx.x * PS_CPB >= pr.kc_pad;
     if (extra) {
         if (wave == 0 && qa.n_pairs && !qa.probe) quantize_pair_i8_wave(qa, 0u, 0u, 0u, lane);
     } else {
         const uint32_t G = pr.dim >> 2;
         const float4 *xt = pr.cent_t + c;
-        const float *qv = pr.queries;
+        const float4 *qv = reinterpret_cast<const float4 *>(pr.queries);
         float sum = 0.0f;
         for (uint32_t s0 = 0; s0 < G; s0 += PS_SLAB) {
             const uint32_t sl = G - s0 < PS_SLAB ? G - s0 : PS_SLAB;
-            // wave w: groups w, w + 16, ... of the slab, 12 in flight (a 768-dim row: all of them at once)
-            for (uint32_t gb = (uint32_t)wave; gb < sl; gb += 192) {
-                float4 x[12];
+            // a load instruction covers 4 groups x 16 centroids (256-byte runs); thread (wave, gs): groups 4 wave + gs + 64 u
+            for (uint32_t gb = (uint32_t)wave * 4u + gs; gb < sl; gb += 256) {
+                float4 x[4], qq[4];
 #pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const uint32_t g = gb + 16u * (uint32_t)u;
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t g = gb + 64u * (uint32_t)u;
                     x[u] = xt[(uint64_t)(s0 + (g < sl ? g : gb)) * pr.kc_pad];
+                    qq[u] = qv[s0 + (g < sl ? g : gb)];
                 }
 #pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const uint32_t g = gb + 16u * (uint32_t)u;
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t g = gb + 64u * (uint32_t)u;
                     if (g < sl) {
-                        const float4 qq = load4_uniform<true>(qv + (s0 + g) * 4);
-                        const float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
+                        const float d0 = qq[u].x - x[u].x, d1 = qq[u].y - x[u].y, d2 = qq[u].z - x[u].z, d3 = qq[u].w - x[u].w;
                         float t = d0 * d0 + d1 * d1;
                         t = t + d2 * d2;
                         t = t + d3 * d3;
-                        ts[g * 64u + (uint32_t)lane] = t;
+                        ts[g * PS_CPB + cl] = t;
                     }
                 }
             }
             PQV_STAMP_MAX(1);
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0 && lane < (int)PS_CPB) {
                 uint32_t g = 0;
                 for (; g + 16 <= sl; g += 16) {
                     float t[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) t[u] = ts[(g + u) * 64u + (uint32_t)lane];
+                    for (int u = 0; u < 16; ++u) t[u] = ts[(g + u) * PS_CPB + cl];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) sum = sum + t[u];
                 }
-                for (; g < sl; ++g) sum = sum + ts[g * 64u + (uint32_t)lane];
+                for (; g < sl; ++g) sum = sum + ts[g * PS_CPB + cl];
             }
             __syncthreads();
         }
         if (c < pr.kc) key = ((uint64_t)__float_as_uint(sum) << 32) | c;
     }
     PQV_STAMP_MAX(2);
-    if (wave == 0 && !extra)
+    if (wave == 0 && !extra && lane < (int)PS_CPB)
     __hip_atomic_store(pr.part_keys + c, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The keys are published by agent-scope atomic stores (write-through to the memory side) and read back by agent-scope
     // atomic loads: all the ticket needs is that the stores have completed -- a release fence would also write the L2 back,
@@ -1009,6 +1088,7 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
     PQV_STAMP_MAX(3);
     __shared__ uint32_t s_probe_c[64];
     if (wave != 0) {
+        if (wave == 1) probe_query_norms(a, 0u, lane);      // (beside wave 0's selection instead of after it)
         probe_merge_helpers(a, 0u);
         if (qa.n_pairs && qa.probe) {
             __syncthreads();                   // wave 0 has the probe order
@@ -1063,7 +1143,7 @@ __global__ __launch_bounds__(1024) void probe_single_kernel(const ProbeRowsArgs 
         s_probe_c[lane] = ((uint32_t)lane < a.k && tk.key[0] != KEY_EMPTY) ? tk.val[0] : 0xFFFFFFFFu;
         __syncthreads();
     }
-    probe_merge_tail<1>(a, 0u, lane, tk);
+    probe_merge_tail<1>(a, 0u, lane, tk, false);
     PQV_STAMP_MAX(6);
 }
 hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, const PairQuantArgs *quant, hipStream_t s) {
@@ -1075,7 +1155,7 @@ hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint
         if (qa.dim % 4 || qa.nprobe == 0 || (qa.probe ? (qa.n_pairs != a.k || !qa.pair_lb) : qa.n_pairs != 1)) return hipErrorInvalidValue;
     }
     const uint32_t extra = (qa.n_pairs && !qa.probe) ? 1u : 0u;
-    hipLaunchKernelGGL(probe_single_kernel, dim3(pr.kc_pad / 64 + extra), dim3(1024), 0, s, pr, a, ticket, qa);
+    hipLaunchKernelGGL(probe_single_kernel, dim3(pr.kc_pad / PS_CPB + extra), dim3(1024), 0, s, pr, a, ticket, qa);
     return hipGetLastError();
 }
 
@@ -1833,7 +1913,7 @@ __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
                         a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf, reinterpret_cast<float *>(qs_tail), a.seed_tail.lds_floats);
 }
 // U: operand stages a wave keeps in flight.  1 for batches (other waves fill the stalls); a one-query call has ONE 64-row
-// tile per wave and nothing else on the CU, so its 48 KB are requested 6 stages at a time.  Only the U > 1 instances
+// tile per wave and nothing else on the CU, so its 48 KB are requested 12 stages at a time.  Only the U > 1 instances
 // carry the one-query tail (select + refinement by the last block): its register needs (16 row chunks + 16 query chunks
 // in flight per lane) would otherwise set the allocation -- and halve the occupancy -- of the batched instances.
 template <int NG, bool QLDS, int OP, int U = 1>
@@ -1841,6 +1921,12 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
     static_assert(!I8 || QLDS, "int8 operands: queries staged in LDS");
     constexpr uint32_t NQ = 16 * NG;
+    // One-query instance (U > 1; launched only for nq == 1, so a quad holds ONE query): a block takes one 64-row tile and
+    // each of its waves ONE 16-row sub-tile of it (TS = 1) -- four times the blocks, because a CU takes in ~25-40 GB/s
+    // and the sample's 12 MB are cold; the waves' bounds are combined through LDS, so seed_ub looks exactly as when one
+    // wave walks the whole tile.  Only group 0 exists (NGE = 1).
+    constexpr bool ONE = U > 1;
+    constexpr int TS = ONE ? 1 : 4, NGE = ONE ? 1 : NG;
     PQV_STAMP_MIN(8);
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
@@ -1851,9 +1937,12 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const uint32_t sub = blockIdx.z * NQ;
     if (sub >= quad.z) { if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); } return; }
     const uint32_t c = quad.x, p0 = quad.y + sub, cnt = quad.z - sub < NQ ? quad.z - sub : NQ;
-    const uint32_t ng = (cnt + 15) >> 4;
+    const uint32_t ng = ONE ? 1u : (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (requested before the list bounds are waited for: one round trip for both)
+    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
+    const uint32_t my_pair = a.pairs[my_slot];
 
     extern __shared__ float4 qs[];
     __shared__ __attribute__((aligned(16))) float qn_all[4 * 64];
@@ -1863,8 +1952,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 
     const uint64_t lbeg = a.list_off[c], lend = a.list_off[c + 1];
     const uint64_t len = lend - lbeg;
-    const uint64_t wrows = a.rows_per_block / 4;
-    uint64_t r0 = a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
+    const uint64_t wrows = ONE ? 64 : a.rows_per_block / 4;
+    uint64_t r0 = ONE ? a.row_offset + (uint64_t)bx * 64 : a.row_offset + (uint64_t)bx * a.rows_per_block + (uint64_t)wave * wrows;
     uint64_t r1 = r0 + wrows;
     if (r1 > len) r1 = len;
     if (a.row_end && r1 > a.row_end) r1 = a.row_end;
@@ -1876,8 +1965,22 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const float c16 = F16 ? 1.25f * 9.765625e-04f : 0.0f;               // f16 operands: see wide_filter_kernel
     const float isc2 = F16 ? 1.0f / a.scale2 : 1.0f;                    // scores are contracted at scale^2
 
-    const uint32_t my_slot = p0 + ((uint32_t)lane < cnt ? (uint32_t)lane : cnt - 1);
-    const uint32_t my_pair = a.pairs[my_slot];
+    const int l15 = lane & 15, kk = lane >> 4;
+    const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
+    const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;
+    // one-query instance: the wave's operand stages are requested NOW, next to the chain pair -> bases -> query image that
+    // follows (every step of either chain is a cold round trip, and nothing else runs on the CU to hide it)
+    [[maybe_unused]] float4 xpre[ONE ? U : 1];
+    if constexpr (ONE) {
+        if (r1 > r0) {
+            uint64_t T = blk0 + ((r0 + 16u * (uint32_t)wave) >> 4);
+            if (T > blk_last) T = blk_last;
+            const __amdgpu_buffer_rsrc_t xr0 = operand_rsrc(a.mat_blk + T * G * 16);
+            const uint32_t nks0 = G >> 2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) xpre[u] = buf_ld16(xr0, lane_off * 16u, ((uint32_t)u < nks0 ? (uint32_t)u : nks0 - 1) * 1024);
+        }
+    }
     const uint32_t my_qrow = my_pair / a.nprobe;
     const uint64_t my_cbase = a.cand_base[my_pair];
     // list offsets below my_lim are candidates of this query (max_candidates cap)
@@ -1896,8 +1999,13 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         const uint32_t sw = q & 15u;
         if constexpr (I8) {        // the image of the (query, this list) PAIR: the residual against the list's centre
             const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)__shfl((int)my_img, (int)q, 64) * dim);
+            if constexpr (U > 1) {
+#pragma unroll 16
+                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
+            } else {
 #pragma unroll 4
-            for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
+                for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
+            }
         } else if constexpr (F16) {
 #pragma unroll 4
             for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = pack_f16x8(src[2 * ch], src[2 * ch + 1], a.scale);
@@ -1911,58 +2019,62 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
-    const int l15 = lane & 15, kk = lane >> 4;
-    const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;
-    const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;
-    float mins[NG][4];
+    float mins[NGE][4];
     // I8: the largest dot - ceil(Nx / 2) a lane sees per query bounds the smallest |qi - xi|^2 from above
-    [[maybe_unused]] int maxs[NG][4];
+    [[maybe_unused]] int maxs[NGE][4];
     [[maybe_unused]] float rmax = 0.0f;          // largest residual bound among the rows this lane saw
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int g = 0; g < NGE; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { mins[g][r] = INFINITY; maxs[g][r] = -(1 << 30); }
 
     for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
         const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
-        const float4 *xbase[4];
-        float xn[4];
-        [[maybe_unused]] int xn2i[4];
+        const float4 *xbase[TS];
+        float xn[TS];
+        [[maybe_unused]] int xn2i[TS];
+        const int tb = ONE ? wave : 0;               // first 16-row sub-tile of this wave
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int tt = 0; tt < TS; ++tt) {
+            const int t = tb + tt;
             uint32_t rr = (uint32_t)(16 * t + l15);
             if (rr >= nvalid) rr = nvalid - 1;
             if constexpr (I8) {
-                xn[t] = 0.0f;
-                xn2i[t] = a.row_n2i[lbeg + t0 + rr];
+                xn[tt] = 0.0f;
+                xn2i[tt] = a.row_n2i[lbeg + t0 + rr];
                 if ((uint32_t)(16 * t + l15) < nvalid) rmax = fmaxf(rmax, a.row_res[lbeg + t0 + rr]);
             } else
-            xn[t] = a.row_norm2[lbeg + t0 + rr];
+            xn[tt] = a.row_norm2[lbeg + t0 + rr];
             uint64_t T = blk0 + ((t0 + 16 * t) >> 4);
             if (T > blk_last) T = blk_last;
-            xbase[t] = a.mat_blk + T * G * 16;
+            xbase[tt] = a.mat_blk + T * G * 16;
         }
         const __amdgpu_buffer_rsrc_t xr = operand_rsrc(xbase[0]);
-        uint32_t xso[4];
+        uint32_t xso[TS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
+        for (int t = 0; t < TS; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
         using acc_t = std::conditional_t<I8, i32x4_acc, f32x4_acc>;
-        acc_t acc[NG][4];
+        acc_t acc[NGE][TS];
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NGE; ++g)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TS; ++t) {
                 if constexpr (I8) { const int init = -((xn2i[t] + 1) >> 1); acc[g][t] = (i32x4_acc){init, init, init, init}; }
                 else acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
             }
         const uint32_t nks = G >> 2;
         for (uint32_t ks0 = 0; ks0 < nks; ks0 += U) {
-            float4 x[U][4];
+            float4 x[U][TS];
+            if (ONE && ks0 == 0) {          // (one branch around the whole stage set, not a select per load)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t ks = ks0 + u < nks ? ks0 + u : nks - 1;
+                for (int u = 0; u < U; ++u) x[u][0] = xpre[ONE ? u : 0];
+            } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x[u][t] = buf_ld16(xr, lane_off * 16u, xso[t] + ks * 1024);
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t ks = ks0 + u < nks ? ks0 + u : nks - 1;
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) x[u][t] = buf_ld16(xr, lane_off * 16u, xso[t] + ks * 1024);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1970,19 +2082,19 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 if (U > 1 && ks >= nks) break;
                 const uint32_t chq = ks * 4 + (uint32_t)kk;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
+                for (int g = 0; g < NGE; ++g) {
                     if ((uint32_t)g < ng) {
                         float4 qc;
                         if constexpr (QLDS) qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
                         else qc = buf_ld16(qr, lane_off * 16u, (uint32_t)g * G * 256 + ks * 1024);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[u][t]);
+                        for (int t = 0; t < TS; ++t) mfma_step<OP>(acc[g][t], qc, x[u][t]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int g = 0; g < NGE; ++g) {
             const float4 q4 = *reinterpret_cast<const float4 *>(qnl + 16 * g + 4 * kk);
             const uint4 l4 = *reinterpret_cast<const uint4 *>(liml + 16 * g + 4 * kk);
             const float qn[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -1990,14 +2102,15 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int tt = 0; tt < TS; ++tt) {
+                    const int t = tb + tt;
                     const uint32_t roff = (uint32_t)t0 + (uint32_t)(16 * t + l15);     // list offset (< 2^32 rows per list)
                     const bool valid = (uint32_t)(16 * t + l15) < nvalid && roff < lim[r];
                     if constexpr (I8) {
-                        if (valid) maxs[g][r] = max(maxs[g][r], acc[g][t][r]);
+                        if (valid) maxs[g][r] = max(maxs[g][r], acc[g][tt][r]);
                     } else {
-                        const float nn = qn[r] + xn[t];
-                        const float dt = nn - 2.0f * (acc[g][t][r] * isc2);
+                        const float nn = qn[r] + xn[tt];
+                        const float dt = nn - 2.0f * (acc[g][tt][r] * isc2);
                         const float ub = dt + cmargin * (2.0f * nn + fabsf(dt)) + c16 * nn;
                         if (valid) mins[g][r] = fminf(mins[g][r], ub);                     // NaN bounds are ignored
                     }
@@ -2006,10 +2119,32 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         }
     }
     PQV_STAMP_MAX(10);
+    if constexpr (ONE) {
+        // the four sub-tiles' bounds: wave 0 takes the best of each lane position (int8: the largest dot and the largest
+        // residual bound, which enter the bound together below)
+        __shared__ float s_red[4][5][64];
+        float *mine = &s_red[wave][0][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[r * 64] = I8 ? __int_as_float(maxs[0][r]) : mins[0][r];
+        mine[4 * 64] = rmax;
+        __syncthreads();
+        if (wave == 0)
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o = s_red[w][r][lane];
+                if constexpr (I8) maxs[0][r] = max(maxs[0][r], __float_as_int(o));
+                else mins[0][r] = fminf(mins[0][r], o);
+            }
+            rmax = fmaxf(rmax, s_red[w][4][lane]);
+        }
+    }
     // publish: one value per (query, this wave, lane & 15)
     const uint32_t my_j = my_pair % a.nprobe;
+    if (!ONE || wave == 0)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NGE; ++g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t qi = (uint32_t)(16 * g + kk * 4 + r);
@@ -2027,7 +2162,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
                 }
             }
             if (qi < cnt) {
-                float *dst = a.seed_ub + (((uint64_t)qrow * a.nprobe + j) * a.seed_sw + bx * 4 + wave) * 16 + l15;
+                float *dst = a.seed_ub + (((uint64_t)qrow * a.nprobe + j) * a.seed_sw + (ONE ? bx : bx * 4 + wave)) * 16 + l15;
                 if constexpr (U > 1) __hip_atomic_store(dst, fmaxf(mins[g][r], 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = fmaxf(mins[g][r], 0.0f);
             }
@@ -2059,6 +2194,16 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
     const uint32_t v_hi = refine ? (v_lo + quarter < n_vals ? v_lo + quarter : n_vals) : n_vals;
     // (the one-query tail -- the only caller with LDS for the terms -- reads bounds this very launch published: agent-scope loads)
     const bool same_launch = lds_terms != nullptr;
+    // the refinement needs first row, end and candidate base of the probed lists: fetched now (two dependent round trips that
+    // hide behind the selection) instead of after it
+    __shared__ uint64_t s_lbeg[64], s_lend[64], s_cbase[64];
+    const bool pre_lists = refine && same_launch && rf.nprobe <= 64u;
+    if (pre_lists && wave == 3 && (uint32_t)lane < rf.nprobe) {
+        const uint32_t c = rf.probe[(uint64_t)q * rf.nprobe + lane];
+        s_lbeg[lane] = rf.list_off[c];
+        s_lend[lane] = rf.list_off[c + 1];
+        s_cbase[lane] = rf.cand_base[(uint64_t)q * rf.nprobe + lane];
+    }
     auto ld_ub = [&](uint32_t idx) {
         const float *p = seed_ub + (uint64_t)q * n_vals + idx;
         return same_launch ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
@@ -2175,7 +2320,11 @@ __device__ __forceinline__ void seed_select_body(const uint32_t q, const float *
                 const uint32_t l15 = idx & 15u, slot = (idx >> 4) % rf.seed_sw, j = (idx >> 4) / rf.seed_sw;
                 const uint32_t row = (slot >> 2) * 256u + (slot & 3u) * 64u + 16u * t + l15;
                 uint64_t lbeg = 0;
-                if (valid) {
+                if (valid && pre_lists) {
+                    lbeg = s_lbeg[j];
+                    pos = s_cbase[j] + row;
+                    valid = row < rf.seed_rows && lbeg + row < s_lend[j] && pos < rf.max_pos;
+                } else if (valid) {
                     const uint32_t c = rf.probe[(uint64_t)q * rf.nprobe + j];
                     lbeg = rf.list_off[c];
                     pos = rf.cand_base[(uint64_t)q * rf.nprobe + j] + row;
@@ -2354,14 +2503,14 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const float *seed_ub, 
     {                                                                                                                   \
         TileArgs b = a;                                                                                                 \
         b.seed_tail.lds_floats = (uint32_t)((size_t)(LDS_) / 4);                                                        \
-        if (deep) hipLaunchKernelGGL((wide_seed_kernel<NG_, true, OP_, 6>), GRID_, dim3(256), (LDS_), s, b);            \
+        if (deep) { dim3 g4 = GRID_; g4.x *= 4; hipLaunchKernelGGL((wide_seed_kernel<NG_, true, OP_, 12>), g4, dim3(256), (LDS_), s, b); } \
         else hipLaunchKernelGGL((wide_seed_kernel<NG_, true, OP_>), GRID_, dim3(256), (LDS_), s, b);                    \
     }
 hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     if (a.max_quads == 0 || a.grid_x == 0) return hipSuccess;
     if ((a.dim % 64) != 0 || !a.mat_blk || a.row_of || !a.seed_ub) return hipErrorInvalidValue;
     const size_t lds4 = 64ull * a.dim * 4, lds2 = 32ull * a.dim * 4;
-    const bool deep = a.seed_tail.enable != 0;       // a one-query call: six operand stages in flight per wave
+    const bool deep = a.seed_tail.enable != 0 && a.nq == 1;       // a one-query call: twelve operand stages in flight per wave
     if (a.i8) {       // int8 images: 32 queries x dim bytes per block
         if ((a.dim % 256) != 0 || !a.q_i8 || !a.q_n2i || !a.q_resu || !a.list_scale || !a.row_n2i || !a.row_res || (a.quad_width % 32) != 0 ||
             32ull * a.dim > 65536) return hipErrorInvalidValue;
@@ -2387,10 +2536,10 @@ hipError_t launch_wide_seed(const TileArgs &a, hipStream_t s) {
     else if (a.quad_width == 32 && lds2 <= 32768)
         SEED_LAUNCH(2, OP_F32, dim3(a.grid_x, a.max_quads), lds2)
     else if (a.quad_width == 32 && a.q_blk) {
-        if (deep) hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32, 6>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        if (deep) hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32, 12>), dim3(a.grid_x * 4, a.max_quads), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wide_seed_kernel<2, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     } else if (a.quad_width == 64 && a.q_blk) {
-        if (deep) hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32, 6>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
+        if (deep) hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32, 12>), dim3(a.grid_x * 4, a.max_quads), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wide_seed_kernel<4, false, OP_F32>), dim3(a.grid_x, a.max_quads), dim3(256), 0, s, a);
     }
     else return hipErrorInvalidValue;
