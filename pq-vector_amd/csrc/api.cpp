@@ -246,6 +246,9 @@ struct pqv_searcher {
         uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
         int pair_prune = 1;                // int8 path: drop (query, list) pairs whose centre-distance bound exceeds the query's threshold
         int i8_form = 0;                   // int8 images: 0 by rule (per-list residual where the lists are tight), 1 one centre, 2 residual
+        int wide_quads = 1;                // int8, 96-query quads: lists probed by 97..160 queries of the batch take ONE 160-query quad
+                                           // (8-wave blocks on 32-row tiles) instead of two passes; 0 = off
+        uint32_t wide_quad_rows = 0;       // rows per block of that instance (0 = by rule: 6144)
     };
     mutable Opts opt;
     mutable pqv_counters_t counters{};
@@ -1183,6 +1186,8 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
+    o.wide_quads = static_cast<int>(num("PQV_WIDE_QUADS", o.wide_quads));
+    o.wide_quad_rows = static_cast<uint32_t>(num("PQV_WIDE_QUAD_ROWS", o.wide_quad_rows));
     o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
     o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
 }
@@ -1430,6 +1435,8 @@ struct TopkPlan {
     uint32_t filter_rows_per_block, max_quads, quad_width;
     uint32_t block_waves;   // wide kernel: waves per block (4, or 8 sharing one staged quad on a whole CU)
     uint32_t slots_per_pair;   // partial lists per (query, probe rank)
+    uint32_t wide_width;    // > 0: quads of 97..wide_width pairs go to the wide-quad instance (its own item table)
+    uint32_t wide_rows_per_block, wide_bpl;
 };
 
 // Exact refinement of the seed threshold (SeedRefine): where survivors are expensive (rows of >= 256 dims; C2, 128 dims:
@@ -1564,6 +1571,17 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 p.filter_bpl = static_cast<uint32_t>((max_len + r - 1) / r);
                 p.rr_bpl = p.filter_bpl;
                 p.slots_per_pair = p.block_waves * p.filter_bpl;
+                // Lists that more than 96 queries of the batch probe (the long, popular ones: 36 % of C3's distinct probed
+                // rows) would be streamed twice; a quad of up to 160 queries on 32-row tiles (same accumulator registers) in
+                // one 8-wave block per CU reads them once.  Batches only (pairs >= 16 per list on average), work-item grid.
+                if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && o.item_grid >= 1 && 160ull * s->sdim <= 122880 &&
+                    pairs >= 16ull * s->n_clusters) {
+                    p.wide_width = 160;
+                    const uint64_t wr = o.wide_quad_rows >= 512 ? o.wide_quad_rows / 256 * 256 : 6144ull;
+                    p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
+                    p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
+                    p.slots_per_pair = std::max(p.slots_per_pair, 8 * p.wide_bpl);
+                }
             } else {                // narrow kernel: exact seed window (slot chunk 0), screened remainder
                 p.filter_bpl = static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
                 p.rr_bpl = 1 + p.filter_bpl;
@@ -1641,7 +1659,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         // u32 scratch: hist[R][kc] cursor[R][kc] pair_off[kc+1] group_off[kc+1] n_groups[1] quad_off[kc+1] n_quads[1]
         // (R = HIST_REPLICAS partial copies); the probe kernel zeroes hist, the probe merge fills it, the scan sets cursor
         constexpr uint64_t R = pqv::HIST_REPLICAS;
-        HIP_TRY(sc.s_pair_u32.ensure(((2 * R + 4) * kc_pairs + 8) * sizeof(uint32_t)));      // + item_off[kc+1] n_items[1]
+        HIP_TRY(sc.s_pair_u32.ensure(((2 * R + 5) * kc_pairs + 10) * sizeof(uint32_t)));      // + item_off[kc+1] n_items[1] wide_item_off[kc+1] wide_n_items[1]
         pair_u32 = sc.s_pair_u32.as<uint32_t>();
         pa.zero_u32 = pair_u32; pa.zero_n = static_cast<uint32_t>(R * kc_pairs);
         HIP_TRY(sc.s_gthr.ensure(static_cast<size_t>(nq) * sizeof(unsigned long long)));
@@ -1690,11 +1708,13 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
     const bool items = p.tile && p.filter && p.quad && (s->opt.item_grid > 1 || (s->opt.item_grid == 1 && p.block_waves == 4)) &&
                        static_cast<uint64_t>(p.max_quads) * p.filter_bpl <= (1ull << 24);
     const uint32_t max_items = items ? p.max_quads * p.filter_bpl : 0;
+    const bool wide = items && p.wide_width != 0 && !single_bucket;
+    const uint32_t wide_max_items = wide ? p.max_quads * p.wide_bpl : 0;
     if (p.tile) {
         HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
         HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
         HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
-        if (items) HIP_TRY(sc.s_items.ensure(static_cast<size_t>(max_items) * sizeof(uint32_t)));
+        if (items) HIP_TRY(sc.s_items.ensure((static_cast<size_t>(max_items) + wide_max_items) * sizeof(uint32_t)));
     }
     if (single_bucket) {
         uint32_t *v = pair_u32 + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc_pairs);
@@ -1749,7 +1769,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ps.hist = u; ps.hist_stride = kc; ps.nprobe = p.np; ps.cursor = u + pqv::HIST_REPLICAS * static_cast<uint64_t>(kc);
         ps.pair_off = v + 2ull * kc; ps.group_off = v + 3ull * kc + 1;
         ps.n_groups = v + 4ull * kc + 2;
-        ps.quad_off = v + 4ull * kc + 3; ps.n_quads = v + 5ull * kc + 4; ps.quad_width = p.quad_width ? p.quad_width : 64;
+        ps.quad_off = v + 4ull * kc + 3; ps.n_quads = v + 5ull * kc + 4; ps.quad_width = wide ? p.wide_width : p.quad_width ? p.quad_width : 64;
         ps.pairs = sc.s_pairs.as<uint32_t>(); ps.groups = sc.s_groups.as<uint4>(); ps.quads = sc.s_quads.as<uint4>();
         // work items of the wide filter kernel (quad x row chunk that exists): its grid then has no holes
         // (the 8-wave blocks keep the 2-D grid with its quad-to-XCD affinity: C2 7.25 against 7.13 M QPS)
@@ -1757,6 +1777,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ps.list_off = s->d_list_off.as<uint64_t>(); ps.item_rows = p.filter_rows_per_block;
             ps.item_off = v + 5ull * kc + 5; ps.n_items = v + 6ull * kc + 6;
             ps.item_quad = sc.s_items.as<uint32_t>(); ps.max_items = max_items;
+            if (wide) {
+                ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
+                ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
+                ps.wide_item_quad = sc.s_items.as<uint32_t>() + max_items; ps.wide_max_items = wide_max_items;
+            }
         }
         if (!single_bucket) HIP_TRY(launch_pair_sort(ps, stream));
         TileArgs ta{};
@@ -1823,6 +1848,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = sc.s_spilled.as<uint32_t>();
             // thresholds: upper bounds of the first seed_rows rows of every probed list
             TileArgs seed = ta;
+            if (wide) seed.quad_width = p.wide_width;      // (the seed kernel samples a quad in slices of its own 64 queries)
             seed.row_offset = 0; seed.row_end = p.seed_rows; seed.rows_per_block = 256;
             seed.grid_x = (p.seed_rows + 255) / 256; seed.seed_sw = 4 * seed.grid_x;
             const uint32_t n_vals = p.np * seed.seed_sw * 16;
@@ -1861,6 +1887,11 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
             if (items) { ta.item_quad = ps.item_quad; ta.n_items = ps.n_items; ta.max_items = max_items; }
+            if (wide) {
+                ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
+                ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
+                s->counters.kernel_launches += 1;
+            }
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
@@ -2253,6 +2284,8 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "pair_prune") o.pair_prune = value != 0;
+    else if (n == "wide_quads") o.wide_quads = value != 0;
+    else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "i8_form") {        // takes effect when the int8 copy is (re)built
         o.i8_form = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));
         (void)hipSetDevice(s->device);
@@ -2277,7 +2310,7 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         return PQV_OK;
     }
     const TopkPlan p = plan_topk(s, std::max<uint32_t>(1, nq), nprobe, k, metric);
-    char t[512];
+    char t[768];
     if (p.tile && p.filter && p.quad)
         std::snprintf(t, sizeof t, "wide_seed_kernel + seed_select_kernel + wide_filter_kernel: %s screen operands, quads of %u queries "
                       "staged %s, %u waves per block, %u rows per block, threshold sample %u rows per list%s%s",
@@ -2293,6 +2326,11 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         std::snprintf(t, sizeof t, "tile_rerank_kernel: exact arithmetic, 16-query groups, %u rows per block", p.rr_rows_per_block);
     else
         std::snprintf(t, sizeof t, "stream_kernel: one candidate stream per (query, probed list), %u rows per block", p.rr_rows_per_block);
+    if (p.tile && p.filter && p.quad && p.wide_width) {
+        const size_t l = std::strlen(t);
+        std::snprintf(t + l, sizeof t - l, "; lists probed by %u..%u queries: one quad, 8 waves per block on 32-row tiles, %u rows per block",
+                      p.quad_width + 1, p.wide_width, p.wide_rows_per_block);
+    }
     if (s->sdim != s->dim) {
         const size_t l = std::strlen(t);
         std::snprintf(t + l, sizeof t - l, "; rows stored zero-padded from %u to %u dims", s->dim, s->sdim);
@@ -2305,10 +2343,15 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         const bool pf = p.f16 && s->sdim <= 128 && p.block_waves == 4 && p.quad_width != 96;
         const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
         const int seed_ng = p.i8 ? (64ull * s->sdim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->sdim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
-        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",
+        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
+                      (p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) ? "true" : "false",
                       seed_ng, qlds ? "true" : "false", op, S,
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
+        if (p.wide_width) {
+            const size_t l = std::strlen(kn);
+            std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, false, 2>", p.wide_width / 16, S);
+        }
     }
     std::snprintf(buf, len, "%s; centroid probe: %s%s", t, p.probe_rows ? "probe_rows_kernel (a lane per centroid)" : "stream_kernel", kn);
     return PQV_OK;

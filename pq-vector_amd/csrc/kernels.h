@@ -179,6 +179,16 @@ struct PairSortArgs {
     uint32_t       *n_items;   // [1]
     uint32_t       *item_quad; // [max_items] quad of each item; quads[q].w = the quad's first item
     uint32_t        max_items;
+    // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
+    // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
+    // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the
+    // last) stay in item_quad
+    uint32_t        wide_min;
+    uint32_t        wide_item_rows;
+    uint32_t       *wide_item_off;  // [n_clusters + 1]
+    uint32_t       *wide_n_items;   // [1]
+    uint32_t       *wide_item_quad; // [wide_max_items]
+    uint32_t        wide_max_items;
 };
 // hist -> scan -> scatter; three tiny launches
 hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
@@ -266,6 +276,11 @@ struct TileArgs {
     const uint32_t *item_quad;   // wide_filter_kernel: work-item table (PairSortArgs::item_quad); nullptr = 2-D grid
     const uint32_t *n_items;
     uint32_t        max_items;
+    // second launch for the WIDE quads (PairSortArgs::wide_*): 8-wave blocks, quads of wide_width queries on 32-row tiles
+    uint32_t        wide_width;  // 0 = none
+    const uint32_t *wide_item_quad;
+    const uint32_t *wide_n_items;
+    uint32_t        wide_max_items, wide_rows_per_block;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates
     uint64_t       *cand_keys;   // [nq][cand_cap]
     uint32_t       *cand_vals;

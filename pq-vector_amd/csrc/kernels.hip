@@ -74,10 +74,17 @@ typedef float f32x4_raw __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const void *base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7FFFFFFF, 0x00020000);
 }
+template <int AUX = 0>      // cache policy bits of the load (2 = nt: a stream that is read once)
 __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
-    const f32x4_raw v = __builtin_bit_cast(f32x4_raw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
+    const f32x4_raw v = __builtin_bit_cast(f32x4_raw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, AUX));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+#ifndef PQV_ROW_AUX
+#define PQV_ROW_AUX 0
+#endif
+#ifndef PQV_STAGE_UNROLL
+#define PQV_STAGE_UNROLL 12
+#endif
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 // One K step of the score contraction for a 16 x 16 tile.  f32 operands: 16 dims, four 16x16x4 MFMAs;
 // f16 operands (8 halves per lane, see launch_block_rows_f16): 32 dims, one 16x16x32 MFMA.
@@ -1184,10 +1191,10 @@ __global__ __launch_bounds__(256) void pair_hist_kernel(const PairSortArgs a) {
 
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     // single block: exclusive scans of hist and of ceil(hist / TILE_QB)
-    __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024], s_item[1024];
-    __shared__ uint32_t carry_pair, carry_grp, carry_quad, carry_item;
+    __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024], s_item[1024], s_witem[1024];
+    __shared__ uint32_t carry_pair, carry_grp, carry_quad, carry_item, carry_witem;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; }
+    if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; carry_witem = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
         const uint32_t c = base + tid;
@@ -1206,18 +1213,23 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
         }
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
         const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
-        uint32_t ni = 0;                     // work items of the cluster: quads x row chunks of its list
+        uint32_t ni = 0, nwi = 0;            // work items of the cluster: quads x row chunks of its list
         if (a.item_rows && c < a.n_clusters) {
             const uint64_t len = a.list_off[c + 1] - a.list_off[c];
-            ni = qd * (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+            uint32_t nwq = 0;                // wide quads: the full ones + a remainder of >= wide_min pairs
+            if (a.wide_min) {
+                nwq = h / a.quad_width + ((h % a.quad_width) >= a.wide_min ? 1u : 0u);
+                nwi = nwq * (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
+            }
+            ni = (qd - nwq) * (uint32_t)((len + a.item_rows - 1) / a.item_rows);
         }
-        s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd; s_item[tid] = ni;
+        s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd; s_item[tid] = ni; s_witem[tid] = nwi;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t vp = 0, vg = 0, vq = 0, vi = 0;
-            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; vq = s_quad[tid - off]; vi = s_item[tid - off]; }
+            uint32_t vp = 0, vg = 0, vq = 0, vi = 0, vw = 0;
+            if (tid >= off) { vp = s_pair[tid - off]; vg = s_grp[tid - off]; vq = s_quad[tid - off]; vi = s_item[tid - off]; vw = s_witem[tid - off]; }
             __syncthreads();
-            s_pair[tid] += vp; s_grp[tid] += vg; s_quad[tid] += vq; s_item[tid] += vi;
+            s_pair[tid] += vp; s_grp[tid] += vg; s_quad[tid] += vq; s_item[tid] += vi; s_witem[tid] += vw;
             __syncthreads();
         }
         if (c < a.n_clusters) {
@@ -1225,9 +1237,13 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
             a.group_off[c] = carry_grp + s_grp[tid] - g;
             a.quad_off[c] = carry_quad + s_quad[tid] - qd;
             if (a.item_rows) a.item_off[c] = carry_item + s_item[tid] - ni;
+            if (a.item_rows && a.wide_min) a.wide_item_off[c] = carry_witem + s_witem[tid] - nwi;
         }
         __syncthreads();
-        if (tid == 1023) { carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; carry_quad += s_quad[1023]; carry_item += s_item[1023]; }
+        if (tid == 1023) {
+            carry_pair += s_pair[1023]; carry_grp += s_grp[1023]; carry_quad += s_quad[1023]; carry_item += s_item[1023];
+            carry_witem += s_witem[1023];
+        }
         __syncthreads();
     }
     if (tid == 0) {
@@ -1237,6 +1253,10 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
         *a.n_groups = carry_grp;
         *a.n_quads = carry_quad;
         if (a.item_rows) { a.item_off[a.n_clusters] = carry_item; *a.n_items = carry_item < a.max_items ? carry_item : a.max_items; }
+        if (a.item_rows && a.wide_min) {
+            a.wide_item_off[a.n_clusters] = carry_witem;
+            *a.wide_n_items = carry_witem < a.wide_max_items ? carry_witem : a.wide_max_items;
+        }
     }
 }
 
@@ -1256,13 +1276,21 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
         const uint32_t h = a.hist[c];
         const uint32_t qi = a.quad_off[c] + i / a.quad_width;
         uint32_t first = 0;
+        const uint32_t qcnt = h - i < a.quad_width ? h - i : a.quad_width;
         if (a.item_rows) {
             const uint64_t len = a.list_off[c + 1] - a.list_off[c];
-            const uint32_t nch = (uint32_t)((len + a.item_rows - 1) / a.item_rows);
-            first = a.item_off[c] + (i / a.quad_width) * nch;
-            for (uint32_t t = 0; t < nch && first + t < a.max_items; ++t) a.item_quad[first + t] = qi;
+            if (a.wide_min && qcnt >= a.wide_min) {         // a wide quad: the list's quads before it are wide too
+                const uint32_t nch = (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
+                first = a.wide_item_off[c] + (i / a.quad_width) * nch;
+                for (uint32_t t = 0; t < nch && first + t < a.wide_max_items; ++t) a.wide_item_quad[first + t] = qi;
+            } else {
+                const uint32_t nch = (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+                // (with wide quads about, a quad of < wide_min pairs is the list's last and its only one in this table)
+                first = a.item_off[c] + (a.wide_min ? 0u : (i / a.quad_width) * nch);
+                for (uint32_t t = 0; t < nch && first + t < a.max_items; ++t) a.item_quad[first + t] = qi;
+            }
         }
-        a.quads[qi] = make_uint4(c, slot, h - i < a.quad_width ? h - i : a.quad_width, first);
+        a.quads[qi] = make_uint4(c, slot, qcnt, first);
     }
 }
 
@@ -2003,7 +2031,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
 #pragma unroll 16
                 for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
             } else {
-#pragma unroll 4
+#pragma unroll PQV_STAGE_UNROLL
                 for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
             }
         } else if constexpr (F16) {
@@ -2589,33 +2617,51 @@ hipError_t launch_seed_select(const float *seed_ub, uint32_t nq, uint32_t n_vals
 template <int QS>
 __device__ __forceinline__ uint32_t qsel_u32(const uint32_t (&v)[QS], uint32_t qi) {
     uint32_t r = (uint32_t)__shfl((int)v[0], (int)(qi & 63u), 64);
-    if constexpr (QS > 1) { const uint32_t r1 = (uint32_t)__shfl((int)v[1], (int)(qi & 63u), 64); r = qi < 64u ? r : r1; }
+#pragma unroll
+    for (int s = 1; s < QS; ++s) { const uint32_t rs = (uint32_t)__shfl((int)v[s], (int)(qi & 63u), 64); r = (qi >> 6) == (uint32_t)s ? rs : r; }
     return r;
 }
 template <int QS>
 __device__ __forceinline__ uint64_t qsel_u64(const uint64_t (&v)[QS], uint32_t qi) {
     uint64_t r = shfl_u64(v[0], (int)(qi & 63u));
-    if constexpr (QS > 1) { const uint64_t r1 = shfl_u64(v[1], (int)(qi & 63u)); r = qi < 64u ? r : r1; }
+#pragma unroll
+    for (int s = 1; s < QS; ++s) { const uint64_t rs = shfl_u64(v[s], (int)(qi & 63u)); r = (qi >> 6) == (uint32_t)s ? rs : r; }
     return r;
 }
 template <int QS>
 __device__ __forceinline__ uint32_t qread_u32(const uint32_t (&v)[QS], uint32_t qq) {      // qq wave-uniform
-    if constexpr (QS > 1) return readlane_u32(qq < 64u ? v[0] : v[1], (int)(qq & 63u));
-    else return readlane_u32(v[0], (int)qq);
+    uint32_t x = v[0];
+#pragma unroll
+    for (int s = 1; s < QS; ++s) x = (qq >> 6) == (uint32_t)s ? v[s] : x;
+    return readlane_u32(x, (int)(qq & 63u));
 }
 template <int QS>
 __device__ __forceinline__ uint64_t qread_u64(const uint64_t (&v)[QS], uint32_t qq) {
-    if constexpr (QS > 1) return readlane_u64(qq < 64u ? v[0] : v[1], (int)(qq & 63u));
-    else return readlane_u64(v[0], (int)qq);
+    uint64_t x = v[0];
+#pragma unroll
+    for (int s = 1; s < QS; ++s) x = (qq >> 6) == (uint32_t)s ? v[s] : x;
+    return readlane_u64(x, (int)(qq & 63u));
 }
 
-template <int NG, int NW, int S, bool QLDS, int OP, bool PF>
+// ONCE: every row of the launch is read by exactly one block (a batch that fits one quad, a one-query call above all): the
+// operand stream carries the nt policy, so it does not displace the queries' images and thresholds from L2 / the Infinity
+// Cache (C3 single query 174 -> 166 us; on batches whose long lists are streamed twice the same hint costs 3.5 %).
+// TS: 16-row sub-tiles per wave tile.  4 (64-row tiles) everywhere but the WIDE-QUAD instance <10, 8, .., TS = 2>: 32-row tiles
+// halve the accumulator registers per query group, so ONE block holds a quad of 160 queries (120 KB of int8 images) and a
+// list that 97..160 queries of the batch probe is streamed once instead of twice (launch_tile_filter, TileArgs::wide_*).
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF, bool ONCE, int TS>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && OP != OP_F32)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
+    constexpr int ROW_AUX = ONCE ? 2 : PQV_ROW_AUX;
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
     static_assert(!PF || (QLDS && F16), "whole-tile operand prefetch: f16 rows of <= 128 dims");
     static_assert(!I8 || QLDS, "int8 operands: queries staged in LDS");
-    static_assert(TILE_QB == 16 && NG >= 2 && NG <= 8 && (NG % 2) == 0 && (NW == 4 || NW == 8), "16-row MFMA tiles, 2..8 groups, 4 or 8 waves");
+    static_assert(TILE_QB == 16 && NG >= 2 && NG <= 12 && (NG % 2) == 0 && (NW == 4 || NW == 8), "16-row MFMA tiles, 2..12 groups, 4 or 8 waves");
+    static_assert(TS == 4 || (TS == 2 && QLDS && !PF && OP != OP_F32), "32-row tiles: staged queries, int8 / f16 operands");
+    constexpr uint32_t TROWS = 16 * TS;            // rows per wave tile
+    constexpr uint32_t FW = 4 * TS, GPW = 32 / FW; // keep-bits per lane and group; groups per 32-bit word
+    constexpr int NWD = (NG + (int)GPW - 1) / (int)GPW;
     constexpr uint32_t NQ = 16 * NG;
+    constexpr uint32_t QSH = NQ > 128 ? 24 : 25;   // queue entry = (query index << QSH) | row offset from the wave's r0
     constexpr int QS = (NQ + 63) / 64;        // state slots per lane
     // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
     // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
@@ -2681,7 +2727,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     const uint32_t ng = (cnt + 15) >> 4;             // active groups (wave-uniform)
 
     extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
-    __shared__ uint32_t pend_all[NW * PEND];         // (query index << 25) | row offset from the wave's r0
+    __shared__ uint32_t pend_all[NW * PEND];         // (query index << QSH) | row offset from the wave's r0
     uint32_t *pend = pend_all + wave * PEND;
     __shared__ __attribute__((aligned(16))) float aq_all[NW * NQ];   // per-wave, per-query screen terms
     float *aq = aq_all + wave * NQ;
@@ -2696,7 +2742,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // (staging the quad's queries, the final partial batch of exact evaluations) would be wasted
         const uint64_t nch = (len + a.rows_per_block - 1) / a.rows_per_block;
         if (bx >= nch) return;
-        wrows = ((len + NW * nch - 1) / (NW * nch) + 63) / 64 * 64;
+        wrows = ((len + NW * nch - 1) / (NW * nch) + TROWS - 1) / TROWS * TROWS;
         r0 = ((uint64_t)bx * NW + (uint64_t)wave) * wrows;
     }
     uint64_t r1 = r0 + wrows;
@@ -2731,7 +2777,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     constexpr bool LST = NW == 8 || I8 || NG == 6;
     __shared__ uint64_t qst_cbase[LST ? NQ : 1];
     __shared__ uint32_t qst_pair[LST ? NQ : 1];
-    __shared__ float qst_qn[LST ? NQ : 1];            // |q|^2; NaN = never skip this query (float operand forms)
+    __shared__ float qst_qn[LST && !I8 ? NQ : 1];     // |q|^2; NaN = never skip this query (float operand forms)
     __shared__ float qst_res[LST ? NQ : 1];           // int8: residual bound (+inf = never skip)
     __shared__ int qst_n2i[LST ? NQ : 1];             // int8: |qi|^2
     uint32_t my_qrow[QS];
@@ -2757,7 +2803,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             if (qi < NQ) {
                 qst_pair[qi] = pair;
                 qst_cbase[qi] = a.cand_base[pair];
-                qst_qn[qi] = noskip ? __uint_as_float(0x7FC00000u) : qn;
+                if constexpr (!I8) qst_qn[qi] = noskip ? __uint_as_float(0x7FC00000u) : qn;
                 if constexpr (I8) { qst_n2i[qi] = a.q_n2i[my_pairi[s]]; qst_res[qi] = a.q_res[my_pairi[s]]; }   // +inf: non-finite query
             }
         } else {
@@ -2774,7 +2820,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // !QLDS (rows too long for LDS): the A operands come from the quad's BLOCKED query copy in global
     // memory (pack_queries_kernel; L2-resident), fetched like the B operands -- 1 KiB per load.
     if constexpr (QLDS) {
-        constexpr uint32_t NQP2 = NQ <= 32 ? 32 : NQ <= 64 ? 64 : 128;
+        constexpr uint32_t NQP2 = NQ <= 32 ? 32 : NQ <= 64 ? 64 : NQ <= 128 ? 128 : 256;
         constexpr uint32_t TPQ = NT / NQP2;
         const uint32_t q = threadIdx.x / TPQ, c0 = threadIdx.x % TPQ;
         const uint32_t q_src = qsel_u32<QS>(my_qrow, q < NQ ? q : NQ - 1);
@@ -2787,7 +2833,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const uint32_t sw = q & 15u;
             if constexpr (I8) {        // the int8 images were made once per batch and pair (quantize_pairs_i8_kernel)
                 const float4 *s8 = reinterpret_cast<const float4 *>(a.q_i8 + (uint64_t)p_src * dim);
-#pragma unroll 4
+#pragma unroll PQV_STAGE_UNROLL
                 for (uint32_t ch = c0; ch < G; ch += TPQ) dst[ch ^ sw] = s8[ch];
             } else if constexpr (F16) {
                 if (a.q32_lds) {          // short rows: the exact f32 queries too, for the exact evaluation of survivors
@@ -2818,7 +2864,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint32_t npend = 0;
     uint32_t n_exact = 0;
 #ifdef PQV_PROFILE_PHASES
-    uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0, ph_top_sum = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
+    uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0, ph_top_sum = 0, ph_xt = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
     uint64_t cur_gthr[QS];
@@ -2841,8 +2887,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const bool valid = pi < count;
         const bool have = valid && pj == 0u;
         const uint32_t pe = pend[start + (valid ? pi : 0)];
-        const uint32_t qsl = pe >> 25;                        // query index in the quad
-        const uint64_t roff = r0 + (pe & 0x01FFFFFFu);         // row offset in the list
+        const uint32_t qsl = pe >> QSH;                       // query index in the quad
+        const uint64_t roff = r0 + (pe & ((1u << QSH) - 1u));  // row offset in the list
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const float *x = a.mat + (uint64_t)srow * dim;
@@ -3050,19 +3096,37 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifndef PQV_NS_WIDE
 #define PQV_NS_WIDE 2
 #endif
+#ifndef PQV_NS_TS2
+#define PQV_NS_TS2 2
+#endif
+#ifndef PQV_APD_TS2
+#define PQV_APD_TS2 2
+#endif
+#ifndef PQV_APD
+#define PQV_APD 0
+#endif
+#ifndef PQV_XTA_TS2
+#define PQV_XTA_TS2 1
+#endif
+#ifndef PQV_XTA
+#define PQV_XTA 0
+#endif
+#ifndef PQV_ABL
+#define PQV_ABL 0          // timing ablations of the wide-quad instance (wrong results): 1 = two groups' MFMAs only, 2 = no operand loads inside the K loop
+#endif
 #ifndef PQV_XT
 #define PQV_XT 1
 #endif
 #ifndef PQV_XPF
 #define PQV_XPF 1
 #endif
-    constexpr int NS = (OP != OP_F32 && QLDS && !PF && NG <= 6 && NW == 8) ? PQV_NS_WIDE : 2;      // operand stages in flight
+    constexpr int NS = TS == 2 ? PQV_NS_TS2 : (OP != OP_F32 && QLDS && !PF && NG <= 6 && NW == 8) ? PQV_NS_WIDE : 2;      // operand stages in flight
     constexpr bool XPF = PQV_XPF;          // the next tile's first stages are requested before this tile's screen
-    float4 xs[NS][4];
-    auto tile_desc = [&](uint64_t tn, uint32_t (&so)[4]) {
+    float4 xs[NS][TS];
+    auto tile_desc = [&](uint64_t tn, uint32_t (&so)[TS]) {
         const float4 *b0 = nullptr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TS; ++t) {
             uint64_t T = blk0 + ((tn + 16 * t) >> 4);
             if (T > blk_last) T = blk_last;             // tiles past the list's end: masked by the screen
             const float4 *b = a.mat_blk + T * G * 16;
@@ -3076,41 +3140,67 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     constexpr bool XT = PQV_XT && QLDS && !PF && OP != OP_F32;
     if constexpr (XT && XPF) {
         if (r0 < r1) {
-            uint32_t so[4];
+            uint32_t so[TS];
             const __amdgpu_buffer_rsrc_t r = tile_desc(r0, so);
 #pragma unroll
             for (int j = 0; j < NS; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(r, lane_b, so[t] + j * 1024);
+                for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(r, lane_b, so[t] + j * 1024);
         }
     }
-    [[maybe_unused]] int xn2i_next[4] = {0, 0, 0, 0};
-    [[maybe_unused]] float xres_next[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] int xn2i_next[TS] = {};
+    [[maybe_unused]] float xres_next[TS] = {};
+    // XTA: nothing is waited for between two K loops -- the thresholds of tile i + 1's screen and the row terms of tile i + 2
+    // are requested behind K loop i, AHEAD of tile i + 1's operand stages in the (in-order) load queue, so they have landed
+    // whenever an operand has.  A threshold is then one tile old when it screens (it only ever tightens: a few more
+    // survivors), and the fabric round trip of an agent-scope load (~3 us under load, 19 % of a wave's time on 32-row
+    // tiles) leaves the critical path.
+    constexpr bool XTA = XT && I8 && (TS == 2 ? PQV_XTA_TS2 : PQV_XTA);
+    [[maybe_unused]] int xn2i_nn[XTA ? TS : 1] = {};
+    [[maybe_unused]] float xres_nn[XTA ? TS : 1] = {};
+    [[maybe_unused]] uint64_t gthr_pf[XTA ? QS : 1];
+    if constexpr (XTA) {
+#pragma unroll
+        for (int s = 0; s < QS; ++s) gthr_pf[s] = cur_gthr[s];
+    }
     if constexpr (I8) {
         if (r0 < r1) {
-            const uint32_t nv = (r1 - r0 < 64) ? (uint32_t)(r1 - r0) : 64u;
+            const uint32_t nv = (r1 - r0 < TROWS) ? (uint32_t)(r1 - r0) : TROWS;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TS; ++t) {
                 uint32_t rr = (uint32_t)(16 * t + l15);
                 if (rr >= nv) rr = nv - 1;
                 xn2i_next[t] = a.row_n2i[lbeg + r0 + rr];
                 xres_next[t] = a.row_res[lbeg + r0 + rr];
             }
+            if constexpr (XTA) {
+                const uint64_t t2 = r0 + TROWS;
+                if (t2 < r1) {
+                    const uint32_t nv2 = (r1 - t2 < TROWS) ? (uint32_t)(r1 - t2) : TROWS;
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {
+                        uint32_t rr = (uint32_t)(16 * t + l15);
+                        if (rr >= nv2) rr = nv2 - 1;
+                        xn2i_nn[t] = a.row_n2i[lbeg + t2 + rr];
+                        xres_nn[t] = a.row_res[lbeg + t2 + rr];
+                    }
+                }
+            }
         }
     }
-    for (uint64_t t0 = r0; t0 < r1; t0 += 64) {
+    for (uint64_t t0 = r0; t0 < r1; t0 += TROWS) {
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_top = __builtin_amdgcn_s_memtime();
 #endif
-        const uint32_t nvalid = (r1 - t0 < 64) ? (uint32_t)(r1 - t0) : 64u;
+        const uint32_t nvalid = (r1 - t0 < TROWS) ? (uint32_t)(r1 - t0) : TROWS;
         // B operands come from the BLOCKED copy of the lists (launch_block_rows): 16-row tile T,
         // 16-byte column ch, row j of the tile at float4 index (T * G + ch) * 16 + j -- the 64 lanes
         // (j = lane & 15, ch = k0 / 4 + lane >> 4) of one load read 1 KiB contiguous.  Tile bases are
         // wave-uniform (scalar registers); the lane offset is shared by all loads.
-        const float4 *xbase[4];
-        float xn[4];
+        const float4 *xbase[TS];
+        float xn[TS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TS; ++t) {
             uint32_t rr = (uint32_t)(16 * t + l15);
             if (rr >= nvalid) rr = nvalid - 1;
             if constexpr (I8) xn[t] = 0.0f; else xn[t] = pf ? xn_pf[t] : a.row_norm2[lbeg + t0 + rr];
@@ -3120,18 +3210,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
         // I8: the rows' integer norms and residual bounds feed the accumulators' start values, so they are fetched
         // one tile ahead (their latency would otherwise sit in front of the K loop)
-        [[maybe_unused]] int xn2i[4];
-        [[maybe_unused]] float xres[4];
+        [[maybe_unused]] int xn2i[TS];
+        [[maybe_unused]] float xres[TS];
         if constexpr (I8) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { xn2i[t] = xn2i_next[t]; xres[t] = xres_next[t]; }
+            for (int t = 0; t < TS; ++t) { xn2i[t] = xn2i_next[t]; xres[t] = xres_next[t]; }
         }
         // one descriptor per tile (base = its first 16-row sub-tile); the other sub-tiles and the K steps
         // are scalar byte offsets (< 1 MiB)
         const __amdgpu_buffer_rsrc_t xr = operand_rsrc(xbase[0]);
-        uint32_t xso[4];
+        uint32_t xso[TS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
+        for (int t = 0; t < TS; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
         uint64_t my_thr[QS];
         if constexpr (!XT) {
 #pragma unroll
@@ -3143,7 +3233,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         }
 
         using acc_t = std::conditional_t<I8, i32x4_acc, f32x4_acc>;
-        acc_t acc[NG][4];
+        acc_t acc[NG][TS];
         if constexpr (I8) {
             // int8 operands.  x = c + xi / S + e_x and q = c + qi / S + e_q (c = per-dimension mid-range, S one global
             // scale, xi / qi the int8 images, |e_x| <= rx and |e_q| <= rq stored upper bounds of the residual norms), so
@@ -3155,7 +3245,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             // (known before the K loop, no threshold in it), the query term one integer add per pair after the loop,
             // the sign bit the answer.  All roundings go up (never skip wrongly); the contraction itself is exact.
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TS; ++t) {
                 const int init = -(xn2i[t] >> 1);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) acc[g][t] = (i32x4_acc){init, init, init, init};
@@ -3164,7 +3254,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < TS; ++t) acc[g][t] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
         }
 
 #ifdef PQV_PROFILE_PHASES
@@ -3176,14 +3266,44 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // per-group branches it falls back to vmcnt(0) in front of every MFMA group, which serialises
         // the prefetch).
         const uint32_t nks = G >> 2;          // K steps (4 operand columns = 1 KiB per 16-row sub-tile each): a multiple of 4
-        auto mma = [&](const float4 (&x)[4], uint32_t ks, auto full) {
+        // A operands: one ds_read_b128 per group and K step.  Left to itself the compiler keeps ONE register quad for them
+        // -- read, wait out the LDS latency, TS MFMAs, read ... -- which costs little behind four MFMAs but is most of a
+        // K step behind two (the wide-quad instance: 1500 cycles per K step for 256 cycles of MFMA).  APD > 0: the read of
+        // group g + APD is issued before the MFMAs of group g (rotating register quads; group indices past the quad's last
+        // group are clamped to it, the staged part of the LDS).
+        constexpr int APD = TS == 2 ? PQV_APD_TS2 : PQV_APD;
+        auto mma = [&](const float4 (&x)[TS], uint32_t ks, auto full) {
             const uint32_t chq = ks * 4 + (uint32_t)kk;
+            if constexpr (APD == 0) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (decltype(full)::value || (uint32_t)g < ng) {
-                    const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
+                for (int g = 0; g < NG; ++g) {
+                    if (decltype(full)::value || (uint32_t)g < ng) {
+                        const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
+                        for (int t = 0; t < TS; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
+                    }
+                }
+            } else {
+                const float4 *qb0 = qs + (uint32_t)l15 * G + (chq ^ (uint32_t)l15);
+                const uint32_t gstride = 16u * G;
+                float4 qb[APD + 1];
+#pragma unroll
+                for (int g = 0; g < APD && g < NG; ++g) {
+                    const uint32_t gi = decltype(full)::value || (uint32_t)g < ng ? (uint32_t)g : ng - 1u;
+                    qb[g] = qb0[gi * gstride];
+                }
+#pragma unroll
+                for (int g = 0; g < (PQV_ABL == 1 ? 2 : NG); ++g) {
+                    if (decltype(full)::value || (uint32_t)g < ng) {
+                        if (g + APD < NG) {
+                            const uint32_t gi = decltype(full)::value || (uint32_t)(g + APD) < ng ? (uint32_t)(g + APD) : ng - 1u;
+                            qb[(g + APD) % (APD + 1)] = qb0[gi * gstride];
+                        }
+#pragma unroll
+                        for (int t = 0; t < TS; ++t) mfma_step<OP>(acc[g][t], qb[g % (APD + 1)], x[t]);
+                        // (the machine scheduler otherwise sinks every read back in front of its use to save the registers)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         };
@@ -3192,7 +3312,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(xr, lane_b, xso[t] + j * 1024);
+                    for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(xr, lane_b, xso[t] + j * 1024);
             }
             // on entry xs[j] holds (or awaits) K step j of this tile; nks is a multiple of 4 >= NS
             uint32_t ks = 0;
@@ -3200,8 +3320,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     mma(xs[j], ks + j, full);
+#if PQV_ABL != 2
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(xr, lane_b, xso[t] + (ks + j + NS) * 1024);
+                    for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(xr, lane_b, xso[t] + (ks + j + NS) * 1024);
+#endif
                 }
             }
 #pragma unroll
@@ -3241,14 +3363,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             if (ks < nks) mmag(x0, q0);
             if (ks + 1 < nks) mmag(x1, q1);
         };
-        if constexpr (!QLDS) kloop_gq();
-        else if (pf) {
+        if constexpr (!QLDS) { if constexpr (TS == 4) kloop_gq(); }
+        else if constexpr (PF) {
 #pragma unroll
-            for (int ks = 0; ks < (CAN_PF ? 4 : 1); ++ks)
+            for (int ks = 0; ks < 4; ++ks)
                 if ((uint32_t)ks < nks) mma(xt[ks], (uint32_t)ks, std::false_type{});
         }
-        else if (ng == (uint32_t)NG) kloop(std::true_type{});
+        // (32-row tiles: always the branch-free body -- a wide quad has 7..10 of its 10 groups, the matrix pipe has room for
+        //  the idle ones, whose garbage scores are masked with the queries past cnt, and the per-group branches would cost
+        //  the exact wait counts of the A-operand pipeline)
+        else if (ng == (uint32_t)NG || TS == 2) kloop(std::true_type{});
         else kloop(std::false_type{});
+#ifdef PQV_PROFILE_PHASES
+        const uint64_t ph_x0 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (XT) {
             // Between the K loops NOTHING this wave loads may be consumed while operand prefetches are in flight: loads
             // return in order, so waiting for a fresh one drains the whole queue (and a register the allocator spills
@@ -3256,14 +3384,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             // and the next tile's row terms are requested and waited for while the queue is empty anyway -- an L2 round
             // trip, and the thresholds are as fresh as they can be; (2) only then the next tile's first operand stages
             // go out, to fly during the screen, the expansion and the exact evaluations.
+            const uint64_t tn = t0 + TROWS;
+            if constexpr (XTA) {
 #pragma unroll
-            for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t tn = t0 + 64;
-            if constexpr (I8) {
+                for (int s = 0; s < QS; ++s) {
+                    cur_gthr[s] = gthr_pf[s];
+                    gthr_pf[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int t = 0; t < TS; ++t) { xn2i_next[t] = xn2i_nn[t]; xres_next[t] = xres_nn[t]; }
+                const uint64_t t2 = tn + TROWS;
+                if (t2 < r1) {
+                    const uint32_t nv2 = (r1 - t2 < TROWS) ? (uint32_t)(r1 - t2) : TROWS;
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {
+                        uint32_t rr = (uint32_t)(16 * t + l15);
+                        if (rr >= nv2) rr = nv2 - 1;
+                        xn2i_nn[t] = a.row_n2i[lbeg + t2 + rr];
+                        xres_nn[t] = a.row_res[lbeg + t2 + rr];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if constexpr (I8 && !XTA) {
                 if (tn < r1) {
-                    const uint32_t nv = (r1 - tn < 64) ? (uint32_t)(r1 - tn) : 64u;
+                    const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < TS; ++t) {
                         uint32_t rr = (uint32_t)(16 * t + l15);
                         if (rr >= nv) rr = nv - 1;
                         xn2i_next[t] = a.row_n2i[lbeg + tn + rr];
@@ -3273,21 +3422,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             }
 #pragma unroll
             for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
-            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
+            if constexpr (!XTA) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
             __builtin_amdgcn_sched_barrier(0);
             if (XPF && tn < r1) {
-                uint32_t nso[4];
+                uint32_t nso[TS];
                 const __amdgpu_buffer_rsrc_t nxr = tile_desc(tn, nso);
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) xs[j][t] = buf_ld16(nxr, lane_b, nso[t] + j * 1024);
+                    for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(nxr, lane_b, nso[t] + j * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 
 #ifdef PQV_PROFILE_PHASES
-        const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a;
+        const uint64_t ph_b = __builtin_amdgcn_s_memtime(); ph_k += ph_b - ph_a; ph_xt += ph_b - ph_x0;
 #endif
         // Screen.  skip  <=>  lb > thr  <=>  d~ > (thr + 2 c nn) / (1 - c)  <=>  s < smin, with
         //     smin = (nn - (thr + 2 c nn) / (1 - c)) / 2 = (alpha |q|^2 - beta thr) + alpha |x|^2
@@ -3300,15 +3449,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // bits = 2 bits + keep (v_addc with the compare's carry) -- three VALU ops per pair, no
         // branches, and the accumulators die here: the expansion of the bits into queue entries and the
         // exact evaluation below do not have to share registers with them.
-        float bt[4];
+        float bt[TS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
+        for (int t = 0; t < TS; ++t) bt[t] = (uint32_t)(16 * t + l15) < nvalid ? alpha * xn[t] : INFINITY;
         // per-query terms through LDS: lane q publishes a_q, then every lane reads the four values of its
         // kk for each group as one 16-byte load
         if constexpr (I8) {
             float R = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) R = fmaxf(R, (uint32_t)(16 * t + l15) < nvalid ? xres[t] : 0.0f);
+            for (int t = 0; t < TS; ++t) R = fmaxf(R, (uint32_t)(16 * t + l15) < nvalid ? xres[t] : 0.0f);
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) R = fmaxf(R, __shfl_xor(R, off, 64));
             wave_lds_fence();
@@ -3343,9 +3492,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             }
             wave_lds_fence();
         }
-        uint32_t bits[NG / 2];
+        // keep-bits of this lane's pairs: FW = 4 TS bits per group -- (r, t) at bit FW - 1 - (TS r + t) of the group's field --
+        // GPW groups per word, the first group of a word in its highest field
+        uint32_t bits[NWD];
 #pragma unroll
-        for (int w = 0; w < NG / 2; ++w) bits[w] = 0;
+        for (int w = 0; w < NWD; ++w) bits[w] = 0;
         if constexpr (I8) {
             // skip <=> acc + A2 < 0: one integer add per pair, the sign bit shifted into the lane's mask
 #pragma unroll
@@ -3355,12 +3506,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        bits[g >> 1] = __builtin_amdgcn_alignbit(bits[g >> 1], (uint32_t)(acc[g][t][r] + ar[r]), 31);
+                    for (int t = 0; t < TS; ++t)
+                        bits[g / (int)GPW] = __builtin_amdgcn_alignbit(bits[g / (int)GPW], (uint32_t)(acc[g][t][r] + ar[r]), 31);
                 }
             }
 #pragma unroll
-            for (int w = 0; w < NG / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
+            for (int w = 0; w < NWD; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
         } else if constexpr (F16) {
             // f16 operands: every term is finite by construction (rows scaled below 2^14, query images clamped
             // to the f16 range, never-skip / unset thresholds carry -3e38, invalid ones +inf), so
@@ -3373,9 +3524,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
                     const f32x2_t ar2 = rp ? f32x2_t{a4.z, a4.w} : f32x2_t{a4.x, a4.y};
-                    f32x2_t dd[4];
+                    f32x2_t dd[TS];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < TS; ++t) {
                         const f32x2_t smin = ar2 + f32x2_t{bt[t], bt[t]};
                         const f32x2_t av = {acc[g][t][2 * rp], acc[g][t][2 * rp + 1]};
                         dd[t] = av - smin;
@@ -3383,13 +3534,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            bits[g >> 1] = __builtin_amdgcn_alignbit(bits[g >> 1], __float_as_uint(dd[t][rr]), 31);
+                        for (int t = 0; t < TS; ++t)
+                            bits[g / (int)GPW] = __builtin_amdgcn_alignbit(bits[g / (int)GPW], __float_as_uint(dd[t][rr]), 31);
                     }
                 }
             }
 #pragma unroll
-            for (int w = 0; w < NG / 2; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
+            for (int w = 0; w < NWD; ++w) bits[w] = ~bits[w];      // sign bits say "skip"
         } else {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -3398,90 +3549,94 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < TS; ++t) {
                         const bool keep = !(acc[g][t][r] < ar[r] + bt[t]);
-                        bits[g >> 1] = bits[g >> 1] + bits[g >> 1] + (keep ? 1u : 0u);
+                        bits[g / (int)GPW] = bits[g / (int)GPW] + bits[g / (int)GPW] + (keep ? 1u : 0u);
                     }
                 }
             }
         }
-        // bit (15 - (4 r + t)) of the group's 16-bit field: group g even -> high half of bits[g / 2]
-        uint32_t rowmask4 = 0;                         // bit 3 - t: row 16 t + l15 of the tile belongs to this wave
+        // (a last word that holds fewer than GPW groups: its fields move up to where a full word has them)
+        if constexpr ((NG % (int)GPW) != 0) bits[NWD - 1] <<= FW * (GPW - (uint32_t)(NG % (int)GPW));
+        uint32_t rowmask = 0;                          // bit TS - 1 - t: row 16 t + l15 of the tile belongs to this wave
 #pragma unroll
-        for (int t = 0; t < 4; ++t) rowmask4 |= ((uint32_t)(16 * t + l15) < nvalid) ? (8u >> t) : 0u;
+        for (int t = 0; t < TS; ++t) rowmask |= ((uint32_t)(16 * t + l15) < nvalid) ? ((1u << (TS - 1)) >> t) : 0u;
         // the accumulators are dead from here on: the next tile's operands can take their registers
-        if (pf && t0 + 64 < r1) issue_tile(t0 + 64);
+        if constexpr (PF) { if (pf && t0 + 64 < r1) issue_tile(t0 + 64); }
         const uint32_t rowbase = (uint32_t)(t0 - r0) + (uint32_t)l15;
         // Fast path (almost every tile): all survivors of the tile fit the queue at once -- ONE prefix scan and
-        // one drain per tile.  Otherwise the bits are expanded a pass (PASS / 256 of a lane's four queries per
-        // group) at a time with the drain in between; after the last tile one extra pass flushes the queue.
+        // one drain per tile.  Otherwise the bits are expanded a pass (BP of a lane's FW pair bits per group) at a
+        // time with the drain in between; after the last tile one extra pass flushes the queue.
         // Explicit validity (rows past the wave's range, queries past the quad's count): the compare above keeps
         // a pair whenever its operands are NaN -- an unset threshold, non-finite data -- and an out-of-range row
         // must never reach the exact evaluation.
-        uint32_t vw[NG / 2];
+        uint32_t vw[NWD];
         uint32_t tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < NG / 2; ++ww) {
+        for (int ww = 0; ww < NWD; ++ww) {
             uint32_t vmw = 0;
 #pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const uint32_t g = 2 * ww + gg;
-                uint32_t vm = 0;
+            for (int gl = 0; gl < (int)GPW; ++gl) {
+                const uint32_t g = GPW * (uint32_t)ww + (uint32_t)gl;
+                if (g < (uint32_t)NG) {
+                    uint32_t vm = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask4 << (12 - 4 * r) : 0u;
-                vmw |= g < ng ? (gg ? vm : vm << 16) : 0u;
+                    for (int r = 0; r < 4; ++r) vm |= (16 * g + 4 * (uint32_t)kk + (uint32_t)r < cnt) ? rowmask << (FW - TS * (r + 1)) : 0u;
+                    vmw |= g < ng ? vm << (FW * (GPW - 1u - (uint32_t)gl)) : 0u;
+                }
             }
             vw[ww] = bits[ww] & vmw;
             tot += (uint32_t)__popc(vw[ww]);
         }
         const uint32_t incl_all = wave_incl_scan_u32(tot);
         const bool one_pass = readlane_u32(incl_all, 63) <= (uint32_t)PASS - 64u;
+        const bool last_tile = t0 + TROWS >= r1;
         if (one_pass) {
             uint32_t at = npend + incl_all - tot;
 #pragma unroll
-            for (int ww = 0; ww < NG / 2; ++ww) {
+            for (int ww = 0; ww < NWD; ++ww) {
                 uint32_t mm = vw[ww];
                 while (mm) {
-                    const uint32_t b = 31u - (uint32_t)__clz(mm);        // bit 31 - (16 (g & 1) + 4 r + t) of word g / 2
+                    const uint32_t b = 31u - (uint32_t)__clz(mm);
                     mm &= ~(1u << b);
-                    const uint32_t cc = 31u - b;                         // cc = 16 (g & 1) + 4 r + t
-                    const uint32_t qslot = 32u * ww + (cc & 16u) + 4u * (uint32_t)kk + ((cc >> 2) & 3u);
-                    pend[at++] = (qslot << 25) + rowbase + 16u * (cc & 3u);
+                    const uint32_t cc = 31u - b;                         // cc = FW gl + TS r + t
+                    const uint32_t gl = cc / FW, rt = cc % FW;
+                    const uint32_t qslot = 16u * (GPW * (uint32_t)ww + gl) + 4u * (uint32_t)kk + rt / TS;
+                    pend[at++] = (qslot << QSH) + rowbase + 16u * (rt % TS);
                 }
             }
             npend += readlane_u32(incl_all, 63);
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
 #endif
-            drain(t0 + 64 >= r1 ? 1u : 64u);
+            drain(last_tile ? 1u : 64u);
 #ifdef PQV_PROFILE_PHASES
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
         }
-        // slow path: passes of BP = PASS / 64 of a lane's 16 pair bits (cc = 4 r + t) per group: 8 (half a group per
-        // pass), 4 (a quarter) or 2
-        constexpr uint32_t BP = PASS / 64;
-        constexpr uint32_t PPG = 16 / BP;                    // passes per group
-        const uint32_t hend = one_pass ? 0u : PPG * ng + (t0 + 64 >= r1 ? 1u : 0u);
+        // slow path: passes of BP of a lane's FW pair bits (cc = TS r + t) per group
+        constexpr uint32_t BP = (uint32_t)PASS / 64u < FW ? (uint32_t)PASS / 64u : FW;
+        constexpr uint32_t PPG = FW / BP;                    // passes per group
+        const uint32_t hend = one_pass ? 0u : PPG * ng + (last_tile ? 1u : 0u);
 #pragma unroll 1
         for (uint32_t hg = 0; hg < hend; ++hg) {
             const uint32_t g = hg / PPG, ps = hg % PPG;
             if (g < ng) {
                 uint32_t w = vw[0];
 #pragma unroll
-                for (int ww = 1; ww < NG / 2; ++ww) w = (g >> 1) == (uint32_t)ww ? vw[ww] : w;
-                uint32_t mm = (g & 1u) ? (w & 0xFFFFu) : (w >> 16);
-                // cc = 4 r + t lives in bit 15 - cc: pass ps takes cc in [ps BP, ps BP + BP)
-                mm &= ((((1u << BP) - 1u) << (16 - BP)) & 0xFFFFu) >> (BP * ps);
+                for (int ww = 1; ww < NWD; ++ww) w = (g / GPW) == (uint32_t)ww ? vw[ww] : w;
+                uint32_t mm = (w >> (FW * (GPW - 1u - g % GPW))) & ((1u << FW) - 1u);
+                // cc = TS r + t lives in bit FW - 1 - cc: pass ps takes cc in [ps BP, ps BP + BP)
+                mm &= ((((1u << BP) - 1u) << (FW - BP)) & ((1u << FW) - 1u)) >> (BP * ps);
                 const uint32_t cntl = (uint32_t)__popc(mm);
                 const uint32_t incl = wave_incl_scan_u32(cntl);
                 uint32_t at = npend + incl - cntl;
-                const uint32_t qb = (16 * g + 4 * (uint32_t)kk) << 25;
+                const uint32_t qb = (16 * g + 4 * (uint32_t)kk) << QSH;
                 while (mm) {
                     const uint32_t b = 31u - (uint32_t)__clz(mm);        // highest set bit first
                     mm &= ~(1u << b);
-                    const uint32_t cc = 15u - b;                         // cc = 4 r + t
-                    pend[at++] = qb + ((cc >> 2) << 25) + rowbase + 16u * (cc & 3u);
+                    const uint32_t cc = FW - 1u - b;                     // cc = TS r + t
+                    pend[at++] = qb + ((cc / TS) << QSH) + rowbase + 16u * (cc % TS);
                 }
                 npend += readlane_u32(incl, 63);
             }
@@ -3513,7 +3668,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const unsigned long long wid = atomicAdd(&a.stats[6], 1ull);
             if (wid < 65536ull) {
                 unsigned long long *rec = a.stats + 8 + 8 * wid;
-                rec[0] = ph_t0; rec[1] = ph_pro | (ph_top_sum << 24); rec[2] = ph_k; rec[3] = ph_s - ph_e; rec[4] = ph_e;
+                rec[0] = ph_t0; rec[1] = ph_pro | (ph_top_sum << 24); rec[2] = ph_k | (ph_xt << 32); rec[3] = ph_s - ph_e; rec[4] = ph_e;
                 rec[5] = __builtin_amdgcn_s_memtime(); rec[6] = ph_em; rec[7] = cnt | ((unsigned long long)n_exact << 32);
             }
         }
@@ -3564,9 +3719,9 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 }
 
 // dynamic LDS beyond 64 KB has to be allowed per kernel once
-template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false>
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false, bool ONCE = false, int TS = 4>
 static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
-    auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF>;
+    auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF, ONCE, TS>;
     if (lds > 65536) {          // raise the kernel's dynamic-LDS ceiling to what this launch needs (static + dynamic <= 160 KB)
         static std::atomic<size_t> allowed{65536};
         if (lds > allowed.load(std::memory_order_relaxed)) {
@@ -3605,8 +3760,29 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
             const size_t lds = (size_t)live_w * a.dim;
             if ((size_t)a.quad_width * a.dim > 147456) return hipErrorInvalidValue;
             if (nw == 4) {        // two 4-wave blocks per CU
-                if (a.quad_width == 64 && 64ull * a.dim <= 65536) return launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
-                if (a.quad_width == 96 && 96ull * a.dim <= 73728) return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
+                if (a.quad_width == 64 && 64ull * a.dim <= 65536)
+                    return a.nq <= 64u ? launch_wide<4, 4, S, true, OP_I8, false, true>(a, lds, s)      // one quad per list: rows read once
+                                       : launch_wide<4, 4, S, true, OP_I8>(a, lds, s);
+                if (a.quad_width == 96 && 96ull * a.dim <= 73728) {
+                    if (a.wide_width) {
+                        // lists that 97..160 queries of the batch probe: ONE quad on 32-row tiles, one 8-wave block per CU --
+                        // every row of such a list is read once instead of twice.  Launched first: its blocks are the long ones.
+                        if (a.wide_width != 160 || !a.item_quad || !a.wide_item_quad || !a.wide_max_items || !a.wide_rows_per_block)
+                            return hipErrorInvalidValue;
+                        TileArgs w = a;
+                        w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0;
+                        w.item_quad = a.wide_item_quad; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
+                        w.rows_per_block = a.wide_rows_per_block;
+#ifdef PQV_WIDE_LAST
+                        const hipError_t e0 = launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
+                        if (e0 != hipSuccess) return e0;
+                        return launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
+#endif
+                        const hipError_t e = launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
+                        if (e != hipSuccess) return e;
+                    }
+                    return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
+                }
                 return hipErrorInvalidValue;
             }
             if (a.quad_width == 128) return launch_wide<8, 8, S, true, OP_I8>(a, lds, s);

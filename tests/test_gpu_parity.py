@@ -1226,3 +1226,45 @@ def test_f16_block_forms_match_oracle(pqv, oracle, monkeypatch, dim, waves):
     assert (nc == onc).all() and (nf == onf).all()
     assert (_bits(dist) == _bits(odist)).all()
     assert (rows == orows).all()
+
+
+@pytest.mark.parametrize("dim,k,wide_rows", [(256, 10, 0), (768, 10, 512), (768, 1, 0), (512, 32, 1024)])
+def test_wide_quads_stream_popular_lists_once(pqv, oracle, dim, k, wide_rows):
+    """Round 3: a list that more than 96 queries of the batch probe used to be streamed once per 96-query quad.  With
+    `wide_quads` (default) such a list's pairs are cut into quads of up to 160 and every quad of 97..160 pairs runs in the
+    wide-quad instance of the filter kernel (8 waves on 32-row tiles, its own work-item table), the remainder (<= 96) in
+    the regular one.  Few unequal lists and many queries give every case at once: lists with 0 .. 96, 97 .. 160,
+    161 .. 256 (a wide quad + a regular one) and > 320 pairs (two wide quads), lists whose length is no multiple of 32,
+    one- and multi-chunk lists.  Ids and distance bits must equal the oracle's with the instance on and off, the screened
+    pair count must be the same, and the dispatch must say which form ran."""
+    rng = np.random.default_rng(11 + dim + k)
+    kc, nprobe, nq = 9, 3, 700
+    sizes = [4001, 2977, 1500, 833, 700, 650, 517, 300, 45]
+    cen = (rng.standard_normal((kc, dim)) * 2.0).astype(np.float32)
+    data = np.concatenate([cen[c] + 0.3 * rng.standard_normal((m, dim)).astype(np.float32) for c, m in enumerate(sizes)])
+    data = np.ascontiguousarray(data[rng.permutation(len(data))].astype(np.float32))
+    # queries drawn near the centres with very unequal popularity
+    pop = np.array([0.45, 0.2, 0.12, 0.08, 0.06, 0.04, 0.03, 0.015, 0.005])
+    queries = (cen[rng.choice(kc, size=nq, p=pop)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=10)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    corpus = pqv.Corpus.upload(data)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    probes = np.stack([np.asarray(oidx.find_closest_centroids(q, nprobe)) for q in queries])
+    per_list = np.bincount(probes.ravel(), minlength=kc)
+    assert per_list.max() > 320 and ((per_list % 160) > 96).any() and ((per_list > 0) & (per_list <= 96)).any(), per_list
+    screened = {}
+    for on in (1, 0):
+        s = pqv.Searcher(index, corpus)
+        s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2); s.set_option("wide_quads", on)
+        if wide_rows:
+            s.set_option("wide_quad_rows", wide_rows)
+        d = s.describe(nq, k, nprobe)
+        assert "int8 screen operands" in d and "quads of 96 queries" in d, d
+        assert ("lists probed by 97..160 queries" in d) == bool(on), d
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (_bits(dist) == _bits(odist)).all(), on
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+        screened[on] = s.counters()["screened_pairs"]
+    assert screened[1] == screened[0], screened
