@@ -2343,10 +2343,10 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         const bool pf = p.f16 && s->sdim <= 128 && p.block_waves == 4 && p.quad_width != 96;
         const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
         const int seed_ng = p.i8 ? (64ull * s->sdim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->sdim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
-        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4>; wide_seed_kernel<%d, %s, %d>; seed_select_kernel<%d>@%u",
+        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4>; wide_seed_kernel<%d, %s, %d, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
                       (p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) ? "true" : "false",
-                      seed_ng, qlds ? "true" : "false", op, S,
+                      seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 64 && s->opt.single_bucket > 0) ? 12 : 1, S,
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
         if (p.wide_width) {
             const size_t l = std::strlen(kn);
