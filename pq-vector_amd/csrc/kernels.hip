@@ -85,6 +85,28 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
 #ifndef PQV_STAGE_UNROLL
 #define PQV_STAGE_UNROLL 12
 #endif
+// build-time knobs of wide_filter_kernel (tools/variant.sh builds A/B libraries with other values; the defaults are the measured ones)
+#ifndef PQV_NS_WIDE
+#define PQV_NS_WIDE 2          // operand stages in flight, 8-wave blocks of <= 96 queries
+#endif
+#ifndef PQV_NS_TS2
+#define PQV_NS_TS2 2           // ... of the wide-quad instance (32-row tiles): 3 / 4 / 6 measured no faster, 4 and 6 spill
+#endif
+#ifndef PQV_APD_TS2
+#define PQV_APD_TS2 2          // A operands read this many groups ahead in the wide-quad instance (0: 1066, 2: 966, 4: 1004 us on C3)
+#endif
+#ifndef PQV_APD
+#define PQV_APD 0              // ... in the 64-row-tile instances (1 and 2 measured no faster: four MFMAs hide the read)
+#endif
+#ifndef PQV_XTA_TS2
+#define PQV_XTA_TS2 1          // thresholds / row terms requested a tile early in the wide-quad instance (1050 -> 966 us on C3)
+#endif
+#ifndef PQV_XTA
+#define PQV_XTA 0              // ... in the 64-row-tile instances (measured 3 % slower: 8 more spills)
+#endif
+#ifndef PQV_EVAL_NB_TS2
+#define PQV_EVAL_NB_TS2 16     // row chunks in flight per lane in the wide-quad instance's exact evaluations
+#endif
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 // One K step of the score contraction for a 16 x 16 tile.  f32 operands: 16 dims, four 16x16x4 MFMAs;
 // f16 operands (8 halves per lane, see launch_block_rows_f16): 32 dims, one 16x16x32 MFMA.
@@ -2880,8 +2902,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // scattered reads are latency, and a 768-dim row is 24 round trips for one lane, 3 for eight -- and the
         // reference's chain passes through them in chunk order (lane 0's eight adds, then lane 1's, ...), so the
         // sum is bit-identical.  The pair's first lane carries on with the result.
+        // (32-row tiles: 16 row chunks in flight per lane -- its batches are larger (a lane per pair: 12 round trips per
+        //  768-dim row instead of 24), and the accumulators, dead here, leave the registers)
+        constexpr int NB = TS == 2 ? PQV_EVAL_NB_TS2 : 8;
         uint32_t lg = 0;
-        while (lg < 3 && (count << (lg + 1)) <= 64u && (Gx % (16u << lg)) == 0u) ++lg;      // wave-uniform
+        while (lg < 3 && (count << (lg + 1)) <= 64u && (Gx % ((2u * NB) << lg)) == 0u) ++lg;      // wave-uniform
         const uint32_t L = 1u << lg;
         const uint32_t pi = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);
         const bool valid = pi < count;
@@ -2901,7 +2926,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // round trips per 128-dim row instead of four -- measured no faster and costs the last free registers)
         const bool q_global = !QLDS || I8 || (F16 && !a.q32_lds);      // wave-uniform
         auto chain = [&](auto qg_c) {
-            constexpr int NB = 8;
             constexpr bool QG = decltype(qg_c)::value;
             const uint32_t first = (uint32_t)lane & ~(L - 1u);          // first lane of this pair's group
             for (uint32_t g0 = 0; g0 < Gx; g0 += NB * L) {
@@ -3093,27 +3117,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // B-operand registers of the K loop (two ping-pong stages).  They persist across tiles: the loads of a tile's
     // first two K steps are issued behind the LAST MFMAs of the previous tile, so they fly during its screen /
     // expansion / exact evaluations instead of opening the K loop with a full memory round trip.
-#ifndef PQV_NS_WIDE
-#define PQV_NS_WIDE 2
-#endif
-#ifndef PQV_NS_TS2
-#define PQV_NS_TS2 2
-#endif
-#ifndef PQV_APD_TS2
-#define PQV_APD_TS2 2
-#endif
-#ifndef PQV_APD
-#define PQV_APD 0
-#endif
-#ifndef PQV_XTA_TS2
-#define PQV_XTA_TS2 1
-#endif
-#ifndef PQV_XTA
-#define PQV_XTA 0
-#endif
-#ifndef PQV_ABL
-#define PQV_ABL 0          // timing ablations of the wide-quad instance (wrong results): 1 = two groups' MFMAs only, 2 = no operand loads inside the K loop
-#endif
 #ifndef PQV_XT
 #define PQV_XT 1
 #endif
@@ -3293,7 +3296,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                     qb[g] = qb0[gi * gstride];
                 }
 #pragma unroll
-                for (int g = 0; g < (PQV_ABL == 1 ? 2 : NG); ++g) {
+                for (int g = 0; g < NG; ++g) {
                     if (decltype(full)::value || (uint32_t)g < ng) {
                         if (g + APD < NG) {
                             const uint32_t gi = decltype(full)::value || (uint32_t)(g + APD) < ng ? (uint32_t)(g + APD) : ng - 1u;
@@ -3320,10 +3323,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     mma(xs[j], ks + j, full);
-#if PQV_ABL != 2
 #pragma unroll
                     for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(xr, lane_b, xso[t] + (ks + j + NS) * 1024);
-#endif
                 }
             }
 #pragma unroll
@@ -3773,11 +3774,6 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                         w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0;
                         w.item_quad = a.wide_item_quad; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
                         w.rows_per_block = a.wide_rows_per_block;
-#ifdef PQV_WIDE_LAST
-                        const hipError_t e0 = launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
-                        if (e0 != hipSuccess) return e0;
-                        return launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
-#endif
                         const hipError_t e = launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
                         if (e != hipSuccess) return e;
                     }
