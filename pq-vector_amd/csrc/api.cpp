@@ -240,6 +240,7 @@ struct pqv_searcher {
         int single_bucket = 1;             // one query: the probe merge writes the bucketing, no pair-sort launches
         int seed_refine = 1;               // exact distances behind the k selected seed bounds tighten the first threshold (k <= 16)
         int item_grid = 1;                 // wide filter kernel: 1-D grid over (quad, existing row chunk) items
+        int chunk_major = 1;               // ... numbered chunk-major (row chunk 0 of every quad first)
         int wide_waves = 0;                // waves per block of the wide kernel: 0 by rule, 4 or 8
         int probe_rows = 1;                // batched centroid probe (probe_rows_kernel) when dim % 4 == 0; 0 = stream_kernel
         uint32_t quad_width = 0;           // queries per quad of the wide kernel (0 = by rule)
@@ -1181,6 +1182,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
     o.item_grid = static_cast<int>(num("PQV_ITEM_GRID", o.item_grid));
+    o.chunk_major = static_cast<int>(num("PQV_CHUNK_MAJOR", o.chunk_major));
     o.seed_refine = static_cast<int>(num("PQV_SEED_REFINE", o.seed_refine));
     o.single_bucket = static_cast<int>(num("PQV_SINGLE_BUCKET", o.single_bucket));
     o.probe_rows = static_cast<int>(num("PQV_PROBE_ROWS", o.probe_rows));
@@ -1714,7 +1716,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
         HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
         HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
-        if (items) HIP_TRY(sc.s_items.ensure((static_cast<size_t>(max_items) + wide_max_items) * sizeof(uint32_t)));
+        if (items) HIP_TRY(sc.s_items.ensure((2 * (static_cast<size_t>(max_items) + wide_max_items) + 4 * pqv::ITEM_LEVELS) * sizeof(uint32_t)));
     }
     if (single_bucket) {
         uint32_t *v = pair_u32 + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc_pairs);
@@ -1777,6 +1779,10 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ps.list_off = s->d_list_off.as<uint64_t>(); ps.item_rows = p.filter_rows_per_block;
             ps.item_off = v + 5ull * kc + 5; ps.n_items = v + 6ull * kc + 6;
             ps.item_quad = sc.s_items.as<uint32_t>(); ps.max_items = max_items;
+            if (s->opt.chunk_major && !single_bucket) {
+                ps.item_chunk = ps.item_quad + max_items + wide_max_items; ps.wide_item_chunk = ps.item_chunk + max_items;
+                ps.lvl = ps.wide_item_chunk + wide_max_items;
+            }
             if (wide) {
                 ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
                 ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
@@ -1886,7 +1892,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.row_offset = 0; ta.slot_base = 0; ta.grid_x = p.filter_bpl;
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
-            if (items) { ta.item_quad = ps.item_quad; ta.n_items = ps.n_items; ta.max_items = max_items; }
+            if (items) { ta.item_quad = ps.item_quad; ta.item_chunk = ps.item_chunk; ta.wide_item_chunk = ps.wide_item_chunk; ta.n_items = ps.n_items; ta.max_items = max_items; }
             if (wide) {
                 ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
                 ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
@@ -2280,6 +2286,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "single_bucket") o.single_bucket = static_cast<int>(value);      // 2 = bucketing in the merge, separate probe launch
     else if (n == "seed_refine") o.seed_refine = static_cast<int>(value);       // 2 = any dim / batch size
     else if (n == "item_grid") o.item_grid = static_cast<int>(value);          // 2 = also for the 8-wave blocks
+    else if (n == "chunk_major") o.chunk_major = value != 0;
     else if (n == "probe_rows") o.probe_rows = static_cast<int>(value);       // 2 = for any batch size
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));

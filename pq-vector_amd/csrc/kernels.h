@@ -151,6 +151,7 @@ constexpr uint32_t HIST_REPLICAS = 16;
 // survivors (wide_filter_kernel), + {2, 3} candidate rows / embeddings fetched (probe merge)
 constexpr uint32_t STATS_SLOTS = 64;
 
+constexpr uint32_t ITEM_LEVELS = 64;
 struct PairSortArgs {
     const uint32_t *probe;     // [nq * nprobe] cluster of pair p = q*nprobe + j
     uint32_t        n_pairs, n_clusters;
@@ -179,6 +180,12 @@ struct PairSortArgs {
     uint32_t       *n_items;   // [1]
     uint32_t       *item_quad; // [max_items] quad of each item; quads[q].w = the quad's first item
     uint32_t        max_items;
+    // chunk-major item order (item_chunk != nullptr): items are numbered level by level -- row chunk 0 of every quad, then
+    // chunk 1, ... (levels >= ITEM_LEVELS - 1 share the last one) -- so a query's thresholds have seen the first chunk of
+    // all its lists before any later chunk is screened.  lvl: [4 ITEM_LEVELS] = bases / cursors of this table and the wide one.
+    uint32_t       *item_chunk;      // [max_items] row chunk of each item
+    uint32_t       *wide_item_chunk; // [wide_max_items]
+    uint32_t       *lvl;
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
     // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
     // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the
@@ -279,6 +286,7 @@ struct TileArgs {
     // second launch for the WIDE quads (PairSortArgs::wide_*): 8-wave blocks, quads of wide_width queries on 32-row tiles
     uint32_t        wide_width;  // 0 = none
     const uint32_t *wide_item_quad;
+    const uint32_t *item_chunk, *wide_item_chunk;   // chunk-major tables (PairSortArgs::item_chunk); nullptr = chunk = item - quads[q].w
     const uint32_t *wide_n_items;
     uint32_t        wide_max_items, wide_rows_per_block;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates

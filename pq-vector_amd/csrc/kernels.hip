@@ -1215,7 +1215,10 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     // single block: exclusive scans of hist and of ceil(hist / TILE_QB)
     __shared__ uint32_t s_pair[1024], s_grp[1024], s_quad[1024], s_item[1024], s_witem[1024];
     __shared__ uint32_t carry_pair, carry_grp, carry_quad, carry_item, carry_witem;
+    __shared__ uint32_t s_lvl[2 * ITEM_LEVELS];        // chunk-major tables: items per level (this table, the wide one)
     const uint32_t tid = threadIdx.x;
+    const bool levels = a.item_rows && a.item_chunk;
+    if (levels && tid < 2 * ITEM_LEVELS) s_lvl[tid] = 0;
     if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; carry_witem = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
@@ -1243,7 +1246,20 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                 nwq = h / a.quad_width + ((h % a.quad_width) >= a.wide_min ? 1u : 0u);
                 nwi = nwq * (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
             }
-            ni = (qd - nwq) * (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+            const uint32_t nch = (uint32_t)((len + a.item_rows - 1) / a.item_rows);
+            ni = (qd - nwq) * nch;
+            if (levels) {
+                constexpr uint32_t LL = ITEM_LEVELS - 1;
+                if (qd > nwq) {
+                    for (uint32_t t = 0; t < nch && t < LL; ++t) atomicAdd(&s_lvl[t], qd - nwq);
+                    if (nch > LL) atomicAdd(&s_lvl[LL], (qd - nwq) * (nch - LL));
+                }
+                if (nwq) {
+                    const uint32_t wnch = (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
+                    for (uint32_t t = 0; t < wnch && t < LL; ++t) atomicAdd(&s_lvl[ITEM_LEVELS + t], nwq);
+                    if (wnch > LL) atomicAdd(&s_lvl[ITEM_LEVELS + LL], nwq * (wnch - LL));
+                }
+            }
         }
         s_pair[tid] = h; s_grp[tid] = g; s_quad[tid] = qd; s_item[tid] = ni; s_witem[tid] = nwi;
         __syncthreads();
@@ -1280,6 +1296,14 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
             *a.wide_n_items = carry_witem < a.wide_max_items ? carry_witem : a.wide_max_items;
         }
     }
+    if (levels && tid < 2) {           // level bases (exclusive scan) and zeroed cursors of table `tid`
+        uint32_t b = 0;
+        for (uint32_t t = 0; t < ITEM_LEVELS; ++t) {
+            a.lvl[2 * tid * ITEM_LEVELS + t] = b;
+            a.lvl[(2 * tid + 1) * ITEM_LEVELS + t] = 0;
+            b += s_lvl[tid * ITEM_LEVELS + t];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a) {
@@ -1301,7 +1325,19 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
         const uint32_t qcnt = h - i < a.quad_width ? h - i : a.quad_width;
         if (a.item_rows) {
             const uint64_t len = a.list_off[c + 1] - a.list_off[c];
-            if (a.wide_min && qcnt >= a.wide_min) {         // a wide quad: the list's quads before it are wide too
+            const bool wq = a.wide_min && qcnt >= a.wide_min;      // a wide quad: the list's quads before it are wide too
+            if (a.item_chunk) {                // chunk-major: one slot per row chunk, taken from the chunk's level (order inside a level is arbitrary)
+                const uint32_t nch = (uint32_t)((len + (wq ? a.wide_item_rows : a.item_rows) - 1) / (wq ? a.wide_item_rows : a.item_rows));
+                const uint32_t *base = a.lvl + (wq ? 2 * ITEM_LEVELS : 0);
+                uint32_t *cur = a.lvl + (wq ? 3 * ITEM_LEVELS : ITEM_LEVELS);
+                uint32_t *iq = wq ? a.wide_item_quad : a.item_quad, *ic = wq ? a.wide_item_chunk : a.item_chunk;
+                const uint32_t lim = wq ? a.wide_max_items : a.max_items;
+                for (uint32_t t = 0; t < nch; ++t) {
+                    const uint32_t lv = t < ITEM_LEVELS - 1 ? t : ITEM_LEVELS - 1;
+                    const uint32_t idx = base[lv] + atomicAdd(&cur[lv], 1u);
+                    if (idx < lim) { iq[idx] = qi; ic[idx] = t; }
+                }
+            } else if (wq) {
                 const uint32_t nch = (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
                 first = a.wide_item_off[c] + (i / a.quad_width) * nch;
                 for (uint32_t t = 0; t < nch && first + t < a.wide_max_items; ++t) a.wide_item_quad[first + t] = qi;
@@ -2705,7 +2741,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         if (item >= *a.n_items) return;
         by = a.item_quad[item];
         quad = a.quads[by];
-        bx = item - quad.w;
+        bx = a.item_chunk ? a.item_chunk[item] : item - quad.w;
     } else {
         quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
         if (by >= *a.n_quads) return;
@@ -3772,7 +3808,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                             return hipErrorInvalidValue;
                         TileArgs w = a;
                         w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0;
-                        w.item_quad = a.wide_item_quad; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
+                        w.item_quad = a.wide_item_quad; w.item_chunk = a.wide_item_chunk; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
                         w.rows_per_block = a.wide_rows_per_block;
                         const hipError_t e = launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
                         if (e != hipSuccess) return e;
