@@ -159,6 +159,8 @@ struct pqv_corpus {
     mutable std::mutex aux_mu;
     mutable DevBuf aux_rnorm, aux_norm2, aux_v16;      // aux_v16: L2-normalised f16 images [n, dim_p] (the f16 screen of pqv_brute_topk)
     mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0, aux_v16_rows = 0;
+    mutable DevBuf aux_v8, aux_v8_sr, aux_v8_n;        // int8 images [n, dim_p8] + {1 / S, residual, mid-range, sum} + norm per row (the int8 screen of pqv_brute_topk)
+    mutable uint64_t aux_v8_rows = 0;
     ~pqv_corpus() {
         if (d_rows && owned) (void)hipFree(d_rows);
         if (stream) (void)hipStreamDestroy(stream);
@@ -2600,12 +2602,35 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
     // Round 3: beyond the first row range the contraction runs on the f16 matrix pipe as a screen (kernels.hip:
     // brute_f16_kernel) and only what it lets through is scored in f32.  Needs the normalised f16 image of the
     // corpus (+ 1 / |v| whatever the metric); PQV_BRUTE_F16=0 keeps the f32 contraction everywhere.
+    // The screen's operand form: int8 images (twice the matrix rate, half the staged bytes; PQV_BRUTE_OP=f16 keeps the f16 images).
     static const bool f16_env = [] { const char *e = std::getenv("PQV_BRUTE_F16"); return !(e && *e == '0'); }();
-    const uint32_t dim_p = (dim + 31) / 32 * 32;
+    const bool i8_env = [] { const char *e = std::getenv("PQV_BRUTE_OP"); return !(e && !std::strcmp(e, "f16")); }();      // (read per call: tests run both forms)
+    const bool use_i8 = i8_env;
+    const uint32_t dim_p = use_i8 ? (dim + 63) / 64 * 64 : (dim + 31) / 32 * 32;
     const bool use_f16 = f16_env && n >= 32768 && static_cast<uint64_t>(dim_p) * 2 * 320 < 0x7FFFFFFFull;
     const uint16_t *d_v16 = nullptr;
+    const int8_t *d_v8 = nullptr;
+    const float4 *d_v8_sr = nullptr;
+    const float *d_v8_n = nullptr;
     const float *d_vn2 = nullptr;
-    if (use_f16) {
+    if (use_f16 && use_i8) {
+        std::lock_guard<std::mutex> lock(c->aux_mu);
+        if (c->aux_rnorm_rows != n || !c->aux_rnorm.p) {
+            HIP_TRY(c->aux_rnorm.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
+            HIP_TRY(launch_row_norms(c->d_rows, n, dim, 0, c->aux_rnorm.as<float>(), stream));
+            c->aux_rnorm_rows = n;
+        }
+        if (mode == 1) d_vn2 = d_row_aux;
+        if (c->aux_v8_rows != n || !c->aux_v8.p) {
+            HIP_TRY(c->aux_v8.alloc(std::max<uint64_t>(1, n) * dim_p));
+            HIP_TRY(c->aux_v8_sr.alloc(std::max<uint64_t>(1, n) * sizeof(float4)));
+            HIP_TRY(c->aux_v8_n.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
+            HIP_TRY(launch_normalize_i8(c->d_rows, c->aux_rnorm.as<float>(), n, dim, dim_p, c->aux_v8.p, c->aux_v8_sr.p, c->aux_v8_n.as<float>(), stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            c->aux_v8_rows = n;
+        }
+        d_v8 = c->aux_v8.as<int8_t>(); d_v8_sr = c->aux_v8_sr.as<float4>(); d_v8_n = c->aux_v8_n.as<float>();
+    } else if (use_f16) {
         std::lock_guard<std::mutex> lock(c->aux_mu);
         if (c->aux_rnorm_rows != n || !c->aux_rnorm.p) {
             HIP_TRY(c->aux_rnorm.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
@@ -2621,7 +2646,9 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         }
         d_v16 = c->aux_v16.as<uint16_t>();
     }
-    const float f16_eps = 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
+    // (int8: the image bound is per pair, inside the kernel; eps carries the f32 roundings of the normalisation and of both sums)
+    const float f16_eps = use_i8 ? 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 4.0e-6f
+                                 : 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
 
     const uint32_t cap = std::max<uint32_t>(16384, 4 * k);
     const uint32_t qbatch = std::min<uint32_t>(nq, 4096);
@@ -2636,10 +2663,11 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
     HIP_TRY(d_rows_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(uint32_t)));
     HIP_TRY(d_dist_out.alloc(static_cast<size_t>(qbatch) * k * sizeof(float)));
     HIP_TRY(d_nf.alloc(static_cast<size_t>(qbatch) * sizeof(uint32_t)));
-    DevBuf d_q16, d_qrn;
+    DevBuf d_q16, d_qrn, d_qsr, d_qn;
     if (use_f16) {
         HIP_TRY(d_q16.alloc(static_cast<size_t>(qbatch) * dim_p * sizeof(uint16_t)));
         HIP_TRY(d_qrn.alloc(static_cast<size_t>(qbatch) * sizeof(float)));
+        if (use_i8) { HIP_TRY(d_qsr.alloc(static_cast<size_t>(qbatch) * sizeof(float4))); HIP_TRY(d_qn.alloc(static_cast<size_t>(qbatch) * sizeof(float))); }
     }
 
     for (uint32_t q0 = 0; q0 < nq; q0 += qbatch) {
@@ -2649,7 +2677,8 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, mode, d_qaux.as<float>(), stream));
         if (use_f16) {
             HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, 0, d_qrn.as<float>(), stream));
-            HIP_TRY(launch_normalize_f16(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, stream));
+            if (use_i8) HIP_TRY(launch_normalize_i8(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, d_qsr.p, d_qn.as<float>(), stream));
+            else HIP_TRY(launch_normalize_f16(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, stream));
         }
         HIP_TRY(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(b) * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_thr.p, 0xFF, static_cast<size_t>(b) * sizeof(unsigned long long), stream));
@@ -2689,6 +2718,12 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
             if (screen) {
                 BruteF16Args fa{};
                 fa.v16 = d_v16; fa.q16 = d_q16.as<uint16_t>(); fa.row_aux = d_vn2; fa.query_aux = d_qaux.as<float>();
+                if (use_i8) {
+                    fa.v8 = d_v8; fa.q8 = d_q16.as<int8_t>(); fa.row_sr = d_v8_sr; fa.query_sr = d_qsr.as<float4>();
+                    fa.row_n = d_v8_n; fa.query_n = d_qn.as<float>(); fa.dim_f = static_cast<float>(dim);
+                    // a wave sums dim / 64 components per lane + 6 exchange steps: error <= (dim / 64 + 7) 2^-24 sum |v^_i| <= .. sqrt(dim)
+                    fa.eps_sum = (static_cast<float>(dim) / 64.0f + 8.0f) * 5.9604645e-08f * std::sqrt(static_cast<float>(dim)) * 1.01f;
+                }
                 fa.row_begin = range.first; fa.row_end = range.second; fa.nq = b; fa.dim_p = dim_p;
                 fa.metric = ba.metric; fa.eps = f16_eps;
                 fa.thr = ba.thr; fa.cand = ba.cand; fa.cand_cnt = ba.cand_cnt; fa.cap = cap;
@@ -2713,6 +2748,15 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
                 todo.emplace_back(mid, range.second);
                 todo.emplace_back(range.first, mid);
                 continue;
+            }
+            if (screen && std::getenv("PQV_BRUTE_STATS")) {        // diagnostic: pairs the screen let through in this range
+                std::vector<uint32_t> h1(b), h0(b);
+                HIP_TRY(hipMemcpy(h1.data(), d_cnt.p, b * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h0.data(), d_cnt_saved.p, b * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint64_t t = 0;
+                for (uint32_t i = 0; i < b; ++i) t += h1[i] - h0[i];
+                std::fprintf(stderr, "pqv_brute_topk: rows [%llu, %llu): %.1f screen survivors per query\n",
+                             (unsigned long long)range.first, (unsigned long long)range.second, (double)t / b);
             }
             if (screen) HIP_TRY(launch_brute_rescore(ba, d_cnt_saved.as<uint32_t>(), stream));     // exact f32 keys for what the screen let through
             HIP_TRY(launch_brute_select(d_cand.as<unsigned long long>(), d_cnt.as<uint32_t>(), cap, b, k,

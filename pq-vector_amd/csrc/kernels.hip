@@ -4098,7 +4098,17 @@ constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;       // assign_f16_kernel's
 //                 matrix pipe busy 29 % of the time, 8.4 TB/s of L2 reads with 92 % hits: bound by the L2 -> LDS traffic
 //                 of a tile that does 85 flops per staged byte)
 //   <2, 4, 4, 2>: 256 x 256, 512 threads, one block per CU: 128 flops per staged byte
-template <int NWM, int NWN, int TM, int TN>
+// I8: the same tiles on int8 images (v_mfma_i32_32x32x32_i8: twice the f16 rate, half the staged bytes per flop -- and the
+// staging traffic is what bounds the f16 form).  Images: the L2-normalised vector times S = 127 / max |component| (per
+// vector), rounded to int8 -- of the vector MINUS its own mid-range b along (1, .., 1), so one-sided data (the bench's
+// uniform [0, 1) rows) uses the whole grid:  q^.v^ = (q^ - a 1).(v^ - b 1) + b sum(q^) + a sum(v^) - a b dim.  Per vector
+// {1 / S, r >= |(v^ - b 1) - image / S|, b, sum(v^)} and n >= |v^ - b 1| (normalize_i8_kernel).  With D = the image dot
+// product (exact in int32) and s~ = D / (S_q S_v) + b sum(q^) + a sum(v^) - a b dim:
+//     |s~ - s^| <= n_q r_v + n_v r_q + 3 r_q r_v      (Cauchy-Schwarz on the residuals; |image / S| <= n + r)
+// -- a bound per PAIR, wider than the f16 one, so more pairs reach the exact re-scoring; that is still far cheaper than the
+// contraction time the int8 pipe saves.
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+template <int NWM, int NWN, int TM, int TN, bool I8>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
     constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
     constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;          // 16-byte chunks a thread stages per K stage
@@ -4107,6 +4117,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     __shared__ float4 Bs4[2][BN * 4];
     __shared__ unsigned long long thr_s[BM];
     __shared__ float qaux_s[BM];
+    __shared__ float4 qsr_s[I8 ? BM : 1];            // int8 form: {1 / S, r, a, sum} of the tile's queries
+    __shared__ float qn_s[I8 ? BM : 1];              //            |q^ - a 1|
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -4118,22 +4130,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     const uint64_t n0 = a.row_begin + vt * BN;
     if (n0 >= a.row_end) return;
     const uint32_t m0 = qt * BM;
-    const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32); 2 bytes each
+    const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32, 2 bytes each; int8: of 64, 1 byte each)
+    const uint32_t rbytes = I8 ? dp : dp * 2;        // bytes per image row; a K stage is 64 of them
 
     constexpr int RPS = NT / 4;                      // rows one staging step of the block covers
     const int ld_r = tid >> 2, ld_ch = tid & 3;      // staging: row ld_r (+ RPS h), 16-byte chunk ld_ch of the stage
     float4 ra[CA], rb[CB];
-    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * dp * 2 : 0, vleft = (a.row_end - n0) * dp * 2;
+    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * rbytes : 0, vleft = (a.row_end - n0) * rbytes;
+    const char *qbase = I8 ? reinterpret_cast<const char *>(a.q8) : reinterpret_cast<const char *>(a.q16);
+    const char *vbase = I8 ? reinterpret_cast<const char *>(a.v8) : reinterpret_cast<const char *>(a.v16);
     const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t *>(a.q16 + (uint64_t)m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+        const_cast<char *>(qbase + (uint64_t)m0 * rbytes), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
     const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t *>(a.v16 + n0 * dp), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
-    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, step_b = (uint32_t)RPS * dp * 2;
-    auto fetch = [&](uint32_t k0) {
+        const_cast<char *>(vbase + n0 * rbytes), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * rbytes + (uint32_t)ld_ch * 16, step_b = (uint32_t)RPS * rbytes;
+    auto fetch = [&](uint32_t kb) {                  // kb: byte offset of the stage inside a row
 #pragma unroll
-        for (int h = 0; h < CA; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * step_b);
+        for (int h = 0; h < CA; ++h) ra[h] = buf_ld16(qres, lane_b, kb + h * step_b);
 #pragma unroll
-        for (int h = 0; h < CB; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * step_b);
+        for (int h = 0; h < CB; ++h) rb[h] = buf_ld16(vres, lane_b, kb + h * step_b);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -4142,21 +4157,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
         for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
     };
 
-    f32x16_t acc[TM][TN];
+    using acc_t = std::conditional_t<I8, i32x16_t, f32x16_t>;
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     if (tid < BM) {
         const uint32_t qi = m0 + tid;
         thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
         qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
+        if constexpr (I8) {
+            qsr_s[tid] = qi < a.nq ? a.query_sr[qi] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qn_s[tid] = qi < a.nq ? a.query_n[qi] : 0.0f;
+        }
     }
 
-    const uint32_t nk = dp / BH_BK;
+    const uint32_t nk = rbytes / 64;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -4170,19 +4190,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
     for (uint32_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1u);
-        if (kt + 1 < nk) fetch((kt + 1) * BH_BK);
+        if (kt + 1 < nk) fetch((kt + 1) * 64);
+        // (int8: v_mfma_i32_32x32x32_i8 takes 16 bytes per lane as well -- lane group lk owns one half of the instruction's 32
+        //  k values; which half is immaterial, both operands read the same chunk)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f16x8_t av[TM], bv[TN];
+            float4 av[TM], bv[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
+            for (int t = 0; t < TM; ++t) av[t] = As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
+            for (int t = 0; t < TN; ++t) bv[t] = Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jj = 0; jj < TN; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+                for (int jj = 0; jj < TN; ++jj) {
+                    if constexpr (I8)
+                        acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, av[i]), __builtin_bit_cast(i32x4_acc, bv[jj]), acc[i][jj], 0, 0, 0);
+                    else
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[i]), __builtin_bit_cast(f16x8_t, bv[jj]), acc[i][jj], 0, 0, 0);
+                }
         }
         if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
         __syncthreads();
@@ -4195,18 +4221,30 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
         const uint64_t vj = n0 + wn * 32 * TN + j * 32 + l31;
         const bool jv = vj < a.row_end;
         const float vaux = (jv && a.metric != BRUTE_COSINE) ? a.row_aux[vj] : 0.0f;          // l2: |v|^2 (cosine: no row term)
+        [[maybe_unused]] float4 vsr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        [[maybe_unused]] float vn = 0.0f;
+        if constexpr (I8) { if (jv) { vsr = a.row_sr[vj]; vn = a.row_n[vj]; } }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const uint32_t qi = m0 + ml;
-                const float sc = acc[i][j][r] * inv;
+                float sc, eps;
+                if constexpr (I8) {
+                    const float4 qsr = qsr_s[ml];
+                    sc = ((float)acc[i][j][r] * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
+                    // n_q r_v + n_v r_q + 3 r_q r_v, rounded up, + the f32 roundings of both sides (a.eps) and of the two
+                    // component sums (a.eps_sum per unit of |a| + |b|)
+                    eps = (qn_s[ml] * vsr.y + qsr.y * (vn + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
+                } else {
+                    sc = acc[i][j][r] * inv; eps = a.eps;
+                }
                 float lb;
-                if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - a.eps;
+                if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - eps;
                 else {
                     const float qv = sqrtf(qaux_s[ml] * vaux) * 1.000001f;     // |q| |v|
-                    lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * a.eps - 1.0e-6f * (qaux_s[ml] + vaux);
+                    lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * eps - 1.0e-6f * (qaux_s[ml] + vaux);
                     lb = lb < 0.0f ? 0.0f : lb;
                 }
                 // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
@@ -4221,7 +4259,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
 }
 hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
-    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const bool i8 = a.v8 != nullptr;
+    if (i8 ? ((a.dim_p % 64) != 0 || !a.q8 || !a.row_sr || !a.query_sr || !a.row_n || !a.query_n) : (a.dim_p % BH_BK) != 0) return hipErrorInvalidValue;
+    if ((uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
     // 256 x 256 tiles from 256 queries on (PQV_BRUTE_TILE=128 keeps the 128 x 256 form for comparison)
     static const int tile_env = [] { const char *e = std::getenv("PQV_BRUTE_TILE"); return e ? std::atoi(e) : 0; }();
     const bool big = tile_env == 256 || (tile_env != 128 && a.nq > 128);
@@ -4229,8 +4269,68 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     const uint64_t nb = (a.row_end - a.row_begin + bn - 1) / bn, ny = (a.nq + bm - 1) / bm;
     const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    if (i8) {
+        if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2, true>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    } else {
+        if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2, false>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// int8 images of the L2-normalised rows (brute_f16_kernel<.., I8>): one wave per row.  v^ = row * rnorm (f32); b = the mid-range
+// of its components; S = 127 / max |v^_i - b|; image_i = rint((v^_i - b) S) (padding: 0); sr[r] = {1 / S, r_v, b, sum(v^)},
+// nrm[r] = n_v with r_v >= |(v^ - b 1) - image / S| (against the stored 1 / S) and n_v >= |v^ - b 1|, both rounded up.
+// A zero row has image 0 and r_v = n_v = 0 (its cosine is what the exact pass says); a row with a non-finite value gets
+// r_v = +inf and is never skipped.
+__global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restrict__ rows, const float *__restrict__ rnorm,
+                                                          uint64_t n, uint32_t dim, uint32_t dim_p, int8_t *__restrict__ out,
+                                                          float4 *__restrict__ sr, float *__restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        const float rn = rnorm[r];
+        float mx = -3.0e38f, mn = 3.0e38f, sum = 0.0f;
+        bool bad = !(rn == rn) || rn > 3.0e38f;
+        for (uint32_t e = lane; e < dim; e += 64) {
+            const float v = p[e] * rn;
+            bad |= !(fabsf(v) <= 3.0e38f);
+            mx = fmaxf(mx, v); mn = fminf(mn, v); sum += v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64)); mn = fminf(mn, __shfl_xor(mn, off, 64)); sum += __shfl_xor(sum, off, 64);
+        }
+        bad = __any(bad);
+        const float b = bad ? 0.0f : 0.5f * (mx + mn);
+        const float half = bad ? 0.0f : fmaxf(mx - b, b - mn);
+        const float S = half > 0.0f ? 127.0f / half : 0.0f;
+        const float invS = S > 0.0f ? 1.0f / S : 0.0f;
+        float res2 = 0.0f, n2 = 0.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            const float v = (e < dim && !bad) ? p[e] * rn - b : 0.0f;
+            float qf = rintf(v * S);
+            qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+            out[r * dim_p + e] = (int8_t)(int)qf;
+            const float d = v - qf * invS;
+            res2 += d * d; n2 += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { res2 += __shfl_xor(res2, off, 64); n2 += __shfl_xor(n2, off, 64); }
+        if (lane == 0) {
+            sr[r] = make_float4(invS, bad ? __builtin_inff() : sqrtf(res2) * 1.0001f + 1.0e-6f, b, bad ? 0.0f : sum);
+            nrm[r] = bad ? __builtin_inff() : sqrtf(n2) * 1.0001f + 1.0e-6f;
+        }
+    }
+}
+hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(normalize_i8_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<int8_t *>(out), static_cast<float4 *>(sr), nrm);
     return hipGetLastError();
 }
 

@@ -579,7 +579,9 @@ def _f64_brute(data, queries, k, metric):
     (300, 7, 3, 400),           # k > n
 ])
 @pytest.mark.parametrize("metric", ["cos", "l2"])
-def test_brute_mfma_matches_f64_oracle(pqv, n, dim, nq, k, metric):
+@pytest.mark.parametrize("op", ["i8", "f16"])
+def test_brute_mfma_matches_f64_oracle(pqv, monkeypatch, n, dim, nq, k, metric, op):
+    monkeypatch.setenv("PQV_BRUTE_OP", op)          # operand form of the screen beyond the first row range (read per call)
     rng = np.random.default_rng(n + dim)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
@@ -605,6 +607,43 @@ def test_brute_mfma_matches_f64_oracle(pqv, n, dim, nq, k, metric):
         assert set(sure.tolist()) <= set(got.tolist())
         assert (np.diff(dist[q, :kk]) >= 0).all()
     assert (rows[:, kk:] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("metric", ["cos", "l2"])
+@pytest.mark.parametrize("op", ["i8", "f16"])
+def test_brute_screen_on_hostile_data(pqv, monkeypatch, metric, op):
+    """The int8 / f16 screens of pqv_brute_topk are bounds, not approximations: rows with one dominant component (a coarse
+    int8 grid for everything else), near-duplicates of the queries (results decided inside the image's slack), tiny and
+    huge norms, a zero row -- the result must still be the exact f32 one."""
+    monkeypatch.setenv("PQV_BRUTE_OP", op)
+    n, dim, nq, k = 120_000, 192, 70, 10
+    rng = np.random.default_rng(99)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    data[40_000:40_500, 7] += 60.0                       # one component carries the norm: S = 127 / ~1, the rest falls to 0 / +-1
+    data[50_000:50_200] *= np.float32(1e-12)             # tiny norms
+    data[60_000:60_200] *= np.float32(1e12)              # huge norms
+    data[70_000] = 0
+    for q in range(nq):                                  # 30 near-duplicates of every query, far beyond the first exact range
+        data[80_000 + 30 * q:80_000 + 30 * q + 30] = queries[q] + 1e-3 * rng.standard_normal((30, dim)).astype(np.float32)
+    queries[3, 11] += 80.0                               # a query with a dominant component
+    corpus = pqv.Corpus.upload(data)
+    m = pqv.PQV_COSINE if metric == "cos" else pqv.PQV_L2SQ_MFMA
+    rows, dist, nf = corpus.brute_topk(queries, k, m)
+    order, odist, full = _f64_brute(data, queries, k, metric)
+    assert (nf == k).all()
+    scale = np.maximum(np.abs(odist), 1e-3)
+    # (the norm-expansion form |q|^2 + |v|^2 - 2 q.v cancels for near-duplicates: its f32 error scales with the norms)
+    q2 = (queries.astype(np.float64) ** 2).sum(1)
+    v2 = (data.astype(np.float64) ** 2).sum(1)
+    canc = 4e-6 * (q2[:, None] + v2[order]) if metric == "l2" else 0.0
+    assert (np.abs(dist - odist) <= 1e-4 * scale + 1e-6 + canc).all()
+    for q in range(nq):
+        kth = odist[q, -1]
+        tol = 1e-4 * max(abs(kth), 1e-3) + 1e-6 + (4e-6 * (q2[q] + v2[order[q]].max()) if metric == "l2" else 0.0)
+        assert (full[q, rows[q]] <= kth + tol).all(), q
+        sure = order[q][odist[q] < kth - tol]
+        assert set(sure.tolist()) <= set(rows[q].tolist()), q
 
 
 def test_brute_rejects_bad_arguments(pqv):
