@@ -736,28 +736,33 @@ def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank,
     ms = elapsed / steps * 1e3
     flops = 2.0 * nq * n * dim
     f32_only = os.environ.get("PQV_BRUTE_F16", "1") == "0"
-    peak_tf = 157.3 if f32_only else 2500.0
+    i8 = not f32_only and os.environ.get("PQV_BRUTE_OP", "i8") != "f16"
+    # dense MFMA peaks (MI355X_MICROARCH.md): f32 157.3 TF, f16 2.5 PF, int8 16x16x64 / 32x32x32 >= 3944 TOPS
+    peak_tf = 157.3 if f32_only else 3944.0 if i8 else 2500.0
+    op_name = "int8" if i8 else "f16"
     result = {
         "metric": "topk_queries_per_s_k10", "value": nq * steps / elapsed, "unit": "queries/s",
         "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if f32_only else "f16 screen (f32 accumulate) + f32 exact re-scoring of what it lets through",
+        "dtype": "f32" if f32_only else f"{op_name} screen ({'int32' if i8 else 'f32'} accumulate) + f32 exact re-scoring of what it lets through",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: brute-force cosine top-{K} over {n}x{dim} uniform f32, "
-                               f"{nq} queries/step, Q.V^T on " + ("v_mfma_f32_32x32x2_f32" if f32_only else "v_mfma_f32_32x32x16_f16 (screen) + f32 re-scoring"),
+                               f"{nq} queries/step, Q.V^T on " + ("v_mfma_f32_32x32x2_f32" if f32_only else ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16") + " (screen) + f32 re-scoring"),
                    "rows": n, "dim": dim, "k": K, "queries_per_step": nq, "shards": 1},
         "timed_region_s": elapsed,
         "roofline": {"bound": "mfma",
                      "kernel": "brute_mfma_kernel (128x128 tiles, f32 in / f32 accumulate)" if f32_only else
-                               "brute_f16_kernel (128x256 tiles of normalised f16 images, f32 accumulate, XCD-aware grid) + brute_rescore_kernel; "
-                               "the first 8192 rows through brute_mfma_kernel (f32)",
+                               f"brute_f16_kernel (256x256 tiles of normalised {op_name} images, 128-byte K stages, XCD-aware grid) + brute_rescore_kernel; "
+                               "the first 2048 rows through brute_mfma_kernel (f32)",
                      "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                      "frac": flops / (ms * 1e-3) / 1e12 / peak_tf, "traffic": None,
                      "algo_flops_per_step": flops,
                      "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / 157.3,
                      "note": "achieved = 2*nq*n*dim / whole-step wall time (queries uploaded, 5 progressive "
                              "row ranges with a host check each, select passes, results downloaded): a lower bound for the kernel; "
-                             "peak = dense f16 MFMA (2.5 PF) for the screened path, f32 MFMA (157.3 TF) with PQV_BRUTE_F16=0"},
+                             "peak = the dense MFMA rate of the screen's operand form: int8 3944 TOPS (default), f16 2.5 PF "
+                             "(PQV_BRUTE_OP=f16), f32 157.3 TF (PQV_BRUTE_F16=0)",
+                     "unit_note": "TFLOP/s reads Tera-op/s for the int8 form"},
     }
     rc = 0
     if not args.no_cpu:

@@ -4108,13 +4108,16 @@ constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;       // assign_f16_kernel's
 // -- a bound per PAIR, wider than the f16 one, so more pairs reach the exact re-scoring; that is still far cheaper than the
 // contraction time the int8 pipe saves.
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
-template <int NWM, int NWN, int TM, int TN, bool I8>
+// ST: 16-byte chunks per row and K stage -- 4 (64-byte stages) or 8 (128-byte stages: half the barriers and twice the MFMAs
+// between them; 128 KB of LDS for the 256 x 256 tile, chunks swizzled by the row's low three bits).
+template <int NWM, int NWN, int TM, int TN, bool I8, int ST>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
     constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
-    constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;          // 16-byte chunks a thread stages per K stage
-    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "staging split");
-    __shared__ float4 As4[2][BM * 4];
-    __shared__ float4 Bs4[2][BN * 4];
+    constexpr int CA = BM * ST / NT, CB = BN * ST / NT;        // 16-byte chunks a thread stages per K stage
+    static_assert(BM * ST % NT == 0 && BN * ST % NT == 0 && (ST == 4 || ST == 8), "staging split");
+    extern __shared__ float4 brute_lds[];                      // [2][BM * ST] query stages, [2][BN * ST] row stages
+    float4 *const As4 = brute_lds, *const Bs4 = brute_lds + 2 * BM * ST;
+    auto sw = [](int r) { return ST == 4 ? (r >> 2) & 3 : r & 7; };
     __shared__ unsigned long long thr_s[BM];
     __shared__ float qaux_s[BM];
     __shared__ float4 qsr_s[I8 ? BM : 1];            // int8 form: {1 / S, r, a, sum} of the tile's queries
@@ -4133,8 +4136,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32, 2 bytes each; int8: of 64, 1 byte each)
     const uint32_t rbytes = I8 ? dp : dp * 2;        // bytes per image row; a K stage is 64 of them
 
-    constexpr int RPS = NT / 4;                      // rows one staging step of the block covers
-    const int ld_r = tid >> 2, ld_ch = tid & 3;      // staging: row ld_r (+ RPS h), 16-byte chunk ld_ch of the stage
+    constexpr int RPS = NT / ST;                     // rows one staging step of the block covers
+    const int ld_r = tid / ST, ld_ch = tid % ST;     // staging: row ld_r (+ RPS h), 16-byte chunk ld_ch of the stage
     float4 ra[CA], rb[CB];
     const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * rbytes : 0, vleft = (a.row_end - n0) * rbytes;
     const char *qbase = I8 ? reinterpret_cast<const char *>(a.q8) : reinterpret_cast<const char *>(a.q16);
@@ -4152,9 +4155,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < CA; ++h) { const int r = ld_r + RPS * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
+        for (int h = 0; h < CA; ++h) { const int r = ld_r + RPS * h; As4[buf * BM * ST + r * ST + (ld_ch ^ sw(r))] = ra[h]; }
 #pragma unroll
-        for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
+        for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf * BN * ST + r * ST + (ld_ch ^ sw(r))] = rb[h]; }
     };
 
     using acc_t = std::conditional_t<I8, i32x16_t, f32x16_t>;
@@ -4176,7 +4179,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
         }
     }
 
-    const uint32_t nk = rbytes / 64;
+    const uint32_t nk = rbytes / (16 * ST);
     fetch(0);
     stash(0);
     __syncthreads();
@@ -4185,30 +4188,39 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     const int l31 = lane & 31, lk = lane >> 5;
     int rowa[TM], rowb[TN], swa[TM], swb[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
+    for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = sw(rowa[t]); }
 #pragma unroll
-    for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
+    for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = sw(rowb[t]); }
     for (uint32_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1u);
-        if (kt + 1 < nk) fetch((kt + 1) * 64);
+        if (kt + 1 < nk) fetch((kt + 1) * 16 * ST);
         // (int8: v_mfma_i32_32x32x32_i8 takes 16 bytes per lane as well -- lane group lk owns one half of the instruction's 32
         //  k values; which half is immaterial, both operands read the same chunk)
+        // operands of K step j + 1 are read while the MFMAs of step j run (two register sets; the compiler on its own reuses
+        // one set and waits for every read right in front of its MFMA)
+        float4 av[2][TM], bv[2][TN];
+        auto lds_read = [&](int j, int set) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float4 av[TM], bv[TN];
+            for (int t = 0; t < TM; ++t) av[set][t] = As4[buf * BM * ST + rowa[t] * ST + ((2 * j + lk) ^ swa[t])];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) av[t] = As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])];
+            for (int t = 0; t < TN; ++t) bv[set][t] = Bs4[buf * BN * ST + rowb[t] * ST + ((2 * j + lk) ^ swb[t])];
+        };
+        lds_read(0, 0);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bv[t] = Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])];
+        for (int j = 0; j < ST / 2; ++j) {
+            const int set = j & 1;
+            if (j + 1 < ST / 2) lds_read(j + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);          // the reads are issued before this step's MFMAs, which cover their latency
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jj = 0; jj < TN; ++jj) {
                     if constexpr (I8)
-                        acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, av[i]), __builtin_bit_cast(i32x4_acc, bv[jj]), acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, av[set][i]), __builtin_bit_cast(i32x4_acc, bv[set][jj]), acc[i][jj], 0, 0, 0);
                     else
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[i]), __builtin_bit_cast(f16x8_t, bv[jj]), acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[set][i]), __builtin_bit_cast(f16x8_t, bv[set][jj]), acc[i][jj], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
         __syncthreads();
@@ -4269,14 +4281,26 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     const uint64_t nb = (a.row_end - a.row_begin + bn - 1) / bn, ny = (a.nq + bm - 1) / bm;
     const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // 128-byte K stages for the 256 x 256 tile where the image rows are a multiple of them (PQV_BRUTE_STAGE=64 keeps 64)
+    static const int stage_env = [] { const char *e = std::getenv("PQV_BRUTE_STAGE"); return e ? std::atoi(e) : 0; }();
+    const uint64_t rbytes = i8 ? a.dim_p : (uint64_t)a.dim_p * 2;
+    const bool st8 = big && stage_env != 64 && (rbytes % 128) == 0;
+    auto launch = [&](auto kern, uint32_t threads, size_t lds) -> hipError_t {
+        if (lds > 65536) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+        }
+        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(threads), lds, s, a);
+        return hipGetLastError();
+    };
     if (i8) {
-        if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2, true>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
-    } else {
-        if (big) hipLaunchKernelGGL((brute_f16_kernel<2, 4, 4, 2, false>), dim3((uint32_t)blocks), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((brute_f16_kernel<2, 2, 2, 4, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a);
+        if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 8>, 512, 2 * 512 * 8 * 16);
+        if (big) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4>, 512, 2 * 512 * 4 * 16);
+        return launch(brute_f16_kernel<2, 2, 2, 4, true, 4>, 256, 2 * 384 * 4 * 16);
     }
-    return hipGetLastError();
+    if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, false, 8>, 512, 2 * 512 * 8 * 16);
+    if (big) return launch(brute_f16_kernel<2, 4, 4, 2, false, 4>, 512, 2 * 512 * 4 * 16);
+    return launch(brute_f16_kernel<2, 2, 2, 4, false, 4>, 256, 2 * 384 * 4 * 16);
 }
 
 // int8 images of the L2-normalised rows (brute_f16_kernel<.., I8>): one wave per row.  v^ = row * rnorm (f32); b = the mid-range
