@@ -159,6 +159,7 @@ struct pqv_corpus {
     mutable std::mutex aux_mu;
     mutable DevBuf aux_rnorm, aux_norm2, aux_v16;      // aux_v16: L2-normalised f16 images [n, dim_p] (the f16 screen of pqv_brute_topk)
     mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0, aux_v16_rows = 0;
+    mutable DevBuf aux_v8_max;                         // [4] maxima over the rows (kernels.h: BruteF16Args::row_max)
     mutable DevBuf aux_v8, aux_v8_sr, aux_v8_n;        // int8 images [n, dim_p8] + {1 / S, residual, mid-range, sum} + norm per row (the int8 screen of pqv_brute_topk)
     mutable uint64_t aux_v8_rows = 0;
     ~pqv_corpus() {
@@ -2625,7 +2626,10 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
             HIP_TRY(c->aux_v8.alloc(std::max<uint64_t>(1, n) * dim_p));
             HIP_TRY(c->aux_v8_sr.alloc(std::max<uint64_t>(1, n) * sizeof(float4)));
             HIP_TRY(c->aux_v8_n.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
-            HIP_TRY(launch_normalize_i8(c->d_rows, c->aux_rnorm.as<float>(), n, dim, dim_p, c->aux_v8.p, c->aux_v8_sr.p, c->aux_v8_n.as<float>(), stream));
+            HIP_TRY(c->aux_v8_max.alloc(4 * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->aux_v8_max.p, 0, 4 * sizeof(float), stream));
+            HIP_TRY(launch_normalize_i8(c->d_rows, c->aux_rnorm.as<float>(), n, dim, dim_p, c->aux_v8.p, c->aux_v8_sr.p, c->aux_v8_n.as<float>(),
+                                        c->aux_v8_max.as<float>(), stream));
             HIP_TRY(hipStreamSynchronize(stream));
             c->aux_v8_rows = n;
         }
@@ -2677,7 +2681,7 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, mode, d_qaux.as<float>(), stream));
         if (use_f16) {
             HIP_TRY(launch_row_norms(d_q.as<float>(), b, dim, 0, d_qrn.as<float>(), stream));
-            if (use_i8) HIP_TRY(launch_normalize_i8(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, d_qsr.p, d_qn.as<float>(), stream));
+            if (use_i8) HIP_TRY(launch_normalize_i8(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, d_qsr.p, d_qn.as<float>(), nullptr, stream));
             else HIP_TRY(launch_normalize_f16(d_q.as<float>(), d_qrn.as<float>(), b, dim, dim_p, d_q16.p, stream));
         }
         HIP_TRY(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(b) * sizeof(uint32_t), stream));
@@ -2720,7 +2724,7 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
                 fa.v16 = d_v16; fa.q16 = d_q16.as<uint16_t>(); fa.row_aux = d_vn2; fa.query_aux = d_qaux.as<float>();
                 if (use_i8) {
                     fa.v8 = d_v8; fa.q8 = d_q16.as<int8_t>(); fa.row_sr = d_v8_sr; fa.query_sr = d_qsr.as<float4>();
-                    fa.row_n = d_v8_n; fa.query_n = d_qn.as<float>(); fa.dim_f = static_cast<float>(dim);
+                    fa.row_n = d_v8_n; fa.query_n = d_qn.as<float>(); fa.dim_f = static_cast<float>(dim); fa.row_max = c->aux_v8_max.as<float>();
                     // a wave sums dim / 64 components per lane + 6 exchange steps: error <= (dim / 64 + 7) 2^-24 sum |v^_i| <= .. sqrt(dim)
                     fa.eps_sum = (static_cast<float>(dim) / 64.0f + 8.0f) * 5.9604645e-08f * std::sqrt(static_cast<float>(dim)) * 1.01f;
                 }

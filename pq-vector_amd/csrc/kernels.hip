@@ -4110,9 +4110,15 @@ constexpr int BH_BM = 128, BH_BN = 256, BH_BK = 32;       // assign_f16_kernel's
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 // ST: 16-byte chunks per row and K stage -- 4 (64-byte stages) or 8 (128-byte stages: half the barriers and twice the MFMAs
 // between them; 128 KB of LDS for the 256 x 256 tile, chunks swizzled by the row's low three bits).
-template <int NWM, int NWN, int TM, int TN, bool I8, int ST>
+// RING (0 or 4): the K stages arrive by direct-to-LDS buffer loads into a ring of RING 64-byte stages instead of through
+// registers: three stages are in flight while one is contracted, the loads stay outstanding ACROSS the per-stage barrier
+// (counted s_waitcnt vmcnt + a raw s_barrier; the operand reads are inline asm so that the compiler does not drain the
+// load queue in front of them) -- with one 8-wave block per CU nothing else hides the L2 / HBM latency of a stage.
+typedef float f32x4_raw_t __attribute__((ext_vector_type(4)));
+template <int NWM, int NWN, int TM, int TN, bool I8, int ST, int RING = 0>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
     constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
+    static_assert(RING == 0 || (RING == 4 && ST == 4 && BM % (NT / 4) == 0 && BN % (NT / 4) == 0 && TM == 4 && TN == 2), "ring form: 64-byte stages, whole 16-row blocks per wave");
     constexpr int CA = BM * ST / NT, CB = BN * ST / NT;        // 16-byte chunks a thread stages per K stage
     static_assert(BM * ST % NT == 0 && BN * ST % NT == 0 && (ST == 4 || ST == 8), "staging split");
     extern __shared__ float4 brute_lds[];                      // [2][BM * ST] query stages, [2][BN * ST] row stages
@@ -4122,6 +4128,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     __shared__ float qaux_s[BM];
     __shared__ float4 qsr_s[I8 ? BM : 1];            // int8 form: {1 / S, r, a, sum} of the tile's queries
     __shared__ float qn_s[I8 ? BM : 1];              //            |q^ - a 1|
+    __shared__ float4 qk_s[BM];                      // quick-screen constants of the tile's queries (cosine)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
@@ -4177,11 +4184,38 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
             qsr_s[tid] = qi < a.nq ? a.query_sr[qi] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             qn_s[tid] = qi < a.nq ? a.query_n[qi] : 0.0f;
         }
+        // Quick screen of the cosine epilogue (one compare, or three FMAs and a compare, per pair instead of the full bound --
+        // the epilogue's VALU work took longer than the MFMAs): per query the constants of a test that every pair the exact
+        // test keeps also passes; the exact test (below) runs only on what passes.
+        //   f16:  keep  =>  acc 2^-16 >= (1 - T) - eps - slack                                      qk = {that / 2^-16}
+        //   int8: keep  =>  D iv_j + (a / iq) A_j + (sum_q / iq) C_j >= ((1 - T) - K - slack) / iq,   qk = {a / iq, sum_q / iq, -rhs}
+        //         K = the per-pair eps with the row's terms replaced by their corpus-wide maxima (a.row_max), A_j = sum_v - b_j dim, C_j = b_j
+        float4 qk = make_float4(0.0f, 0.0f, __builtin_inff(), 0.0f);          // int8: always passes (rhs = -inf); f16: x = -inf
+        if (!I8) qk.x = -__builtin_inff();
+        if (qi < a.nq && a.metric == BRUTE_COSINE) {
+            const uint32_t th = (uint32_t)(thr_s[tid] >> 32);
+            if (th < 0xFF800000u) {                  // a finite threshold distance T (else: no threshold yet, everything passes)
+                const float T = unsortable_bits(th);
+                if constexpr (I8) {
+                    const float4 q = qsr_s[tid];
+                    const float mA = a.row_max[0], mB = a.row_max[1], mC = a.row_max[2], mE = a.row_max[3];
+                    const float K = (q.y * mB + qn_s[tid] * mE) * 1.00002f + a.eps + a.eps_sum * (fabsf(q.z) + mC);
+                    const float slack = 1.0e-5f * (2.0f + fabsf(q.z) * mA + fabsf(q.w) * mC);
+                    const float rhs = (1.0f - T) - K - slack;
+                    qk = make_float4(q.z / q.x, q.w / q.x, -(rhs / q.x), 0.0f);      // (iq = 0: NaN / inf -- the pair passes)
+                } else {
+                    qk.x = ((1.0f - T) - a.eps - 4.0e-6f) * 65536.0f;
+                }
+            }
+        }
+        qk_s[tid] = qk;
     }
 
     const uint32_t nk = rbytes / (16 * ST);
-    fetch(0);
-    stash(0);
+    if constexpr (RING == 0) {
+        fetch(0);
+        stash(0);
+    }
     __syncthreads();
     // operand roles of v_mfma_f32_32x32x16_f16: lane (l31, lk) owns row l31 of a 32-row tile and the 8 consecutive k
     // values 8 lk .. 8 lk + 7 of the instruction's 16; MFMA j of a stage takes chunk 2 j + lk (term order is free)
@@ -4191,6 +4225,73 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
     for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = sw(rowa[t]); }
 #pragma unroll
     for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = sw(rowb[t]); }
+    if constexpr (RING != 0) {
+        constexpr int NW = NT / 64, RA = BM / 16 / NW, RB = BN / 16 / NW;      // 16-row blocks (1 KiB of a stage) per wave
+        constexpr uint32_t STG = (uint32_t)(BM + BN) * 4;                      // float4s of a ring slot: BM query rows, BN corpus rows
+        typedef __attribute__((address_space(3))) void lds_void;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)brute_lds;
+        // lane l of a load instruction fills 16-byte slot l of its 1 KiB: row l / 4 of the block, stored chunk l % 4 -- which holds the
+        // row's chunk (l % 4) ^ sw(row) (the block's 16 rows start at a multiple of 16, so sw depends on l only)
+        const uint32_t voff = (uint32_t)(lane >> 2) * rbytes + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);      // (scalar: LDS base and buffer offset of a load are wave-uniform)
+        auto issue = [&](uint32_t st) {
+            float4 *dst = brute_lds + (st & (RING - 1)) * STG;
+#pragma unroll
+            for (int h = 0; h < RA; ++h) {
+                const uint32_t blk = wave_u * RA + h;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_void *)(dst + blk * 64), 16, (int)voff, (int)(blk * 16 * rbytes + st * 64), 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < RB; ++h) {
+                const uint32_t blk = wave_u * RB + h;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_void *)(dst + BM * 4 + blk * 64), 16, (int)voff, (int)(blk * 16 * rbytes + st * 64), 0, 0);
+            }
+        };
+        uint32_t offa[2][TM], offb[2][TN];          // byte offsets of this lane's operands inside a ring slot, K steps 0 / 1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) offa[j][t] = lds0 + (uint32_t)(rowa[t] * 4 + ((2 * j + lk) ^ swa[t])) * 16;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) offb[j][t] = lds0 + (uint32_t)(BM * 4 + rowb[t] * 4 + ((2 * j + lk) ^ swb[t])) * 16;
+        }
+        for (uint32_t st = 0; st < 3 && st < nk; ++st) issue(st);
+        for (uint32_t kt = 0; kt < nk; ++kt) {
+            // this wave's part of stage kt has landed (later stages stay in flight: RA + RB loads each); after the barrier
+            // everybody's has, and everybody is done with stage kt - 1, whose slot stage kt + 3 takes
+            const uint32_t ahead = nk - 1 - kt;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (RA + RB)) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(RA + RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 3 < nk) issue(kt + 3);
+            const uint32_t sb = (kt & (RING - 1)) * STG * 16;
+            f32x4_raw_t oa[2][TM], ob[2][TN];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(oa[j][t]) : "v"(offa[j][t] + sb));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ob[j][t]) : "v"(offb[j][t] + sb));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // LDS reads return in order: K step 0's six operands are there once six reads remain outstanding
+                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(oa[0][0]), "+v"(oa[0][1]), "+v"(oa[0][2]), "+v"(oa[0][3]), "+v"(ob[0][0]), "+v"(ob[0][1]) : "n"(TM + TN));
+                else { __builtin_amdgcn_sched_barrier(0); }
+                if (j == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oa[1][0]), "+v"(oa[1][1]), "+v"(oa[1][2]), "+v"(oa[1][3]), "+v"(ob[1][0]), "+v"(ob[1][1]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        if constexpr (I8)
+                            acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, oa[j][i]), __builtin_bit_cast(i32x4_acc, ob[j][jj]), acc[i][jj], 0, 0, 0);
+                        else
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, oa[j][i]), __builtin_bit_cast(f16x8_t, ob[j][jj]), acc[i][jj], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    } else
     for (uint32_t kt = 0; kt < nk; ++kt) {
         const int buf = (int)(kt & 1u);
         if (kt + 1 < nk) fetch((kt + 1) * 16 * ST);
@@ -4228,43 +4329,67 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
 
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const float inv = 1.52587890625e-05f;            // 2^-16: the two images carry 2^8 each
+    uint64_t vjs[TN];
+    bool jvs[TN];
+    float vauxs[TN];
+    [[maybe_unused]] float4 vsrs[TN];
+    [[maybe_unused]] float vns[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const uint64_t vj = n0 + wn * 32 * TN + j * 32 + l31;
-        const bool jv = vj < a.row_end;
-        const float vaux = (jv && a.metric != BRUTE_COSINE) ? a.row_aux[vj] : 0.0f;          // l2: |v|^2 (cosine: no row term)
-        [[maybe_unused]] float4 vsr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        [[maybe_unused]] float vn = 0.0f;
-        if constexpr (I8) { if (jv) { vsr = a.row_sr[vj]; vn = a.row_n[vj]; } }
+        vjs[j] = n0 + wn * 32 * TN + j * 32 + l31;
+        jvs[j] = vjs[j] < a.row_end;
+        vauxs[j] = (jvs[j] && a.metric != BRUTE_COSINE) ? a.row_aux[vjs[j]] : 0.0f;          // l2: |v|^2 (cosine: no row term)
+        vsrs[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); vns[j] = 0.0f;
+        if constexpr (I8) { if (jvs[j]) { vsrs[j] = a.row_sr[vjs[j]]; vns[j] = a.row_n[vjs[j]]; } }
+    }
+    // the exact test of one pair: lower bound of its distance against the query's threshold key
+    auto exact = [&](int ml, int j, auto accv) {
+        const uint32_t qi = m0 + ml;
+        const float vaux = vauxs[j];
+        float sc, eps;
+        if constexpr (I8) {
+            const float4 qsr = qsr_s[ml], vsr = vsrs[j];
+            sc = ((float)accv * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
+            // n_q r_v + n_v r_q + 3 r_q r_v, rounded up, + the f32 roundings of both sides (a.eps) and of the two
+            // component sums (a.eps_sum per unit of |a| + |b|)
+            eps = (qn_s[ml] * vsr.y + qsr.y * (vns[j] + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
+        } else {
+            sc = accv * inv; eps = a.eps;
+        }
+        float lb;
+        if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - eps;
+        else {
+            const float qv = sqrtf(qaux_s[ml] * vaux) * 1.000001f;     // |q| |v|
+            lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * eps - 1.0e-6f * (qaux_s[ml] + vaux);
+            lb = lb < 0.0f ? 0.0f : lb;
+        }
+        // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
+        const bool keep = !((unsigned long long)sortable_bits(lb) > (thr_s[ml] >> 32));
+        if (jvs[j] && qi < a.nq && keep) {
+            const uint32_t slot2 = atomicAdd(&a.cand_cnt[qi], 1u);
+            if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vjs[j];
+        }
+    };
+    const bool quick = a.metric == BRUTE_COSINE;
+    [[maybe_unused]] float rowA[TN], rowC[TN], rowI[TN];       // int8 quick screen: A_j, C_j, iv_j
+    if constexpr (I8) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) { rowI[j] = vsrs[j].x; rowC[j] = vsrs[j].z; rowA[j] = vsrs[j].w - vsrs[j].z * a.dim_f; }
+    }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const uint32_t qi = m0 + ml;
-                float sc, eps;
-                if constexpr (I8) {
-                    const float4 qsr = qsr_s[ml];
-                    sc = ((float)acc[i][j][r] * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
-                    // n_q r_v + n_v r_q + 3 r_q r_v, rounded up, + the f32 roundings of both sides (a.eps) and of the two
-                    // component sums (a.eps_sum per unit of |a| + |b|)
-                    eps = (qn_s[ml] * vsr.y + qsr.y * (vn + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
-                } else {
-                    sc = acc[i][j][r] * inv; eps = a.eps;
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float4 qk = qk_s[ml];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bool pass = true;
+                if (quick) {
+                    if constexpr (I8) pass = !(__builtin_fmaf((float)acc[i][j][r], rowI[j], __builtin_fmaf(qk.x, rowA[j], __builtin_fmaf(qk.y, rowC[j], qk.z))) < 0.0f);
+                    else pass = !(acc[i][j][r] < qk.x);
                 }
-                float lb;
-                if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - eps;
-                else {
-                    const float qv = sqrtf(qaux_s[ml] * vaux) * 1.000001f;     // |q| |v|
-                    lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * eps - 1.0e-6f * (qaux_s[ml] + vaux);
-                    lb = lb < 0.0f ? 0.0f : lb;
-                }
-                // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
-                const bool keep = !((unsigned long long)sortable_bits(lb) > (thr_s[ml] >> 32));
-                if (jv && qi < a.nq && keep) {
-                    const uint32_t slot2 = atomicAdd(&a.cand_cnt[qi], 1u);
-                    if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vj;
-                }
+                if (pass) exact(ml, j, acc[i][j][r]);
             }
         }
     }
@@ -4272,7 +4397,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
 hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
     const bool i8 = a.v8 != nullptr;
-    if (i8 ? ((a.dim_p % 64) != 0 || !a.q8 || !a.row_sr || !a.query_sr || !a.row_n || !a.query_n) : (a.dim_p % BH_BK) != 0) return hipErrorInvalidValue;
+    if (i8 ? ((a.dim_p % 64) != 0 || !a.q8 || !a.row_sr || !a.query_sr || !a.row_n || !a.query_n || !a.row_max) : (a.dim_p % BH_BK) != 0) return hipErrorInvalidValue;
     if ((uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
     // 256 x 256 tiles from 256 queries on (PQV_BRUTE_TILE=128 keeps the 128 x 256 form for comparison)
     static const int tile_env = [] { const char *e = std::getenv("PQV_BRUTE_TILE"); return e ? std::atoi(e) : 0; }();
@@ -4293,6 +4418,13 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(threads), lds, s, a);
         return hipGetLastError();
     };
+    // the ring form (direct-to-LDS stages, loads in flight across the barriers) of the 256 x 256 tile measures the same as the
+    // register-staged one with 128-byte stages (C5, int8: 19.7 against 19.5 ms) -- opt-in: PQV_BRUTE_RING=1 (read per launch: tests)
+    const bool ring_env = [] { const char *e = std::getenv("PQV_BRUTE_RING"); return e && *e == '1'; }();
+    if (big && ring_env && (rbytes % 64) == 0) {
+        if (i8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4, 4>, 512, 4 * 512 * 4 * 16);
+        return launch(brute_f16_kernel<2, 4, 4, 2, false, 4, 4>, 512, 4 * 512 * 4 * 16);
+    }
     if (i8) {
         if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 8>, 512, 2 * 512 * 8 * 16);
         if (big) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4>, 512, 2 * 512 * 4 * 16);
@@ -4310,10 +4442,11 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
 // r_v = +inf and is never skipped.
 __global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restrict__ rows, const float *__restrict__ rnorm,
                                                           uint64_t n, uint32_t dim, uint32_t dim_p, int8_t *__restrict__ out,
-                                                          float4 *__restrict__ sr, float *__restrict__ nrm) {
+                                                          float4 *__restrict__ sr, float *__restrict__ nrm, uint32_t *__restrict__ maxima) {
     const int lane = threadIdx.x & 63;
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nw = (uint64_t)gridDim.x * 4;
+    float mxA = 0.0f, mxB = 0.0f, mxC = 0.0f, mxE = 0.0f;       // corpus-wide maxima of |sum - b dim|, n + 3 r, |b|, r (brute_f16_kernel's quick screen)
     for (uint64_t r = w; r < n; r += nw) {
         const float *p = rows + r * dim;
         const float rn = rnorm[r];
@@ -4344,17 +4477,24 @@ __global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restri
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { res2 += __shfl_xor(res2, off, 64); n2 += __shfl_xor(n2, off, 64); }
+        const float rr = bad ? __builtin_inff() : sqrtf(res2) * 1.0001f + 1.0e-6f, nn = bad ? __builtin_inff() : sqrtf(n2) * 1.0001f + 1.0e-6f;
         if (lane == 0) {
-            sr[r] = make_float4(invS, bad ? __builtin_inff() : sqrtf(res2) * 1.0001f + 1.0e-6f, b, bad ? 0.0f : sum);
-            nrm[r] = bad ? __builtin_inff() : sqrtf(n2) * 1.0001f + 1.0e-6f;
+            sr[r] = make_float4(invS, rr, b, bad ? 0.0f : sum);
+            nrm[r] = nn;
         }
+        mxA = fmaxf(mxA, bad ? __builtin_inff() : fabsf(sum - b * (float)dim) * 1.00001f);
+        mxB = fmaxf(mxB, (nn + 3.0f * rr) * 1.00001f); mxC = fmaxf(mxC, fabsf(b)); mxE = fmaxf(mxE, rr * 1.00001f);
+    }
+    if (maxima && lane == 0) {        // non-negative floats (or +inf): their bit patterns order like the values
+        atomicMax(&maxima[0], __float_as_uint(mxA)); atomicMax(&maxima[1], __float_as_uint(mxB));
+        atomicMax(&maxima[2], __float_as_uint(mxC)); atomicMax(&maxima[3], __float_as_uint(mxE));
     }
 }
-hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm, hipStream_t s) {
+hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm, float *maxima, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(normalize_i8_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<int8_t *>(out), static_cast<float4 *>(sr), nrm);
+    hipLaunchKernelGGL(normalize_i8_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<int8_t *>(out), static_cast<float4 *>(sr), nrm, reinterpret_cast<uint32_t *>(maxima));
     return hipGetLastError();
 }
 

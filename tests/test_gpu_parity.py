@@ -610,13 +610,14 @@ def test_brute_mfma_matches_f64_oracle(pqv, monkeypatch, n, dim, nq, k, metric, 
 
 
 @pytest.mark.parametrize("metric", ["cos", "l2"])
-@pytest.mark.parametrize("op", ["i8", "f16"])
+@pytest.mark.parametrize("op", ["i8", "f16", "i8-ring", "f16-ring"])
 def test_brute_screen_on_hostile_data(pqv, monkeypatch, metric, op):
     """The int8 / f16 screens of pqv_brute_topk are bounds, not approximations: rows with one dominant component (a coarse
     int8 grid for everything else), near-duplicates of the queries (results decided inside the image's slack), tiny and
     huge norms, a zero row -- the result must still be the exact f32 one."""
-    monkeypatch.setenv("PQV_BRUTE_OP", op)
-    n, dim, nq, k = 120_000, 192, 70, 10
+    monkeypatch.setenv("PQV_BRUTE_OP", op.split("-")[0])
+    monkeypatch.setenv("PQV_BRUTE_RING", "1" if op.endswith("ring") else "0")      # direct-to-LDS form of the 256 x 256 tile
+    n, dim, nq, k = 120_000, 192, 170, 10                # > 128 queries: the 256 x 256 tile
     rng = np.random.default_rng(99)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
