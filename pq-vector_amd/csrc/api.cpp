@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1299,6 +1300,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
                                    pqv_searcher **out) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
     *out = nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     if (!index || !corpus) return fail(PQV_ERR_INVALID, "index/corpus must not be NULL");
     if (index->dim != corpus->dim)
         return fail(PQV_ERR_INVALID, "index dimension " + std::to_string(index->dim) +
@@ -1332,6 +1334,17 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
                            std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
     opts_from_env(s->opt);
+    // PQV_CREATE_STATS=1: wall time of the phases below on stderr (diagnostic; synchronises the stream at every mark)
+    const bool create_stats = std::getenv("PQV_CREATE_STATS") != nullptr;
+    auto t_last = t_enter;
+    auto mark = [&](const char *what) {
+        if (!create_stats) return;
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pqv_searcher_create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    mark("validation + host copies");
     S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
     S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
@@ -1348,12 +1361,14 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     if (!index->list_rows.empty())
         S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice, s->stream));
+    mark("tables + ids upload");
     if (flags & PQV_LAYOUT_ROW_ORDER) {
         s->d_mat = corpus->d_rows;
         s->d_row_of = s->d_ids.as<uint32_t>();
         s->d_final_ids = nullptr;
     } else {
         S_TRY(s->d_mat_ivf.alloc(std::max<size_t>(1, s->n) * s->sdim * sizeof(float)));
+        mark("allocate the IVF-ordered copy");
         if (s->sdim != s->dim)
             S_TRY(pqv::launch_pad_rows(corpus->d_rows, s->d_ids.as<uint32_t>(), s->n, s->dim, s->sdim, s->d_mat_ivf.as<float>(), s->stream));
         else
@@ -1363,6 +1378,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         s->d_row_of = nullptr;
         s->d_final_ids = s->d_ids.as<uint32_t>();
     }
+    mark("gather rows into list order");
 #ifdef PQV_PROFILE_PHASES
     S_TRY(s->d_stats.alloc((8 + 8 * 65536) * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 8 * 65536) * sizeof(unsigned long long), s->stream));
@@ -1397,16 +1413,19 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     // the blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide
     // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
     // int8 form of the blocked copy: finite data (f16_ok), rows of a multiple of 256 dims, IVF-ordered rows
+    mark("row norms + maximum");
     s->i8_ok = s->f16_ok && (s->sdim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0;
     if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 192) {
         if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
     }
     S_TRY(hipStreamSynchronize(s->stream));
+    mark("blocked operand copy");
     if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
         (void)hipFree(corpus->d_rows);
         corpus->d_rows = nullptr;
     }
 #undef S_TRY
+    mark("release / epilogue");
     *out = s;
     return PQV_OK;
 }
@@ -1719,7 +1738,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         HIP_TRY(sc.s_quads.ensure(static_cast<size_t>(p.max_quads) * sizeof(uint4)));
         HIP_TRY(sc.s_pairs.ensure(static_cast<size_t>(nq) * p.np * sizeof(uint32_t)));
         HIP_TRY(sc.s_groups.ensure(static_cast<size_t>(p.max_groups) * sizeof(uint4)));
-        if (items) HIP_TRY(sc.s_items.ensure((2 * (static_cast<size_t>(max_items) + wide_max_items) + 4 * pqv::ITEM_LEVELS) * sizeof(uint32_t)));
+        if (items) HIP_TRY(sc.s_items.ensure(2 * (static_cast<size_t>(max_items) + wide_max_items) * sizeof(uint32_t)));
     }
     if (single_bucket) {
         uint32_t *v = pair_u32 + 2 * (pqv::HIST_REPLICAS - 1) * static_cast<uint64_t>(kc_pairs);
@@ -1784,7 +1803,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ps.item_quad = sc.s_items.as<uint32_t>(); ps.max_items = max_items;
             if (s->opt.chunk_major && !single_bucket) {
                 ps.item_chunk = ps.item_quad + max_items + wide_max_items; ps.wide_item_chunk = ps.item_chunk + max_items;
-                ps.lvl = ps.wide_item_chunk + wide_max_items;
             }
             if (wide) {
                 ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;

@@ -182,10 +182,9 @@ struct PairSortArgs {
     uint32_t        max_items;
     // chunk-major item order (item_chunk != nullptr): items are numbered level by level -- row chunk 0 of every quad, then
     // chunk 1, ... (levels >= ITEM_LEVELS - 1 share the last one) -- so a query's thresholds have seen the first chunk of
-    // all its lists before any later chunk is screened.  lvl: [4 ITEM_LEVELS] = bases / cursors of this table and the wide one.
+    // all its lists before any later chunk is screened.  pair_scan_kernel writes the tables (order inside a level: by cluster).
     uint32_t       *item_chunk;      // [max_items] row chunk of each item
     uint32_t       *wide_item_chunk; // [wide_max_items]
-    uint32_t       *lvl;
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
     // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
     // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the

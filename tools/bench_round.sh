@@ -11,10 +11,10 @@ except Exception as e:
     print("$name FAILED", e)
 PY
 }
-run c2           python bench.py --steps 40
-run c2_serial    python bench.py --steps 40 --streams 1
-run c2_f32screen env PQV_SCREEN_F16=0 python bench.py --steps 40
-run c2_single    python bench.py --steps 20 --single 200
+run c2           python bench.py --workload c2 --steps 40
+run c2_serial    python bench.py --workload c2 --steps 40 --streams 1
+run c2_f32screen env PQV_SCREEN_F16=0 python bench.py --workload c2 --steps 40
+run c2_single    python bench.py --workload c2 --steps 20 --single 200
 run c3           python bench.py --workload c3 --steps 20
 run c4           python bench.py --workload c4 --steps 10
 run rb           python bench.py --workload refbench --k 100 --steps 6
