@@ -173,6 +173,8 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *                   threshold (k <= 16; default 1)
  *   "item_grid"     wide kernel grid: 1 = one workgroup per (quad, existing row chunk) for the 4-wave blocks (default),
  *                   2 = for the 8-wave blocks too, 0 = (chunks of the longest list) x quads
+ *   "chunk_major"   order of those work items: 1 (default) = row chunk 0 of every quad, then chunk 1, ... -- a query's
+ *                   thresholds have seen a piece of each of its lists before the bulk is screened; 0 = list by list
  *   "probe_rows"    batched centroid probe (a lane per centroid): 1 for batches of >= 8 queries (default), 2 always,
  *                   0 = the per-query stream over the centroid table
  * The same names, upper-cased with a PQV_ prefix, are read from the environment ONCE when a searcher is created

@@ -1308,3 +1308,50 @@ def test_wide_quads_stream_popular_lists_once(pqv, oracle, dim, k, wide_rows):
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
         screened[on] = s.counters()["screened_pairs"]
     assert screened[1] == screened[0], screened
+
+
+@pytest.mark.parametrize("case", ["levels", "clusters"])
+def test_chunk_major_work_items(pqv, oracle, case):
+    """Round 3: the filter kernel's work items are numbered chunk-major (row chunk 0 of every quad first) by pair_scan_kernel.
+    `levels`: lists of more row chunks than the table has levels (64) in both instances -- the last level then holds the rest;
+    `clusters`: more clusters than the scan's 1024 threads (several rounds).  Ids, distance bits and the screened pair count
+    must equal the list-major numbering's and the oracle's."""
+    rng = np.random.default_rng(77)
+    if case == "levels":
+        dim, kc, nprobe, nq, k = 256, 5, 2, 500, 10
+        sizes = [36000, 17000, 3000, 900, 400]
+        cen = (rng.standard_normal((kc, dim)) * 2.0).astype(np.float32)
+        data = np.concatenate([cen[c] + 0.1 * rng.standard_normal((m, dim)).astype(np.float32) for c, m in enumerate(sizes)])
+        data = np.ascontiguousarray(data[rng.permutation(len(data))].astype(np.float32))
+        pop = np.array([0.5, 0.3, 0.1, 0.06, 0.04])
+        queries = (cen[rng.choice(kc, size=nq, p=pop)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
+        oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=10)
+        opts = {"wide_rows": 256, "wide_quad_rows": 512}
+    else:
+        dim, kc, nprobe, nq, k = 64, 1100, 8, 512, 10
+        data = rng.random((kc * 210, dim), dtype=np.float32)
+        queries = rng.random((nq, dim), dtype=np.float32)
+        oidx = oracle.build_index(data, n_clusters=kc, workers=4, max_iters=1)
+        opts = {}
+    lens = np.diff(oidx.list_off.astype(np.int64))
+    if case == "levels":
+        assert lens.max() > 64 * 512, lens
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    corpus = pqv.Corpus.upload(data)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    screened = {}
+    for cm in (1, 0):
+        s = pqv.Searcher(index, corpus)
+        s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2); s.set_option("chunk_major", cm)
+        for name, v in opts.items():
+            s.set_option(name, v)
+        d = s.describe(nq, k, nprobe)
+        assert "wide_filter_kernel" in d, d
+        if case == "levels":
+            assert "lists probed by 97..160 queries" in d, d
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (_bits(dist) == _bits(odist)).all(), cm
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+        screened[cm] = s.counters()["screened_pairs"]
+    assert screened[1] == screened[0], screened
