@@ -1290,20 +1290,25 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     __syncthreads();
     const int lane = tid & 63;
     constexpr uint32_t LL = ITEM_LEVELS - 1;
+    uint32_t mn = 0, mw = 0, nch = 0, wnch = 0, q0 = 0;      // normal / wide quads of the cluster, their row chunks, first quad
+    auto cluster_shape = [&](uint32_t c) {
+        mn = mw = nch = wnch = q0 = 0;
+        if (c < a.n_clusters) {
+            const uint32_t h = a.hist[c];
+            const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
+            const uint64_t len = a.list_off[c + 1] - a.list_off[c];
+            if (a.wide_min) mw = h / a.quad_width + ((h % a.quad_width) >= a.wide_min ? 1u : 0u);
+            mn = qd - mw;
+            nch = mn ? (uint32_t)((len + a.item_rows - 1) / a.item_rows) : 0u;
+            wnch = mw ? (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows) : 0u;
+            q0 = a.quad_off[c];
+        }
+    };
+    const bool one_round = a.n_clusters <= 1024;       // every thread keeps its cluster's shape in registers for both passes
+    if (one_round) cluster_shape(tid);
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
-            const uint32_t c = base + tid;
-            uint32_t mn = 0, mw = 0, nch = 0, wnch = 0, q0 = 0;      // normal / wide quads of the cluster, their row chunks, first quad
-            if (c < a.n_clusters) {
-                const uint32_t h = a.hist[c];
-                const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
-                const uint64_t len = a.list_off[c + 1] - a.list_off[c];
-                if (a.wide_min) mw = h / a.quad_width + ((h % a.quad_width) >= a.wide_min ? 1u : 0u);
-                mn = qd - mw;
-                nch = mn ? (uint32_t)((len + a.item_rows - 1) / a.item_rows) : 0u;
-                wnch = mw ? (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows) : 0u;
-                q0 = a.quad_off[c];
-            }
+            if (!one_round) cluster_shape(base + tid);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {          // table 0: the quads of <= quad_width pairs; table 1: the wide quads (the cluster's first mw quads)
                 const uint32_t m = tb ? mw : mn, n = tb ? wnch : nch, qf = tb ? q0 : q0 + mw;

@@ -1307,7 +1307,9 @@ def test_wide_quads_stream_popular_lists_once(pqv, oracle, dim, k, wide_rows):
         assert (_bits(dist) == _bits(odist)).all(), on
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
         screened[on] = s.counters()["screened_pairs"]
-    assert screened[1] == screened[0], screened
+    # (pairs whose centre-distance bound exceeds the query's threshold AT THE TIME a block looks are dropped, so the count
+    #  depends on the order the blocks run in: the two forms agree closely, not exactly)
+    assert abs(screened[1] - screened[0]) <= 0.02 * screened[0], screened
 
 
 @pytest.mark.parametrize("case", ["levels", "clusters"])
@@ -1354,4 +1356,4 @@ def test_chunk_major_work_items(pqv, oracle, case):
         assert (_bits(dist) == _bits(odist)).all(), cm
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
         screened[cm] = s.counters()["screened_pairs"]
-    assert screened[1] == screened[0], screened
+    assert abs(screened[1] - screened[0]) <= 0.02 * screened[0], screened      # (order-dependent pair pruning, as above)

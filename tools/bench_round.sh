@@ -21,4 +21,6 @@ run rb           python bench.py --workload refbench --k 100 --steps 6
 run c2s2         python bench.py --workload c2s2 --steps 40
 run c2s4         python bench.py --workload c2s4 --steps 40
 run c2s8         python bench.py --workload c2s8 --steps 40
-run c5           python bench.py --workload c5 --steps 3
+run c3h          python bench.py --workload c3h --steps 20
+run c2d          python bench.py --workload c2d --steps 40
+run c5           python bench.py --workload c5 --steps 5
