@@ -48,9 +48,12 @@ typedef enum pqv_metric {
 } pqv_metric;
 
 /* Metrics of pqv_brute_topk (an EXTENSION: the reference has neither cosine distance nor a
- * batched brute-force path -- SURVEY F5; BASELINE.json configs[4] asks for it).  Scores are a
- * dense Q.V^T contraction on the f32 matrix cores, so distances agree with an f64 oracle to
- * ~1e-6 relative (well inside the north star's 1e-4), not bit for bit. */
+ * batched brute-force path -- SURVEY F5; BASELINE.json configs[4] asks for it).  Every returned
+ * distance comes from an f32 dot product (f32 matrix cores for the first rows, an exact f32
+ * re-scoring behind the int8 / f16 matrix-core screen of the rest: the screen is a rigorous
+ * bound, it never drops a row of the result), so distances agree with an f64 oracle to ~1e-6
+ * relative (well inside the north star's 1e-4), not bit for bit.  The first call builds the
+ * screen's image of the corpus (+ 1 byte per value; PQV_BRUTE_OP=f16: + 2). */
 #define PQV_COSINE      2   /* 1 - q.v / (|q| |v|); zero-norm vectors get distance 1            */
 #define PQV_L2SQ_MFMA   3   /* |q|^2 + |v|^2 - 2 q.v (norm-expansion form, clamped at 0)        */
 
