@@ -1218,7 +1218,9 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     __shared__ uint32_t s_lvl[2 * ITEM_LEVELS];        // chunk-major tables: items per level (this table, the wide one)
     const uint32_t tid = threadIdx.x;
     const bool levels = a.item_rows && a.item_chunk;
+    __shared__ uint32_t s_ext[2];                      // ... items beyond the last level
     if (levels && tid < 2 * ITEM_LEVELS) s_lvl[tid] = 0;
+    if (levels && tid < 2) s_ext[tid] = 0;
     if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; carry_witem = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < a.n_clusters; base += 1024) {
@@ -1312,6 +1314,16 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {          // table 0: the quads of <= quad_width pairs; table 1: the wide quads (the cluster's first mw quads)
                 const uint32_t m = tb ? mw : mn, n = tb ? wnch : nch, qf = tb ? q0 : q0 + mw;
+                if (pass == 0) {
+                    // counts per level as a difference array: + m at level 0, - m behind the cluster's last level; what lies
+                    // beyond the table's levels is added to the last one
+                    if (m && n) {
+                        atomicAdd(&s_lvl[tb * ITEM_LEVELS], m);
+                        atomicAdd(&s_lvl[tb * ITEM_LEVELS + (n < LL ? n : LL)], 0u - m);
+                        if (n > LL) atomicAdd(&s_ext[tb], m * (n - LL));
+                    }
+                    continue;
+                }
                 uint32_t nmax = n;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nmax, off, 64); nmax = o > nmax ? o : nmax; }
@@ -1321,9 +1333,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                     const uint32_t incl = wave_incl_scan_u32(mine);
                     const uint32_t total = readlane_u32(incl, 63);
                     if (total == 0) continue;
-                    if (pass == 0) {
-                        if (lane == 0) atomicAdd(&s_lvl[tb * ITEM_LEVELS + lv], total);
-                    } else {
+                    {
                         uint32_t first = 0;
                         if (lane == 0) first = atomicAdd(&s_lvl[tb * ITEM_LEVELS + lv], total);
                         first = readlane_u32(first, 0) + incl - mine;
@@ -1336,10 +1346,14 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
             }
         }
         __syncthreads();
-        if (pass == 0) {               // counts -> first slot of every level (the running cursors of pass 1)
+        if (pass == 0) {               // differences -> counts -> first slot of every level (the running cursors of pass 1)
             if (tid < 2) {
-                uint32_t b = 0;
-                for (uint32_t t = 0; t < ITEM_LEVELS; ++t) { const uint32_t v = s_lvl[tid * ITEM_LEVELS + t]; s_lvl[tid * ITEM_LEVELS + t] = b; b += v; }
+                uint32_t b = 0, cnt = 0;
+                for (uint32_t t = 0; t < ITEM_LEVELS; ++t) {
+                    cnt += s_lvl[tid * ITEM_LEVELS + t];
+                    s_lvl[tid * ITEM_LEVELS + t] = b;
+                    b += cnt + (t == LL ? s_ext[tid] : 0u);
+                }
             }
             __syncthreads();
         }
@@ -4468,6 +4482,8 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
         if (i8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4, 4>, 512, 4 * 512 * 4 * 16);
         return launch(brute_f16_kernel<2, 4, 4, 2, false, 4, 4>, 512, 4 * 512 * 4 * 16);
     }
+    // (measured and dropped: four waves of 128 x 128 -- 16 accumulator tiles per wave in AGPRs, one wave per SIMD, half the LDS
+    //  reads per MFMA: hipcc keeps 1 KB of scratch per lane for it and the launch takes 136 ms against 18.5)
     if (i8) {
         if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 8>, 512, 2 * 512 * 8 * 16);
         if (big) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4>, 512, 2 * 512 * 4 * 16);
