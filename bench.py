@@ -402,6 +402,10 @@ def main():
     rr_ms = rerank_ms / max(1, ncalls)
     ctr = searcher.counters()
     fp = searcher.footprint()
+    # what the LIBRARY holds next to the caller's column (here a torch tensor: row_order_bytes is the caller's, and a library-owned
+    # corpus can drop its row-order copy with PQV_RELEASE_ROW_ORDER once the searcher exists)
+    fp["library_bytes"] = fp["ivf_rows_bytes"] + fp["blocked_bytes"] + fp["other_bytes"]
+    fp["library_over_corpus"] = fp["library_bytes"] / max(1, n_shard * dim * 4)
     screened = "wide_filter_kernel" in plan_text or "tile_filter_kernel" in plan_text
     wide = "wide_filter_kernel" in plan_text
     f16 = "f16 screen operands" in plan_text
