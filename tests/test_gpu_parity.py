@@ -575,6 +575,7 @@ def _f64_brute(data, queries, k, metric):
     (20000, 1536, 130, 10),     # C5-shaped rows (ada-002 dim), > 1 query tile, partial tiles
     (9000, 96, 33, 10),
     (70000, 64, 260, 25),       # several progressive ranges (8k, 64k)
+    (40000, 100, 140, 10),      # screened ranges with rows padded to the image's K granule (100 -> 128 values), one partial 256-query tile
     (500, 50, 5, 10),           # dim % 16 != 0, dim % 4 != 0, fewer rows than a tile
     (300, 7, 3, 400),           # k > n
 ])
