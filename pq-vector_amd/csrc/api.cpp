@@ -2724,6 +2724,7 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
             }
             todo.assign(fwd.rbegin(), fwd.rend());   // stack: pop_back() yields ascending ranges
         }
+        bool first_range = true;
         while (!todo.empty()) {
             const auto range = todo.back();
             todo.pop_back();
@@ -2751,8 +2752,14 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
                 fa.thr = ba.thr; fa.cand = ba.cand; fa.cand_cnt = ba.cand_cnt; fa.cap = cap;
                 HIP_TRY(launch_brute_f16(fa, stream));
             } else {
+                // the very first range: nothing to compare with yet, every pair is kept -- written to its own slot instead of one
+                // atomic append per pair (2048 rows x 1024 queries: 1.07 -> 0.1 ms on C5)
+                const bool dense = first_range && range.second - range.first <= cap;
+                ba.dense = dense ? 1u : 0u;
                 HIP_TRY(launch_brute_mfma(ba, stream));
+                if (dense) HIP_TRY(hipMemsetD32Async(static_cast<hipDeviceptr_t>(d_cnt.p), static_cast<int>(range.second - range.first), b, stream));
             }
+            first_range = false;
             // overflow is checked BEFORE the select pass touches the buffer fronts, so a
             // rollback only has to restore the counts
             HIP_TRY(launch_brute_overflow_check(d_cnt.as<uint32_t>(), b, cap, d_flag.as<uint32_t>(), stream));

@@ -350,6 +350,9 @@ struct BruteArgs {
     unsigned long long *cand;          // [nq][cap] appended keys
     uint32_t    *cand_cnt;             // [nq]
     uint32_t     cap;
+    // dense != 0: no thresholds yet and empty buffers (the first row range): EVERY pair is kept, in slot row - row_begin of
+    // its query -- no atomic per pair; the caller sets cand_cnt to the range's length (<= cap) afterwards
+    uint32_t     dense;
 };
 hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s);
 // The f16 screen of the same search (kernels.hip: brute_f16_kernel): L2-normalised f16 images x 2^8 of rows / queries

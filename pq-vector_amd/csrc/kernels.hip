@@ -4103,7 +4103,9 @@ __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
                 else { d = qaux_s[ml] + vaux - 2.0f * sc; d = d < 0.0f ? 0.0f : d; }
                 const unsigned long long key =
                     ((unsigned long long)sortable_bits(d) << 32) | (unsigned long long)(uint32_t)vj;
-                if (jv && qi < a.nq && key < thr_s[ml]) {
+                if (a.dense) {
+                    if (jv && qi < a.nq) a.cand[(uint64_t)qi * a.cap + (uint32_t)(vj - a.row_begin)] = key;
+                } else if (jv && qi < a.nq && key < thr_s[ml]) {
                     const uint32_t slot = atomicAdd(&a.cand_cnt[qi], 1u);
                     if (slot < a.cap) a.cand[(uint64_t)qi * a.cap + slot] = key;
                 }
@@ -4114,6 +4116,7 @@ __global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
 
 hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
+    if (a.dense && a.row_end - a.row_begin > a.cap) return hipErrorInvalidValue;
     const uint64_t nb = (a.row_end - a.row_begin + BR_BN - 1) / BR_BN;
     if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)nb, (a.nq + BR_BM - 1) / BR_BM);
