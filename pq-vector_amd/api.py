@@ -425,7 +425,7 @@ class Searcher:
         return self
 
     def describe(self, nq, k, nprobe, metric=_ffi.PQV_L2SQ_REF4):
-        buf = C.create_string_buffer(640)
+        buf = C.create_string_buffer(2048)
         _check(_ffi.lib().pqv_searcher_describe(self._h, nq, k, nprobe, metric, buf, len(buf)))
         return buf.value.decode()
 

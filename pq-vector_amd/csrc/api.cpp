@@ -206,6 +206,9 @@ struct pqv_searcher {
     // batch's probe / bucketing / seed kernels) instead of serialising on shared buffers
     mutable std::mutex mu;
     mutable Scratch lanes[PQV_LANES];
+    // {wide items, of which in single-quad lists} of a recent batch, written by pair_scan_kernel straight into this pinned
+    // buffer (a hint for the NEXT batch's cache policy, read without synchronisation -- wide_rows_nt)
+    mutable PinnedBuf h_wide_stats;
     mutable uint32_t lane_rr = 0;
     // blocked MFMA-operand copies of the lists, one per operand form in use (0 f32, 1 f16, 2 int8); built at creation
     // for the form the dispatch rule picks, a second form only if a later call asks for it (e.g. k > 32 on short lists)
@@ -1198,6 +1201,16 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
 }
 
+// Cache policy of the wide-quad instance's row stream (kernels.hip, launch_filter_s): nt unless a recent batch had more than a
+// quarter of its wide work items in lists of several quads (those share their rows through the caches).  A hint only: it
+// is read without synchronisation and never changes a result; before the first batch has reported: nt.
+bool wide_rows_nt(const pqv_searcher *s) {
+    if (!s->h_wide_stats.p) return true;
+    const volatile uint32_t *h = s->h_wide_stats.as<uint32_t>();
+    const uint32_t total = h[0], lone = h[1];
+    return total == 0 || static_cast<uint64_t>(lone) * 4 >= static_cast<uint64_t>(total) * 3;
+}
+
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
 bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && !s->d_row_of && s->n > 0; }
 
@@ -1804,6 +1817,13 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             if (s->opt.chunk_major && !single_bucket) {
                 ps.item_chunk = ps.item_quad + max_items + wide_max_items; ps.wide_item_chunk = ps.item_chunk + max_items;
             }
+            if (wide && ps.item_chunk) {         // pair_scan_kernel writes the two counts straight into pinned host memory
+                if (!s->h_wide_stats.p) {
+                    HIP_TRY(s->h_wide_stats.ensure(2 * sizeof(uint32_t)));
+                    std::memset(s->h_wide_stats.p, 0, 2 * sizeof(uint32_t));
+                }
+                ps.wide_stats = s->h_wide_stats.as<uint32_t>();
+            }
             if (wide) {
                 ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
                 ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
@@ -1917,6 +1937,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             if (wide) {
                 ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
                 ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
+                ta.wide_nt = wide_rows_nt(s) ? 1u : 0u;
                 s->counters.kernel_launches += 1;
             }
             HIP_TRY(launch_tile_filter(ta, stream));
@@ -2373,12 +2394,12 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         const int seed_ng = p.i8 ? (64ull * s->sdim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->sdim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
         std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4>; wide_seed_kernel<%d, %s, %d, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
-                      (p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) ? "true" : "false",
+                      ((p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) || p.wide_width) ? "true" : "false",
                       seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 64 && s->opt.single_bucket > 0) ? 12 : 1, S,
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
         if (p.wide_width) {
             const size_t l = std::strlen(kn);
-            std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, false, 2>", p.wide_width / 16, S);
+            std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, %s, 2>", p.wide_width / 16, S, wide_rows_nt(s) ? "true" : "false");
         }
     }
     std::snprintf(buf, len, "%s; centroid probe: %s%s", t, p.probe_rows ? "probe_rows_kernel (a lane per centroid)" : "stream_kernel", kn);

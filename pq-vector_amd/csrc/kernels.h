@@ -185,6 +185,7 @@ struct PairSortArgs {
     // all its lists before any later chunk is screened.  pair_scan_kernel writes the tables (order inside a level: by cluster).
     uint32_t       *item_chunk;      // [max_items] row chunk of each item
     uint32_t       *wide_item_chunk; // [wide_max_items]
+    uint32_t       *wide_stats;      // optional [2]: items of the wide table, and how many of them belong to lists with no other quad
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
     // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
     // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the
@@ -286,6 +287,7 @@ struct TileArgs {
     uint32_t        wide_width;  // 0 = none
     const uint32_t *wide_item_quad;
     const uint32_t *item_chunk, *wide_item_chunk;   // chunk-major tables (PairSortArgs::item_chunk); nullptr = chunk = item - quads[q].w
+    uint32_t        wide_nt;         // the wide-quad instance streams its rows with the nt policy (most of its lists have one quad)
     const uint32_t *wide_n_items;
     uint32_t        wide_max_items, wide_rows_per_block;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates

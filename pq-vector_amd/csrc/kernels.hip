@@ -1219,6 +1219,8 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     const uint32_t tid = threadIdx.x;
     const bool levels = a.item_rows && a.item_chunk;
     __shared__ uint32_t s_ext[2];                      // ... items beyond the last level
+    __shared__ uint32_t s_lone;                        // wide items of lists whose only quad is that wide one
+    if (tid == 0) s_lone = 0;
     if (levels && tid < 2 * ITEM_LEVELS) s_lvl[tid] = 0;
     if (levels && tid < 2) s_ext[tid] = 0;
     if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; carry_witem = 0; }
@@ -1318,6 +1320,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                     // counts per level as a difference array: + m at level 0, - m behind the cluster's last level; what lies
                     // beyond the table's levels is added to the last one
                     if (m && n) {
+                        if (tb == 1 && mw == 1 && mn == 0) atomicAdd(&s_lone, n);
                         atomicAdd(&s_lvl[tb * ITEM_LEVELS], m);
                         atomicAdd(&s_lvl[tb * ITEM_LEVELS + (n < LL ? n : LL)], 0u - m);
                         if (n > LL) atomicAdd(&s_ext[tb], m * (n - LL));
@@ -1354,6 +1357,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                     s_lvl[tid * ITEM_LEVELS + t] = b;
                     b += cnt + (t == LL ? s_ext[tid] : 0u);
                 }
+                if (tid == 1 && a.wide_stats) { a.wide_stats[0] = b; a.wide_stats[1] = s_lone; }
             }
             __syncthreads();
         }
@@ -3856,15 +3860,17 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                         w.rows_per_block = a.wide_rows_per_block;
                         // the regular instance first: most lists are its, so every query's thresholds have met most of its lists'
                         // first chunks before the popular lists are read (C3: 257 -> 225 exact evaluations per query, the serial
-                        // step's kernels 2.09 -> 2.065 ms; PQV_WIDE_LAST=0: the wide instance first)
-                        static const int swap_env = getenv("PQV_WIDE_LAST") ? atoi(getenv("PQV_WIDE_LAST")) : 1;
-                        if (swap_env) {
-                            const hipError_t e = launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
-                            if (e != hipSuccess) return e;
-                            return launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
-                        }
-                        const hipError_t e = launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
+                        // step's kernels 2.09 -> 2.065 ms against the wide instance first)
+                        // Cache policy of the row streams.  A list has ONE quad in the regular table: its rows are read once by that
+                        // launch and stream with the nt policy (they do not displace query images, thresholds and survivors' rows
+                        // from L2 / the Infinity Cache).  In the wide table a list of more than 160 pairs has several quads, which run
+                        // side by side and share its rows through the caches -- nt pays there only when such lists are rare: the
+                        // caller decides from the previous batch's counts (TileArgs::wide_nt).  Measured, nt on regular / wide /
+                        // both: C3 +0.5 / +3.5 / +4 %, mixture +2.5 / -6 / -4 %.
+                        hipError_t e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
                         if (e != hipSuccess) return e;
+                        return a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, s)
+                                         : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
                     }
                     return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
                 }
