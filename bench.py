@@ -563,6 +563,19 @@ def main():
                                             "entry_points": "pqv_shard_unique_id / pqv_shard_comm_create / pqv_shard_exchange"}
                 comm.close()
 
+    elif exchange:
+        # generic exchange (gloo path check: ranks may share a device): host-staged all-gather + the torch stable-sort merge
+        step(0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            xchg_l[0].exchange(dist_l[0], rows_l[0].to(torch.int64) & 0xFFFFFFFF, lo)
+        torch.cuda.synchronize()
+        result["exchange"] = {"ranks": world, "backend": args.backend, "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
+                              "bytes_per_rank_per_step": nq * K * 16,
+                              "collective": "one all_gather_into_tensor of packed {f32 distance bits, i64 global row} pairs + stable-sort merge"}
+
     # ---- N > 1: the other multi-GPU mode on the same hardware, as a secondary object -------------------------
     if world > 1 and not replica and not args.force_dist and args.multi == "auto":
         result["replicas"] = replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps=max(20, min(steps, 200)))

@@ -913,8 +913,24 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
         HIP_TRY(hipStreamSynchronize(stream));
         const float *md = h_min.as<float>();
         // total = sum over worker chunks of the chunk's sequential f32 sum (:356-370)
+        // Each chunk's sum is its own sequential f32 chain and the chains are independent of each other, so eight
+        // full chunks run side by side (one dependent add per 3-4 host cycles otherwise: 40 us of an 80 us round);
+        // the chunk sums still join `total` in ascending chunk order.
         float total = 0.0f;
-        for (uint64_t s = 0; s < init_n; s += chunk) {
+        uint64_t s = 0;
+        if (chunk < init_n) {
+            for (; s + 8 * chunk <= init_n; s += 8 * chunk) {
+                const float *p = md + s;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f, a5 = 0.0f, a6 = 0.0f, a7 = 0.0f;
+                for (uint64_t t = 0; t < chunk; ++t) {
+                    a0 = a0 + p[t];             a1 = a1 + p[chunk + t];     a2 = a2 + p[2 * chunk + t]; a3 = a3 + p[3 * chunk + t];
+                    a4 = a4 + p[4 * chunk + t]; a5 = a5 + p[5 * chunk + t]; a6 = a6 + p[6 * chunk + t]; a7 = a7 + p[7 * chunk + t];
+                }
+                total = total + a0; total = total + a1; total = total + a2; total = total + a3;
+                total = total + a4; total = total + a5; total = total + a6; total = total + a7;
+            }
+        }
+        for (; s < init_n; s += chunk) {
             const uint64_t e = std::min(init_n, s + chunk);
             float local = 0.0f;
             for (uint64_t t = s; t < e; ++t) local = local + md[t];
