@@ -14,6 +14,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <system_error>
+#include <thread>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -603,6 +606,54 @@ namespace {
 // false if an assignment is out of range (a kernel bug must surface as an error, not as host memory corruption)
 bool lists_from_assignment(const uint32_t *cluster_of, uint64_t n, uint32_t k,
                            std::vector<uint64_t> &off, std::vector<uint32_t> &rows) {
+    // Large inputs: a stable counting sort over T contiguous row ranges on T host threads.  Range t's rows of a cluster
+    // follow those of the ranges before it, so every list is in ascending row order -- the sequential scan's result.
+    // PQV_LIST_THREADS=1 keeps the sequential scan (A/B)
+    static const uint32_t t_max = [] { const char *e = std::getenv("PQV_LIST_THREADS"); const long v = e ? std::strtol(e, nullptr, 10) : 8;
+                                       return static_cast<uint32_t>(std::min<long>(64, std::max<long>(1, v))); }();
+    const uint32_t T = n >= (1u << 20) ? std::min<uint32_t>(t_max, std::max<uint32_t>(1, host_workers())) : 1;
+    if (T > 1) {
+        try {
+            std::vector<uint64_t> cnt(static_cast<size_t>(T) * k, 0);
+            std::atomic<bool> bad{false};
+            auto run_ranges = [&](auto &&body) {
+                std::vector<std::thread> th;
+                th.reserve(T);
+                for (uint32_t t = 0; t < T; ++t) th.emplace_back([&, t] { body(t, n * t / T, n * (t + 1) / T); });
+                for (auto &x : th) x.join();
+            };
+            run_ranges([&](uint32_t t, uint64_t lo, uint64_t hi) {
+                uint64_t *c = cnt.data() + static_cast<size_t>(t) * k;
+                for (uint64_t r = lo; r < hi; ++r) {
+                    const uint32_t v = cluster_of[r];
+                    if (v >= k) { bad.store(true); return; }
+                    c[v]++;
+                }
+            });
+            if (bad.load()) return false;
+            off.assign(static_cast<size_t>(k) + 1, 0);
+            uint64_t run = 0;
+            for (uint32_t c = 0; c < k; ++c) {
+                off[c] = run;
+                for (uint32_t t = 0; t < T; ++t) {
+                    uint64_t &slot = cnt[static_cast<size_t>(t) * k + c];
+                    const uint64_t x = slot;
+                    slot = run;
+                    run += x;
+                }
+            }
+            off[k] = run;
+            rows.resize(n);
+            uint32_t *out = rows.data();
+            run_ranges([&](uint32_t t, uint64_t lo, uint64_t hi) {
+                uint64_t *cur = cnt.data() + static_cast<size_t>(t) * k;
+                for (uint64_t r = lo; r < hi; ++r) out[cur[cluster_of[r]]++] = static_cast<uint32_t>(r);
+            });
+            return true;
+        } catch (const std::system_error &) {
+            // no threads to be had: the sequential scan below
+        }
+    }
     for (uint64_t r = 0; r < n; ++r) if (cluster_of[r] >= k) return false;
     off.assign(static_cast<size_t>(k) + 1, 0);
     for (uint64_t r = 0; r < n; ++r) off[cluster_of[r] + 1]++;
@@ -874,9 +925,15 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
                                    d_init_own.as<float>(), stream));
         d_init = d_init_own.as<float>();
     }
-    const uint64_t first_choice = rng.range_usize(0, init_n);                          // :340
-    HIP_TRY(hipMemcpyAsync(d_centroids, d_init + first_choice * dim, dim * sizeof(float),
-                           hipMemcpyDeviceToDevice, stream));                          // :342
+    // Centroid i is row picks[i] of the subset (~0: none, the centroid keeps its zero fill).  A round measures against that
+    // row where it lies and the rows are copied into the table once, after the last round, so that a round is ONE command
+    // on the stream: no device-to-device copy before its kernel, no download after it (the kernel mirrors the minima into
+    // pinned host memory) -- the copy engine hand-overs were a third of a round's 80 us.
+    std::vector<uint64_t> picks(k, ~0ull);
+    picks[0] = rng.range_usize(0, init_n);                                             // :340-342
+    auto centroid_row = [&](uint32_t j) -> const float * {
+        return picks[j] != ~0ull ? d_init + picks[j] * dim : d_centroids + static_cast<uint64_t>(j) * dim;
+    };
 
     // min_distances (:344-352), then one streaming pass per round (:354-369)
     DevBuf d_min;
@@ -896,26 +953,25 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     sa.blocks_per_list = static_cast<uint32_t>((init_n + 255) / 256);
     sa.max_pos = ~0ull; sa.metric = PQV_L2SQ_REF4;
     sa.out_f32 = d_min.as<float>();
+    sa.mirror_f32 = h_min.as<float>();
 
     // chunking of the partial sums (:259-265,:305-306)
     const uint64_t w = std::max<uint64_t>(1, std::min<uint64_t>(workers, init_n));
     const uint64_t chunk = (init_n + w - 1) / w;
 
     const double t_pp0 = now_s();
-    sa.queries = d_centroids;  // distances to centroid 0
+    sa.queries = centroid_row(0);  // distances to centroid 0
     HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
     for (uint32_t i = 1; i < k; ++i) {
         if (i > 1) {  // round 1 would re-measure centroid 0: min-update is the identity
-            sa.queries = d_centroids + static_cast<uint64_t>(i - 1) * dim;
+            sa.queries = centroid_row(i - 1);
             HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
         }
-        HIP_TRY(hipMemcpyAsync(h_min.p, d_min.p, init_n * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         const float *md = h_min.as<float>();
         // total = sum over worker chunks of the chunk's sequential f32 sum (:356-370)
         // Each chunk's sum is its own sequential f32 chain and the chains are independent of each other, so eight
-        // full chunks run side by side (one dependent add per 3-4 host cycles otherwise: 40 us of an 80 us round);
-        // the chunk sums still join `total` in ascending chunk order.
+        // full chunks run side by side; the chunk sums still join `total` in ascending chunk order.
         float total = 0.0f;
         uint64_t s = 0;
         if (chunk < init_n) {
@@ -936,20 +992,34 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
             for (uint64_t t = s; t < e; ++t) local = local + md[t];
             total = total + local;
         }
-        uint64_t pick = ~0ull;
         if (total > 0.0f) {
             const float threshold = rng.unit_f32() * total;                            // :373
             float cumsum = 0.0f;
             for (uint64_t slot = 0; slot < init_n; ++slot) {                           // :375-383
                 cumsum = cumsum + md[slot];
-                if (cumsum >= threshold) { pick = slot; break; }
+                if (cumsum >= threshold) { picks[i] = slot; break; }
             }
         } else {
-            pick = rng.range_usize(0, init_n);                                         // :385
+            picks[i] = rng.range_usize(0, init_n);                                     // :385
         }
-        if (pick != ~0ull)  // otherwise centroid i keeps its zero fill, as in the reference
-            HIP_TRY(hipMemcpyAsync(d_centroids + static_cast<uint64_t>(i) * dim, d_init + pick * dim,
-                                   dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    // the chosen rows -> the centroid table (a centroid without a pick keeps its zero fill, as in the reference)
+    {
+        bool all = true;
+        for (uint32_t i = 0; i < k; ++i) all = all && picks[i] != ~0ull;
+        if (all) {
+            DevBuf d_picks;
+            HIP_TRY(d_picks.alloc(static_cast<size_t>(k) * sizeof(uint64_t)));
+            HIP_TRY(hipMemcpyAsync(d_picks.p, picks.data(), static_cast<size_t>(k) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(launch_gather_rows(d_init, nullptr, d_picks.as<uint64_t>(), k, dim, d_centroids, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        } else {
+            for (uint32_t i = 0; i < k; ++i)
+                if (picks[i] != ~0ull)
+                    HIP_TRY(hipMemcpyAsync(d_centroids + static_cast<uint64_t>(i) * dim, d_init + picks[i] * dim,
+                                           dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
     }
     d_min.release(); d_init_own.release(); d_idx.release();
     HIP_TRY(hipStreamSynchronize(stream));
