@@ -4848,10 +4848,94 @@ __global__ __launch_bounds__(256) void assign_rescore_kernel(const float *__rest
     }
     if (live && cl == 0) cluster[row] = best == KEY_EMPTY ? 0u : (uint32_t)best;
 }
+// The same result with coalesced reads: a wave still owns 16 rows x 4 candidate slots per round, but the 64 lanes read one
+// row (and each of its candidates' centroids) 1 KB at a time -- lane g computes the 4-group term of group g -- and park the
+// terms in LDS [group][slot] (stride 65: conflict-free both ways); lane `slot` then adds its 64 terms in ascending group order,
+// which is the reference's chain (index.rs:461-480).  A row is read once for its four slots.
+__global__ __launch_bounds__(128) void assign_rescore_wave_kernel(const float *__restrict__ rows, const float *__restrict__ centroids, uint64_t m,
+                                                                 uint32_t dim, uint32_t kc, const uint32_t *__restrict__ cand,
+                                                                 const uint32_t *__restrict__ cand_cnt, uint32_t cap, uint32_t *__restrict__ cluster) {
+    __shared__ float lds_all[2][64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float *lds = lds_all[wv];
+    const uint64_t wave_row0 = ((uint64_t)blockIdx.x * 2 + (uint32_t)wv) * 16;
+    const uint64_t row = wave_row0 + (uint32_t)(lane >> 2);
+    const uint32_t cl = (uint32_t)lane & 3u;
+    const bool live = row < m;
+    uint32_t cnt = live ? cand_cnt[row] : 0u;
+    const bool all = cnt > cap;                       // list overflowed: every centroid is a candidate
+    if (all) cnt = kc;
+    const uint32_t G = dim >> 2;
+    uint64_t best = KEY_EMPTY;
+    for (uint32_t t = 0;; ++t) {
+        const uint32_t ci = 4 * t + cl;
+        const bool act = ci < cnt;
+        const uint64_t mask = __ballot(act);
+        if (mask == 0) break;
+        const uint32_t j = act ? (all ? ci : cand[row * cap + ci]) : 0u;
+        float sum = 0.0f;
+        for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+            const uint32_t ng = (G - g0 < 64u) ? (G - g0) : 64u;
+            const bool gv = (uint32_t)lane < ng;
+            const uint32_t goff = (g0 + (gv ? (uint32_t)lane : 0u)) * 4;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m4 = (uint32_t)(mask >> (4 * r)) & 0xFu;     // wave-uniform
+                if (m4 == 0) continue;
+                const float4 xv = load4<true>(rows + (wave_row0 + (uint32_t)r) * dim + goff);
+                float4 cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t jp = readlane_u32(j, 4 * r + u);
+                    cv[u] = load4<true>(centroids + (uint64_t)jp * dim + goff);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d0 = xv.x - cv[u].x, d1 = xv.y - cv[u].y, d2 = xv.z - cv[u].z, d3 = xv.w - cv[u].w;
+                    float tt = d0 * d0 + d1 * d1;
+                    tt = tt + d2 * d2;
+                    tt = tt + d3 * d3;
+                    if (gv) lds[lane * 65 + 4 * r + u] = tt;
+                }
+            }
+            wave_lds_fence();
+            uint32_t e = 0;
+            for (; e + 8 <= ng; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = lds[(e + u) * 65 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; e < ng; ++e) sum = sum + lds[e * 65 + lane];
+            wave_lds_fence();
+        }
+        if (act) {
+            const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | j;
+            best = key < best ? key : best;
+        }
+    }
+    // the row's four lanes: smallest (distance bits, index) = strict '<' in ascending centroid order (index.rs:408-415)
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint64_t o = shfl_u64(best, lane ^ off);
+        best = o < best ? o : best;
+    }
+    if (live && cl == 0) cluster[row] = best == KEY_EMPTY ? 0u : (uint32_t)best;
+}
 hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint64_t m, uint32_t dim, uint32_t kc, const uint32_t *cand,
                                  const uint32_t *cand_cnt, uint32_t cap, uint32_t *cluster, hipStream_t s) {
     if (m == 0) return hipSuccess;
     if ((dim % 4) != 0) return hipErrorInvalidValue;
+    // PQV_RESCORE_WAVE=0: the lane-per-(row, candidate) form above (A/B)
+    static const bool wave_form = [] { const char *e = getenv("PQV_RESCORE_WAVE"); return !(e && *e == '0'); }();
+    if (wave_form && dim >= 64) {
+        const uint64_t wblocks = (m + 31) / 32;
+        if (wblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(assign_rescore_wave_kernel, dim3((uint32_t)wblocks), dim3(128), 0, s, rows, centroids, m, dim, kc, cand, cand_cnt, cap, cluster);
+        return hipGetLastError();
+    }
     const uint64_t blocks = (m + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, centroids, m, dim, kc, cand, cand_cnt, cap, cluster);
