@@ -188,7 +188,6 @@ inline std::vector<uint64_t> index_sample(StdRng &rng, uint64_t length, uint64_t
         for (uint32_t v : idx) out.push_back(v);
     } else {
         std::unordered_set<uint32_t> seen;
-        seen.reserve(static_cast<size_t>(amt) * 2);
         const uint32_t reject = (0xFFFFFFFFu - len + 1u) % len;
         const uint32_t zone = 0xFFFFFFFFu - reject;
         auto draw = [&]() {
@@ -197,6 +196,24 @@ inline std::vector<uint64_t> index_sample(StdRng &rng, uint64_t length, uint64_t
                 if (static_cast<uint32_t>(wide) <= zone) return static_cast<uint32_t>(wide >> 32);
             }
         };
+        if (len <= (1u << 28)) {
+            // membership as a bit per index (<= 32 MB): the draws and their order are the hash set's, the test is one load
+            std::vector<uint64_t> bits((static_cast<size_t>(len) + 63) / 64, 0);
+            auto test_and_set = [&](uint32_t p) {
+                uint64_t &w = bits[p >> 6];
+                const uint64_t b = 1ull << (p & 63);
+                const bool fresh = (w & b) == 0;
+                w |= b;
+                return fresh;
+            };
+            for (uint32_t i = 0; i < amt; ++i) {
+                uint32_t p = draw();
+                while (!test_and_set(p)) p = draw();
+                out.push_back(p);
+            }
+            return out;
+        }
+        seen.reserve(static_cast<size_t>(amt) * 2);
         for (uint32_t i = 0; i < amt; ++i) {
             uint32_t p = draw();
             while (!seen.insert(p).second) p = draw();
