@@ -945,6 +945,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     }
     PinnedBuf h_min;
     HIP_TRY(h_min.ensure(init_n * sizeof(float)));
+    for (uint64_t t = 0; t < init_n; ++t) h_min.as<float>()[t] = INFINITY;     // the mirror starts equal to d_min
     StreamArgs sa{};
     sa.mat = d_init; sa.row_of = nullptr; sa.list_off = nullptr; sa.probe = nullptr; sa.cand_base = nullptr;
     sa.single_begin = 0; sa.single_end = init_n;

@@ -37,8 +37,9 @@ struct StreamArgs {
     uint32_t       *part_vals;
     // DIST / MINUPD output, indexed by candidate position (single-list mode)
     float          *out_f32;
-    // MINUPD, optional: the value out_f32[pos] holds after this pass is also written here (pinned host memory: the
-    // k-means++ host scan reads it after the stream is drained, with no copy command between the rounds' kernels)
+    // MINUPD, optional: every value this pass writes to out_f32 is also written here (pinned host memory that starts as a
+    // copy of out_f32: the k-means++ host scan reads it after the stream is drained, with no copy command between the
+    // rounds' kernels, and only the minima that changed cross the bus)
     float          *mirror_f32;
     // optional: zero_u32[0 .. zero_n) = 0 (scratch of the kernels that follow in the stream)
     uint32_t       *zero_u32;

@@ -418,8 +418,10 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs a) {
         } else if constexpr (MODE == STREAM_MINUPD) {
             if (valid) {
                 const float old = a.out_f32[pos];
-                if (sum < old) a.out_f32[pos] = sum;   // index.rs:363-365
-                if (a.mirror_f32) a.mirror_f32[pos] = sum < old ? sum : old;
+                if (sum < old) {                       // index.rs:363-365
+                    a.out_f32[pos] = sum;
+                    if (a.mirror_f32) a.mirror_f32[pos] = sum;
+                }
             }
         } else {
             if (valid) a.out_f32[pos] = sum;
