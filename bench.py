@@ -59,7 +59,7 @@ WORKLOADS = {
 }
 K = 10
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def log(*a):
@@ -104,9 +104,17 @@ def pmc_traffic(workload, kernels):
     MI355X_MICROARCH.md #HBM) + WRITE_SIZE, KiB -> bytes, summed over the named kernels.  `kernels`: exact
     instantiation names as the library's dispatch description gives them, optionally "name@grid_x_threads"
     (the index build launches some of the same templates with other grids)."""
+    for rnd in (PROFILE_ROUND, "r03"):          # this round's summaries; the previous round's while the kernels keep their names
+        got = _pmc_traffic_round(rnd, workload, kernels)
+        if got[0] is not None:
+            return got
+    return None, None
+
+
+def _pmc_traffic_round(rnd, workload, kernels):
     total, srcs = 0.0, []
     for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc_{ctr}.txt")
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_pmc_{ctr}.txt")
         if not os.path.exists(path):
             return None, None
         got = set()
@@ -124,6 +132,213 @@ def pmc_traffic(workload, kernels):
             return None, None
         srcs.append(os.path.relpath(path, ROOT))
     return total, srcs
+
+
+class OracleParity:
+    """Bit-for-bit comparison of GPU answers with the CPU oracle (oracle/: test infrastructure -- the checker, never the
+    thing measured).  The oracle index is parsed from the GPU-built blob (IvfIndex::from_bytes), the rows are a host copy
+    of the very matrix the GPU searched; one query per host thread (results are independent per query)."""
+
+    def __init__(self, blob, host_rows, native=True):
+        from oracle_binding import Oracle, build_oracle
+        if native:
+            build_oracle("native")
+        self.oracle = Oracle(native=native)
+        self.oidx = self.oracle.index_from_bytes(blob)
+        self.host = host_rows
+        self.st = {"ids": True, "dist": True, "tie": True, "ncand": True, "groups": 0, "replayed": 0, "replay_ok": True, "checked": 0}
+
+    def one(self, q, k, nprobe):
+        return self.oidx.topk_batch(self.host, q.reshape(1, -1), k, nprobe)
+
+    def compare(self, qs, sel, grows, gdist, k, nprobe, searcher=None, gncand=None, threads=None):
+        """qs [nq, dim] host queries; sel: indices into the batch to check; grows u32 / gdist f32 [nq, k] GPU answers."""
+        from concurrent.futures import ThreadPoolExecutor
+        sel = list(sel)
+        if not sel:
+            return
+        nthr = max(1, min(len(sel), threads or (os.cpu_count() or 1), 256))
+        with ThreadPoolExecutor(max_workers=nthr) as ex:
+            res = list(ex.map(lambda q: self.one(qs[q], k, nprobe), sel))
+        st = self.st
+        for q, (orows, odist, onf, onc) in zip(sel, res):
+            st["checked"] += 1
+            g, gd = grows[q], gdist[q]
+            st["dist"] &= bool((odist[0].view(np.uint32) == gd.view(np.uint32)).all())
+            if gncand is not None:
+                st["ncand"] &= int(onc[0]) == int(gncand[q])
+            if (orows[0] == g).all():
+                continue
+            st["ids"] = False
+            # pqv_topk_device orders equal output distances by (d2, position); Rust orders them by heap history (the
+            # host API pqv_topk replays that exactly).  Inside a group of equal distance the id SETS must still agree.
+            if searcher is not None:
+                hr, hd, _, _ = searcher.topk(qs[q:q + 1], k, nprobe)
+                st["replayed"] += 1
+                st["replay_ok"] &= bool((hr[0] == orows[0]).all()) and bool((hd.view(np.uint32)[0] == odist.view(np.uint32)[0]).all())
+            j = 0
+            while j < k:
+                e = j
+                while e + 1 < k and odist[0, e + 1] == odist[0, j]:
+                    e += 1
+                if e > j:
+                    st["groups"] += 1
+                st["tie"] &= sorted(orows[0, j:e + 1].tolist()) == sorted(g[j:e + 1].tolist())
+                j = e + 1
+
+    def ok(self):
+        st = self.st
+        return bool(st["dist"] and st["tie"] and st["ncand"] and (st["ids"] or (st["replayed"] > 0 and st["replay_ok"])))
+
+    def record(self):
+        st = self.st
+        return {"checker": "CPU oracle (oracle/pqv_oracle.c), index parsed from the GPU-built blob, rows = host copy of the searched matrix",
+                "queries_checked": st["checked"], "row_idx_identical": st["ids"], "dist_bit_identical": st["dist"],
+                "n_candidates_identical": st["ncand"],
+                "row_idx_identical_up_to_order_inside_equal_distance_groups": st["tie"],
+                "equal_distance_groups_seen": st["groups"], "queries_replayed_through_pqv_topk": st["replayed"],
+                "row_idx_identical_after_replay": bool(st["ids"] or (st["replayed"] > 0 and st["replay_ok"])),
+                "ok": self.ok()}
+
+
+def spread(nq, m):
+    """m query indices spread over a batch of nq (first, last and evenly between)."""
+    m = min(m, nq)
+    return sorted(set(int(round(i * (nq - 1) / max(1, m - 1))) for i in range(m)))
+
+
+def ivf_measure(pqv, torch, dev, searcher, index, queries_t, nq, k, nprobe, dim, min_time=0.4, steps=20, exchange=None):
+    """Timed blocks of `steps` steps over two stream lanes (median block), then a serial pass with HIP events around the
+    re-rank kernels; min_bytes of the step (see roofline.min_bytes_definition).  Returns (record, lane-0 outputs)."""
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=dev)]
+    rows = [torch.empty((nq, k), dtype=torch.int32, device=dev) for _ in range(2)]
+    dd = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
+    nc = [torch.empty((nq,), dtype=torch.int64, device=dev) for _ in range(2)]
+
+    def st(i):
+        s_ = streams[i % 2]
+        with torch.cuda.stream(s_):
+            searcher.topk_device(queries_t.data_ptr(), nq, k, nprobe, rows[i % 2].data_ptr(), dd[i % 2].data_ptr(), 0, nc[i % 2].data_ptr(),
+                                 stream=s_.cuda_stream)
+            if exchange is not None:
+                exchange[i % 2].exchange_u32(dd[i % 2], rows[i % 2])
+
+    for i in range(4):
+        st(i)
+    torch.cuda.synchronize()
+    c0 = searcher.counters()
+    blocks = []
+    while sum(blocks) < min_time and len(blocks) < 200:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            st(i)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    c1 = searcher.counters()
+    el = float(np.median(blocks))
+    # serial pass: isolated kernel durations (HIP events recorded by the library on the call's stream)
+    searcher.set_timing(True)
+    torch.cuda.synchronize()
+    ns = 10
+    t1 = time.perf_counter()
+    for _ in range(ns):
+        st(0)
+        torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t1) / ns * 1e3
+    searcher.set_timing(False)
+    rr, tot, ncalls = searcher.timing_read()
+    k_ms = rr / max(1, ncalls)
+    plan_text = searcher.describe(nq, k, nprobe)
+    # min_bytes: the operand image of every DISTINCT probed row once + 8 bytes per row + the f32 row of every survivor
+    qs_host = queries_t.cpu().numpy()
+    lens = np.diff(index.list_offsets.astype(np.int64))
+    probed = np.zeros(len(lens), dtype=bool)
+    for i in (range(nq) if nq <= 256 else range(0, nq, max(1, nq // 256))):
+        probed[searcher.probe(qs_host[i], nprobe)] = True
+    distinct_rows = int(lens[probed].sum())
+    nqs = max(1, c1["queries"] - c0["queries"])
+    surv = (c1["screen_survivors"] - c0["screen_survivors"]) / nqs * nq
+    wide = "wide_filter_kernel" in plan_text
+    opb = 1 if "int8 screen operands" in plan_text else 2 if "f16 screen operands" in plan_text else 4
+    cand_rows = int(nc[0].sum().item())
+    if wide:
+        min_bytes = distinct_rows * (opb * dim + 8) + surv * 4 * dim
+    else:
+        min_bytes = cand_rows * (4 * dim + 4) if "stream_kernel" in plan_text else distinct_rows * (4 * dim + 4)
+    rec = {"value": nq * steps / el, "unit": "queries/s", "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": len(blocks),
+           "ms_per_step_serial": serial_ms,
+           "roofline": {"bound": "hbm", "kernel_ms": k_ms, "min_bytes": min_bytes,
+                        "min_bytes_frac": (min_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
+                        "achieved": (min_bytes / (k_ms * 1e-3) / 1e9) if k_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "basis": "min_bytes (operand image of every distinct probed row once + 8 B per row + 4 dim per survivor) / HIP-event "
+                                 "time of the re-rank kernels of a serially issued step"},
+           "candidates_per_query": cand_rows / nq,
+           "screen_survivors_per_query": (c1["screen_survivors"] - c0["screen_survivors"]) / nqs,
+           "screened_rows_per_query": (c1["screened_pairs"] - c0["screened_pairs"]) / nqs,
+           "dispatch": plan_text}
+    st(0)
+    torch.cuda.synchronize()
+    return rec, (rows[0], dd[0], nc[0], qs_host)
+
+
+def ivf_config(args, pqv, torch, dev, local_rank, name, k, data="uniform", parity_queries=64, rccl=False, mixture_centres=0, recall=0):
+    """One IVF configuration end to end for the `configs` object of the default line: synthetic corpus on the device, index
+    build, searcher, timed steps, roofline on min_bytes, and the oracle check of `parity_queries` queries of the timed
+    batch (host copy of the corpus downloaded once)."""
+    n, dim, kc, nprobe, nq = WORKLOADS[name]
+    t_all = time.perf_counter()
+    if data == "mixture":
+        corpus_t = synth_mixture(torch, dev, 1234, n, dim, mixture_centres or kc or 1024)
+        q_t = synth_mixture(torch, dev, 7, nq, dim, mixture_centres or kc or 1024)
+    else:
+        corpus_t = synth(torch, dev, 1234, n, dim)
+        q_t = synth(torch, dev, 7, nq, dim)
+    torch.cuda.synchronize()
+    corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n, dim, device=local_rank, keepalive=corpus_t)
+    t0 = time.perf_counter()
+    b = pqv.IndexBuilder(corpus).max_iters(20).seed(42).workers(os.cpu_count() or 1)
+    index = b.n_clusters(kc).build() if kc else b.build()
+    build_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    srch = pqv.Searcher(index, corpus)
+    create_s = time.perf_counter() - t0
+    xchg = None
+    if rccl:
+        import torch.distributed as dist
+        from pq_vector_amd.sharding import ShardExchange
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        xchg = [ShardExchange(1, nq, k, dev, always_collective=True, row_bases=[0]) for _ in range(2)]
+    rec, (rows_t, dist_t, nc_t, qs_host) = ivf_measure(pqv, torch, dev, srch, index, q_t, nq, k, nprobe, dim, exchange=xchg)
+    rec.update({"config": f"{name}: {n}x{dim} {data} f32, n_clusters {index.n_clusters}, k {k}, nprobe {nprobe}, {nq} queries/step"
+                          + (", one shard on one rank: RCCL all-gather (1 rank) + device merge inside every step" if rccl else ""),
+                "index_build_s": build_s, "index_build_vectors_per_s": n / build_s, "searcher_create_s": create_s,
+                "time_to_first_query_s": build_s + create_s})
+    if rccl:
+        out_d, out_r = xchg[0].exchange_u32(dist_t, rows_t)
+        torch.cuda.synchronize()
+        rec["exchange_check"] = bool(torch.equal(out_d, dist_t) and torch.equal(out_r, rows_t.to(torch.int64) & 0xFFFFFFFF))
+    if recall:
+        m = min(recall, nq)
+        br, _, _ = corpus.brute_topk(qs_host[:m], k, pqv.PQV_L2SQ_MFMA)
+        got = rows_t[:m].cpu().numpy().view(np.uint32)
+        rec["recall_at_k"] = sum(len(set(got[i].tolist()) & set(br[i].tolist())) for i in range(m)) / float(m * k)
+    if parity_queries and not args.no_cpu:
+        t0 = time.perf_counter()
+        host = corpus_t.cpu().numpy()
+        par = OracleParity(index.to_bytes(), host)
+        par.compare(qs_host, spread(nq, parity_queries), rows_t.cpu().numpy().view(np.uint32), dist_t.cpu().numpy(), k, nprobe,
+                    searcher=srch, gncand=nc_t.cpu().numpy())
+        rec["parity"] = par.record()
+        rec["parity"]["seconds"] = time.perf_counter() - t0
+        del host, par
+    rec["seconds"] = time.perf_counter() - t_all
+    srch.close(); corpus.close()
+    del corpus_t
+    torch.cuda.empty_cache()
+    return rec
 
 
 def build_record(n, dim, kc, build_s):
@@ -212,6 +427,7 @@ def main():
                          "always on for --force-dist with one rank, opt-in beyond (a second communicator that has never met real "
                          "multi-GPU hardware must not be able to cost a scaling run its line)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Gaussian-mixture pass that follows the default C3 run")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c2 / refbench / c4-shard / c5 passes that follow the default C3 run")
     ap.add_argument("--parity-queries", type=int, default=64, help="queries of the step checked bit for bit against the CPU oracle")
     ap.add_argument("--recall", type=int, default=32, help="queries checked against an exact brute force (0 disables)")
     args = ap.parse_args()
@@ -440,7 +656,10 @@ def main():
                                 if " | kernels: " in plan_text and args.data == "uniform" and nq == nq_default else (None, None))
 
     k_ms = serial_rr_ms if serial_rr_ms else rr_ms          # isolated launches: what rocprofv3 --kernel-trace reports
-    achieved = (traffic if traffic else min_bytes) / (k_ms * 1e-3) / 1e9 if k_ms and k_ms > 0 else 0.0
+    # headline: the bytes the design has to move (min_bytes, recomputed from THIS run's probe sets and survivor counters) over
+    # the kernel time measured in THIS run; the committed counter bytes only enter `traffic` / `fabric_frac`
+    achieved = min_bytes / (k_ms * 1e-3) / 1e9 if k_ms and k_ms > 0 else 0.0
+    fabric = traffic / (k_ms * 1e-3) / 1e9 if traffic and k_ms and k_ms > 0 else None
     mf = 2.0 * dim * cand_rows                         # the Q.X^T contraction of the screen
     result = {
         "metric": f"topk_queries_per_s_k{K}",
@@ -479,6 +698,7 @@ def main():
         "index_build_s": build_s,
         "index_build": build_info,
         "searcher_create_s": layout_s,
+        "time_to_first_query_s": build_s + layout_s,
         "candidates_per_query": cand_rows / nq,
         "corpus_row_scans_per_s": n_total * nq * steps / elapsed if not replica else world * n_total * nq * steps / elapsed,
         "hbm_footprint": fp,
@@ -488,14 +708,15 @@ def main():
         "bound": "hbm", "kernel": " + ".join(k.split("@")[0] for k in kernels),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src,
-        "traffic_label": "fabric bytes per step: L2 misses served by HBM OR the 256 MB Infinity Cache (FETCH_SIZE counts MALL hits "
-                         "too), so `frac` is a memory-system utilisation, an upper bound of the HBM-only figure",
+        "traffic_label": "fabric bytes per step from the committed rocprofv3 PMC summaries of this workload (FETCH_SIZE x 2 + WRITE_SIZE): "
+                         "L2 misses served by HBM OR the 256 MB Infinity Cache (FETCH_SIZE counts MALL hits too); fabric_frac = traffic / "
+                         "kernel_ms / peak is a memory-system utilisation, an upper bound of the HBM-only figure",
+        "fabric_frac": (fabric / HBM_PEAK_GBS) if fabric else None,
         "min_bytes": min_bytes,
         "min_bytes_frac": (min_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms and k_ms > 0 else None,
         "traffic_over_min": (traffic / min_bytes) if traffic and min_bytes else None,
         "kernel_ms": k_ms, "kernel_ms_in_timed_region": rr_ms,
-        "achieved_basis": ("PMC traffic of this workload (FETCH_SIZE x 2 + WRITE_SIZE per launch, committed rocprofv3 summaries)"
-                           if traffic else "min_bytes (no PMC summary committed for this workload / batch shape)") + " / kernel_ms",
+        "achieved_basis": "min_bytes of this run / kernel_ms of this run (frac == min_bytes_frac)",
         "min_bytes_definition": ("screened path: (operand bytes per value x dim + 8) per DISTINCT probed row of the step + 4 dim per "
                                  "survivor of the screen" if wide else "SURVEY 8d bytes"),
         "note": "kernel_ms = HIP events around the re-rank kernels (threshold sample + select + screen/exact evaluation) with steps "
@@ -629,12 +850,6 @@ def main():
         result["recall_at_k"] = {"queries": m, "recall": hits / float(m * K),
                                  "note": "fraction of the exact top-k (pqv_brute_topk, L2) found by the IVF search at this nprobe; "
                                          "on uniform random data IVF recall is low by nature (benches/query.rs prints the same figure)"}
-    # ---- secondary data set where IVF works: the same shape as a Gaussian mixture ---------------------
-    if rank == 0 and world == 1 and args.workload == "c3" and args.data == "uniform" and not args.no_secondary:
-        try:
-            result["secondary_mixture"] = secondary_mixture(args, pqv, torch, dev, local_rank, n_shard, dim, n_clusters, nprobe, nq)
-        except Exception as e:           # the headline must not depend on it
-            result["secondary_mixture"] = {"error": str(e)[:300]}
     # ---- CPU baseline (rank 0, N = 1): the oracle, natively compiled -----------
     rc = 0
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -644,6 +859,42 @@ def main():
         par = result["cpu_baseline"]["parity"]
         if not (par["dist_bit_identical"] and par["row_idx_identical_up_to_order_inside_equal_distance_groups"]):
             rc = 3
+    # ---- the default line also carries the other BASELINE configurations (each with its own oracle check) -------------
+    if rank == 0 and world == 1 and args.workload == "c3" and args.data == "uniform" and not use_dist and K == 10 and \
+            not (args.no_secondary and args.no_configs):
+        # release the headline's corpus and searcher first: every configuration below builds its own
+        searcher.close(); corpus.close()
+        del corpus_t, rows_l, dist_l, nf_l, nc_l
+        torch.cuda.empty_cache()
+
+        def guarded(fn):
+            try:
+                return fn()
+            except Exception as e:           # the headline must not depend on a secondary configuration
+                import traceback
+                log(traceback.format_exc())
+                return {"error": str(e)[:300]}
+        if not args.no_secondary:
+            # secondary data set where IVF works: the same shape as a Gaussian mixture, oracle-checked like the headline
+            result["secondary_mixture"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "c3", K, data="mixture",
+                                                                     parity_queries=args.parity_queries, recall=32))
+        if not args.no_configs:
+            cfg = {}
+            cfg["c2"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "c2", 10, parity_queries=64))
+            cfg["refbench"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "refbench", 100, parity_queries=64))
+            cfg["c4_shard_1rank_rccl"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "c4", 10, parity_queries=64, rccl=True))
+            cfg["c5"] = guarded(lambda: brute_measure(args, pqv, torch, dev, local_rank, "c5", 10, steps=5))
+            result["configs"] = cfg
+            result["configs_note"] = ("BASELINE.json configs[1] (c2), the reference's own bench shape benches/query.rs:27-31 (refbench: 1 M x 1024, "
+                                      "default n_clusters, K 100, nprobe 16), one configs[3] shard on one rank with the RCCL exchange in every step "
+                                      "(c4_shard_1rank_rccl) and configs[4] (c5), each generated, built, timed and checked inside this run")
+        for name, r in [("secondary_mixture", result.get("secondary_mixture"))] + list((result.get("configs") or {}).items()):
+            if isinstance(r, dict) and isinstance(r.get("parity"), dict) and r["parity"].get("ok") is False:
+                log(f"[bench] PARITY FAILURE in {name}")
+                rc = 3
+        import torch.distributed as _d
+        if _d.is_initialized() and not use_dist:
+            _d.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
@@ -652,54 +903,6 @@ def main():
     if rc:
         log("[bench] PARITY FAILURE against the CPU oracle")
         sys.exit(rc)
-
-
-def secondary_mixture(args, pqv, torch, dev, local_rank, n, dim, kc, nprobe, nq):
-    """The headline shape on data WITH cluster structure: n_clusters Gaussian components (centres uniform in [0,1)^dim,
-    sigma 0.1), queries from the same mixture.  Uniform random data -- the reference's bench recipe -- has recall@10
-    of ~0.16 at nprobe 32; here the IVF answer is the exact one, which is the regime an IVF index exists for."""
-    corpus_t = synth_mixture(torch, dev, 1234, n, dim, kc)
-    q_t = synth_mixture(torch, dev, 7, nq, dim, kc)
-    corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n, dim, device=local_rank, keepalive=corpus_t)
-    t0 = time.perf_counter()
-    index = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(20).seed(42).workers(os.cpu_count() or 1).build()
-    build_s = time.perf_counter() - t0
-    srch = pqv.Searcher(index, corpus)
-    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=dev)]
-    rows = [torch.empty((nq, K), dtype=torch.int32, device=dev) for _ in range(2)]
-    dd = [torch.empty((nq, K), dtype=torch.float32, device=dev) for _ in range(2)]
-
-    def mstep(i):
-        st = streams[i % 2]
-        with torch.cuda.stream(st):
-            srch.topk_device(q_t.data_ptr(), nq, K, nprobe, rows[i % 2].data_ptr(), dd[i % 2].data_ptr(), stream=st.cuda_stream)
-
-    for i in range(4):
-        mstep(i)
-    torch.cuda.synchronize()
-    c0 = srch.counters()
-    blocks = []
-    steps = 20
-    while sum(blocks) < 0.5 and len(blocks) < 50:
-        t0 = time.perf_counter()
-        for i in range(steps):
-            mstep(i)
-        torch.cuda.synchronize()
-        blocks.append(time.perf_counter() - t0)
-    c1 = srch.counters()
-    el = float(np.median(blocks))
-    m = min(32, nq)
-    got = rows[(steps - 1) % 2][:m].cpu().numpy().view(np.uint32)
-    br, _, _ = corpus.brute_topk(q_t[:m].cpu().numpy(), K, pqv.PQV_L2SQ_MFMA)
-    hits = sum(len(set(got[i].tolist()) & set(br[i].tolist())) for i in range(m))
-    nqs = max(1, c1["queries"] - c0["queries"])
-    return {"value": nq * steps / el, "unit": "queries/s", "ms_per_step": el / steps * 1e3, "steps": steps, "repeats": len(blocks),
-            "data": f"synthetic gaussian mixture: {kc} components, sigma 0.1, {n}x{dim}, k {K}, nprobe {nprobe}, {nq} queries/step",
-            "recall_at_k": hits / float(m * K), "index_build_s": build_s,
-            "screen_survivors_per_query": (c1["screen_survivors"] - c0["screen_survivors"]) / nqs,
-            "screened_rows_per_query": (c1["screened_pairs"] - c0["screened_pairs"]) / nqs,
-            "candidates_per_query": (c1["candidate_rows"] - c0["candidate_rows"]) / nqs,
-            "dispatch": srch.describe(nq, K, nprobe)}
 
 
 def replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps):
@@ -735,19 +938,58 @@ def replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps
             "note": "query-parallel replicas: no data-path collective, per-GPU work fixed"}
 
 
-def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank, world, real_stdout):
-    """BASELINE config 5: exhaustive cosine top-k of nq queries per step as a Q.V^T contraction on
-    the f32 matrix cores (pqv_brute_topk; an extension -- the reference has no cosine)."""
-    if world != 1:
-        raise SystemExit("the c5 workload is single-GPU")
-    steps = args.steps if args.steps > 0 else 5
+def brute_f64_check(torch, corpus_t, queries_t, rows, dist, sel, k):
+    """f64 brute force ON THE SAME resident corpus for the queries `sel` (torch f64 matmul on the device, in row slabs --
+    an independent checker: nothing of the library is involved): max relative error of the returned cosine distances
+    against the true k smallest, and whether every row clearly inside the true top-k was returned."""
+    n, dim = corpus_t.shape
+    q = queries_t[sel].double()
+    qn = q.norm(dim=1)
+    best_d = torch.full((len(sel), k), float("inf"), dtype=torch.float64, device=corpus_t.device)
+    best_r = torch.zeros((len(sel), k), dtype=torch.int64, device=corpus_t.device)
+    slab = max(1, (1 << 28) // dim)
+    for s0 in range(0, n, slab):
+        x = corpus_t[s0:s0 + slab].double()
+        d = 1.0 - (q @ x.T) / (qn[:, None] * x.norm(dim=1)[None, :])
+        cd = torch.cat((best_d, d), dim=1)
+        cr = torch.cat((best_r, torch.arange(s0, s0 + x.shape[0], device=x.device).expand(len(sel), -1)), dim=1)
+        best_d, idx = torch.topk(cd, k, dim=1, largest=False, sorted=True)
+        best_r = torch.gather(cr, 1, idx)
+        del x, d, cd, cr
+    ref_d, ref_r = best_d.cpu().numpy(), best_r.cpu().numpy()
+    got_d, got_r = dist[sel].astype(np.float64), rows[sel].astype(np.int64)
+    err = float(np.max(np.abs(got_d - ref_d) / np.maximum(np.abs(ref_d), 1e-3)))
+    missed = 0
+    for i in range(len(sel)):
+        kth = ref_d[i, -1]
+        tol = 1e-4 * max(abs(kth), 1e-3) + 1e-6
+        clearly_in = ref_r[i][ref_d[i] < kth - tol]
+        missed += len(set(clearly_in.tolist()) - set(got_r[i].tolist()))
+    return {"checker": "f64 brute force of the SAME resident corpus (torch f64 matmul on the device, independent of the library)",
+            "queries_checked": len(sel), "rows": n, "max_rel_dist_err": err, "tolerance": 1e-4,
+            "ids_equal_fraction": float((got_r == ref_r).mean()), "clearly_closer_rows_missed": missed,
+            "ok": bool(err <= 1e-4 and missed == 0)}
+
+
+def brute_measure(args, pqv, torch, dev, local_rank, name, k, steps=5, corpus_t=None, queries_t=None):
+    """BASELINE config 5: exhaustive cosine top-k of nq queries per step as a Q.V^T contraction on the matrix cores
+    (pqv_brute_topk; an extension -- the reference has no cosine).  The 32 checked queries are answers of the timed run."""
+    n, dim, _, _, nq = WORKLOADS[name]
+    t_all = time.perf_counter()
+    if corpus_t is None:
+        corpus_t = synth(torch, dev, 1234, n, dim)
+        queries_t = synth(torch, dev, 7, nq, dim)
+        torch.cuda.synchronize()
+    corpus = pqv.Corpus.from_device_ptr(corpus_t.data_ptr(), n, dim, device=local_rank, keepalive=corpus_t)
     q_host = queries_t.cpu().numpy()
+    t0 = time.perf_counter()
     for _ in range(max(1, args.warmup)):
-        rows, dist, nf = corpus.brute_topk(q_host, K, pqv.PQV_COSINE)
+        rows, dist, nf = corpus.brute_topk(q_host, k, pqv.PQV_COSINE)
     torch.cuda.synchronize()
+    first_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(steps):
-        rows, dist, nf = corpus.brute_topk(q_host, K, pqv.PQV_COSINE)
+        rows, dist, nf = corpus.brute_topk(q_host, k, pqv.PQV_COSINE)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = elapsed / steps * 1e3
@@ -757,51 +999,61 @@ def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank,
     # dense MFMA peaks (MI355X_MICROARCH.md): f32 157.3 TF, f16 2.5 PF, int8 16x16x64 / 32x32x32 >= 3944 TOPS
     peak_tf = 157.3 if f32_only else 3944.0 if i8 else 2500.0
     op_name = "int8" if i8 else "f16"
+    rec = {"value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": ms, "steps": steps,
+           "config": f"{name}: brute-force cosine top-{k} over {n}x{dim} uniform f32, {nq} queries/step, Q.V^T on "
+                     + ("v_mfma_f32_32x32x2_f32" if f32_only else ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16") + " (screen) + f32 re-scoring"),
+           "dtype": "f32" if f32_only else f"{op_name} screen ({'int32' if i8 else 'f32'} accumulate) + f32 exact re-scoring of what it lets through",
+           "warmup_s_including_image_build": first_s,
+           "roofline": {"bound": "mfma",
+                        "kernel": "brute_mfma_kernel (128x128 tiles, f32 in / f32 accumulate)" if f32_only else
+                                  f"brute_f16_kernel (256x256 tiles of normalised {op_name} images, 128-byte K stages, XCD-aware grid) + brute_rescore_kernel; "
+                                  "the first 2048 rows through brute_mfma_kernel (f32)",
+                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / peak_tf, "traffic": None,
+                        "algo_flops_per_step": flops,
+                        "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / 157.3,
+                        "note": "achieved = 2*nq*n*dim / whole-step wall time (queries uploaded, 5 progressive "
+                                "row ranges with a host check each, select passes, results downloaded): a lower bound for the kernel; "
+                                "peak = the dense MFMA rate of the screen's operand form: int8 3944 TOPS (default), f16 2.5 PF "
+                                "(PQV_BRUTE_OP=f16), f32 157.3 TF (PQV_BRUTE_F16=0)",
+                        "unit_note": "TFLOP/s reads Tera-op/s for the int8 form"}}
+    rec["parity"] = brute_f64_check(torch, corpus_t, queries_t, rows, dist, spread(nq, 32), k)
+    rec["seconds"] = time.perf_counter() - t_all
+    corpus.close()
+    return rec
+
+
+def bench_brute(args, pqv, torch, corpus, corpus_t, queries_t, n, dim, nq, rank, world, real_stdout):
+    """`--workload c5 / c5s` as the line of its own."""
+    if world != 1:
+        raise SystemExit("the c5 workload is single-GPU")
+    steps = args.steps if args.steps > 0 else 5
+    rec = brute_measure(args, pqv, torch, corpus_t.device, corpus_t.device.index or 0, args.workload, K, steps=steps,
+                        corpus_t=corpus_t, queries_t=queries_t)
     result = {
-        "metric": "topk_queries_per_s_k10", "value": nq * steps / elapsed, "unit": "queries/s",
-        "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": ms,
+        "metric": "topk_queries_per_s_k10", "value": rec["value"], "unit": "queries/s",
+        "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if f32_only else f"{op_name} screen ({'int32' if i8 else 'f32'} accumulate) + f32 exact re-scoring of what it lets through",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: brute-force cosine top-{K} over {n}x{dim} uniform f32, "
-                               f"{nq} queries/step, Q.V^T on " + ("v_mfma_f32_32x32x2_f32" if f32_only else ("v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_f16") + " (screen) + f32 re-scoring"),
-                   "rows": n, "dim": dim, "k": K, "queries_per_step": nq, "shards": 1},
-        "timed_region_s": elapsed,
-        "roofline": {"bound": "mfma",
-                     "kernel": "brute_mfma_kernel (128x128 tiles, f32 in / f32 accumulate)" if f32_only else
-                               f"brute_f16_kernel (256x256 tiles of normalised {op_name} images, 128-byte K stages, XCD-aware grid) + brute_rescore_kernel; "
-                               "the first 2048 rows through brute_mfma_kernel (f32)",
-                     "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
-                     "frac": flops / (ms * 1e-3) / 1e12 / peak_tf, "traffic": None,
-                     "algo_flops_per_step": flops,
-                     "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / 157.3,
-                     "note": "achieved = 2*nq*n*dim / whole-step wall time (queries uploaded, 5 progressive "
-                             "row ranges with a host check each, select passes, results downloaded): a lower bound for the kernel; "
-                             "peak = the dense MFMA rate of the screen's operand form: int8 3944 TOPS (default), f16 2.5 PF "
-                             "(PQV_BRUTE_OP=f16), f32 157.3 TF (PQV_BRUTE_F16=0)",
-                     "unit_note": "TFLOP/s reads Tera-op/s for the int8 form"},
+        "dtype": rec["dtype"], "data": "synthetic",
+        "config": {"workload": rec["config"], "rows": n, "dim": dim, "k": K, "queries_per_step": nq, "shards": 1},
+        "timed_region_s": rec["ms_per_step"] * steps * 1e-3,
+        "roofline": rec["roofline"], "parity": rec["parity"],
     }
-    rc = 0
+    rc = 0 if rec["parity"]["ok"] else 3
     if not args.no_cpu:
-        # f64 numpy brute force on a row slice (multithreaded BLAS), extrapolated linearly in rows
+        # CPU column: f64 numpy brute force on a row slice (multithreaded BLAS), extrapolated linearly in rows
+        q_host = queries_t.cpu().numpy()
         m = min(n, 200_000)
         sub = corpus_t[:m].cpu().numpy().astype(np.float64)
         qs = q_host[:32].astype(np.float64)
         t1 = time.perf_counter()
         s = qs @ sub.T
         d = 1.0 - s / (np.linalg.norm(qs, axis=1)[:, None] * np.linalg.norm(sub, axis=1)[None, :])
-        ref = np.argsort(d, axis=1, kind="stable")[:, :K]
+        np.argsort(d, axis=1, kind="stable")[:, :K]
         spent = time.perf_counter() - t1
-        got_r, got_d, _ = pqv.Corpus.upload(corpus_t[:m].cpu().numpy()).brute_topk(q_host[:32], K, pqv.PQV_COSINE)
-        refd = np.take_along_axis(d, ref, axis=1)
-        err = float(np.max(np.abs(got_d - refd) / np.maximum(np.abs(refd), 1e-3)))
         result["cpu_baseline"] = {
             "value": 32 / spent * (m / n), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"numpy f64 matmul + argsort, 32 queries x {m} rows in {spent:.2f} s, scaled by {m}/{n} rows",
-            "parity": {"queries_checked": 32, "max_rel_dist_err": err, "tolerance": 1e-4,
-                       "ids_equal_fraction": float((got_r == ref).mean())}}
-        if not err <= 1e-4:
-            rc = 3
+            "sample": f"numpy f64 matmul + argsort, 32 queries x {m} rows in {spent:.2f} s, scaled by {m}/{n} rows"}
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if rc:

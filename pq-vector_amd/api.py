@@ -119,6 +119,7 @@ class Corpus:
         if self._h:
             _ffi.lib().pqv_corpus_free(self._h)
             self._h = None
+        self._keepalive = None
 
     def __del__(self):
         try:

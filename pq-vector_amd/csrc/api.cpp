@@ -5,7 +5,7 @@
 //   IvfIndex::{to_bytes,from_bytes,candidate_rows}    src/ivf/index.rs:57-128
 //   topk()                                            src/ivf/search.rs:83-142
 // There is no CPU compute fallback: distances, argmins and top-k selection only ever run
-// in the HIP kernels of kernels.hip; the host draws the seeded choices, walks the two
+// in the HIP kernels of kernels_*.hip; the host draws the seeded choices, walks the two
 // order-sensitive f32 scalar scans of k-means++ (index.rs:370-383) and moves bytes.
 #include "../../include/pqv.h"
 
@@ -188,7 +188,7 @@ struct pqv_searcher {
     int device = 0;
     uint32_t dim = 0, n_clusters = 0;
     // storage dimension of the IVF-ordered rows: dim, or dim zero-padded to a multiple of 64 / 128 / 256 where the MFMA
-    // screen has no tiling for dim itself (dim % 4 == 0; kernels.hip: pad_rows_kernel -- distances stay bit-identical).
+    // screen has no tiling for dim itself (dim % 4 == 0; kernels_layout.hip: pad_rows_kernel -- distances stay bit-identical).
     // Everything downstream of the probe (blocked copies, screen, exact evaluation, replays) works on sdim-wide rows
     // and sdim-wide copies of the batch's queries.
     uint32_t sdim = 0;
@@ -201,8 +201,13 @@ struct pqv_searcher {
     uint32_t kc_pad = 0;
     DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats, d_row_norm2;   // |x|^2 per storage row (MFMA screen)
     const float *d_mat = nullptr;          // row storage the re-rank reads
-    const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout)
-    const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout)
+    const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout, and the images-only IVF layout)
+    const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout with its own f32 copy)
+    // IVF-ordered layout WITHOUT a second f32 copy of the corpus (round 4): everything the screen streams -- the blocked operand
+    // images, row terms and norms -- is in list order, while the exact evaluations (0.03 % of the pairs, the seed refinement, tie
+    // replays) read the caller's row-order matrix through d_row_of.  Footprint 2.28 x -> 1.28 x the corpus on C3, and searcher
+    // creation no longer allocates and writes n x dim floats.
+    bool images_only = false;
     hipStream_t stream = nullptr;
     // scratch (guarded by mu): PQV_LANES independent sets, one per stream in use, so calls enqueued on
     // different streams overlap on the GPU (the tail of one batch's screen kernel is filled by the next
@@ -223,7 +228,7 @@ struct pqv_searcher {
     // int8 operands (rows of a multiple of 256 dims): per LIST the images of (x - centre_c) * S_c -- the IVF residual:
     // centre_c the per-dimension mid-range of the list's rows, S_c mapping the list's largest |x - centre_c| component
     // to 127 -- per row |xi|^2 and an upper bound of the residual norm, per list a radius >= |x - centre_c| (see
-    // kernels.hip: block_rows_i8_kernel); built with the blocked copy (ensure_blocked_copy)
+    // kernels_layout.hip: block_rows_i8_kernel); built with the blocked copy (ensure_blocked_copy)
     bool i8_ok = false;
     // i8_residual: the per-list (residual) form pays where the lists are much tighter than the corpus (clustered data:
     // a per-list scale twice the global one halves the bound's slack); where they are not (uniform data) the one-centre
@@ -818,7 +823,7 @@ struct ScreenedAssign {
 };
 
 // ---------------------------------------------------------------------------------------
-// Round 3: the assignment as a dense f16 contraction + exact re-scoring (kernels.hip: assign_f16_kernel,
+// Round 3: the assignment as a dense f16 contraction + exact re-scoring (kernels_build.hip: assign_f16_kernel,
 // assign_rescore_kernel).  Rows and centroids are imaged as unit vectors about a common centre mu (the column mean of
 // the centroids: the distance is translation invariant, and |x - mu| |c - mu| is what scales the bound's slack); the
 // screen leaves a handful of candidate centroids per row, the exact pass evaluates those in the reference's order and
@@ -1307,7 +1312,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
 }
 
-// Cache policy of the wide-quad instance's row stream (kernels.hip, launch_filter_s): nt unless a recent batch had more than a
+// Cache policy of the wide-quad instance's row stream (kernels_screen.hip, launch_filter_s): nt unless a recent batch had more than a
 // quarter of its wide work items in lists of several quads (those share their rows through the caches).  A hint only: it
 // is read without synchronisation and never changes a result; before the first batch has reported: nt.
 bool wide_rows_nt(const pqv_searcher *s) {
@@ -1318,7 +1323,7 @@ bool wide_rows_nt(const pqv_searcher *s) {
 }
 
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
-bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && !s->d_row_of && s->n > 0; }
+bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && (!s->d_row_of || s->images_only) && s->n > 0; }
 
 // Operand form of the screen for this searcher (pqv::ScreenOp numbering: 0 f32, 1 f16, 2 int8)
 // int8 images halve the bytes per streamed row but widen the bound (residual norms): where lists are short and k is
@@ -1339,12 +1344,28 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
     using namespace pqv;
     DevBuf &blk = s->d_mat_blk_op[op];
     if (blk.p) return PQV_OK;
+    // A copy counts as built only once its LAST step has succeeded: any failure on the way (an allocation, a launch, a
+    // synchronisation) releases it, so that the next call rebuilds instead of screening against half-written images, row
+    // terms or list scales (the bound would no longer hold and true neighbours could be pruned silently).
+    struct Undo {
+        const pqv_searcher *s; DevBuf &blk; int op; bool done = false;
+        ~Undo() {
+            if (done) return;
+            (void)hipDeviceSynchronize();       // nothing still in flight may write into what is released
+            blk.release();
+            if (op == 2) {
+                s->d_row_n2i.release(); s->d_row_res.release(); s->d_center.release(); s->d_list_scale.release();
+                s->d_list_half.release(); s->d_list_radius.release(); s->i8_residual = true;
+            }
+        }
+    } undo{s, blk, op};
     const uint32_t kc = s->n_clusters;
     std::vector<uint64_t> boff(static_cast<size_t>(kc) + 1, 0);
     for (uint32_t c = 0; c < kc; ++c) boff[c + 1] = boff[c] + (s->h_list_off[c + 1] - s->h_list_off[c] + 15) / 16;
     if (!s->d_blk_off.p) {
         HIP_TRY(s->d_blk_off.alloc(boff.size() * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        const hipError_t ce = hipMemcpy(s->d_blk_off.p, boff.data(), boff.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (ce != hipSuccess) { s->d_blk_off.release(); HIP_TRY(ce); }
     }
     const uint64_t tiles = std::max<uint64_t>(1, boff[kc]);
     if (op == 2) {
@@ -1362,7 +1383,7 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
         HIP_TRY(s->d_list_scale.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
         HIP_TRY(s->d_list_half.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
         HIP_TRY(s->d_list_radius.alloc(std::max<uint32_t>(1, kc) * sizeof(float)));
-        HIP_TRY(launch_list_minmax(s->d_mat, s->d_list_off.as<uint64_t>(), kc, s->max_list_len, s->sdim, kmin, kmax, stream));
+        HIP_TRY(launch_list_minmax(s->d_mat, s->d_list_off.as<uint64_t>(), kc, s->max_list_len, s->sdim, kmin, kmax, stream, s->d_row_of));
         HIP_TRY(launch_list_center(kmin, kmax, kc, s->sdim, s->d_list_off.as<uint64_t>(), s->d_center.as<float>(), s->d_list_half.as<float>(),
                                    s->d_list_scale.as<float>(), s->d_list_radius.as<float>(), stream));
         {   // residual or one-centre form: compare the lists' scales with the scale ONE centre for the whole corpus would get
@@ -1398,18 +1419,19 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
         HIP_TRY(launch_block_rows_i8(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
                                      (s->max_list_len + 15) / 16, s->sdim, s->d_center.as<float>(), s->d_list_scale.as<float>(),
                                      s->d_list_half.as<float>(), s->d_list_radius.as<float>(), blk.p, s->d_row_n2i.as<int>(),
-                                     s->d_row_res.as<float>(), stream));
+                                     s->d_row_res.as<float>(), stream, s->d_row_of));
         HIP_TRY(hipStreamSynchronize(stream));      // d_mm is released at scope exit
     } else if (op == 1) {
         HIP_TRY(blk.alloc(tiles * 16 * s->sdim * 2));
         HIP_TRY(launch_block_rows_f16(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                      (s->max_list_len + 15) / 16, s->sdim, s->f16_scale, blk.p, stream));
+                                      (s->max_list_len + 15) / 16, s->sdim, s->f16_scale, blk.p, stream, s->d_row_of));
     } else {
         HIP_TRY(blk.alloc(tiles * 16 * s->sdim * sizeof(float)));
         HIP_TRY(launch_block_rows(s->d_mat, s->d_list_off.as<uint64_t>(), s->d_blk_off.as<uint64_t>(), kc,
-                                  (s->max_list_len + 15) / 16, s->sdim, blk.p, stream));
+                                  (s->max_list_len + 15) / 16, s->sdim, blk.p, stream, s->d_row_of));
     }
     HIP_TRY(hipStreamSynchronize(stream));      // one-off; calls on other streams may follow at once
+    undo.done = true;
     return PQV_OK;
 }
 
@@ -1481,7 +1503,15 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice, s->stream));
     mark("tables + ids upload");
-    if (flags & PQV_LAYOUT_ROW_ORDER) {
+    // images-only IVF layout: where the wide screened path will serve this searcher (rows of a multiple of 64 dims, lists of
+    // >= 192 rows on average) and the caller's matrix stays (no PQV_RELEASE_ROW_ORDER); PQV_IVF_COPY=1 keeps the second copy (A/B)
+    {
+        const char *e = std::getenv("PQV_IVF_COPY");
+        const bool want_copy = e && *e && *e != '0';
+        s->images_only = !(flags & PQV_LAYOUT_ROW_ORDER) && !((flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) && !want_copy && s->sdim == s->dim &&
+                         (s->dim % 64) == 0 && s->n > 0 && s->n / std::max<uint32_t>(1, s->n_clusters) >= 192;
+    }
+    if ((flags & PQV_LAYOUT_ROW_ORDER) || s->images_only) {
         s->d_mat = corpus->d_rows;
         s->d_row_of = s->d_ids.as<uint32_t>();
         s->d_final_ids = nullptr;
@@ -1505,18 +1535,16 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     S_TRY(s->d_stats.alloc((8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long), s->stream));
 #endif
-    // squared norms of the storage rows, for the MFMA screen of the batched re-rank
+    // squared norms of the rows for the MFMA screen of the batched re-rank (indexed by storage row; by list position in the
+    // images-only layout) and, in the same pass, the corpus maximum -> power-of-two scale that maps it below 2^14 (f16 operand copy)
     {
-        const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
-        S_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, n_storage) * sizeof(float)));
-        S_TRY(pqv::launch_row_norms(s->d_mat, n_storage, s->sdim, 1, s->d_row_norm2.as<float>(), s->stream));
-    }
-    {   // corpus maximum -> power-of-two scale that maps it below 2^14 (f16 operand copy of the screened path)
         DevBuf d_max;
         S_TRY(d_max.alloc(sizeof(uint32_t)));
         S_TRY(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), s->stream));
         const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
-        S_TRY(pqv::launch_maxabs(s->d_mat, n_storage * s->sdim, d_max.as<uint32_t>(), s->stream));
+        S_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, n_storage) * sizeof(float)));
+        S_TRY(pqv::launch_row_norms_max(s->d_mat, s->images_only ? s->d_row_of : nullptr, n_storage, s->sdim, s->d_row_norm2.as<float>(),
+                                        d_max.as<uint32_t>(), s->stream));
         uint32_t bits = 0;
         S_TRY(hipMemcpyAsync(&bits, d_max.p, sizeof bits, hipMemcpyDeviceToHost, s->stream));
         S_TRY(hipStreamSynchronize(s->stream));
@@ -1592,7 +1620,7 @@ static uint32_t cand_cap_for(const pqv_searcher *s, uint32_t k) {
 }
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
     (void)nq;
-    return s->opt.seed_refine && !s->d_row_of && (s->sdim % 32) == 0 && k <= 16 && (s->opt.seed_refine > 1 || s->sdim >= 256);
+    return s->opt.seed_refine && (!s->d_row_of || s->images_only) && (s->sdim % 32) == 0 && k <= 16 && (s->opt.seed_refine > 1 || s->sdim >= 256);
 }
 TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t k = 1, int metric = 0) {
     TopkPlan p{};
@@ -1947,7 +1975,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.slots_per_pair = p.slots_per_pair; ta.slot_base = 0; ta.n_part = p.n_part_rr;
         ta.gthr = sc.s_gthr.as<unsigned long long>();
         ta.part_keys = sc.s_part_keys.as<uint64_t>(); ta.part_vals = sc.s_part_vals.as<uint32_t>();
-        ta.row_norm2 = s->d_row_norm2.as<float>();
+        ta.row_norm2 = s->d_row_norm2.as<float>(); ta.norm_by_pos = s->images_only ? 1 : 0;
         ta.stats = s->d_stats.as<unsigned long long>();
         ta.xcd_swizzle = 0;
         if (p.filter && p.quad) {
@@ -2015,7 +2043,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             }
             pqv::SeedRefine rf{};
             if (seed_refine_on(s, nq, k)) {
-                rf.mat = s->d_mat; rf.queries = d_queries_s; rf.list_off = s->d_list_off.as<uint64_t>();
+                rf.mat = s->d_mat; rf.row_of = s->d_row_of; rf.queries = d_queries_s; rf.list_off = s->d_list_off.as<uint64_t>();
                 rf.probe = sc.s_probe.as<uint32_t>(); rf.cand_base = sc.s_cand_base.as<uint64_t>();
                 rf.dim = s->sdim; rf.nprobe = p.np; rf.seed_sw = seed.seed_sw; rf.seed_rows = p.seed_rows; rf.max_pos = max_pos;
             }
@@ -2346,11 +2374,12 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     std::lock_guard<std::mutex> lock(s->mu);
     // One extra merged entry (the runner-up) lets the merge kernel see ties at the k-th
     // distance; queries it flags are replayed through the exact heap (replay_query_exact).
-    const uint32_t k_int = k + 1;
+    // (k == UINT32_MAX -- "keep everything": the reference takes any NonZeroUsize -- must not wrap to a plan with k = 0)
+    const uint32_t k_int = k >= 1024u ? k : k + 1;
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
     Scratch &sc = *lane;
-    if (beyond_kernel_lists(s, k_int, nprobe)) {
+    if (k >= 1024u || beyond_kernel_lists(s, k_int, nprobe)) {
         const int rc = topk_unbounded(s, sc, queries, nq, k, nprobe, max_candidates, metric, sqrt_out, row_idx, dist, n_found, n_candidates);
         const int rc2 = lane_release(sc, s->stream);
         return rc ? rc : rc2;
@@ -2745,7 +2774,7 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
         }
         d_row_aux = buf.as<float>();
     }
-    // Round 3: beyond the first row range the contraction runs on the f16 matrix pipe as a screen (kernels.hip:
+    // Round 3: beyond the first row range the contraction runs on the f16 matrix pipe as a screen (kernels_brute.hip:
     // brute_f16_kernel) and only what it lets through is scored in f32.  Needs the normalised f16 image of the
     // corpus (+ 1 / |v| whatever the metric); PQV_BRUTE_F16=0 keeps the f32 contraction everywhere.
     // The screen's operand form: int8 images (twice the matrix rate, half the staged bytes; PQV_BRUTE_OP=f16 keeps the f16 images).
@@ -3141,6 +3170,7 @@ int rerank_enqueue(RerankCtx &c, const float *d_query, const float *d_cand, cons
     if (c.off_m != m || c.base_k != k_out) {      // the one-list descriptor of the stream kernel (changes with the batch size only)
         const uint64_t h_base = k_out, h_off[2] = {0, m};
         const uint32_t h_probe0 = 0;
+        c.off_m = ~0ull; c.base_k = ~0ull;        // nothing cached until all three copies have landed
         HIP_TRY(hipMemcpyAsync(c.d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c.d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c.d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
@@ -3264,6 +3294,7 @@ static int rerank_host(int device, const float *query, const T *cand, const uint
     if (c->off_m != mv || c->base_k != 0) {       // the one-list descriptor of the stream kernel
         const uint64_t h_base = 0, h_off[2] = {0, mv};
         const uint32_t h_probe0 = 0;
+        c->off_m = ~0ull; c->base_k = ~0ull;      // nothing cached until all three copies have landed
         HIP_TRY(hipMemcpyAsync(c->d_base.p, &h_base, sizeof h_base, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c->d_probe0.p, &h_probe0, sizeof h_probe0, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(c->d_off.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
@@ -3283,7 +3314,7 @@ static int rerank_host(int device, const float *query, const T *cand, const uint
     HIP_TRY(hipStreamSynchronize(stream));
 
     std::vector<HeapEnt> heap;
-    heap.reserve(static_cast<size_t>(k) + 1);
+    heap.reserve(static_cast<size_t>(std::min<uint64_t>(k, static_cast<uint64_t>(*io_count) + mv)) + 1);     // sized by the data, not by a huge "keep everything" k
     for (uint32_t i = 0; i < *io_count; ++i) heap.push_back(HeapEnt{io_d2[i], io_rows[i]});     // the array IS the heap
     uint64_t o = 0;
     for (uint64_t i = 0; i < m; ++i) {

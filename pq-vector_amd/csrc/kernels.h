@@ -67,7 +67,7 @@ struct PairQuantArgs;
 hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint32_t *ticket, const PairQuantArgs *quant, hipStream_t s);
 hipError_t launch_transpose_rows4(const float *rows, uint32_t kc, uint32_t kc_pad, uint32_t dim, void *out, hipStream_t s);
 
-// int8 images of (query, probed list) pairs (kernels.hip: quantize_pair_i8_wave)
+// int8 images of (query, probed list) pairs (kernels_probe.hip: quantize_pair_i8_wave)
 struct PairQuantArgs {
     const float    *queries;     // [nq, dim]
     const uint32_t *probe;       // [nq * nprobe] cluster of pair p
@@ -209,7 +209,8 @@ hipError_t launch_pair_sort(const PairSortArgs &a, hipStream_t s);
 // and the k-th smallest of those -- still k distinct candidates, so still an upper bound of the final k-th distance --
 // replaces the k-th bound: the threshold loses the slack of the operand form (int8: ~1 % of d2) before the screen starts.
 struct SeedRefine {
-    const float    *mat;        // IVF-ordered rows [*, dim] (nullptr = no refinement)
+    const float    *mat;        // f32 rows [*, dim] (nullptr = no refinement): list position p is storage row row_of ? row_of[p] : p
+    const uint32_t *row_of;
     const float    *queries;    // [nq, dim]
     const uint64_t *list_off;
     const uint32_t *probe;      // [nq, nprobe]
@@ -281,7 +282,8 @@ struct TileArgs {
     const float    *row_res;     // per storage row: upper bound of |x - c - xi / S|
     const float4   *q_blk;       // wide kernels without LDS staging (long rows): blocked queries per quad
                                  // (launch_pack_queries), [max_quads][quad_width / 16][dim / 4][16] float4
-    const float    *row_norm2;   // indexed like mat rows
+    const float    *row_norm2;   // indexed like mat rows (norm_by_pos: by LIST POSITION -- images in list order over row-order f32 rows)
+    int             norm_by_pos;
     const float    *query_norm2; // [nq]
     int             xcd_swizzle; // 1: XCD-aware workgroup remap (speed only)
     const uint32_t *item_quad;   // wide_filter_kernel: work-item table (PairSortArgs::item_quad); nullptr = 2-D grid
@@ -361,7 +363,7 @@ struct BruteArgs {
     uint32_t     dense;
 };
 hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s);
-// The f16 screen of the same search (kernels.hip: brute_f16_kernel): L2-normalised f16 images x 2^8 of rows / queries
+// The f16 screen of the same search (kernels_brute.hip: brute_f16_kernel): L2-normalised f16 images x 2^8 of rows / queries
 // ([*, dim_p], dim_p a multiple of 32, launch_normalize_f16), lower-bound keys against the exact thresholds; appended
 // entries are then rewritten with their exact f32 keys by launch_brute_rescore (entries [first[q], cand_cnt[q]) of query q).
 struct BruteF16Args {
@@ -387,7 +389,7 @@ struct BruteF16Args {
     uint32_t     cap;
 };
 hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s);
-// The k-means assignment on the f16 matrix pipe (kernels.hip: assign_f16_kernel): images of (row - mu) / |row - mu| * 2^8
+// The k-means assignment on the f16 matrix pipe (kernels_build.hip: assign_f16_kernel): images of (row - mu) / |row - mu| * 2^8
 // for rows and centroids (launch_center_normalize_f16; the centroid table padded to kc_pad rows, a multiple of 256),
 // candidate lists per row, then launch_assign_rescore picks the exact argmin among them.
 struct AssignF16Args {
@@ -441,8 +443,9 @@ hipError_t launch_pack_pairs(const float *dist, const uint32_t *rows, uint64_t n
 
 // MFMA-operand copy of the IVF-ordered lists: 16-row tiles, tile T column ch row j at float4 index
 // (T * dim/4 + ch) * 16 + j; blk_off[c] = first tile of list c (lists are padded to 16 rows with zeros)
+// (row_of, here and below: list position p reads source row row_of[p]; nullptr = the source is already in list order)
 hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
-                             uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s);
+                             uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s, const uint32_t *row_of = nullptr);
 
 // blocked copy of every quad's queries (see TileArgs::q_blk); ngrp = quad_width / 16
 hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, const uint4 *quads, const uint32_t *n_quads,
@@ -456,7 +459,7 @@ hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads,
 hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s);
 hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s);
 
-// pqv_rerank's running state <-> merge lists (see kernels.hip)
+// pqv_rerank's running state <-> merge lists (see kernels_layout.hip)
 hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k, uint32_t k_list,
                                   uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s);
 hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
@@ -469,13 +472,16 @@ hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_byte
 // f16 form of the blocked copy (values * scale rounded to nearest f16, 8 dims per 16-byte column, tile T column
 // cc row j at 16-byte index (T * dim/8 + cc) * 16 + j) and the corpus maximum it is scaled by
 hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
-                                 uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s);
+                                 uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s, const uint32_t *row_of = nullptr);
 hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out_bits, hipStream_t s);
-// int8 form (see kernels.hip): per-list, per-dimension min / max keys (kmin preset to 0xFF bytes, kmax to 0; [n_clusters, dim]),
+// one pass over n rows (row r = source row row_of ? row_of[r] : r): out_norm2[r] = sum x^2 and *max_bits = max(*max_bits, bits(max |x|))
+hipError_t launch_row_norms_max(const float *rows, const uint32_t *row_of, uint64_t n, uint32_t dim, float *out_norm2, uint32_t *max_bits,
+                                hipStream_t s);
+// int8 form (see kernels_layout.hip): per-list, per-dimension min / max keys (kmin preset to 0xFF bytes, kmax to 0; [n_clusters, dim]),
 // the per-list mid-range centre, half range, scale and (zeroed) radius, the blocked int8 copy of the residuals + per-row
 // |xi|^2 and residual bound + the per-list radius, and the per-batch images of the (query, probed list) pairs
 hipError_t launch_list_minmax(const float *rows, const uint64_t *list_off, uint32_t n_clusters, uint64_t max_list_len, uint32_t dim,
-                              uint32_t *kmin, uint32_t *kmax, hipStream_t s);
+                              uint32_t *kmin, uint32_t *kmax, hipStream_t s, const uint32_t *row_of = nullptr);
 hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
                               float *center, float *half, float *scale, float *radius, hipStream_t s);
 hipError_t launch_global_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
@@ -484,7 +490,7 @@ hipError_t launch_broadcast_center(const float *g_center, const float *g_half_sc
                                    float *half, float *scale, hipStream_t s);
 hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
                                 uint64_t max_tiles, uint32_t dim, const float *center, const float *list_scale, const float *list_half,
-                                float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s);
+                                float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s, const uint32_t *row_of = nullptr);
 hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe, const float *center, const float *scale, const float *half,
                                     const float *radius, uint32_t n_pairs, uint32_t nprobe, uint32_t dim, void *q_i8, int *q_n2i,
                                     float *q_res, float *q_resu, float *pair_lb, hipStream_t s);

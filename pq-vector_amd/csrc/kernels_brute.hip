@@ -1,0 +1,765 @@
+// kernels_brute.hip -- batched brute force as a dense Q.V^T contraction on the matrix cores (BASELINE config 5; the reference's
+// bench baseline benches/query.rs:76-98 with cosine as an extension): brute_mfma_kernel (f32), brute_f16_kernel (f16 / int8 screen),
+// brute_rescore_kernel, the image builders and the select / finish passes.
+#include "device_common.hpp"
+
+namespace pqv {
+
+// ------------------------------------------------------------------------------------
+// Batched brute force on the matrix cores (BASELINE config 5: cosine, 1024-query batches).
+//
+// brute_mfma_kernel: block tile 128 queries x 128 rows, 4 waves as 2 x 2, each wave a
+// 64 x 64 sub-tile = 2 x 2 MFMA tiles of v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate:
+// a k-ordered fmaf chain, exact f32 products -- bf16 would miss the 1e-4 tolerance).
+// K is walked in 16-float stages: each thread fetches 2+2 float4 (queries / rows) into
+// registers one stage ahead, the tiles sit in LDS as [row][k] with a 17-dword row stride so
+// the MFMA operand reads (32 rows x same k per half-wave) are bank-conflict-free.
+// Epilogue: distance from the score, a sortable key (distance bits | row id) per (query, row),
+// compared with the query's admission threshold staged in LDS; the rare survivors are
+// appended to the query's candidate buffer with one atomic each.  Nothing of the
+// nq x n score matrix is ever written.
+// ------------------------------------------------------------------------------------
+constexpr int BR_BM = 128, BR_BN = 128, BR_BK = 16;
+
+template <bool FAST>      // FAST: dim % 16 == 0 -- operand fetches through buffer resources (no bounds or address VALU)
+__global__ __launch_bounds__(256) void brute_mfma_kernel(const BruteArgs a) {
+    // two stages of [row][16 k] tiles as 16-byte chunks; chunk c of row r sits at position c ^ ((r >> 2) & 3),
+    // so the staging writes (one chunk per thread) and the operand reads (two chunks per lane, 16 lanes x 16
+    // distinct 16-byte slots of a 256-byte bank window) are both bank-conflict free without padding
+    __shared__ float4 As4[2][BR_BM * 4];
+    __shared__ float4 Bs4[2][BR_BN * 4];
+    __shared__ unsigned long long thr_s[BR_BM];
+    __shared__ float qaux_s[BR_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint64_t n0 = a.row_begin + (uint64_t)blockIdx.x * BR_BN;
+    const uint32_t m0 = blockIdx.y * BR_BM;
+    const uint32_t dim = a.dim;
+    const bool al4 = (dim & 3u) == 0;
+
+    // staging: thread -> (row ld_r / ld_r + 64, chunk ld_ch = 4 consecutive k)
+    const int ld_r = tid >> 2, ld_ch = tid & 3;
+    float4 ra[2], rb[2];
+    // FAST: descriptors at the tile's first query / row; rows past nq / row_end are out of range and read as 0
+    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * dim * 4 : 0, vleft = a.row_end > n0 ? (a.row_end - n0) * dim * 4 : 0;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.queries + (uint64_t)m0 * dim), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.rows + n0 * dim), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = ((uint32_t)ld_r * dim + (uint32_t)ld_ch * 4) * 4, half_b = 64u * dim * 4;
+    auto fetch = [&](uint32_t k0) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ra[h] = buf_ld16(qres, lane_b, k0 * 4 + h * half_b);
+                rb[h] = buf_ld16(vres, lane_b, k0 * 4 + h * half_b);
+            }
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t qi = m0 + ld_r + 64 * h;
+            const uint64_t vj = n0 + ld_r + 64 * h;
+            const uint32_t kk = k0 + ld_ch * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (qi < a.nq) {
+                const float *p = a.queries + (uint64_t)qi * dim + kk;
+                if (al4 && kk + 4 <= dim) va = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (kk < dim) va.x = p[0];
+                    if (kk + 1 < dim) va.y = p[1];
+                    if (kk + 2 < dim) va.z = p[2];
+                    if (kk + 3 < dim) va.w = p[3];
+                }
+            }
+            if (vj < a.row_end) {
+                const float *p = a.rows + vj * dim + kk;
+                if (al4 && kk + 4 <= dim) vb = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (kk < dim) vb.x = p[0];
+                    if (kk + 1 < dim) vb.y = p[1];
+                    if (kk + 2 < dim) vb.z = p[2];
+                    if (kk + 3 < dim) vb.w = p[3];
+                }
+            }
+            ra[h] = va; rb[h] = vb;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = ld_r + 64 * h;
+            const int pos = r * 4 + (ld_ch ^ ((r >> 2) & 3));
+            As4[buf][pos] = ra[h];
+            Bs4[buf][pos] = rb[h];
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (tid < BR_BM) {
+        const uint32_t qi = m0 + tid;
+        thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
+        qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
+    }
+
+    const uint32_t nk = (dim + BR_BK - 1) / BR_BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    // MFMA operand roles: lane (l31, lk) owns row l31 of a 32-row tile and, per stage, the 8 consecutive k
+    // values 8 lk .. 8 lk + 7 (instruction j of the stage contracts k = 8 lk + j; the order of a dot
+    // product's terms is free here) -- two 16-byte LDS reads per tile and stage
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[2], rowb[2], swa[2], swb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3;
+        rowb[t] = wn * 64 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3;
+    }
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1u);
+        if (kt + 1 < nk) fetch((kt + 1) * BR_BK);
+        float av[2][8], bv[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 x = As4[buf][rowa[t] * 4 + ((2 * lk + h) ^ swa[t])];
+                const float4 y = Bs4[buf][rowb[t] * 4 + ((2 * lk + h) ^ swb[t])];
+                av[t][4 * h] = x.x; av[t][4 * h + 1] = x.y; av[t][4 * h + 2] = x.z; av[t][4 * h + 3] = x.w;
+                bv[t][4 * h] = y.x; bv[t][4 * h + 1] = y.y; bv[t][4 * h + 2] = y.z; bv[t][4 * h + 3] = y.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jj][j], acc[i][jj], 0, 0, 0);
+        if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint64_t vj = n0 + wn * 64 + j * 32 + l31;
+        const bool jv = vj < a.row_end;
+        const float vaux = jv ? a.row_aux[vj] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const uint32_t qi = m0 + ml;
+                const float sc = acc[i][j][r];
+                float d;
+                if (a.metric == BRUTE_COSINE) d = 1.0f - sc * qaux_s[ml] * vaux;
+                else { d = qaux_s[ml] + vaux - 2.0f * sc; d = d < 0.0f ? 0.0f : d; }
+                const unsigned long long key =
+                    ((unsigned long long)sortable_bits(d) << 32) | (unsigned long long)(uint32_t)vj;
+                if (a.dense) {
+                    if (jv && qi < a.nq) a.cand[(uint64_t)qi * a.cap + (uint32_t)(vj - a.row_begin)] = key;
+                } else if (jv && qi < a.nq && key < thr_s[ml]) {
+                    const uint32_t slot = atomicAdd(&a.cand_cnt[qi], 1u);
+                    if (slot < a.cap) a.cand[(uint64_t)qi * a.cap + slot] = key;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
+    if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
+    if (a.dense && a.row_end - a.row_begin > a.cap) return hipErrorInvalidValue;
+    const uint64_t nb = (a.row_end - a.row_begin + BR_BN - 1) / BR_BN;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((uint32_t)nb, (a.nq + BR_BM - 1) / BR_BM);
+    // the fast variant needs 16-dim stages that never cross a row end and 32-bit byte offsets inside a tile
+    if ((a.dim % 16) == 0 && (uint64_t)a.dim * 4 * 192 < 0x7FFFFFFFull) hipLaunchKernelGGL(brute_mfma_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(brute_mfma_kernel<false>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Round 3: the same batched brute force on the f16 matrix pipe (16x the f32 rate) as a SCREEN, exact f32 re-scoring
+// of what it lets through -- the design of the IVF path applied to BASELINE config 5.
+//
+// Images: every row and query is L2-normalised, scaled by 2^8 and rounded to f16 (unit vectors: components <= 1, so
+// nothing overflows and sub-normals are below 2^-22 of the vector), rows padded with zeros to a multiple of 32 dims.
+// With s~ = (image dot product) / 2^16 and s^ the true cosine:
+//     |s~ - s^| <= (2^-10 + 2^-22) sum |q^_i v^_i| + (accumulation) <= eps = 1.01 * 2^-10 + 2 dim 2^-24 + 2e-6
+// (relative 2^-11 per f16 operand, Cauchy-Schwarz on unit vectors; f32 accumulation of dim exact products; the
+// roundings of the normalisation itself).  brute_f16_kernel appends every (query, row) whose LOWER bound
+//     cosine:  (1 - s~) - eps            l2:  (|q|^2 + |v|^2 - 2 |q||v| s~) - 2 |q||v| eps
+// does not exceed the query's threshold (the k-th smallest EXACT distance so far), brute_rescore_kernel replaces each
+// appended entry by its exact f32 key (the arithmetic of the f32 path's epilogue), and the select pass goes on as before:
+// no candidate of the final top-k can be lost, and every returned distance is an f32 one.
+//
+// Block tile 128 queries x 256 rows, 4 waves as 2 x 2, each a 64 x 128 sub-tile = 2 x 4 tiles of
+// v_mfma_f32_32x32x16_f16; K in 32-value stages through double-buffered LDS (64 bytes per row and stage, 16-byte chunks
+// XOR-swizzled like the f32 kernel's).  An LDS operand read feeds 2 (row side) or 4 (query side) MFMAs: 6 reads per 8
+// MFMAs, 96 B/clk/CU at the full matrix rate.  The grid is 1-D and XCD-aware: the 8 query tiles of one row tile run
+// back to back on ONE XCD, so a row tile leaves HBM once and serves the other seven from that XCD's L2.
+// ------------------------------------------------------------------------------------
+
+// NWM x NWN waves, each a (32 TM) x (32 TN) sub-tile: block tile BM = 32 TM NWM queries x BN = 32 TN NWN rows.
+//   <2, 2, 2, 4>: 128 x 256, 256 threads, two blocks per CU (round 3's first form: 0.29 of the f16 peak on C5 -- PMC: the
+//                 matrix pipe busy 29 % of the time, 8.4 TB/s of L2 reads with 92 % hits: bound by the L2 -> LDS traffic
+//                 of a tile that does 85 flops per staged byte)
+//   <2, 4, 4, 2>: 256 x 256, 512 threads, one block per CU: 128 flops per staged byte
+// I8: the same tiles on int8 images (v_mfma_i32_32x32x32_i8: twice the f16 rate, half the staged bytes per flop -- and the
+// staging traffic is what bounds the f16 form).  Images: the L2-normalised vector times S = 127 / max |component| (per
+// vector), rounded to int8 -- of the vector MINUS its own mid-range b along (1, .., 1), so one-sided data (the bench's
+// uniform [0, 1) rows) uses the whole grid:  q^.v^ = (q^ - a 1).(v^ - b 1) + b sum(q^) + a sum(v^) - a b dim.  Per vector
+// {1 / S, r >= |(v^ - b 1) - image / S|, b, sum(v^)} and n >= |v^ - b 1| (normalize_i8_kernel).  With D = the image dot
+// product (exact in int32) and s~ = D / (S_q S_v) + b sum(q^) + a sum(v^) - a b dim:
+//     |s~ - s^| <= n_q r_v + n_v r_q + 3 r_q r_v      (Cauchy-Schwarz on the residuals; |image / S| <= n + r)
+// -- a bound per PAIR, wider than the f16 one, so more pairs reach the exact re-scoring; that is still far cheaper than the
+// contraction time the int8 pipe saves.
+// ST: 16-byte chunks per row and K stage -- 4 (64-byte stages) or 8 (128-byte stages: half the barriers and twice the MFMAs
+// between them; 128 KB of LDS for the 256 x 256 tile, chunks swizzled by the row's low three bits).
+// RING (0 or 4): the K stages arrive by direct-to-LDS buffer loads into a ring of RING 64-byte stages instead of through
+// registers: three stages are in flight while one is contracted, the loads stay outstanding ACROSS the per-stage barrier
+// (counted s_waitcnt vmcnt + a raw s_barrier; the operand reads are inline asm so that the compiler does not drain the
+// load queue in front of them) -- with one 8-wave block per CU nothing else hides the L2 / HBM latency of a stage.
+template <int NWM, int NWN, int TM, int TN, bool I8, int ST, int RING = 0>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
+    constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
+    static_assert(RING == 0 || (RING == 4 && ST == 4 && BM % (NT / 4) == 0 && BN % (NT / 4) == 0 && TM == 4 && TN == 2), "ring form: 64-byte stages, whole 16-row blocks per wave");
+    constexpr int CA = BM * ST / NT, CB = BN * ST / NT;        // 16-byte chunks a thread stages per K stage
+    static_assert(BM * ST % NT == 0 && BN * ST % NT == 0 && (ST == 4 || ST == 8), "staging split");
+    extern __shared__ float4 brute_lds[];                      // [2][BM * ST] query stages, [2][BN * ST] row stages
+    float4 *const As4 = brute_lds, *const Bs4 = brute_lds + 2 * BM * ST;
+    // chunk swizzle by row: a ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
+    // the same + 32 (MI355X_MICROARCH.md #LDS) -- and a group is conflict-free when its 16 chunks cover the 64 banks once.  64-byte
+    // rows: chunk ^ bits 2-3 of the row; 128-byte rows: chunk ^ (bit 1 of the row | bits 2-3 << 1) (r & 7 leaves two-way
+    // conflicts: rows 0 / 24 and 2 / 26 of a group collide)
+    auto sw = [](int r) { return ST == 4 ? (r >> 2) & 3 : ((r >> 1) & 1) | (((r >> 2) & 3) << 1); };
+    __shared__ unsigned long long thr_s[BM];
+    __shared__ float qaux_s[BM];
+    __shared__ float4 qsr_s[I8 ? BM : 1];            // int8 form: {1 / S, r, a, sum} of the tile's queries
+    __shared__ float qn_s[I8 ? BM : 1];              //            |q^ - a 1|
+    __shared__ float4 qk_s[BM];                      // quick-screen constants of the tile's queries (cosine)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    // id -> (XCD, slot): XCD x takes the row tiles = x (mod 8), each followed by all of its query tiles
+    const uint32_t ny = (a.nq + BM - 1) / BM;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint64_t vt = (uint64_t)(slot / ny) * 8u + xcd;
+    const uint32_t qt = slot % ny;
+    const uint64_t n0 = a.row_begin + vt * BN;
+    if (n0 >= a.row_end) return;
+    const uint32_t m0 = qt * BM;
+    const uint32_t dp = a.dim_p;                     // padded dims (a multiple of 32, 2 bytes each; int8: of 64, 1 byte each)
+    const uint32_t rbytes = I8 ? dp : dp * 2;        // bytes per image row; a K stage is 64 of them
+
+    constexpr int RPS = NT / ST;                     // rows one staging step of the block covers
+    const int ld_r = tid / ST, ld_ch = tid % ST;     // staging: row ld_r (+ RPS h), 16-byte chunk ld_ch of the stage
+    float4 ra[CA], rb[CB];
+    const uint64_t qleft = a.nq > m0 ? (uint64_t)(a.nq - m0) * rbytes : 0, vleft = (a.row_end - n0) * rbytes;
+    const char *qbase = I8 ? reinterpret_cast<const char *>(a.q8) : reinterpret_cast<const char *>(a.q16);
+    const char *vbase = I8 ? reinterpret_cast<const char *>(a.v8) : reinterpret_cast<const char *>(a.v16);
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(qbase + (uint64_t)m0 * rbytes), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(vbase + n0 * rbytes), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * rbytes + (uint32_t)ld_ch * 16, step_b = (uint32_t)RPS * rbytes;
+    auto fetch = [&](uint32_t kb) {                  // kb: byte offset of the stage inside a row
+#pragma unroll
+        for (int h = 0; h < CA; ++h) ra[h] = buf_ld16(qres, lane_b, kb + h * step_b);
+#pragma unroll
+        for (int h = 0; h < CB; ++h) rb[h] = buf_ld16(vres, lane_b, kb + h * step_b);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < CA; ++h) { const int r = ld_r + RPS * h; As4[buf * BM * ST + r * ST + (ld_ch ^ sw(r))] = ra[h]; }
+#pragma unroll
+        for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf * BN * ST + r * ST + (ld_ch ^ sw(r))] = rb[h]; }
+    };
+
+    using acc_t = std::conditional_t<I8, i32x16_t, f32x16_t>;
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    if (tid < BM) {
+        const uint32_t qi = m0 + tid;
+        thr_s[tid] = qi < a.nq ? a.thr[qi] : 0ull;
+        qaux_s[tid] = qi < a.nq ? a.query_aux[qi] : 0.0f;
+        if constexpr (I8) {
+            qsr_s[tid] = qi < a.nq ? a.query_sr[qi] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qn_s[tid] = qi < a.nq ? a.query_n[qi] : 0.0f;
+        }
+        // Quick screen of the cosine epilogue (one compare, or three FMAs and a compare, per pair instead of the full bound --
+        // the epilogue's VALU work took longer than the MFMAs): per query the constants of a test that every pair the exact
+        // test keeps also passes; the exact test (below) runs only on what passes.
+        //   f16:  keep  =>  acc 2^-16 >= (1 - T) - eps - slack                                      qk = {that / 2^-16}
+        //   int8: keep  =>  D iv_j + (a / iq) A_j + (sum_q / iq) C_j >= ((1 - T) - K - slack) / iq,   qk = {a / iq, sum_q / iq, -rhs}
+        //         K = the per-pair eps with the row's terms replaced by their corpus-wide maxima (a.row_max), A_j = sum_v - b_j dim, C_j = b_j
+        float4 qk = make_float4(0.0f, 0.0f, __builtin_inff(), 0.0f);          // int8: always passes (rhs = -inf); f16: x = -inf
+        if (!I8) qk.x = -__builtin_inff();
+        if (qi < a.nq && a.metric == BRUTE_COSINE) {
+            const uint32_t th = (uint32_t)(thr_s[tid] >> 32);
+            if (th < 0xFF800000u) {                  // a finite threshold distance T (else: no threshold yet, everything passes)
+                const float T = unsortable_bits(th);
+                if constexpr (I8) {
+                    const float4 q = qsr_s[tid];
+                    const float mA = a.row_max[0], mB = a.row_max[1], mC = a.row_max[2], mE = a.row_max[3];
+                    const float K = (q.y * mB + qn_s[tid] * mE) * 1.00002f + a.eps + a.eps_sum * (fabsf(q.z) + mC);
+                    const float slack = 1.0e-5f * (2.0f + fabsf(q.z) * mA + fabsf(q.w) * mC);
+                    const float rhs = (1.0f - T) - K - slack;
+                    qk = make_float4(q.z / q.x, q.w / q.x, -(rhs / q.x), 0.0f);      // (iq = 0: NaN / inf -- the pair passes)
+                } else {
+                    qk.x = ((1.0f - T) - a.eps - 4.0e-6f) * 65536.0f;
+                }
+            }
+        }
+        qk_s[tid] = qk;
+    }
+
+    const uint32_t nk = rbytes / (16 * ST);
+    if constexpr (RING == 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    // operand roles of v_mfma_f32_32x32x16_f16: lane (l31, lk) owns row l31 of a 32-row tile and the 8 consecutive k
+    // values 8 lk .. 8 lk + 7 of the instruction's 16; MFMA j of a stage takes chunk 2 j + lk (term order is free)
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[TM], rowb[TN], swa[TM], swb[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = sw(rowa[t]); }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = sw(rowb[t]); }
+    if constexpr (RING != 0) {
+        constexpr int NW = NT / 64, RA = BM / 16 / NW, RB = BN / 16 / NW;      // 16-row blocks (1 KiB of a stage) per wave
+        constexpr uint32_t STG = (uint32_t)(BM + BN) * 4;                      // float4s of a ring slot: BM query rows, BN corpus rows
+        typedef __attribute__((address_space(3))) void lds_void;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)brute_lds;
+        // lane l of a load instruction fills 16-byte slot l of its 1 KiB: row l / 4 of the block, stored chunk l % 4 -- which holds the
+        // row's chunk (l % 4) ^ sw(row) (the block's 16 rows start at a multiple of 16, so sw depends on l only)
+        const uint32_t voff = (uint32_t)(lane >> 2) * rbytes + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);      // (scalar: LDS base and buffer offset of a load are wave-uniform)
+        auto issue = [&](uint32_t st) {
+            float4 *dst = brute_lds + (st & (RING - 1)) * STG;
+#pragma unroll
+            for (int h = 0; h < RA; ++h) {
+                const uint32_t blk = wave_u * RA + h;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_void *)(dst + blk * 64), 16, (int)voff, (int)(blk * 16 * rbytes + st * 64), 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < RB; ++h) {
+                const uint32_t blk = wave_u * RB + h;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_void *)(dst + BM * 4 + blk * 64), 16, (int)voff, (int)(blk * 16 * rbytes + st * 64), 0, 0);
+            }
+        };
+        uint32_t offa[2][TM], offb[2][TN];          // byte offsets of this lane's operands inside a ring slot, K steps 0 / 1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) offa[j][t] = lds0 + (uint32_t)(rowa[t] * 4 + ((2 * j + lk) ^ swa[t])) * 16;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) offb[j][t] = lds0 + (uint32_t)(BM * 4 + rowb[t] * 4 + ((2 * j + lk) ^ swb[t])) * 16;
+        }
+        for (uint32_t st = 0; st < 3 && st < nk; ++st) issue(st);
+        for (uint32_t kt = 0; kt < nk; ++kt) {
+            // this wave's part of stage kt has landed (later stages stay in flight: RA + RB loads each); after the barrier
+            // everybody's has, and everybody is done with stage kt - 1, whose slot stage kt + 3 takes
+            const uint32_t ahead = nk - 1 - kt;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (RA + RB)) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(RA + RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 3 < nk) issue(kt + 3);
+            const uint32_t sb = (kt & (RING - 1)) * STG * 16;
+            f32x4_raw_t oa[2][TM], ob[2][TN];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(oa[j][t]) : "v"(offa[j][t] + sb));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ob[j][t]) : "v"(offb[j][t] + sb));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // LDS reads return in order: K step 0's six operands are there once six reads remain outstanding
+                if (j == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(oa[0][0]), "+v"(oa[0][1]), "+v"(oa[0][2]), "+v"(oa[0][3]), "+v"(ob[0][0]), "+v"(ob[0][1]) : "n"(TM + TN));
+                else { __builtin_amdgcn_sched_barrier(0); }
+                if (j == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oa[1][0]), "+v"(oa[1][1]), "+v"(oa[1][2]), "+v"(oa[1][3]), "+v"(ob[1][0]), "+v"(ob[1][1]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        if constexpr (I8)
+                            acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, oa[j][i]), __builtin_bit_cast(i32x4_acc, ob[j][jj]), acc[i][jj], 0, 0, 0);
+                        else
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, oa[j][i]), __builtin_bit_cast(f16x8_t, ob[j][jj]), acc[i][jj], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    } else
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1u);
+        if (kt + 1 < nk) fetch((kt + 1) * 16 * ST);
+        // (int8: v_mfma_i32_32x32x32_i8 takes 16 bytes per lane as well -- lane group lk owns one half of the instruction's 32
+        //  k values; which half is immaterial, both operands read the same chunk)
+        // operands of K step j + 1 are read while the MFMAs of step j run (two register sets; the compiler on its own reuses
+        // one set and waits for every read right in front of its MFMA)
+        float4 av[2][TM], bv[2][TN];
+        auto lds_read = [&](int j, int set) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) av[set][t] = As4[buf * BM * ST + rowa[t] * ST + ((2 * j + lk) ^ swa[t])];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bv[set][t] = Bs4[buf * BN * ST + rowb[t] * ST + ((2 * j + lk) ^ swb[t])];
+        };
+        lds_read(0, 0);
+#pragma unroll
+        for (int j = 0; j < ST / 2; ++j) {
+            const int set = j & 1;
+            if (j + 1 < ST / 2) lds_read(j + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);          // the reads are issued before this step's MFMAs, which cover their latency
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    if constexpr (I8)
+                        acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_acc, av[set][i]), __builtin_bit_cast(i32x4_acc, bv[set][jj]), acc[i][jj], 0, 0, 0);
+                    else
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[set][i]), __builtin_bit_cast(f16x8_t, bv[set][jj]), acc[i][jj], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt + 1 < nk) stash(buf ^ 1);      // the other stage: last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const float inv = 1.52587890625e-05f;            // 2^-16: the two images carry 2^8 each
+    uint64_t vjs[TN];
+    bool jvs[TN];
+    float vauxs[TN];
+    [[maybe_unused]] float4 vsrs[TN];
+    [[maybe_unused]] float vns[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        vjs[j] = n0 + wn * 32 * TN + j * 32 + l31;
+        jvs[j] = vjs[j] < a.row_end;
+        vauxs[j] = (jvs[j] && a.metric != BRUTE_COSINE) ? a.row_aux[vjs[j]] : 0.0f;          // l2: |v|^2 (cosine: no row term)
+        vsrs[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); vns[j] = 0.0f;
+        if constexpr (I8) { if (jvs[j]) { vsrs[j] = a.row_sr[vjs[j]]; vns[j] = a.row_n[vjs[j]]; } }
+    }
+    // the exact test of one pair: lower bound of its distance against the query's threshold key
+    auto exact = [&](int ml, int j, auto accv) {
+        const uint32_t qi = m0 + ml;
+        const float vaux = vauxs[j];
+        float sc, eps;
+        if constexpr (I8) {
+            const float4 qsr = qsr_s[ml], vsr = vsrs[j];
+            sc = ((float)accv * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
+            // n_q r_v + n_v r_q + 3 r_q r_v, rounded up, + the f32 roundings of both sides (a.eps) and of the two
+            // component sums (a.eps_sum per unit of |a| + |b|)
+            eps = (qn_s[ml] * vsr.y + qsr.y * (vns[j] + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
+        } else {
+            sc = accv * inv; eps = a.eps;
+        }
+        float lb;
+        if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - eps;
+        else {
+            const float qv = sqrtf(qaux_s[ml] * vaux) * 1.000001f;     // |q| |v|
+            lb = (qaux_s[ml] + vaux - 2.0f * qv * sc) - 2.0f * qv * eps - 1.0e-6f * (qaux_s[ml] + vaux);
+            lb = lb < 0.0f ? 0.0f : lb;
+        }
+        // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
+        const bool keep = !((unsigned long long)sortable_bits(lb) > (thr_s[ml] >> 32));
+        if (jvs[j] && qi < a.nq && keep) {
+            const uint32_t slot2 = atomicAdd(&a.cand_cnt[qi], 1u);
+            if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vjs[j];
+        }
+    };
+    const bool quick = a.metric == BRUTE_COSINE;
+    [[maybe_unused]] float rowA[TN], rowC[TN], rowI[TN];       // int8 quick screen: A_j, C_j, iv_j
+    if constexpr (I8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { rowI[j] = vsrs[j].x; rowC[j] = vsrs[j].z; rowA[j] = vsrs[j].w - vsrs[j].z * a.dim_f; }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float4 qk = qk_s[ml];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bool pass = true;
+                if (quick) {
+                    if constexpr (I8) pass = !(__builtin_fmaf((float)acc[i][j][r], rowI[j], __builtin_fmaf(qk.x, rowA[j], __builtin_fmaf(qk.y, rowC[j], qk.z))) < 0.0f);
+                    else pass = !(acc[i][j][r] < qk.x);
+                }
+                if (pass) exact(ml, j, acc[i][j][r]);
+            }
+        }
+    }
+}
+hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
+    if (a.row_end <= a.row_begin || a.nq == 0) return hipSuccess;
+    const bool i8 = a.v8 != nullptr;
+    if (i8 ? ((a.dim_p % 64) != 0 || !a.q8 || !a.row_sr || !a.query_sr || !a.row_n || !a.query_n || !a.row_max) : (a.dim_p % BH_BK) != 0) return hipErrorInvalidValue;
+    if ((uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // 256 x 256 tiles from 256 queries on (PQV_BRUTE_TILE=128 keeps the 128 x 256 form for comparison)
+    static const int tile_env = [] { const char *e = std::getenv("PQV_BRUTE_TILE"); return e ? std::atoi(e) : 0; }();
+    const bool big = tile_env == 256 || (tile_env != 128 && a.nq > 128);
+    const uint64_t bm = big ? 256 : 128, bn = 256;
+    const uint64_t nb = (a.row_end - a.row_begin + bn - 1) / bn, ny = (a.nq + bm - 1) / bm;
+    const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    // 128-byte K stages for the 256 x 256 tile where the image rows are a multiple of them (PQV_BRUTE_STAGE=64 keeps 64)
+    static const int stage_env = [] { const char *e = std::getenv("PQV_BRUTE_STAGE"); return e ? std::atoi(e) : 0; }();
+    const uint64_t rbytes = i8 ? a.dim_p : (uint64_t)a.dim_p * 2;
+    const bool st8 = big && stage_env != 64 && (rbytes % 128) == 0;
+    auto launch = [&](auto kern, uint32_t threads, size_t lds) -> hipError_t {
+        if (lds > 65536) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+        }
+        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(threads), lds, s, a);
+        return hipGetLastError();
+    };
+    // the ring form (direct-to-LDS stages, loads in flight across the barriers) of the 256 x 256 tile measures the same as the
+    // register-staged one with 128-byte stages (C5, int8: 19.7 against 19.5 ms) -- opt-in: PQV_BRUTE_RING=1 (read per launch: tests)
+    const bool ring_env = [] { const char *e = std::getenv("PQV_BRUTE_RING"); return e && *e == '1'; }();
+    if (big && ring_env && (rbytes % 64) == 0) {
+        if (i8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4, 4>, 512, 4 * 512 * 4 * 16);
+        return launch(brute_f16_kernel<2, 4, 4, 2, false, 4, 4>, 512, 4 * 512 * 4 * 16);
+    }
+    // (measured and dropped: four waves of 128 x 128 -- 16 accumulator tiles per wave in AGPRs, one wave per SIMD, half the LDS
+    //  reads per MFMA: hipcc keeps 1 KB of scratch per lane for it and the launch takes 136 ms against 18.5)
+    if (i8) {
+        if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 8>, 512, 2 * 512 * 8 * 16);
+        if (big) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4>, 512, 2 * 512 * 4 * 16);
+        return launch(brute_f16_kernel<2, 2, 2, 4, true, 4>, 256, 2 * 384 * 4 * 16);
+    }
+    if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, false, 8>, 512, 2 * 512 * 8 * 16);
+    if (big) return launch(brute_f16_kernel<2, 4, 4, 2, false, 4>, 512, 2 * 512 * 4 * 16);
+    return launch(brute_f16_kernel<2, 2, 2, 4, false, 4>, 256, 2 * 384 * 4 * 16);
+}
+
+// int8 images of the L2-normalised rows (brute_f16_kernel<.., I8>): one wave per row.  v^ = row * rnorm (f32); b = the mid-range
+// of its components; S = 127 / max |v^_i - b|; image_i = rint((v^_i - b) S) (padding: 0); sr[r] = {1 / S, r_v, b, sum(v^)},
+// nrm[r] = n_v with r_v >= |(v^ - b 1) - image / S| (against the stored 1 / S) and n_v >= |v^ - b 1|, both rounded up.
+// A zero row has image 0 and r_v = n_v = 0 (its cosine is what the exact pass says); a row with a non-finite value gets
+// r_v = +inf and is never skipped.
+__global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restrict__ rows, const float *__restrict__ rnorm,
+                                                          uint64_t n, uint32_t dim, uint32_t dim_p, int8_t *__restrict__ out,
+                                                          float4 *__restrict__ sr, float *__restrict__ nrm, uint32_t *__restrict__ maxima) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    float mxA = 0.0f, mxB = 0.0f, mxC = 0.0f, mxE = 0.0f;       // corpus-wide maxima of |sum - b dim|, n + 3 r, |b|, r (brute_f16_kernel's quick screen)
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        const float rn = rnorm[r];
+        float mx = -3.0e38f, mn = 3.0e38f, sum = 0.0f;
+        bool bad = !(rn == rn) || rn > 3.0e38f;
+        for (uint32_t e = lane; e < dim; e += 64) {
+            const float v = p[e] * rn;
+            bad |= !(fabsf(v) <= 3.0e38f);
+            mx = fmaxf(mx, v); mn = fminf(mn, v); sum += v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64)); mn = fminf(mn, __shfl_xor(mn, off, 64)); sum += __shfl_xor(sum, off, 64);
+        }
+        bad = __any(bad);
+        const float b = bad ? 0.0f : 0.5f * (mx + mn);
+        const float half = bad ? 0.0f : fmaxf(mx - b, b - mn);
+        const float S = half > 0.0f ? 127.0f / half : 0.0f;
+        const float invS = S > 0.0f ? 1.0f / S : 0.0f;
+        float res2 = 0.0f, n2 = 0.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            const float v = (e < dim && !bad) ? p[e] * rn - b : 0.0f;
+            float qf = rintf(v * S);
+            qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+            out[r * dim_p + e] = (int8_t)(int)qf;
+            const float d = v - qf * invS;
+            res2 += d * d; n2 += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { res2 += __shfl_xor(res2, off, 64); n2 += __shfl_xor(n2, off, 64); }
+        const float rr = bad ? __builtin_inff() : sqrtf(res2) * 1.0001f + 1.0e-6f, nn = bad ? __builtin_inff() : sqrtf(n2) * 1.0001f + 1.0e-6f;
+        if (lane == 0) {
+            sr[r] = make_float4(invS, rr, b, bad ? 0.0f : sum);
+            nrm[r] = nn;
+        }
+        mxA = fmaxf(mxA, bad ? __builtin_inff() : fabsf(sum - b * (float)dim) * 1.00001f);
+        mxB = fmaxf(mxB, (nn + 3.0f * rr) * 1.00001f); mxC = fmaxf(mxC, fabsf(b)); mxE = fmaxf(mxE, rr * 1.00001f);
+    }
+    if (maxima && lane == 0) {        // non-negative floats (or +inf): their bit patterns order like the values
+        atomicMax(&maxima[0], __float_as_uint(mxA)); atomicMax(&maxima[1], __float_as_uint(mxB));
+        atomicMax(&maxima[2], __float_as_uint(mxC)); atomicMax(&maxima[3], __float_as_uint(mxE));
+    }
+}
+hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm, float *maxima, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(normalize_i8_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<int8_t *>(out), static_cast<float4 *>(sr), nrm, reinterpret_cast<uint32_t *>(maxima));
+    return hipGetLastError();
+}
+
+// L2-normalised f16 images (x 2^8), zero-padded to dim_p: one wave per row.  rnorm: 1 / |row| (0 for a zero row).
+__global__ __launch_bounds__(256) void normalize_f16_kernel(const float *__restrict__ rows, const float *__restrict__ rnorm,
+                                                           uint64_t n, uint32_t dim, uint32_t dim_p, uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        const float sc = rnorm[r] * 256.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            float v = e < dim ? p[e] * sc : 0.0f;
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);          // (a non-finite row: the exact pass decides)
+            const _Float16 h = (_Float16)v;
+            out[r * dim_p + e] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(normalize_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, rnorm, n, dim, dim_p, static_cast<uint16_t *>(out));
+    return hipGetLastError();
+}
+
+// exact f32 keys for the entries the f16 screen appended to the candidate buffers: entry slots [first[q], min(cnt[q], cap)),
+// one wave per entry (the row id sits in the entry's low word).  Same arithmetic as brute_mfma_kernel's epilogue on an
+// f32 dot product.
+__global__ __launch_bounds__(256) void brute_rescore_kernel(const BruteArgs a, const uint32_t *__restrict__ first) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.y;
+    uint32_t cnt = a.cand_cnt[q];
+    if (cnt > a.cap) cnt = a.cap;
+    const float *qp = a.queries + (uint64_t)q * a.dim;
+    const float qaux = a.query_aux[q];
+    for (uint32_t e = first[q] + blockIdx.x * 4u + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4u) {
+        unsigned long long *ent = a.cand + (uint64_t)q * a.cap + e;
+        const uint32_t row = (uint32_t)*ent;
+        const float *vp = a.rows + (uint64_t)row * a.dim;
+        float s = 0.0f;
+        if ((a.dim & 3u) == 0) {
+            for (uint32_t d = lane * 4; d < a.dim; d += 256) {
+                const float4 x = *reinterpret_cast<const float4 *>(qp + d), y = *reinterpret_cast<const float4 *>(vp + d);
+                s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+            }
+        } else {
+            for (uint32_t d = lane; d < a.dim; d += 64) s = fmaf(qp[d], vp[d], s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        float d;
+        const float vaux = a.row_aux[row];
+        if (a.metric == BRUTE_COSINE) d = 1.0f - s * qaux * vaux;
+        else { d = qaux + vaux - 2.0f * s; d = d < 0.0f ? 0.0f : d; }
+        if (lane == 0) *ent = ((unsigned long long)sortable_bits(d) << 32) | row;
+    }
+}
+hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(brute_rescore_kernel, dim3(32, a.nq), dim3(256), 0, s, a, first);
+    return hipGetLastError();
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void brute_select_kernel(unsigned long long *cand, uint32_t *cand_cnt,
+                                                         uint32_t cap, uint32_t k,
+                                                         unsigned long long *thr, uint32_t *overflow) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t cnt = cand_cnt[q];
+    if (cnt > cap) { if (lane == 0) atomicOr(overflow, 1u); return; }
+    unsigned long long *c = cand + (uint64_t)q * cap;
+    WaveTopk<S> tk;
+    tk.init();
+    for (uint32_t i = 0; i < cnt; i += 64) {
+        const uint64_t key = (i + lane < cnt) ? c[i + lane] : KEY_EMPTY;
+        tk.offer(key, 0u, k, lane);
+    }
+    uint32_t kept = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        const bool have = e < k && tk.key[s] != KEY_EMPTY;
+        kept += (uint32_t)__popcll(__ballot(have));
+        if (e < k) c[e] = tk.key[s];
+    }
+    if (lane == 0) {
+        cand_cnt[q] = kept;
+        thr[q] = kept >= k ? tk.kth(k) : KEY_EMPTY;
+    }
+}
+__global__ __launch_bounds__(256) void brute_overflow_kernel(const uint32_t *cand_cnt, uint32_t nq,
+                                                            uint32_t cap, uint32_t *overflow) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nq && cand_cnt[q] > cap) atomicOr(overflow, 1u);
+}
+hipError_t launch_brute_overflow_check(const uint32_t *cand_cnt, uint32_t nq, uint32_t cap, uint32_t *overflow,
+                                       hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(brute_overflow_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, cand_cnt, nq, cap, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_brute_select(unsigned long long *cand, uint32_t *cand_cnt, uint32_t cap, uint32_t nq,
+                               uint32_t k, unsigned long long *thr, uint32_t *overflow, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(brute_select_kernel<1>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else if (k <= 256) hipLaunchKernelGGL(brute_select_kernel<4>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else if (k <= 1024) hipLaunchKernelGGL(brute_select_kernel<16>, dim3(nq), dim3(64), 0, s, cand, cand_cnt, cap, k, thr, overflow);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void brute_finish_kernel(const unsigned long long *cand, const uint32_t *cand_cnt,
+                                                          uint32_t cap, uint32_t nq, uint32_t k,
+                                                          uint32_t *row_idx, float *dist, uint32_t *n_found) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)nq * k) return;
+    const uint32_t q = (uint32_t)(i / k), e = (uint32_t)(i % k);
+    const uint32_t cnt = cand_cnt[q] < k ? cand_cnt[q] : k;
+    if (e < cnt) {
+        const unsigned long long key = cand[(uint64_t)q * cap + e];
+        row_idx[i] = (uint32_t)key;
+        dist[i] = unsortable_bits((uint32_t)(key >> 32));
+    } else {
+        row_idx[i] = 0xFFFFFFFFu;
+        dist[i] = INFINITY;
+    }
+    if (e == 0 && n_found) n_found[q] = cnt;
+}
+hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *cand_cnt, uint32_t cap,
+                               uint32_t nq, uint32_t k, uint32_t *row_idx, float *dist, uint32_t *n_found,
+                               hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)nq * k;
+    hipLaunchKernelGGL(brute_finish_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, cand,
+                       cand_cnt, cap, nq, k, row_idx, dist, n_found);
+    return hipGetLastError();
+}
+
+
+}  // namespace pqv

@@ -1,0 +1,670 @@
+// kernels_build.hip -- index build (src/ivf/index.rs:323-457, :189-206): assign_f16_kernel + assign_rescore(_wave)_kernel (the k-means
+// assignment as an f16 contraction + exact re-scoring), assign_kernel (exact VALU form), lloyd_update_kernel, and the helpers of
+// the f32-screened assignment.
+#include "device_common.hpp"
+
+namespace pqv {
+
+// ------------------------------------------------------------------------------------
+// Round 3: the k-means assignment (index.rs:395-430 Lloyd, :189-206 + :244-257 final) as a dense contraction on the f16
+// matrix pipe + exact re-scoring -- the brute-force design with the roles swapped: every ROW keeps a threshold and a
+// candidate list, the CENTROIDS are the streamed side.
+//
+//   images      x^ = (x - mu) / |x - mu| * 2^8 in f16 for rows and centroids alike (mu: any fixed vector -- the distance is
+//               translation invariant; centring shrinks |x - mu| |c - mu| and with it the bound's slack)
+//   assign_f16_kernel   one block = 128 rows against ALL centroids, 256 at a time (4 waves as 2 x 2, 64 rows x 128
+//               centroids each, v_mfma_f32_32x32x16_f16, K in 32-value stages through double-buffered LDS).  With s~ the image
+//               dot product / 2^16:  d~ = |a|^2 + |b|^2 - 2 |a||b| s~,  |d~ - d| <= err = 2 |a||b| eps + 4e-6 (|a|^2 + |b|^2)
+//               (eps as in brute_f16_kernel), and the reference's computed distance lies within (1 +- cm) of d.  Per row the
+//               smallest UPPER bound seen so far is a running threshold (LDS); every centroid whose LOWER bound does not
+//               exceed it is appended to the row's candidate list.  The true argmin is never dropped: its lower bound is
+//               below its own upper bound, which is below every threshold the row ever had.
+//   assign_rescore_kernel   exact reference-order distances (index.rs:461-480) of a row's candidates, four lanes per row,
+//               argmin by (distance bits, centroid index) = strict '<' in ascending index order; a row whose list
+//               overflowed is compared with every centroid.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void assign_f16_kernel(const AssignF16Args a) {
+    __shared__ float4 As4[2][BH_BM * 4];
+    __shared__ float4 Bs4[2][BH_BN * 4];
+    __shared__ uint32_t thr_s[BH_BM];        // running threshold per row: bits of a non-negative float
+    __shared__ float xn2_s[BH_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint64_t m0 = (uint64_t)blockIdx.x * BH_BM;
+    const uint32_t dp = a.dim_p;
+    const int ld_r = tid >> 2, ld_ch = tid & 3;
+    float4 ra[2], rb[4];
+    const uint64_t qleft = (a.m - m0) * dp * 2;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(a.x16 + m0 * dp), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * dp * 2 + (uint32_t)ld_ch * 16, r64_b = 64u * dp * 2;
+    __shared__ float xs_s[BH_BM];            // |row - mu| (the square roots are taken once per row / centroid, not per pair)
+    if (tid < BH_BM) {
+        thr_s[tid] = 0x7F800000u;            // +inf
+        const float xn = m0 + tid < a.m ? a.xn2[m0 + tid] : 0.0f;
+        xn2_s[tid] = xn;
+        xs_s[tid] = sqrtf(xn) * 1.000001f;
+    }
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[2], rowb[4], swa[2], swb[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { rowa[t] = wm * 64 + t * 32 + l31; swa[t] = (rowa[t] >> 2) & 3; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { rowb[t] = wn * 128 + t * 32 + l31; swb[t] = (rowb[t] >> 2) & 3; }
+    const uint32_t nk = dp / BH_BK;
+    const float inv = 1.52587890625e-05f;    // 2^-16
+
+    for (uint32_t c0 = 0; c0 < a.kc; c0 += BH_BN) {
+        const uint64_t vleft = (uint64_t)(a.kc_pad - c0) * dp * 2;
+        const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(a.c16 + (uint64_t)c0 * dp), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+        auto fetch = [&](uint32_t k0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ra[h] = buf_ld16(qres, lane_b, k0 * 2 + h * r64_b);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) rb[h] = buf_ld16(vres, lane_b, k0 * 2 + h * r64_b);
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int r = ld_r + 64 * h; As4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = ra[h]; }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { const int r = ld_r + 64 * h; Bs4[buf][r * 4 + (ld_ch ^ ((r >> 2) & 3))] = rb[h]; }
+        };
+        f32x16_t acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (uint32_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1u);
+            if (kt + 1 < nk) fetch((kt + 1) * BH_BK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x8_t av[2], bv[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) av[t] = __builtin_bit_cast(f16x8_t, As4[buf][rowa[t] * 4 + ((2 * j + lk) ^ swa[t])]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = __builtin_bit_cast(f16x8_t, Bs4[buf][rowb[t] * 4 + ((2 * j + lk) ^ swb[t])]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+            }
+            if (kt + 1 < nk) stash(buf ^ 1);
+            __syncthreads();
+        }
+        // ---- bounds of this centroid tile.  C/D layout: col = lane & 31 (centroid), row = (r & 3) + 8 (r >> 2) + 4 lk
+        float cn2[4], cs[4];
+        bool cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t vj = c0 + wn * 128 + j * 32 + l31;
+            cv[j] = vj < a.kc;
+            cn2[j] = cv[j] ? a.cn2[vj] : 0.0f;
+            cs[j] = sqrtf(cn2[j]) * 1.000001f;
+        }
+        auto bounds = [&](int i, int j, int r, float &lb, float &ub) {
+            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float xn = xn2_s[ml], nn = xn + cn2[j];
+            const float qv = xs_s[ml] * cs[j];                      // >= |a| |b|
+            const float dt = nn - 2.0f * qv * (acc[i][j][r] * inv);
+            const float err = 2.0f * qv * a.eps + 4.0e-6f * nn;
+            ub = fmaxf(dt + err, 0.0f) * (1.0f + a.cm) + 1.0e-30f;
+            lb = fmaxf(dt - err, 0.0f) * (1.0f - a.cm);
+        };
+        // (1) the rows' running thresholds: smallest upper bound of this tile, reduced over the 32 centroid lanes
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float mn = INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lb, ub;
+                    bounds(i, j, r, lb, ub);
+                    if (cv[j] && ub < mn) mn = ub;                  // (a NaN bound never lowers a threshold)
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+                if (l31 == 0 && mn < INFINITY)
+                    atomicMin(&thr_s[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk], __float_as_uint(mn));
+            }
+        }
+        __syncthreads();
+        // (2) candidates: every centroid whose lower bound does not exceed its row's threshold (NaN bounds are kept)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float thr = __uint_as_float(thr_s[ml]);
+                const uint64_t row = m0 + ml;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lb, ub;
+                    bounds(i, j, r, lb, ub);
+                    if (cv[j] && row < a.m && !(lb > thr)) {
+                        const uint32_t slot = atomicAdd(&a.cand_cnt[row], 1u);
+                        if (slot < a.cap) a.cand[row * a.cap + slot] = c0 + wn * 128 + j * 32 + l31;
+                    }
+                }
+            }
+        }
+        __syncthreads();          // the LDS stages are reused by the next centroid tile
+    }
+}
+hipError_t launch_assign_f16(const AssignF16Args &a, hipStream_t s) {
+    if (a.m == 0 || a.kc == 0) return hipSuccess;
+    if ((a.dim_p % BH_BK) != 0 || (uint64_t)a.dim_p * 2 * 320 >= 0x7FFFFFFFull || (a.kc_pad % BH_BN) != 0 || a.kc_pad < a.kc)
+        return hipErrorInvalidValue;
+    const uint64_t blocks = (a.m + BH_BM - 1) / BH_BM;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assign_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// exact pass: four lanes per row, each walking candidates 4 t + (lane & 3) of its row in the reference's order
+__global__ __launch_bounds__(256) void assign_rescore_kernel(const float *__restrict__ rows, const float *__restrict__ centroids, uint64_t m,
+                                                            uint32_t dim, uint32_t kc, const uint32_t *__restrict__ cand,
+                                                            const uint32_t *__restrict__ cand_cnt, uint32_t cap, uint32_t *__restrict__ cluster) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (uint32_t)(lane >> 2);
+    const uint32_t cl = (uint32_t)lane & 3u;
+    const bool live = row < m;
+    uint32_t cnt = live ? cand_cnt[row] : 0u;
+    const bool all = cnt > cap;                       // list overflowed: every centroid is a candidate
+    if (all) cnt = kc;
+    const float *x = rows + (live ? row : 0) * dim;
+    const uint32_t G = dim >> 2;
+    uint64_t best = KEY_EMPTY;
+    uint32_t rounds = (cnt + 3) >> 2;
+    // (the loop count differs per lane: no cross-lane operation inside)
+    for (uint32_t t = 0; t < rounds; ++t) {
+        const uint32_t ci = 4 * t + cl;
+        if (ci >= cnt) break;
+        const uint32_t j = all ? ci : cand[row * cap + ci];
+        const float *c = centroids + (uint64_t)j * dim;
+        float sum = 0.0f;
+        uint32_t g = 0;
+        for (; g + 8 <= G; g += 8) {
+            float4 xv[8], cvv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = load4<true>(x + (g + u) * 4); cvv[u] = load4<true>(c + (g + u) * 4); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d0 = xv[u].x - cvv[u].x, d1 = xv[u].y - cvv[u].y, d2 = xv[u].z - cvv[u].z, d3 = xv[u].w - cvv[u].w;
+                float tt = d0 * d0 + d1 * d1;
+                tt = tt + d2 * d2;
+                sum = sum + (tt + d3 * d3);
+            }
+        }
+        for (; g < G; ++g) {
+            const float4 xv = load4<true>(x + g * 4), cv = load4<true>(c + g * 4);
+            const float d0 = xv.x - cv.x, d1 = xv.y - cv.y, d2 = xv.z - cv.z, d3 = xv.w - cv.w;
+            float tt = d0 * d0 + d1 * d1;
+            tt = tt + d2 * d2;
+            sum = sum + (tt + d3 * d3);
+        }
+        const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | j;
+        best = key < best ? key : best;
+    }
+    // the row's four lanes: smallest (distance bits, index) = strict '<' in ascending centroid order (index.rs:408-415)
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint64_t o = shfl_u64(best, lane ^ off);
+        best = o < best ? o : best;
+    }
+    if (live && cl == 0) cluster[row] = best == KEY_EMPTY ? 0u : (uint32_t)best;
+}
+// The same result with coalesced reads: a wave still owns 16 rows x 4 candidate slots per round, but the 64 lanes read one
+// row (and each of its candidates' centroids) 1 KB at a time -- lane g computes the 4-group term of group g -- and park the
+// terms in LDS [group][slot] (stride 65: conflict-free both ways); lane `slot` then adds its 64 terms in ascending group order,
+// which is the reference's chain (index.rs:461-480).  A row is read once for its four slots.
+__global__ __launch_bounds__(128) void assign_rescore_wave_kernel(const float *__restrict__ rows, const float *__restrict__ centroids, uint64_t m,
+                                                                 uint32_t dim, uint32_t kc, const uint32_t *__restrict__ cand,
+                                                                 const uint32_t *__restrict__ cand_cnt, uint32_t cap, uint32_t *__restrict__ cluster) {
+    __shared__ float lds_all[2][64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float *lds = lds_all[wv];
+    const uint64_t wave_row0 = ((uint64_t)blockIdx.x * 2 + (uint32_t)wv) * 16;
+    const uint64_t row = wave_row0 + (uint32_t)(lane >> 2);
+    const uint32_t cl = (uint32_t)lane & 3u;
+    const bool live = row < m;
+    uint32_t cnt = live ? cand_cnt[row] : 0u;
+    const bool all = cnt > cap;                       // list overflowed: every centroid is a candidate
+    if (all) cnt = kc;
+    const uint32_t G = dim >> 2;
+    uint64_t best = KEY_EMPTY;
+    for (uint32_t t = 0;; ++t) {
+        const uint32_t ci = 4 * t + cl;
+        const bool act = ci < cnt;
+        const uint64_t mask = __ballot(act);
+        if (mask == 0) break;
+        const uint32_t j = act ? (all ? ci : cand[row * cap + ci]) : 0u;
+        float sum = 0.0f;
+        for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+            const uint32_t ng = (G - g0 < 64u) ? (G - g0) : 64u;
+            const bool gv = (uint32_t)lane < ng;
+            const uint32_t goff = (g0 + (gv ? (uint32_t)lane : 0u)) * 4;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m4 = (uint32_t)(mask >> (4 * r)) & 0xFu;     // wave-uniform
+                if (m4 == 0) continue;
+                const float4 xv = load4<true>(rows + (wave_row0 + (uint32_t)r) * dim + goff);
+                float4 cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t jp = readlane_u32(j, 4 * r + u);
+                    cv[u] = load4<true>(centroids + (uint64_t)jp * dim + goff);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d0 = xv.x - cv[u].x, d1 = xv.y - cv[u].y, d2 = xv.z - cv[u].z, d3 = xv.w - cv[u].w;
+                    float tt = d0 * d0 + d1 * d1;
+                    tt = tt + d2 * d2;
+                    tt = tt + d3 * d3;
+                    if (gv) lds[lane * 65 + 4 * r + u] = tt;
+                }
+            }
+            wave_lds_fence();
+            uint32_t e = 0;
+            for (; e + 8 <= ng; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = lds[(e + u) * 65 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; e < ng; ++e) sum = sum + lds[e * 65 + lane];
+            wave_lds_fence();
+        }
+        if (act) {
+            const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | j;
+            best = key < best ? key : best;
+        }
+    }
+    // the row's four lanes: smallest (distance bits, index) = strict '<' in ascending centroid order (index.rs:408-415)
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint64_t o = shfl_u64(best, lane ^ off);
+        best = o < best ? o : best;
+    }
+    if (live && cl == 0) cluster[row] = best == KEY_EMPTY ? 0u : (uint32_t)best;
+}
+hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint64_t m, uint32_t dim, uint32_t kc, const uint32_t *cand,
+                                 const uint32_t *cand_cnt, uint32_t cap, uint32_t *cluster, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    if ((dim % 4) != 0) return hipErrorInvalidValue;
+    // PQV_RESCORE_WAVE=0: the lane-per-(row, candidate) form above (A/B)
+    static const bool wave_form = [] { const char *e = getenv("PQV_RESCORE_WAVE"); return !(e && *e == '0'); }();
+    if (wave_form && dim >= 64) {
+        const uint64_t wblocks = (m + 31) / 32;
+        if (wblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(assign_rescore_wave_kernel, dim3((uint32_t)wblocks), dim3(128), 0, s, rows, centroids, m, dim, kc, cand, cand_cnt, cap, cluster);
+        return hipGetLastError();
+    }
+    const uint64_t blocks = (m + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assign_rescore_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, centroids, m, dim, kc, cand, cand_cnt, cap, cluster);
+    return hipGetLastError();
+}
+
+// |row - mu|^2 and 1 / |row - mu| per row, and the f16 image of (row - mu) / |row - mu| * 2^8 zero-padded to dim_p:
+// one wave per row (mu == nullptr: no centring).  pad_to rows beyond n are written as zero rows (the centroid table is
+// padded to a multiple of 256 rows).
+__global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *__restrict__ rows, const float *__restrict__ mu, uint64_t n,
+                                                                  uint64_t n_pad, uint32_t dim, uint32_t dim_p, float *__restrict__ out_n2,
+                                                                  uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n_pad; r += nw) {
+        if (r >= n) {
+            for (uint32_t e = lane; e < dim_p; e += 64) out[r * dim_p + e] = 0;
+            continue;
+        }
+        const float *p = rows + r * dim;
+        float acc = 0.0f;
+        if ((dim & 7u) == 0 && dim <= 2048) {
+            // 8 values (two 16-byte loads) per lane and step, kept in registers between the norm and the scaling pass
+            float4 v[4][2];
+            const uint32_t G8 = dim >> 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t g = (uint32_t)lane + 64u * (uint32_t)u;
+                if (g < G8) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(p + g * 8);
+                    float4 a0 = pp[0], a1 = pp[1];
+                    if (mu) {
+                        const float4 *mm = reinterpret_cast<const float4 *>(mu + g * 8);
+                        const float4 m0 = mm[0], m1 = mm[1];
+                        a0.x -= m0.x; a0.y -= m0.y; a0.z -= m0.z; a0.w -= m0.w; a1.x -= m1.x; a1.y -= m1.y; a1.z -= m1.z; a1.w -= m1.w;
+                    }
+                    v[u][0] = a0; v[u][1] = a1;
+                    acc = fmaf(a0.x, a0.x, acc); acc = fmaf(a0.y, a0.y, acc); acc = fmaf(a0.z, a0.z, acc); acc = fmaf(a0.w, a0.w, acc);
+                    acc = fmaf(a1.x, a1.x, acc); acc = fmaf(a1.y, a1.y, acc); acc = fmaf(a1.z, a1.z, acc); acc = fmaf(a1.w, a1.w, acc);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) out_n2[r] = acc;
+            const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+            auto cl = [&](float x) { return fminf(fmaxf(x * sc, -65504.0f), 65504.0f); };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t g = (uint32_t)lane + 64u * (uint32_t)u;
+                if (g < (dim_p >> 3)) {
+                    f16x8_t h = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (g < G8) {
+                        h[0] = (_Float16)cl(v[u][0].x); h[1] = (_Float16)cl(v[u][0].y); h[2] = (_Float16)cl(v[u][0].z); h[3] = (_Float16)cl(v[u][0].w);
+                        h[4] = (_Float16)cl(v[u][1].x); h[5] = (_Float16)cl(v[u][1].y); h[6] = (_Float16)cl(v[u][1].z); h[7] = (_Float16)cl(v[u][1].w);
+                    }
+                    *reinterpret_cast<float4 *>(out + r * dim_p + g * 8) = __builtin_bit_cast(float4, h);
+                }
+            }
+            continue;
+        }
+        for (uint32_t e = lane; e < dim; e += 64) { const float v = p[e] - (mu ? mu[e] : 0.0f); acc = fmaf(v, v, acc); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out_n2[r] = acc;
+        const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+        for (uint32_t e = lane; e < dim_p; e += 64) {
+            float v = e < dim ? (p[e] - (mu ? mu[e] : 0.0f)) * sc : 0.0f;
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            const _Float16 h = (_Float16)v;
+            out[r * dim_p + e] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint64_t n, uint64_t n_pad, uint32_t dim, uint32_t dim_p,
+                                       float *out_n2, void *out, hipStream_t s) {
+    if (n_pad == 0) return hipSuccess;
+    uint64_t blocks = (n_pad + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(center_normalize_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, mu, n, n_pad, dim, dim_p, out_n2,
+                       static_cast<uint16_t *>(out));
+    return hipGetLastError();
+}
+// mu[d] = mean over the k rows of m[., d]: one block per 64 columns, four row slices per column reduced through LDS
+__global__ __launch_bounds__(256) void col_mean_kernel(const float *__restrict__ m, uint32_t k, uint32_t dim, float *__restrict__ mu) {
+    __shared__ float part[4][64];
+    const uint32_t d = blockIdx.x * 64u + (threadIdx.x & 63u), sl = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (d < dim)
+        for (uint32_t r = sl; r < k; r += 4) acc += m[(uint64_t)r * dim + d];
+    part[sl][threadIdx.x & 63u] = acc;
+    __syncthreads();
+    if (sl == 0 && d < dim) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        mu[d] = k ? t / (float)k : 0.0f;
+    }
+}
+hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s) {
+    if (dim == 0) return hipSuccess;
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, m, k, dim, mu);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Helpers of the MFMA-screened assignment (api.cpp: assign_screened): the k-means assignment of a
+// chunk of rows is the top-1 search of every row among the centroids, i.e. the wide screened path
+// with the rows as queries and ONE list holding all centroids.
+//   assign_setup_kernel : identity bucketing (pair i = query i, quads of `width` consecutive queries of
+//                         cluster 0), candidate bases 0, thresholds EMPTY
+//   nonfinite_flag_kernel / count_changed_kernel : see the launchers' comments in kernels.h
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assign_setup_kernel(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base,
+                                                          unsigned long long *gthr, uint32_t nq, uint32_t width) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *n_quads = (nq + width - 1) / width;
+    if (i >= nq) return;
+    pairs[i] = i;
+    cand_base[i] = 0;
+    gthr[i] = ~0ull;
+    if (i % width == 0) quads[i / width] = make_uint4(0u, i, nq - i < width ? nq - i : width, 0u);
+}
+hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base, unsigned long long *gthr,
+                               uint32_t nq, uint32_t width, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(assign_setup_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pairs, quads, n_quads, cand_base, gthr, nq, width);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *v, uint64_t n, uint32_t *flag) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bad |= !(fabsf(v[i]) < INFINITY);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, v, n, flag);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void count_changed_kernel(const uint32_t *cur, const uint32_t *prev, uint64_t n,
+                                                           unsigned long long *changed) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += cur[i] != prev[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_down((int)c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(changed, (unsigned long long)c);
+}
+hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(count_changed_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, cur, prev, n, changed);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// assign_kernel: Lloyd assign + final assignment (index.rs:395-424, :189-201, :244-257).
+// Same skeleton as the tile re-rank: lane-per-row, 128 B of the lane's own row per step, a
+// tile of CT centroids applied to it as wave-uniform scalar operands through the rolled,
+// software-pipelined loop (two chunk register sets ping-ponging behind lgkmcnt(0) waits),
+// running sums in LDS (lsums[centroid][lane]).  Every (row, centroid) chain is summed in
+// ascending group order exactly as squared_l2_distance does; the argmin uses strict '<' in
+// ascending centroid order.  Exact-order f32 VALU-bound.
+// ------------------------------------------------------------------------------------
+template <int CT, bool ALIGNED>
+__global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ rows, uint64_t n,
+                                                    uint32_t dim,
+                                                    const float *__restrict__ cent, uint32_t k,
+                                                    uint32_t *__restrict__ cluster,
+                                                    const uint32_t *__restrict__ prev,
+                                                    unsigned long long *__restrict__ changed,
+                                                    unsigned long long *__restrict__ sizes) {
+    __shared__ float lsums_all[4 * CT * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *lsums = lsums_all + wave * (CT * 64);
+
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r < n;
+    const float *x = rows + (valid ? r : (n - 1)) * dim;
+    const uint32_t G = dim >> 2, tail = dim & 3u;
+    float best = INFINITY;
+    uint32_t bestc = 0;
+
+    for (uint32_t c0 = 0; c0 < k; c0 += CT) {
+        const uint32_t cnt = (k - c0 < (uint32_t)CT) ? (k - c0) : (uint32_t)CT;
+        uint32_t g0 = 0;
+        for (; g0 + 8 <= G; g0 += 8) {
+            float4 xv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) xv[g] = load4<ALIGNED>(x + (g0 + g) * 4);
+            float4 qa[8], qb[8];
+            {
+                const float *cp = cent + (uint64_t)c0 * dim + g0 * 4;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(cp + g * 4);
+            }
+            uint32_t cc = 0;
+#pragma unroll 1
+            for (; cc + 2 <= cnt; cc += 2) {
+                float acc0 = g0 ? lsums[cc * 64 + lane] : 0.0f;
+                float acc1 = g0 ? lsums[(cc + 1) * 64 + lane] : 0.0f;
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+                {
+                    const float *cp = cent + (uint64_t)(c0 + cc + 1) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qb[g] = load4_uniform<ALIGNED>(cp + g * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = xv[g].x - qa[g].x, d1 = xv[g].y - qa[g].y;
+                    const float d2 = xv[g].z - qa[g].z, d3 = xv[g].w - qa[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc0 = acc0 + t;
+                }
+                lsums[cc * 64 + lane] = acc0;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                {
+                    const uint32_t nc2 = cc + 2 < cnt ? cc + 2 : cnt - 1;
+                    const float *cp = cent + (uint64_t)(c0 + nc2) * dim + g0 * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) qa[g] = load4_uniform<ALIGNED>(cp + g * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = xv[g].x - qb[g].x, d1 = xv[g].y - qb[g].y;
+                    const float d2 = xv[g].z - qb[g].z, d3 = xv[g].w - qb[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc1 = acc1 + t;
+                }
+                lsums[(cc + 1) * 64 + lane] = acc1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cc < cnt) {
+                float acc = g0 ? lsums[cc * 64 + lane] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float d0 = xv[g].x - qa[g].x, d1 = xv[g].y - qa[g].y;
+                    const float d2 = xv[g].z - qa[g].z, d3 = xv[g].w - qa[g].w;
+                    float t = d0 * d0 + d1 * d1;
+                    t = t + d2 * d2;
+                    t = t + d3 * d3;
+                    acc = acc + t;
+                }
+                lsums[cc * 64 + lane] = acc;
+            }
+        }
+        for (; g0 < G; ++g0) {
+            const float4 xg = load4<ALIGNED>(x + g0 * 4);
+#pragma unroll 1
+            for (uint32_t cc = 0; cc < cnt; ++cc) {
+                const float4 cv = load4_uniform<ALIGNED>(cent + (uint64_t)(c0 + cc) * dim + g0 * 4);
+                const float d0 = xg.x - cv.x, d1 = xg.y - cv.y;
+                const float d2 = xg.z - cv.z, d3 = xg.w - cv.w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                const float acc = g0 ? lsums[cc * 64 + lane] : 0.0f;
+                lsums[cc * 64 + lane] = acc + t;
+            }
+        }
+        for (uint32_t e = 0; e < tail; ++e) {
+            const float xe = x[G * 4 + e];
+#pragma unroll 1
+            for (uint32_t cc = 0; cc < cnt; ++cc) {
+                const float d = xe - load1_uniform(cent + (uint64_t)(c0 + cc) * dim + G * 4 + e);
+                const float acc = (G || e) ? lsums[cc * 64 + lane] : 0.0f;
+                lsums[cc * 64 + lane] = acc + d * d;
+            }
+        }
+        wave_lds_fence();
+#pragma unroll 1
+        for (uint32_t cc = 0; cc < cnt; ++cc) {
+            const float v = lsums[cc * 64 + lane];
+            if (v < best) { best = v; bestc = c0 + cc; }   // strict '<': lowest centroid wins ties
+        }
+        wave_lds_fence();
+    }
+
+    if (valid) cluster[r] = bestc;
+    // counters: one atomic per wave and distinct cluster / per wave (every row adding to `changed` and to a
+    // hundred cluster sizes on four cache lines serialises at the memory side)
+    if (sizes) {
+        unsigned long long m = __ballot(valid);
+        while (m) {
+            const uint32_t c = readlane_u32(bestc, __builtin_ctzll(m));
+            const unsigned long long same = __ballot(valid && bestc == c);
+            if (lane == __builtin_ctzll(m)) atomicAdd(&sizes[c], (unsigned long long)__popcll(same));
+            m &= ~same;
+        }
+    }
+    if (prev && changed) {
+        const unsigned long long ch = __ballot(valid && prev[r] != bestc);
+        if (lane == 0 && ch) atomicAdd(changed, (unsigned long long)__popcll(ch));
+    }
+}
+
+hipError_t launch_assign(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
+                         uint32_t k, uint32_t *cluster, const uint32_t *prev,
+                         unsigned long long *changed, unsigned long long *sizes, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL((assign_kernel<32, true>), dim3((uint32_t)blocks), dim3(256), 0, s, rows,
+                           n, dim, centroids, k, cluster, prev, changed, sizes);
+    else
+        hipLaunchKernelGGL((assign_kernel<32, false>), dim3((uint32_t)blocks), dim3(256), 0, s, rows,
+                           n, dim, centroids, k, cluster, prev, changed, sizes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// lloyd_update: thread (c, j) adds x[r][j] over cluster c's rows in ascending r -- the
+// same per-element add order as the reference's single-threaded loop (index.rs:438-444)
+// -- then divides by the size (index.rs:446-453); empty clusters stay all-zero.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lloyd_update_kernel(const float *__restrict__ rows,
+                                                          uint32_t dim,
+                                                          const uint32_t *__restrict__ list_rows,
+                                                          const uint64_t *__restrict__ list_off,
+                                                          float *__restrict__ centroids) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t jj = blockIdx.y * 256 + threadIdx.x;
+    if (jj >= dim) return;
+    const uint64_t b = list_off[c], e = list_off[c + 1];
+    float acc = 0.0f;
+    uint64_t i = b;
+    for (; i + 4 <= e; i += 4) {
+        const float v0 = rows[(uint64_t)list_rows[i] * dim + jj];
+        const float v1 = rows[(uint64_t)list_rows[i + 1] * dim + jj];
+        const float v2 = rows[(uint64_t)list_rows[i + 2] * dim + jj];
+        const float v3 = rows[(uint64_t)list_rows[i + 3] * dim + jj];
+        acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+    }
+    for (; i < e; ++i) acc = acc + rows[(uint64_t)list_rows[i] * dim + jj];
+    if (e > b) acc = div_f32_ieee(acc, (float)(e - b));
+    centroids[(uint64_t)c * dim + jj] = acc;
+}
+
+hipError_t launch_lloyd_update(const float *rows, uint32_t dim, const uint32_t *list_rows,
+                               const uint64_t *list_off, uint32_t k, float *centroids,
+                               hipStream_t s) {
+    if (k == 0) return hipSuccess;
+    dim3 grid(k, (dim + 255) / 256);
+    hipLaunchKernelGGL(lloyd_update_kernel, grid, dim3(256), 0, s, rows, dim, list_rows, list_off,
+                       centroids);
+    return hipGetLastError();
+}
+
+
+}  // namespace pqv

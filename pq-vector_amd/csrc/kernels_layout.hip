@@ -1,0 +1,651 @@
+// kernels_layout.hip -- layout and plumbing kernels: row norms, the blocked MFMA-operand images of the inverted lists (f32 / f16 /
+// int8 residual form), the shard merge of the multi-GPU exchange, pqv_rerank's state handling, gathers / pads / narrowing.
+#include "device_common.hpp"
+
+namespace pqv {
+
+// one wave per row; f32 partial sums, wave-reduced
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ rows, uint64_t n,
+                                                       uint32_t dim, int mode, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + r * dim;
+        float acc = 0.0f;
+        if (mode == 2) {                 // max |x_i| (NaN propagates as NaN-free max; non-finite rows are caught by their norm)
+            for (uint32_t e = lane; e < dim; e += 64) acc = fmaxf(acc, fabsf(p[e]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc = fmaxf(acc, __shfl_xor(acc, off, 64));
+            if (lane == 0) out[r] = acc;
+            continue;
+        }
+        for (uint32_t e = lane; e < dim; e += 64) acc = fmaf(p[e], p[e], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out[r] = mode == 0 ? (acc > 0.0f ? 1.0f / sqrtf(acc) : 0.0f) : acc;
+    }
+}
+// searcher creation: |x|^2 of every listed row and the maximum |x_i| over them in ONE pass (row r = source row row_of[r]); a
+// wave per row, 16-byte loads where dim % 4 == 0
+__global__ __launch_bounds__(256) void row_norms_max_kernel(const float *__restrict__ rows, const uint32_t *__restrict__ row_of, uint64_t n,
+                                                           uint32_t dim, float *__restrict__ out, uint32_t *__restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    uint32_t m = 0;
+    for (uint64_t r = w; r < n; r += nw) {
+        const float *p = rows + (uint64_t)(row_of ? row_of[r] : r) * dim;
+        float acc = 0.0f;
+        if ((dim & 3u) == 0u) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(p);
+            for (uint32_t e = lane; e < (dim >> 2); e += 64) {
+                const float4 v = p4[e];
+                acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+                const uint32_t b0 = __float_as_uint(v.x) & 0x7FFFFFFFu, b1 = __float_as_uint(v.y) & 0x7FFFFFFFu;
+                const uint32_t b2 = __float_as_uint(v.z) & 0x7FFFFFFFu, b3 = __float_as_uint(v.w) & 0x7FFFFFFFu;
+                const uint32_t b01 = b0 > b1 ? b0 : b1, b23 = b2 > b3 ? b2 : b3, bb = b01 > b23 ? b01 : b23;
+                m = bb > m ? bb : m;
+            }
+        } else {
+            for (uint32_t e = lane; e < dim; e += 64) {
+                const float v = p[e];
+                acc = fmaf(v, v, acc);
+                const uint32_t b = __float_as_uint(v) & 0x7FFFFFFFu;
+                m = b > m ? b : m;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out[r] = acc;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+    __shared__ uint32_t wm[4];
+    if (lane == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
+        const uint32_t mm = a01 > a23 ? a01 : a23;
+        if (mm) atomicMax(max_bits, mm);
+    }
+}
+hipError_t launch_row_norms_max(const float *rows, const uint32_t *row_of, uint64_t n, uint32_t dim, float *out_norm2, uint32_t *max_bits,
+                                hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_norms_max_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, row_of, n, dim, out_norm2, max_bits);
+    return hipGetLastError();
+}
+hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, n, dim, mode, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// shard_merge_kernel: the exchange step of the sharded search (one list per GPU/file, merged
+// like the reference's single heap over all files, src/df_vector/exec.rs:264-267).
+// ------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(64) void shard_merge_kernel(const float *__restrict__ dist,
+                                                        const uint32_t *__restrict__ rows,
+                                                        const long long *__restrict__ row_base,
+                                                        uint32_t n_shards, uint32_t nq, uint32_t k,
+                                                        float *__restrict__ out_dist,
+                                                        long long *__restrict__ out_rows, uint32_t stride) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    WaveTopk<S> tk;
+    tk.init();
+    const uint32_t total = n_shards * k;
+    for (uint32_t i = 0; i < total; i += 64) {
+        const uint32_t idx = i + lane;
+        uint64_t key = KEY_EMPTY;
+        uint32_t val = 0xFFFFFFFFu;
+        if (idx < total) {
+            const uint32_t sh = idx / k, e = idx % k;
+            const uint64_t src = (((uint64_t)sh * nq + q) * k + e) * stride;
+            const uint32_t r = rows[src];
+            if (r != 0xFFFFFFFFu) {
+                key = ((uint64_t)sortable_bits(dist[src]) << 32) | (uint64_t)idx;   // idx = shard * k + position
+                val = idx;
+            }
+        }
+        tk.offer(key, val, k, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t e = s * 64 + lane;
+        if (e < k) {
+            float d = INFINITY;
+            long long gr = -1;
+            if (tk.key[s] != KEY_EMPTY) {
+                const uint32_t idx = tk.val[s];
+                const uint64_t src = (((uint64_t)(idx / k) * nq + q) * k + (idx % k)) * stride;
+                d = dist[src];
+                gr = row_base[idx / k] + (long long)rows[src];
+            }
+            out_dist[(uint64_t)q * k + e] = d;
+            out_rows[(uint64_t)q * k + e] = gr;
+        }
+    }
+}
+
+hipError_t launch_shard_merge(const float *dist, const uint32_t *rows, const long long *row_base,
+                              uint32_t n_shards, uint32_t nq, uint32_t k, float *out_dist,
+                              long long *out_rows, hipStream_t s, uint32_t stride) {
+    if (nq == 0) return hipSuccess;
+    if (k <= 64) hipLaunchKernelGGL(shard_merge_kernel<1>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
+    else if (k <= 256) hipLaunchKernelGGL(shard_merge_kernel<4>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
+    else if (k <= 1024) hipLaunchKernelGGL(shard_merge_kernel<16>, dim3(nq), dim3(64), 0, s, dist, rows, row_base, n_shards, nq, k, out_dist, out_rows, stride);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// {f32 distance, u32 row} of every result as ONE 8-byte element: the send buffer of the shard exchange's single all-gather
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ rows,
+                                                        uint64_t n, uint2 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_uint2(__float_as_uint(dist[i]), rows[i]);
+}
+hipError_t launch_pack_pairs(const float *dist, const uint32_t *rows, uint64_t n, void *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist, rows, n, static_cast<uint2 *>(out));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// block_rows_kernel: the MFMA-operand copy of the IVF-ordered lists.  Every list is cut into
+// 16-row tiles (the last one zero-padded); tile T stores 16-byte column ch of its row j at float4
+// index (T * G + ch) * 16 + j, so a 16x16x4 MFMA operand fetch (16 rows x 4 columns) is one
+// contiguous 1 KiB read.  grid = (tiles of the longest list, n_clusters).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_rows_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                        const uint64_t *__restrict__ blk_off, uint32_t dim,
+                                                        float4 *__restrict__ out, const uint32_t *__restrict__ row_of) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 2;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        float4 *dst = out + (blk_off[c] + tl) * G * 16;
+        for (uint32_t e = threadIdx.x; e < G * 16; e += 256) {
+            const uint32_t ch = e >> 4, j = e & 15;
+            const uint64_t p = tl * 16 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < len) v = *reinterpret_cast<const float4 *>(src + (uint64_t)(row_of ? row_of[lbeg + p] : lbeg + p) * dim + ch * 4);
+            dst[e] = v;
+        }
+    }
+}
+hipError_t launch_block_rows(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                             uint64_t max_tiles, uint32_t dim, void *out, hipStream_t s, const uint32_t *row_of) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(block_rows_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim,
+                       static_cast<float4 *>(out), row_of);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pack_queries_kernel: the blocked (MFMA A-operand) copy of every quad's queries, for rows too long
+// for LDS staging: q_blk[((quad * NG + g) * G + ch) * 16 + i] = 16-byte column ch of query 16 g + i
+// of the quad (queries past the quad's count alias its last one; they are masked by the kernels).
+// grid = max_quads blocks.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_queries_kernel(const float *__restrict__ queries, const uint32_t *__restrict__ pairs,
+                                                          const uint4 *__restrict__ quads, const uint32_t *__restrict__ n_quads,
+                                                          uint32_t nprobe, uint32_t dim, uint32_t ngrp,
+                                                          float4 *__restrict__ q_blk) {
+    if (blockIdx.x >= *n_quads) return;
+    const uint4 quad = quads[blockIdx.x];
+    const uint32_t p0 = quad.y, cnt = quad.z, G = dim >> 2;
+    float4 *dst = q_blk + (uint64_t)blockIdx.x * ngrp * G * 16;
+    const uint32_t total = ngrp * G * 16;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t i = e & 15u, ch = (e >> 4) % G, g = (e >> 4) / G;
+        const uint32_t q = 16 * g + i;
+        const uint32_t qrow = pairs[p0 + (q < cnt ? q : cnt - 1)] / nprobe;
+        dst[e] = *reinterpret_cast<const float4 *>(queries + (uint64_t)qrow * dim + ch * 4);
+    }
+}
+hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, const uint4 *quads, const uint32_t *n_quads,
+                               uint32_t max_quads, uint32_t nprobe, uint32_t dim, uint32_t ngrp, void *q_blk, hipStream_t s) {
+    if (max_quads == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(max_quads), dim3(256), 0, s, queries, pairs, quads, n_quads, nprobe, dim, ngrp,
+                       static_cast<float4 *>(q_blk));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// block_rows_f16_kernel: the f16 form of the blocked operand copy.  Values are multiplied by `scale` (a
+// power of two chosen so that the corpus maximum lands below 2^14: exact, no overflow) and rounded to
+// nearest f16; a 16-byte column holds 8 consecutive dims, tile T stores column cc of its row j at 16-byte
+// index (T * dim/8 + cc) * 16 + j -- a 16x16x32 MFMA operand fetch (16 rows x 4 columns) is one 1 KiB read.
+// maxabs_kernel: *out = max(*out, bits(max |v|)) (non-negative floats order like their bit patterns).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_rows_f16_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                            const uint64_t *__restrict__ blk_off, uint32_t dim, float scale,
+                                                            float4 *__restrict__ out, const uint32_t *__restrict__ row_of) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 3;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        float4 *dst = out + (blk_off[c] + tl) * G * 16;
+        for (uint32_t e = threadIdx.x; e < G * 16; e += 256) {
+            const uint32_t cc = e >> 4, j = e & 15;
+            const uint64_t p = tl * 16 + j;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (p < len) {
+                const float4 *r = reinterpret_cast<const float4 *>(src + (uint64_t)(row_of ? row_of[lbeg + p] : lbeg + p) * dim + cc * 8);
+                lo = r[0]; hi = r[1];
+            }
+            dst[e] = pack_f16x8(lo, hi, scale);
+        }
+    }
+}
+hipError_t launch_block_rows_f16(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                 uint64_t max_tiles, uint32_t dim, float scale, void *out, hipStream_t s, const uint32_t *row_of) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    if (dim % 8) return hipErrorInvalidValue;
+    const uint32_t gx = (uint32_t)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(block_rows_f16_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, scale,
+                       static_cast<float4 *>(out), row_of);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void maxabs_kernel(const float *v, uint64_t n, uint32_t *out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(v[i]) & 0x7FFFFFFFu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_down((int)m, off, 64); m = o > m ? o : m; }
+    __shared__ uint32_t wm[4];                       // one atomic per block, not per wave: a single address
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
+        const uint32_t mm = a01 > a23 ? a01 : a23;
+        if (mm) atomicMax(out, mm);
+    }
+}
+hipError_t launch_maxabs(const float *v, uint64_t n, uint32_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(maxabs_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, v, n, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// int8 form of the blocked operand copy (wide_filter_kernel<.., OP_I8>).
+//   col_minmax_kernel      per-dimension minimum and maximum of the stored rows, as order-preserving uint keys
+//                          (sortable_bits) so plain atomicMin / atomicMax work for any sign
+//   block_rows_i8_kernel   xi = clamp(rint((x - c) S), -127, 127) with c the per-dimension mid-range and S one global
+//                          scale; a 16-byte column holds 16 consecutive dims, tile T stores column cc of its row j at
+//                          16-byte index (T * dim/16 + cc) * 16 + j -- a 16x16x64 MFMA operand fetch (16 rows x 4
+//                          columns) is one 1 KiB read.  Per row also Nx = |xi|^2 (exact) and an UPPER bound of the
+//                          residual norm |x - c - xi / S| (f32 sum + 0.1 % + the rounding of the residuals themselves).
+//   quantize_queries_i8_kernel   the same image of every query of a batch (row-major [nq, dim] int8), |qi|^2 and the
+//                          residual bound; a query with a non-finite component gets +inf (never skipped).
+// ------------------------------------------------------------------------------------
+// per-list, per-dimension minimum / maximum of the stored rows: grid (row chunks, lists), a thread per dimension
+__global__ __launch_bounds__(256) void list_minmax_kernel(const float *__restrict__ rows, const uint64_t *__restrict__ list_off,
+                                                         uint32_t dim, uint32_t chunk_rows, uint32_t *__restrict__ kmin,
+                                                         uint32_t *__restrict__ kmax, const uint32_t *__restrict__ row_of) {
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], lend = list_off[c + 1];
+    for (uint64_t r0 = lbeg + (uint64_t)blockIdx.x * chunk_rows; r0 < lend; r0 += (uint64_t)gridDim.x * chunk_rows) {
+        const uint64_t r1 = r0 + chunk_rows < lend ? r0 + chunk_rows : lend;
+        for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+            for (uint64_t r = r0; r < r1; ++r) {
+                const uint32_t kb = sortable_bits(rows[(uint64_t)(row_of ? row_of[r] : r) * dim + d]);
+                lo = kb < lo ? kb : lo;
+                hi = kb > hi ? kb : hi;
+            }
+            atomicMin(&kmin[(uint64_t)c * dim + d], lo);
+            atomicMax(&kmax[(uint64_t)c * dim + d], hi);
+        }
+    }
+}
+hipError_t launch_list_minmax(const float *rows, const uint64_t *list_off, uint32_t n_clusters, uint64_t max_list_len, uint32_t dim,
+                              uint32_t *kmin, uint32_t *kmax, hipStream_t s, const uint32_t *row_of) {
+    if (n_clusters == 0 || max_list_len == 0) return hipSuccess;
+    const uint32_t chunk = 1024;
+    const uint64_t gx = (max_list_len + chunk - 1) / chunk;
+    hipLaunchKernelGGL(list_minmax_kernel, dim3((uint32_t)(gx < 64 ? gx : 64), n_clusters), dim3(256), 0, s, rows, list_off, dim, chunk, kmin, kmax, row_of);
+    return hipGetLastError();
+}
+// centre[c][d] = (min + max) / 2 of list c, half[c] = its largest |x - centre| component, scale[c] = 127 / half (a list
+// whose rows all equal the centre, or an empty one, gets scale 1; the scale is capped so that its square stays finite);
+// radius[c] = 0 (block_rows_i8_kernel raises it).  One block per list.
+__global__ __launch_bounds__(256) void list_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax, uint32_t dim,
+                                                         const uint64_t *__restrict__ list_off, float *__restrict__ center,
+                                                         float *__restrict__ half, float *__restrict__ scale, float *__restrict__ radius) {
+    __shared__ float wm[4];
+    const uint32_t c = blockIdx.x;
+    const bool empty = list_off[c + 1] == list_off[c];
+    float h = 0.0f;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        float ctr = 0.0f;
+        if (!empty) {
+            const float lo = unsortable_bits(kmin[(uint64_t)c * dim + d]), hi = unsortable_bits(kmax[(uint64_t)c * dim + d]);
+            ctr = 0.5f * lo + 0.5f * hi;
+            h = fmaxf(h, fabsf(fmaxf(hi - ctr, ctr - lo)));
+        }
+        center[(uint64_t)c * dim + d] = ctr;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h = fmaxf(h, __shfl_xor(h, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        half[c] = h;
+        float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+        if (!(sc < 1.0e15f)) sc = 1.0e15f;
+        if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
+        scale[c] = sc;
+        radius[c] = 0.0f;
+    }
+}
+hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                              float *center, float *half, float *scale, float *radius, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(list_center_kernel, dim3(n_clusters), dim3(256), 0, s, kmin, kmax, dim, list_off, center, half, scale, radius);
+    return hipGetLastError();
+}
+
+// The one-centre form (round 2's): per-dimension min / max over ALL lists -> centre and scale in entry 0 of scratch
+// tables (global_center_kernel), and, if that form is chosen, every list's entry overwritten with them
+// (broadcast_center_kernel) -- block_rows_i8_kernel and the screen kernels then need no second code path.
+__global__ __launch_bounds__(256) void global_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
+                                                           uint32_t n_clusters, uint32_t dim, const uint64_t *__restrict__ list_off,
+                                                           float *__restrict__ g_center, float *__restrict__ g_half_scale) {
+    __shared__ float wm[4];
+    float h = 0.0f;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (list_off[c + 1] == list_off[c]) continue;
+            const uint32_t a = kmin[(uint64_t)c * dim + d], b = kmax[(uint64_t)c * dim + d];
+            lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+        }
+        float ctr = 0.0f;
+        if (lo <= hi) {
+            const float flo = unsortable_bits(lo), fhi = unsortable_bits(hi);
+            ctr = 0.5f * flo + 0.5f * fhi;
+            h = fmaxf(h, fabsf(fmaxf(fhi - ctr, ctr - flo)));
+        }
+        g_center[d] = ctr;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h = fmaxf(h, __shfl_xor(h, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+        if (!(sc < 1.0e15f)) sc = 1.0e15f;
+        if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
+        g_half_scale[0] = h; g_half_scale[1] = sc;
+    }
+}
+__global__ __launch_bounds__(256) void broadcast_center_kernel(const float *__restrict__ g_center, const float *__restrict__ g_half_scale,
+                                                              uint32_t dim, float *__restrict__ center, float *__restrict__ half,
+                                                              float *__restrict__ scale) {
+    const uint32_t c = blockIdx.x;
+    for (uint32_t d = threadIdx.x; d < dim; d += 256) center[(uint64_t)c * dim + d] = g_center[d];
+    if (threadIdx.x == 0) { half[c] = g_half_scale[0]; scale[c] = g_half_scale[1]; }
+}
+hipError_t launch_global_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
+                                float *g_center, float *g_half_scale, hipStream_t s) {
+    hipLaunchKernelGGL(global_center_kernel, dim3(1), dim3(256), 0, s, kmin, kmax, n_clusters, dim, list_off, g_center, g_half_scale);
+    return hipGetLastError();
+}
+hipError_t launch_broadcast_center(const float *g_center, const float *g_half_scale, uint32_t n_clusters, uint32_t dim, float *center,
+                                   float *half, float *scale, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(broadcast_center_kernel, dim3(n_clusters), dim3(256), 0, s, g_center, g_half_scale, dim, center, half, scale);
+    return hipGetLastError();
+}
+
+// xi = clamp(rint((x - centre_c) S_c), -127, 127) for the rows of list c -- the RESIDUAL against the list's own
+// per-dimension mid-range centre at the list's own scale (the IVF residual: a cluster of tight rows gets a fine grid,
+// wherever in space it sits).  Per row: Nx = |xi|^2 (exact), rx >= |x - centre - xi / S| (f32 sum + 0.1 % + the roundings
+// of the residuals themselves); per list: radius >= |x - centre| of every row (atomic max of non-negative float bits).
+__global__ __launch_bounds__(256) void block_rows_i8_kernel(const float *__restrict__ src, const uint64_t *__restrict__ list_off,
+                                                           const uint64_t *__restrict__ blk_off, uint32_t dim,
+                                                           const float *__restrict__ center, const float *__restrict__ list_scale,
+                                                           const float *__restrict__ list_half, float *__restrict__ list_radius,
+                                                           uint4 *__restrict__ out, int *__restrict__ row_n2i, float *__restrict__ row_res,
+                                                           const uint32_t *__restrict__ row_of) {
+    __shared__ int s_n2[16][17];
+    __shared__ float s_e2[16][17], s_v2[16][17];
+    const uint32_t c = blockIdx.y;
+    const uint64_t lbeg = list_off[c], len = list_off[c + 1] - lbeg;
+    const uint64_t ntile = blk_off[c + 1] - blk_off[c];
+    const uint32_t G = dim >> 4;
+    const uint32_t j = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const float scale = list_scale[c], maxabs = list_half[c];
+    const float inv = 1.0f / scale;
+    const float *ctr = center + (uint64_t)c * dim;
+    float rad = 0.0f;
+    for (uint64_t tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        uint4 *dst = out + (blk_off[c] + tl) * G * 16;
+        const uint64_t p = tl * 16 + j;
+        const uint64_t srow = p < len ? (row_of ? (uint64_t)row_of[lbeg + p] : lbeg + p) : 0ull;
+        int n2 = 0;
+        float e2 = 0.0f, v2 = 0.0f;
+        for (uint32_t cc = cg; cc < G; cc += 16) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (p < len) {
+                const float4 *r = reinterpret_cast<const float4 *>(src + srow * dim + cc * 16);
+                const float4 *cv = reinterpret_cast<const float4 *>(ctr + cc * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 x = r[u], cx = cv[u];
+                    const float t[4] = {x.x - cx.x, x.y - cx.y, x.z - cx.z, x.w - cx.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = quant_i8(t[e], scale);
+                        const float res = t[e] - (float)q * inv;
+                        n2 += q * q;
+                        e2 = fmaf(res, res, e2);
+                        v2 = fmaf(t[e], t[e], v2);
+                        w[u] |= (uint32_t)(q & 0xFF) << (8 * e);
+                    }
+                }
+            }
+            dst[cc * 16 + j] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        s_n2[j][cg] = n2; s_e2[j][cg] = e2; s_v2[j][cg] = v2;
+        __syncthreads();
+        if (threadIdx.x < 16 && tl * 16 + threadIdx.x < len) {
+            int tn = 0; float te = 0.0f, tv = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { tn += s_n2[threadIdx.x][g]; te += s_e2[threadIdx.x][g]; tv += s_v2[threadIdx.x][g]; }
+            row_n2i[lbeg + tl * 16 + threadIdx.x] = tn;
+            // upper bound: the f32 sum (+ 0.1 %), plus the roundings of (x - c) and q / S in every residual
+            const float pad = 4.0f * 5.9604645e-08f * sqrtf((float)dim) * (maxabs + 127.0f * inv);
+            row_res[lbeg + tl * 16 + threadIdx.x] = sqrtf(te) * 1.001f + pad;
+            rad = fmaxf(rad, sqrtf(tv) * 1.001f + pad);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) rad = fmaxf(rad, __shfl_xor(rad, off, 64));
+        if (threadIdx.x == 0 && rad > 0.0f) atomicMax(reinterpret_cast<uint32_t *>(list_radius + c), __float_as_uint(rad));
+    }
+}
+hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, const uint64_t *blk_off, uint32_t n_clusters,
+                                uint64_t max_tiles, uint32_t dim, const float *center, const float *list_scale, const float *list_half,
+                                float *list_radius, void *out, int *row_n2i, float *row_res, hipStream_t s, const uint32_t *row_of) {
+    if (n_clusters == 0 || max_tiles == 0) return hipSuccess;
+    if (dim % 16) return hipErrorInvalidValue;
+    const uint32_t gx = (uint32_t)(max_tiles < 64 ? max_tiles : 64);
+    hipLaunchKernelGGL(block_rows_i8_kernel, dim3(gx, n_clusters), dim3(256), 0, s, src, list_off, blk_off, dim, center, list_scale,
+                       list_half, list_radius, static_cast<uint4 *>(out), row_n2i, row_res, row_of);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pqv_rerank's device-side state handling (update_topk_heap, src/df_vector/exec.rs:457-484): the running top-k of a
+// query is (rows, d2, count), sorted by (d2, arrival).  rerank_state_in turns it into partial list 0 of a merge --
+// keys (d2 bits, position 0..count-1: earlier arrivals win ties), values tagged with bit 31 -- and rerank_state_out
+// maps the merged values back to payloads: a tagged value is an old entry, anything else a position in this batch.
+// One wave each; k <= 1024.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rerank_state_in_kernel(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count,
+                                                            uint32_t k, uint32_t k_list, uint64_t *keys, uint32_t *vals, uint32_t *rows_saved) {
+    const uint32_t cnt = *io_count < k ? *io_count : k;      // (a count beyond the state's capacity is clamped)
+    for (uint32_t i = threadIdx.x; i < k_list; i += 64) {
+        if (i < cnt) {
+            keys[i] = ((uint64_t)__float_as_uint(io_d2[i]) << 32) | i;
+            vals[i] = 0x80000000u | i;
+            rows_saved[i] = io_rows[i];
+        } else {
+            keys[i] = KEY_EMPTY;
+            vals[i] = 0xFFFFFFFFu;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void rerank_state_out_kernel(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found,
+                                                             const uint32_t *rows_saved, const uint32_t *ids, uint32_t k,
+                                                             uint32_t *io_rows, float *io_d2, uint32_t *io_count,
+                                                             const uint32_t *m_tie, uint32_t *io_tie) {
+    const uint32_t nf = *m_found < k ? *m_found : k;
+    for (uint32_t i = threadIdx.x; i < nf; i += 64) {
+        const uint32_t v = m_vals[i];
+        io_rows[i] = (v & 0x80000000u) ? rows_saved[v & 0x7FFFFFFFu] : (ids ? ids[v] : v);
+        io_d2[i] = m_d2[i];
+    }
+    if (threadIdx.x == 0) {
+        *io_count = nf;
+        if (io_tie && m_tie && *m_tie) *io_tie = 1u;          // sticky across batches
+    }
+}
+hipError_t launch_rerank_state_in(const uint32_t *io_rows, const float *io_d2, const uint32_t *io_count, uint32_t k, uint32_t k_list,
+                                  uint64_t *keys, uint32_t *vals, uint32_t *rows_saved, hipStream_t s) {
+    hipLaunchKernelGGL(rerank_state_in_kernel, dim3(1), dim3(64), 0, s, io_rows, io_d2, io_count, k, k_list, keys, vals, rows_saved);
+    return hipGetLastError();
+}
+hipError_t launch_rerank_state_out(const uint32_t *m_vals, const float *m_d2, const uint32_t *m_found, const uint32_t *rows_saved,
+                                   const uint32_t *ids, uint32_t k, uint32_t *io_rows, float *io_d2, uint32_t *io_count,
+                                   const uint32_t *m_tie, uint32_t *io_tie, hipStream_t s) {
+    hipLaunchKernelGGL(rerank_state_out_kernel, dim3(1), dim3(64), 0, s, m_vals, m_d2, m_found, rows_saved, ids, k, io_rows, io_d2, io_count, m_tie, io_tie);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// fill_ones2_kernel: two buffers set to all-ones bytes in ONE launch (the EMPTY preset of the
+// partial-list keys and values; hipMemsetAsync costs 2-3 launches per buffer).  16 B per lane.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_ones2_kernel(uint4 *a, uint64_t na16, uint4 *b, uint64_t nb16) {
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < na16 + nb16; i += stride) {
+        if (i < na16) a[i] = ones; else b[i - na16] = ones;
+    }
+}
+hipError_t launch_fill_ones2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, hipStream_t s) {
+    if ((a_bytes | b_bytes) & 15u) return hipErrorInvalidValue;
+    const uint64_t n16 = (a_bytes + b_bytes) / 16;
+    if (n16 == 0) return hipSuccess;
+    const uint64_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(fill_ones2_kernel, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s,
+                       static_cast<uint4 *>(a), a_bytes / 16, static_cast<uint4 *>(b), b_bytes / 16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pad_rows: out[i, 0 .. dim_p) = {src[idx ? idx[i] : i, 0 .. dim), 0 ...} for dim % 4 == 0: rows (and per batch the queries)
+// of a dimension the MFMA screen has no tiling for are stored zero-padded to one it has.  The reference's distance
+// takes 4 elements per step (index.rs:461-473), so a padded group adds ((0 + 0) + 0) + 0 = +0.0 to a non-negative sum:
+// every distance over the padded rows is bit-identical to the one over the originals.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, const uint32_t *__restrict__ idx32, uint64_t m,
+                                                      uint32_t dim, uint32_t dim_p, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t G = dim >> 2, Gp = dim_p >> 2;
+    for (uint64_t i = wave; i < m; i += nwaves) {
+        const uint64_t r = idx32 ? (uint64_t)idx32[i] : i;
+        const float4 *s = reinterpret_cast<const float4 *>(src + r * dim);
+        float4 *d = reinterpret_cast<float4 *>(out + i * dim_p);
+        for (uint32_t g = lane; g < Gp; g += 64) d[g] = g < G ? s[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+hipError_t launch_pad_rows(const float *src, const uint32_t *idx32, uint64_t m, uint32_t dim, uint32_t dim_p, float *out, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    if ((dim % 4) != 0 || (dim_p % 4) != 0 || dim_p < dim) return hipErrorInvalidValue;
+    uint64_t blocks = (m + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, src, idx32, m, dim, dim_p, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// gather_rows: out[i,:] = src[idx[i],:]; one wave per output row, 16 B per lane.
+// ------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
+                                                         const uint32_t *__restrict__ idx32,
+                                                         const uint64_t *__restrict__ idx64,
+                                                         uint64_t m, uint32_t dim,
+                                                         float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = wave; i < m; i += nwaves) {
+        const uint64_t r = idx64 ? idx64[i] : (uint64_t)idx32[i];
+        const float *s = src + r * dim;
+        float *d = out + i * dim;
+        if constexpr (ALIGNED) {
+            const uint32_t G = dim >> 2;
+            for (uint32_t g = lane; g < G; g += 64)
+                reinterpret_cast<float4 *>(d)[g] = reinterpret_cast<const float4 *>(s)[g];
+        } else {
+            for (uint32_t e = lane; e < dim; e += 64) d[e] = s[e];
+        }
+    }
+}
+
+hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,
+                              uint64_t m, uint32_t dim, float *out, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    uint64_t blocks = (m + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, s, src,
+                           idx32, idx64, m, dim, out);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, s, src,
+                           idx32, idx64, m, dim, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void narrow_f64_kernel(const double *__restrict__ src,
+                                                        uint64_t count, float *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        out[i] = (float)src[i];   // `as f32`: round to nearest even (parquet.rs:253)
+}
+hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(narrow_f64_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, src, count, out);
+    return hipGetLastError();
+}
+
+
+}  // namespace pqv

@@ -1,4 +1,4 @@
-"""Model check of the running-threshold counters of wide_filter_kernel (pq-vector_amd/csrc/kernels.hip, "Running
+"""Model check of the running-threshold counters of wide_filter_kernel (pq-vector_amd/csrc/kernels_screen.hip, "Running
 threshold"): per query two 64-bit words of 8-bit counters, counter of bin B = number of appended pairs in bin B or
 nearer, word 0 = bins 8..1 and word 1 = bins 12..9 with the NEARER bin in the LOWER byte; an append in bin b adds 1
 to the counters of bins 1..b with ONE 64-bit add per word, and nothing stops a byte from wrapping.  The kernel
