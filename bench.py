@@ -358,8 +358,8 @@ def build_record(n, dim, kc, build_s):
             "phases_s": {"kmeans_pp": kpp, "lloyd": lloyd, "lloyd_iterations": int(iters), "final_assignment": fa,
                          "host_list_build": host, "sample_rows": int(sample)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("final assignment: center_normalize_f16_kernel + assign_f16_kernel (f16 contraction against all centroids) + "
-                                    "assign_rescore_kernel (exact order)") if gemm else
+                         "kernel": ("final assignment: center_normalize_f16_kernel + assign_wide_kernel (f16 contraction against all centroids, "
+                                    "256 x 256 tiles) + assign_resolve_kernel (exact order where two or more candidates remain)") if gemm else
                                    "final assignment: wide_seed_kernel + seed_select_kernel + wide_filter_kernel<f32 operands> + merge_kernel"
                                    if fa_screen else "final assignment: assign_kernel (exact-order VALU)",
                          "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <system_error>
 #include <thread>
 #include <cmath>
@@ -832,9 +833,15 @@ struct ScreenedAssign {
 // ---------------------------------------------------------------------------------------
 struct GemmAssign {
     uint32_t dim = 0, dim_p = 0, kc = 0, kc_pad = 0, cap = 32;
-    uint64_t chunk = 1u << 20;
+    uint64_t chunk = [] { const char *e = std::getenv("PQV_ASSIGN_CHUNK"); const long v = e ? std::atol(e) : 0; return v >= 4096 ? static_cast<uint64_t>(v) : (1ull << 18); }();
     const float *d_centroids = nullptr;
-    DevBuf mu, c16, cn2, x16, xn2, cand, cnt, flag;
+    DevBuf mu, c16, cn2, x16, xn2, cand, cnt, flag, cand_t, best_t, rstats, d_perm, d_grp;
+    // round 4: 256 x 256 tiles with the rows on the lane-owned side and centroid images at one global scale (assign_wide_kernel +
+    // assign_resolve_kernel); PQV_ASSIGN_TILE=128 keeps round 3's 128 x 256 kernel with its own exact pass (A/B, tests)
+    bool wide = true;
+    float cmaxs = 0.0f, cn_max = 0.0f, kA = 0.0f;
+    std::vector<float> h_cn2;
+    unsigned long long exact_rows = 0, exact_evals = 0, rows_total = 0;
 
     static bool applicable(uint32_t dim, uint32_t kc) {
         const char *e = std::getenv("PQV_ASSIGN_GEMM");          // 0 = off, n > 1 = smallest centroid count that takes this path
@@ -853,23 +860,85 @@ struct GemmAssign {
     }
     int set_centroids(const float *d_c, uint32_t k, uint32_t d, hipStream_t stream, bool *nonfinite) {
         using namespace pqv;
-        dim = d; dim_p = (d + 31) / 32 * 32; kc = k; kc_pad = (k + 255) / 256 * 256; d_centroids = d_c;
+        {
+            const char *e = std::getenv("PQV_ASSIGN_TILE");
+            wide = !(e && std::atoi(e) == 128) && static_cast<uint64_t>((d + 63) / 64 * 64) * 2 * 512 < 0x7FFFFFFFull;
+        }
+        dim = d; dim_p = wide ? (d + 63) / 64 * 64 : (d + 31) / 32 * 32; kc = k; kc_pad = (k + 255) / 256 * 256; d_centroids = d_c;
         HIP_TRY(mu.ensure(static_cast<size_t>(dim) * sizeof(float)));
         HIP_TRY(c16.ensure(static_cast<size_t>(kc_pad) * dim_p * sizeof(uint16_t)));
         HIP_TRY(cn2.ensure(static_cast<size_t>(kc_pad) * sizeof(float)));
         HIP_TRY(launch_col_mean(d_c, kc, dim, mu.as<float>(), stream));
         HIP_TRY(launch_center_normalize_f16(d_c, mu.as<float>(), kc, kc_pad, dim, dim_p, cn2.as<float>(), c16.p, stream));
-        return finite(cn2.as<float>(), kc, stream, nonfinite);
+        if (!wide) return finite(cn2.as<float>(), kc, stream, nonfinite);
+        // one global scale for the centroid images: 2^8 / max |c - mu| (the norms come back anyway: this is the call's one host check)
+        h_cn2.resize(kc);
+        HIP_TRY(hipMemcpyAsync(h_cn2.data(), cn2.p, static_cast<size_t>(kc) * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float mx = 0.0f;
+        bool bad = false;
+        for (float v : h_cn2) { if (!(v <= 3.0e38f)) bad = true; else mx = std::max(mx, v); }
+        *nonfinite = bad;
+        if (bad) return PQV_OK;
+        cn_max = mx * 1.000001f;
+        cmaxs = std::sqrt(mx) * 1.000001f;
+        const float cscale = cmaxs > 0.0f ? 256.0f / cmaxs : 0.0f;
+        if (!(cscale > 0.0f && cscale < 3.0e38f)) { wide = false; return PQV_OK; }      // all centroids at mu / degenerate scale: round 3's kernel (images already written)
+        kA = 2.0f / (256.0f * cscale);
+        // images in ascending-norm order: a 32-centroid group's own largest norm scales its error bound (a table trained on a
+        // sample has a few far-out centroids -- clusters of one or two points -- and the table-wide maximum would loosen every bound)
+        std::vector<uint32_t> perm(kc);
+        for (uint32_t c = 0; c < kc; ++c) perm[c] = c;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return h_cn2[x] < h_cn2[y]; });
+        const uint32_t ngrp = kc_pad / 32;
+        std::vector<float> grp(2 * static_cast<size_t>(ngrp), 0.0f);
+        for (uint32_t g = 0; g < ngrp; ++g) {
+            float gm = 0.0f;
+            for (uint32_t s = g * 32; s < std::min(kc, (g + 1) * 32); ++s) gm = std::max(gm, h_cn2[perm[s]]);
+            grp[g] = std::sqrt(gm) * 1.000001f; grp[ngrp + g] = gm * 1.000001f;
+        }
+        HIP_TRY(d_perm.ensure(static_cast<size_t>(kc) * sizeof(uint32_t)));
+        HIP_TRY(d_grp.ensure(grp.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(d_perm.p, perm.data(), static_cast<size_t>(kc) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_grp.p, grp.data(), grp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_center_normalize_f16(d_c, mu.as<float>(), kc, kc_pad, dim, dim_p, cn2.as<float>(), c16.p, stream, cscale, d_perm.as<uint32_t>()));
+        HIP_TRY(hipStreamSynchronize(stream));          // perm / grp are host vectors of this scope
+        return PQV_OK;
     }
     // cluster[0 .. n) for rows d_rows[0 .. n); *fallback = true if a row norm is not finite (the caller re-runs its old path)
-    int run(const float *d_rows, uint64_t n, uint32_t *d_cluster, hipStream_t stream, bool *fallback) {
+    // h_out (optional): the assignment is also copied to this host array, chunk by chunk on a second stream, each copy behind
+    // the NEXT chunk's kernels (a pageable destination blocks the calling thread, not the GPU: the copies hide behind the compute)
+    int run(const float *d_rows, uint64_t n, uint32_t *d_cluster, hipStream_t stream, bool *fallback, uint32_t *h_out = nullptr) {
         using namespace pqv;
         *fallback = false;
+        const double t_run0 = now_s();
         const uint64_t ch = std::min<uint64_t>(chunk, std::max<uint64_t>(1, n));
+        struct CopyLane {
+            hipStream_t s = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+            ~CopyLane() { if (s) (void)hipStreamDestroy(s); for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+        } cl;
+        if (h_out) {
+            HIP_TRY(hipStreamCreateWithFlags(&cl.s, hipStreamNonBlocking));
+            for (auto &e : cl.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        uint64_t pend_r0 = 0, pend_m = 0; int pend_ev = -1, n_chunk = 0;
+        auto flush_copy = [&]() -> int {
+            if (pend_ev < 0) return PQV_OK;
+            HIP_TRY(hipStreamWaitEvent(cl.s, cl.ev[pend_ev], 0));
+            HIP_TRY(hipMemcpyAsync(h_out + pend_r0, d_cluster + pend_r0, pend_m * sizeof(uint32_t), hipMemcpyDeviceToHost, cl.s));
+            pend_ev = -1;
+            return PQV_OK;
+        };
         HIP_TRY(x16.ensure(ch * dim_p * sizeof(uint16_t)));
         HIP_TRY(xn2.ensure(ch * sizeof(float)));
         HIP_TRY(cand.ensure(ch * cap * sizeof(uint32_t)));
         HIP_TRY(cnt.ensure(ch * sizeof(uint32_t)));
+        if (wide) {
+            HIP_TRY(cand_t.ensure(ch * cap * sizeof(float)));
+            HIP_TRY(best_t.ensure(ch * sizeof(float)));
+            HIP_TRY(rstats.ensure(2 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(rstats.p, 0, 2 * sizeof(unsigned long long), stream));
+        }
         const float eps = 1.01f * 9.765625e-04f + 2.0f * static_cast<float>(dim_p) * 5.9604645e-08f + 2.0e-6f;
         const float cm = static_cast<float>(dim + 16) * 2.384185791015625e-07f;
         // (one host check of the row norms after all chunks: a non-finite one sends the whole call to the caller's old path)
@@ -881,12 +950,32 @@ struct GemmAssign {
             HIP_TRY(launch_center_normalize_f16(rows, mu.as<float>(), m, m, dim, dim_p, xn2.as<float>(), x16.p, stream));
             HIP_TRY(launch_nonfinite_flag(xn2.as<float>(), m, flag.as<uint32_t>(), stream));
             HIP_TRY(hipMemsetAsync(cnt.p, 0, m * sizeof(uint32_t), stream));
+            if (wide) {
+                AssignWideArgs w{};
+                w.x16 = x16.as<uint16_t>(); w.c16 = c16.as<uint16_t>(); w.xn2 = xn2.as<float>(); w.cn2 = cn2.as<float>();
+                w.perm = d_perm.as<uint32_t>(); w.grp_cs = d_grp.as<float>(); w.grp_cn = d_grp.as<float>() + kc_pad / 32;
+                w.m = m; w.kc = kc; w.kc_pad = kc_pad; w.dim_p = dim_p; w.kA = kA; w.eps = eps;
+                // the reference's summation margin, tight: a squared difference carries <= 3 roundings, the 4-group <= 3 more, the
+                // running sum one per group (index.rs:461-480; all terms non-negative) -- (dim / 4 + 6) 2^-24, taken twice over
+                w.cm = static_cast<float>(dim / 4 + 16) * 1.1920928955078125e-07f;
+                w.cand = cand.as<uint32_t>(); w.cand_t = cand_t.as<float>(); w.cand_cnt = cnt.as<uint32_t>(); w.best_t = best_t.as<float>(); w.cap = cap;
+                HIP_TRY(launch_assign_wide(w, stream));
+                // (the two counters are same-address atomics from every wave: diagnostic runs only)
+                HIP_TRY(launch_assign_resolve(w, rows, d_centroids, dim, d_cluster + r0, verbose() ? rstats.as<unsigned long long>() : nullptr, stream));
+            } else {
             AssignF16Args a{};
             a.x16 = x16.as<uint16_t>(); a.c16 = c16.as<uint16_t>(); a.xn2 = xn2.as<float>(); a.cn2 = cn2.as<float>();
             a.m = m; a.kc = kc; a.kc_pad = kc_pad; a.dim_p = dim_p; a.eps = eps; a.cm = cm;
             a.cand = cand.as<uint32_t>(); a.cand_cnt = cnt.as<uint32_t>(); a.cap = cap;
             HIP_TRY(launch_assign_f16(a, stream));
             HIP_TRY(launch_assign_rescore(rows, d_centroids, m, dim, kc, cand.as<uint32_t>(), cnt.as<uint32_t>(), cap, d_cluster + r0, stream));
+            }
+            if (h_out) {
+                const int evi = n_chunk++ & 1;
+                if (int rc = flush_copy()) return rc;                   // the previous chunk: its kernels are done or running, this chunk's are queued
+                HIP_TRY(hipEventRecord(cl.ev[evi], stream));
+                pend_r0 = r0; pend_m = m; pend_ev = evi;
+            }
             if (verbose() && r0 == 0 && n >= 65536) {      // candidates the screen left per row (first chunk)
                 std::vector<uint32_t> hc(m);
                 HIP_TRY(hipMemcpyAsync(hc.data(), cnt.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -897,13 +986,55 @@ struct GemmAssign {
                              static_cast<double>(sum) / static_cast<double>(m), mx, (unsigned long long)over, cap, kc);
             }
         }
+        if (h_out) { if (int rc = flush_copy()) return rc; HIP_TRY(hipStreamSynchronize(cl.s)); }
+        const double t_run1 = now_s();
         uint32_t h = 0;
         HIP_TRY(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        if (verbose() && n >= (1u << 20)) std::fprintf(stderr, "[pqv] f16 assignment: %llu rows enqueued%s in %.1f ms\n", (unsigned long long)n,
+                                                       h_out ? " and downloaded" : "", (t_run1 - t_run0) * 1e3);
+        if (wide && verbose()) {
+            unsigned long long hs[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(hs, rstats.p, sizeof hs, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            exact_rows += hs[0]; exact_evals += hs[1]; rows_total += n;
+            if (n >= 65536) std::fprintf(stderr, "[pqv] f16 assignment (256 x 256 tiles): %.1f %% of %llu rows evaluated exactly, %.2f evaluations per such row\n",
+                                         100.0 * static_cast<double>(hs[0]) / static_cast<double>(n), (unsigned long long)n,
+                                         hs[0] ? static_cast<double>(hs[1]) / static_cast<double>(hs[0]) : 0.0);
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         *fallback = h != 0;
         return PQV_OK;
     }
 };
+
+// acc[c] = ((0 + m[0][c]) + m[1][c]) + ... + m[rows - 1][c] for c in [0, width), width a multiple of 16: `width` independent f32
+// chains, each in its own sequential order (element-wise vector adds do not re-associate anything).  The AVX2 body is chosen at
+// run time; both bodies add the same operands in the same order, so the sums are identical bit for bit.
+typedef float v4f_t __attribute__((vector_size(16), aligned(4)));
+typedef float v8f_t __attribute__((vector_size(32), aligned(4)));
+__attribute__((target("avx2"))) static void chain_sums_avx2(const float *m, uint64_t rows, uint64_t width, float *acc) {
+    for (uint64_t c0 = 0; c0 < width; c0 += 32) {          // four 8-lane accumulators: 32 chains per pass over the rows
+        const uint64_t nb = std::min<uint64_t>(4, (width - c0) / 8);
+        v8f_t s[4] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        for (uint64_t t = 0; t < rows; ++t) {
+            const float *r = m + t * width + c0;
+            for (uint64_t b = 0; b < nb; ++b) s[b] = s[b] + *reinterpret_cast<const v8f_t *>(r + 8 * b);
+        }
+        for (uint64_t b = 0; b < nb; ++b) *reinterpret_cast<v8f_t *>(acc + c0 + 8 * b) = s[b];
+    }
+}
+static void chain_sums(const float *m, uint64_t rows, uint64_t width, float *acc) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { chain_sums_avx2(m, rows, width, acc); return; }
+    for (uint64_t c0 = 0; c0 < width; c0 += 16) {
+        v4f_t s[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (uint64_t t = 0; t < rows; ++t) {
+            const float *r = m + t * width + c0;
+            for (int b = 0; b < 4; ++b) s[b] = s[b] + *reinterpret_cast<const v4f_t *>(r + 4 * b);
+        }
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<v4f_t *>(acc + c0 + 4 * b) = s[b];
+    }
+}
 
 // d_data [n, dim] resident; writes d_centroids [k, dim] (device) and optionally the final
 // assignment (host).
@@ -964,23 +1095,106 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     // chunking of the partial sums (:259-265,:305-306)
     const uint64_t w = std::max<uint64_t>(1, std::min<uint64_t>(workers, init_n));
     const uint64_t chunk = (init_n + w - 1) / w;
+    // With many chunks (a 256-core host: 256 chunks of 196 minima) the w independent chunk chains are added as vector lanes:
+    // the kernels keep a second mirror in chunk-transposed order [position in chunk][chunk] (padding stays +0.0: x + 0.0 == x
+    // for the non-negative sums), and step t adds row t of it to the w running sums -- every chain still in its own order.
+    const uint64_t n_chunks = (init_n + chunk - 1) / chunk;
+    const uint64_t wpad = (n_chunks + 15) / 16 * 16;
+    const bool use_t = n_chunks >= 16 && chunk * wpad <= (64ull << 20);
+    PinnedBuf h_min_t;
+    std::vector<float> chain_acc;
+    if (use_t) {
+        HIP_TRY(h_min_t.ensure(chunk * wpad * sizeof(float)));
+        float *mt = h_min_t.as<float>();
+        for (uint64_t t = 0; t < chunk * wpad; ++t) mt[t] = 0.0f;
+        for (uint64_t pos = 0; pos < init_n; ++pos) mt[(pos % chunk) * wpad + pos / chunk] = INFINITY;
+        sa.mirror_t = mt; sa.mirror_chunk = static_cast<uint32_t>(chunk); sa.mirror_stride = static_cast<uint32_t>(wpad);
+        chain_acc.resize(wpad);
+    }
 
     const double t_pp0 = now_s();
+    // Round 4: from the second measured centroid on, a round first screens the rows with int8 images (minupd_screen_kernel): a row
+    // whose distance to the new centroid provably is not below its current minimum is not evaluated (after a dozen rounds: most).
+    // Rows of a multiple of 64 dims, finite data; PQV_KPP_SCREEN=0 keeps the plain streaming pass (A/B, tests).
+    DevBuf d_kimg, d_kn2i, d_kres, d_kaux, d_kmm;
+    MinUpdScreenArgs ms{};
+    bool kpp_screen = false;
+    {
+        const char *e = std::getenv("PQV_KPP_SCREEN");
+        if (!(e && *e == '0') && (dim % 64) == 0 && dim >= 128 && dim <= 8192 && init_n >= 1024 && k > 8) {
+            const uint64_t n_tiles = (init_n + 15) / 16;
+            // one "list" holding the whole subset: {list_off[2], blk_off[2]} u64, then centre[dim], half, scale, radius floats
+            HIP_TRY(d_kaux.alloc(4 * sizeof(uint64_t) + (static_cast<size_t>(dim) + 3) * sizeof(float)));
+            const uint64_t h_off[4] = {0, init_n, 0, n_tiles};
+            HIP_TRY(hipMemcpyAsync(d_kaux.p, h_off, sizeof h_off, hipMemcpyHostToDevice, stream));
+            const uint64_t *d_loff = d_kaux.as<uint64_t>(), *d_boff = d_loff + 2;
+            float *d_ctr = reinterpret_cast<float *>(d_kaux.as<uint64_t>() + 4), *d_half = d_ctr + dim, *d_scale = d_half + 1, *d_rad = d_scale + 1;
+            HIP_TRY(d_kmm.alloc(2 * static_cast<size_t>(dim) * sizeof(uint32_t)));
+            uint32_t *kmin = d_kmm.as<uint32_t>(), *kmax = kmin + dim;
+            HIP_TRY(hipMemsetAsync(kmin, 0xFF, static_cast<size_t>(dim) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(kmax, 0, static_cast<size_t>(dim) * sizeof(uint32_t), stream));
+            HIP_TRY(d_kimg.alloc(n_tiles * 16 * dim));
+            HIP_TRY(d_kn2i.alloc(init_n * sizeof(int)));
+            HIP_TRY(d_kres.alloc(init_n * sizeof(float)));
+            HIP_TRY(launch_list_minmax(d_init, d_loff, 1, init_n, dim, kmin, kmax, stream));
+            HIP_TRY(launch_list_center(kmin, kmax, 1, dim, d_loff, d_ctr, d_half, d_scale, d_rad, stream));
+            HIP_TRY(launch_block_rows_i8(d_init, d_loff, d_boff, 1, n_tiles, dim, d_ctr, d_scale, d_half, d_rad, d_kimg.p, d_kn2i.as<int>(),
+                                         d_kres.as<float>(), stream));
+            float h_hs[2] = {0.0f, 0.0f};       // {half range, scale}
+            HIP_TRY(hipMemcpyAsync(h_hs, d_half, sizeof h_hs, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            // (a non-finite value anywhere in the subset shows in the half range; a degenerate scale -- all rows equal -- has nothing to screen)
+            if (h_hs[0] > 0.0f && h_hs[0] < 1.0e30f && h_hs[1] > 1.0e-30f && h_hs[1] < 1.0e15f) {
+                ms.rows = d_init; ms.img = static_cast<const float4 *>(d_kimg.p); ms.n2i = d_kn2i.as<int>(); ms.res = d_kres.as<float>();
+                ms.n = init_n; ms.dim = dim; ms.inv_s = 1.0f / h_hs[1];
+                ms.cm = static_cast<float>(dim + 16) * 2.384185791015625e-07f;
+                ms.min_d = d_min.as<float>(); ms.mirror = h_min.as<float>();
+                ms.mirror_t = sa.mirror_t; ms.mirror_chunk = sa.mirror_chunk; ms.mirror_stride = sa.mirror_stride;
+                kpp_screen = true;
+            }
+        }
+    }
+    // (Measured and dropped: the screened rounds as ONE resident kernel fed through pinned memory -- commands polled with relaxed
+    //  system-scope loads, minima mirrored with system-scope stores, a ticket per block -- 45 us a round against 24 for a launch per
+    //  round: the PCIe round trips of the hand-shake cost more than a kernel launch and its completion.  Likewise a completion flag
+    //  written by the last block of a per-round launch: the per-block system-scope release costs the kernel 20 us.)
     sa.queries = centroid_row(0);  // distances to centroid 0
     HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+    double tt_gpu = 0.0, tt_sum = 0.0, tt_pick = 0.0;       // PQV_VERBOSE: where a round's time goes
+    const bool vb = verbose();
     for (uint32_t i = 1; i < k; ++i) {
+        const double tr0 = vb ? now_s() : 0.0;
         if (i > 1) {  // round 1 would re-measure centroid 0: min-update is the identity
-            sa.queries = centroid_row(i - 1);
-            HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+            if (kpp_screen && picks[i - 1] != ~0ull) {
+                ms.pick = picks[i - 1];
+                HIP_TRY(launch_minupd_screen(ms, stream));
+            } else {                                                // (a centroid that is no subset row -- the zero fill -- takes the plain pass)
+                sa.queries = centroid_row(i - 1);
+                HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+            }
         }
-        HIP_TRY(hipStreamSynchronize(stream));
+        {
+            // the round's only command: poll for its completion (the blocking wait's wake-up costs several microseconds a round)
+            hipError_t qe;
+            uint32_t polls = 0;
+            while ((qe = hipStreamQuery(stream)) == hipErrorNotReady && ++polls < 200000u) { }
+            if (qe != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamSynchronize(stream)); }
+        }
+        const double tr1 = vb ? now_s() : 0.0;
         const float *md = h_min.as<float>();
         // total = sum over worker chunks of the chunk's sequential f32 sum (:356-370)
         // Each chunk's sum is its own sequential f32 chain and the chains are independent of each other, so eight
         // full chunks run side by side; the chunk sums still join `total` in ascending chunk order.
         float total = 0.0f;
         uint64_t s = 0;
-        if (chunk < init_n) {
+        if (use_t) {
+            const float *mt = h_min_t.as<float>();
+            float *acc = chain_acc.data();
+            for (uint64_t c = 0; c < wpad; ++c) acc[c] = 0.0f;
+            chain_sums(mt, chunk, wpad, acc);                                          // w independent chains, one per vector lane
+            for (uint64_t c = 0; c < n_chunks; ++c) total = total + acc[c];            // joined in ascending chunk order
+            s = init_n;
+        } else if (chunk < init_n) {
             for (; s + 8 * chunk <= init_n; s += 8 * chunk) {
                 const float *p = md + s;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f, a5 = 0.0f, a6 = 0.0f, a7 = 0.0f;
@@ -998,6 +1212,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
             for (uint64_t t = s; t < e; ++t) local = local + md[t];
             total = total + local;
         }
+        const double tr2 = vb ? now_s() : 0.0;
         if (total > 0.0f) {
             const float threshold = rng.unit_f32() * total;                            // :373
             float cumsum = 0.0f;
@@ -1008,7 +1223,9 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
         } else {
             picks[i] = rng.range_usize(0, init_n);                                     // :385
         }
+        if (vb) { const double tr3 = now_s(); tt_gpu += tr1 - tr0; tt_sum += tr2 - tr1; tt_pick += tr3 - tr2; }
     }
+    if (vb) std::fprintf(stderr, "[pqv] k-means++ rounds: launch + wait %.1f ms, chunk sums %.1f ms, pick scan %.1f ms\n", tt_gpu * 1e3, tt_sum * 1e3, tt_pick * 1e3);
     // the chosen rows -> the centroid table (a centroid without a pick keeps its zero fill, as in the reference)
     {
         bool all = true;
@@ -1027,7 +1244,8 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
             HIP_TRY(hipStreamSynchronize(stream));
         }
     }
-    d_min.release(); d_init_own.release(); d_idx.release();
+    HIP_TRY(hipStreamSynchronize(stream));
+    d_min.release(); d_init_own.release(); d_idx.release(); d_kimg.release(); d_kn2i.release(); d_kres.release(); d_kaux.release(); d_kmm.release();
     HIP_TRY(hipStreamSynchronize(stream));
     const double t_pp1 = now_s();
     g_build_stats[0] = t_pp1 - t_pp0;
@@ -1157,18 +1375,22 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
             });
         } catch (const std::system_error &) { }
     }
-    bool exact_assign = true;
+    bool exact_assign = true, downloaded = false;
     double assign_form = 0.0;
     if (GemmAssign::applicable(dim, static_cast<uint32_t>(k))) {
         GemmAssign gemm;
         bool bad_c = false, bad_r = false;
         if (int rc = gemm.set_centroids(d_centroids.as<float>(), static_cast<uint32_t>(k), dim, stream, &bad_c)) return rc;
         if (!bad_c) {
-            if (int rc = gemm.run(corpus->d_rows, n, d_cluster.as<uint32_t>(), stream, &bad_r)) return rc;
+            // (chunk-wise downloads behind the next chunk's kernels were measured and dropped: a device-to-pageable copy on a
+            //  second stream stalls the compute stream's queue -- 53 ms for the loop against 34 ms of kernels on C3)
+            if (int rc = gemm.run(corpus->d_rows, n, d_cluster.as<uint32_t>(), stream, &bad_r, nullptr)) return rc;
             exact_assign = bad_r;
+            downloaded = false;
         }
         HIP_TRY(hipStreamSynchronize(stream));     // the context's buffers are released at scope exit
         if (!exact_assign) assign_form = 2.0;
+        if (verbose()) std::fprintf(stderr, "[pqv] final assignment: f16 path done at %.1f ms\n", (now_s() - t_fa0) * 1e3);
     }
     if (exact_assign && ScreenedAssign::applicable(dim, static_cast<uint32_t>(k))) {
         ScreenedAssign screen;
@@ -1190,7 +1412,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     idx->list_rows = std::move(rows_buf);
     idx->dim = dim; idx->n_clusters = static_cast<uint32_t>(k);
     idx->centroids.resize(k * dim);
-    hipError_t e = hipMemcpyAsync(cluster_of.data(), d_cluster.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    hipError_t e = downloaded ? hipSuccess : hipMemcpyAsync(cluster_of.data(), d_cluster.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(idx->centroids.data(), d_centroids.p, k * dim * sizeof(float), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);

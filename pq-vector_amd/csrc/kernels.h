@@ -41,6 +41,10 @@ struct StreamArgs {
     // copy of out_f32: the k-means++ host scan reads it after the stream is drained, with no copy command between the
     // rounds' kernels, and only the minima that changed cross the bus)
     float          *mirror_f32;
+    // MINUPD, optional second mirror in CHUNK-TRANSPOSED order: entry pos goes to mirror_t[(pos % mirror_chunk) * mirror_stride +
+    // pos / mirror_chunk], so the host adds the w chunk chains of index.rs:356-370 with vector instructions (lane = chunk)
+    float          *mirror_t;
+    uint32_t        mirror_chunk, mirror_stride;
     // optional: zero_u32[0 .. zero_n) = 0 (scratch of the kernels that follow in the stream)
     uint32_t       *zero_u32;
     uint32_t        zero_n;
@@ -405,10 +409,40 @@ struct AssignF16Args {
     uint32_t        cap;
 };
 hipError_t launch_assign_f16(const AssignF16Args &a, hipStream_t s);
+// Round 4 form of the same screen (kernels_build.hip: assign_wide_kernel): block tile 256 rows x 256 centroids (8 waves, 128-byte K
+// stages), the data rows on the LANE-owned side of the MFMA so that a row's running best needs no cross-lane reduction, centroid
+// images at ONE global scale (cscale = 2^8 / max |c - mu|) so that the whole epilogue of a pair is  t = cn2[c] - kA xs acc  (one
+// FMA + one min; d~ = |x - mu|^2 + t).  Candidates carry their t; launch_assign_resolve filters them against the row's FINAL
+// best (the kernel's own test only sees the best so far), returns the survivor where one is left and evaluates exactly --
+// reference order, argmin by (distance bits, index) -- only the rows that keep two or more.
+struct AssignWideArgs {
+    const uint16_t *x16;     // [m, dim_p] images of (row - mu) / |row - mu| * 2^8, dim_p a multiple of 64
+    const uint16_t *c16;     // [kc_pad, dim_p] images of (centroid - mu) * cscale; rows >= kc are zero
+    const float    *xn2;     // [m]  |row - mu|^2
+    const float    *cn2;     // [kc] |centroid - mu|^2   (c16 / cn2 in SORTED order: ascending norm; perm[s] = the centroid in slot s)
+    const uint32_t *perm;    // [kc]
+    const float    *grp_cs;  // [kc_pad / 32] per group of 32 sorted centroids: >= max |c - mu| ...
+    const float    *grp_cn;  // [kc_pad / 32] ... and >= max cn2 (a group's own maxima scale its error bound, not the table's: the
+                             // few far-out centroids -- clusters of one or two sample points -- loosen only their own group)
+    uint64_t        m;
+    uint32_t        kc, kc_pad, dim_p;
+    float           kA;      // 2 / (2^8 cscale): (row - mu).(centroid - mu) = acc |row - mu| kA / 2
+    float           eps, cm;
+    uint32_t       *cand;     // [m][cap] candidate centroid ids
+    float          *cand_t;   // [m][cap] their lower-bound scores t - E
+    uint32_t       *cand_cnt; // [m] zeroed by the caller; may exceed cap (the row is then compared with every centroid)
+    float          *best_t;   // [m] smallest upper-bound score t + E of the row over all centroids
+    uint32_t        cap;
+};
+hipError_t launch_assign_wide(const AssignWideArgs &a, hipStream_t s);
+hipError_t launch_assign_resolve(const AssignWideArgs &a, const float *rows, const float *centroids, uint32_t dim, uint32_t *cluster,
+                                 unsigned long long *stats /* optional [2]: += rows evaluated exactly, += exact evaluations */, hipStream_t s);
 hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint64_t m, uint32_t dim, uint32_t kc, const uint32_t *cand,
                                  const uint32_t *cand_cnt, uint32_t cap, uint32_t *cluster, hipStream_t s);
+// fixed_scale > 0: every row is multiplied by that one scale instead of 2^8 / its own norm (the centroid images of the round-4 form)
+// idx != nullptr: output row r is made from rows[idx[r]]
 hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint64_t n, uint64_t n_pad, uint32_t dim, uint32_t dim_p,
-                                       float *out_n2, void *out, hipStream_t s);
+                                       float *out_n2, void *out, hipStream_t s, float fixed_scale = 0.0f, const uint32_t *idx = nullptr);
 hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s);
 hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s);
 hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm,
@@ -494,6 +528,28 @@ hipError_t launch_block_rows_i8(const float *src, const uint64_t *list_off, cons
 hipError_t launch_quantize_pairs_i8(const float *queries, const uint32_t *probe, const float *center, const float *scale, const float *half,
                                     const float *radius, uint32_t n_pairs, uint32_t nprobe, uint32_t dim, void *q_i8, int *q_n2i,
                                     float *q_res, float *q_resu, float *pair_lb, hipStream_t s);
+
+// k-means++ round with an int8 screen (kernels_build.hip: minupd_screen_kernel; index.rs:354-369): min_d[r] = min(min_d[r],
+// d2(row r, row `pick`)) in the reference's order -- but a row's exact distance is evaluated only if a rigorous lower bound
+// of it does not exceed min_d[r]: |x - c| >= |xi - ci| / S - rx - rc on int8 images of (row - centre) S (the searcher's residual
+// images with ONE list holding the whole subset: launch_list_minmax / launch_list_center / launch_block_rows_i8), |xi - ci|^2 exact
+// in int32 from one v_mfma_i32_16x16x64_i8 chain.  After the first dozen rounds a few rows in a hundred are evaluated, and the
+// pass reads one byte per value instead of four -- 38 MB for C3's 50 000 x 768 subset, which the L2s keep between rounds.
+struct MinUpdScreenArgs {
+    const float  *rows;      // [n, dim] f32 (exact evaluations), dim % 64 == 0
+    const float4 *img;       // blocked int8 images: 16-row tiles, tile T column cc (16 dims) row j at 16-byte index (T dim/16 + cc) 16 + j
+    const int    *n2i;       // [n] |xi|^2
+    const float  *res;       // [n] >= |x - centre - xi / S|
+    uint64_t      n, pick;
+    uint32_t      dim;
+    float         inv_s;     // 1 / S
+    float         cm;
+    float        *min_d;     // [n]
+    float        *mirror;    // optional pinned mirror of min_d (see StreamArgs::mirror_f32)
+    float        *mirror_t;  // optional chunk-transposed mirror (StreamArgs::mirror_t)
+    uint32_t      mirror_chunk, mirror_stride;
+};
+hipError_t launch_minupd_screen(const MinUpdScreenArgs &a, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

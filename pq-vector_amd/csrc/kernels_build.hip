@@ -317,12 +317,437 @@ hipError_t launch_assign_rescore(const float *rows, const float *centroids, uint
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Round 4: assign_wide_kernel + assign_resolve_kernel (see kernels.h: AssignWideArgs).
+//
+// Block = 256 rows against ALL centroids, 256 at a time; 8 waves as 2 (centroid side, M) x 4 (row side, N), each 128 centroids
+// x 64 rows = 4 x 2 tiles of v_mfma_f32_32x32x16_f16; K in 128-byte stages through double-buffered, chunk-swizzled LDS
+// (brute_f16_kernel's loop).  C/D layout: col = lane & 31 is the N index -- a DATA ROW --, the 16 registers of a tile are
+// centroids (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  A lane therefore owns two rows and sees 64 of a tile's 256 centroids for each.
+//   t_c   = cn2[c] - kA xs acc            (d~ = |x - mu|^2 + t_c;  |d~ - d| <= E = 2 xs cmaxs eps + 4e-6 (|x - mu|^2 + cn_max))
+//   best  = min_c t_c                     lane-local over 64 registers, one cross-half shuffle, one LDS atomicMin per wave pair
+//   keep  <=> !(t_c > cut(best))          cut: assign_cut below -- every centroid whose reference distance could be <= the
+//                                         reference distance of the best one (ties included: the lowest index must win)
+// The test runs per lane on its own minimum first; only a lane that holds a candidate walks its 64 registers.
+// ------------------------------------------------------------------------------------
+// cut for the candidates' LOWER-bound scores, from the row's smallest UPPER-bound score `ub_best` (scores: d~ - |x - mu|^2 -+ E):
+// U >= the reference distance of the best centroid; c can only matter if (d~_c - E_c)(1 - cm) <= U, i.e. (t_c - E_c) <= cut
+__device__ __forceinline__ float assign_cut(float xn, float ub_best, float cm) {
+    const float U = fmaxf(xn + ub_best, 0.0f) * (1.0f + cm) + 1.0e-30f;
+    const float cut = U / (1.0f - cm) - xn;
+    return cut + 4.0e-6f * (fabsf(U) + xn) + 1.0e-30f;          // the f32 roundings of this expression, upward
+}
+
+constexpr int AW_TM = 4, AW_TN = 2, AW_NWM = 2, AW_NWN = 4, AW_ST = 8;
+constexpr int AW_BM = 32 * AW_TM * AW_NWM, AW_BN = 32 * AW_TN * AW_NWN, AW_NT = 64 * AW_NWM * AW_NWN;     // 256 centroids x 256 rows, 512 threads
+__global__ __launch_bounds__(AW_NT, 1) void assign_wide_kernel(const AssignWideArgs a) {
+    constexpr int TM = AW_TM, TN = AW_TN, NWN = AW_NWN, ST = AW_ST, BM = AW_BM, BN = AW_BN, NT = AW_NT;
+    constexpr int CA = BM * ST / NT, CB = BN * ST / NT;        // 16-byte chunks a thread stages per K stage and side
+    extern __shared__ float4 aw_lds[];                         // [2][BM * ST] centroid stages, [2][BN * ST] row stages
+    float4 *const As4 = aw_lds, *const Bs4 = aw_lds + 2 * BM * ST;
+    auto sw = [](int r) { return ((r >> 1) & 1) | (((r >> 2) & 3) << 1); };      // 128-byte rows: brute_f16_kernel's swizzle
+    __shared__ float cn_s[BM];               // cn2 of the current centroid tile (+inf beyond kc)
+    __shared__ float gcs_s[BM / 32], gcn_s[BM / 32];      // per 32-centroid group of the tile: >= max |c - mu|, >= max cn2
+    __shared__ uint32_t best_s[BN];          // sortable bits of the rows' smallest upper-bound score so far
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const uint64_t n0 = (uint64_t)blockIdx.x * BN;             // first data row of the block
+    const uint32_t rbytes = a.dim_p * 2;
+    constexpr int RPS = NT / ST;
+    const int ld_r = tid / ST, ld_ch = tid % ST;
+    float4 ra[CA], rb[CB];
+    const uint64_t vleft = (a.m - n0) * rbytes;
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(a.x16 + n0 * a.dim_p), 0, (int)(vleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vleft), 0x00020000);
+    const uint32_t lane_b = (uint32_t)ld_r * rbytes + (uint32_t)ld_ch * 16, step_b = (uint32_t)RPS * rbytes;
+    if (tid < BN) best_s[tid] = 0xFFFFFFFFu;
+
+    const int l31 = lane & 31, lk = lane >> 5;
+    int rowa[TM], rowb[TN], swa[TM], swb[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { rowa[t] = wm * 32 * TM + t * 32 + l31; swa[t] = sw(rowa[t]); }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { rowb[t] = wn * 32 * TN + t * 32 + l31; swb[t] = sw(rowb[t]); }
+    // the lane's two rows
+    float xn[TN], xs2e[TN], Ar[TN];
+    uint64_t grow[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        grow[j] = n0 + (uint64_t)rowb[j];
+        xn[j] = grow[j] < a.m ? a.xn2[grow[j]] : 0.0f;
+        const float xs = sqrtf(xn[j]) * 1.000001f;
+        xs2e[j] = 2.0f * xs * a.eps;
+        Ar[j] = xs * a.kA;
+    }
+    const uint32_t nk = rbytes / (16 * ST);
+
+    for (uint32_t c0 = 0; c0 < a.kc; c0 += BM) {
+        const uint64_t qleft = (uint64_t)(a.kc_pad - c0) * rbytes;
+        const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(a.c16 + (uint64_t)c0 * a.dim_p), 0, (int)(qleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)qleft), 0x00020000);
+        auto fetch = [&](uint32_t kb) {
+#pragma unroll
+            for (int h = 0; h < CA; ++h) ra[h] = buf_ld16(qres, lane_b, kb + h * step_b);
+#pragma unroll
+            for (int h = 0; h < CB; ++h) rb[h] = buf_ld16(vres, lane_b, kb + h * step_b);
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < CA; ++h) { const int r = ld_r + RPS * h; As4[buf * BM * ST + r * ST + (ld_ch ^ sw(r))] = ra[h]; }
+#pragma unroll
+            for (int h = 0; h < CB; ++h) { const int r = ld_r + RPS * h; Bs4[buf * BN * ST + r * ST + (ld_ch ^ sw(r))] = rb[h]; }
+        };
+        if (tid < BM) cn_s[tid] = c0 + tid < a.kc ? a.cn2[c0 + tid] : INFINITY;
+        if (tid < BM / 32) { gcs_s[tid] = a.grp_cs[c0 / 32 + tid]; gcn_s[tid] = a.grp_cn[c0 / 32 + tid]; }
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (uint32_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1u);
+            if (kt + 1 < nk) fetch((kt + 1) * 16 * ST);
+            float4 av[2][TM], bv[2][TN];
+            auto lds_read = [&](int j, int set) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) av[set][t] = As4[buf * BM * ST + rowa[t] * ST + ((2 * j + lk) ^ swa[t])];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) bv[set][t] = Bs4[buf * BN * ST + rowb[t] * ST + ((2 * j + lk) ^ swb[t])];
+            };
+            lds_read(0, 0);
+#pragma unroll
+            for (int j = 0; j < ST / 2; ++j) {
+                const int set = j & 1;
+                if (j + 1 < ST / 2) lds_read(j + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[set][i]), __builtin_bit_cast(f16x8_t, bv[set][jj]), acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kt + 1 < nk) stash(buf ^ 1);
+            __syncthreads();
+        }
+        // ---- pass 1: t in place of the accumulators; per 32-centroid group the error term E (the centroids are sorted by norm:
+        // a group's own maximum, not the table's, scales its bound), the lane's smallest upper- and lower-bound scores per row
+        float mub[TN], mlb[TN], Eg[TM][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { mub[j] = INFINITY; mlb[j] = INFINITY; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float gcs = gcs_s[wm * TM + i], gcn = gcn_s[wm * TM + i];
+            float mt[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { Eg[i][j] = xs2e[j] * gcs + 4.0e-6f * (xn[j] + gcn); mt[j] = INFINITY; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float cn = cn_s[wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float t = __builtin_fmaf(-Ar[j], acc[i][j][r], cn);
+                    acc[i][j][r] = t;
+                    mt[j] = fminf(mt[j], t);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { mub[j] = fminf(mub[j], mt[j] + Eg[i][j]); mlb[j] = fminf(mlb[j], mt[j] - Eg[i][j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float m2 = fminf(mub[j], __shfl_xor(mub[j], 32, 64));
+            if (lk == 0 && m2 < INFINITY) atomicMin(&best_s[rowb[j]], sortable_bits(m2));
+        }
+        __syncthreads();
+        // ---- pass 2: candidates against the best so far (their lower-bound scores travel with them)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const uint32_t bb = best_s[rowb[j]];
+            const float cut = assign_cut(xn[j], bb == 0xFFFFFFFFu ? INFINITY : unsortable_bits(bb), a.cm);
+            if (grow[j] < a.m && !(mlb[j] > cut)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float tl = acc[i][j][r] - Eg[i][j];
+                        if (!(tl > cut)) {
+                            const uint32_t slot = atomicAdd(&a.cand_cnt[grow[j]], 1u);
+                            if (slot < a.cap) {
+                                a.cand[grow[j] * a.cap + slot] = c0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                                a.cand_t[grow[j] * a.cap + slot] = tl;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();          // cn_s, the group tables and the LDS stages are rewritten by the next centroid tile
+    }
+    if (tid < BN && n0 + tid < a.m) {
+        const uint32_t bb = best_s[tid];
+        a.best_t[n0 + tid] = bb == 0xFFFFFFFFu ? INFINITY : unsortable_bits(bb);
+    }
+}
+hipError_t launch_assign_wide(const AssignWideArgs &a, hipStream_t s) {
+    if (a.m == 0 || a.kc == 0) return hipSuccess;
+    if ((a.dim_p % 64) != 0 || (uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull || (a.kc_pad % AW_BM) != 0 || a.kc_pad < a.kc) return hipErrorInvalidValue;
+    const uint64_t blocks = (a.m + AW_BN - 1) / AW_BN;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    constexpr size_t lds = 2 * (size_t)(AW_BM + AW_BN) * AW_ST * 16;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assign_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    hipLaunchKernelGGL(assign_wide_kernel, dim3((uint32_t)blocks), dim3(AW_NT), lds, s, a);
+    return hipGetLastError();
+}
+
+// The second half: a wave owns 16 rows x 4 candidate slots per round (assign_rescore_wave_kernel's tiling).  A row's candidates
+// are first filtered against the row's FINAL best; a row left with one survivor is done -- its f32 row is never read -- and
+// only rows with two or more (or an overflowed list: every centroid) go through the exact chains.
+__global__ __launch_bounds__(128) void assign_resolve_kernel(const AssignWideArgs a, const float *__restrict__ rows, const float *__restrict__ centroids,
+                                                            uint32_t dim, uint32_t *__restrict__ cluster, unsigned long long *__restrict__ stats) {
+    __shared__ float lds_all[2][64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float *lds = lds_all[wv];
+    const uint64_t wave_row0 = ((uint64_t)blockIdx.x * 2 + (uint32_t)wv) * 16;
+    const uint64_t row = wave_row0 + (uint32_t)(lane >> 2);
+    const uint32_t cl = (uint32_t)lane & 3u;
+    const bool live = row < a.m;
+    uint32_t cnt = live ? a.cand_cnt[row] : 0u;
+    const bool all = cnt > a.cap;                     // list overflowed: every centroid is a candidate
+    float cut = INFINITY;
+    if (live && !all) {
+        cut = assign_cut(a.xn2[row], a.best_t[row], a.cm);
+    }
+    // survivors of the row: count and (where it is the only one) the id
+    uint32_t nsurv = 0, only = 0;
+    if (!all)
+        for (uint32_t ci = cl; ci < cnt; ci += 4)
+            if (!(a.cand_t[row * a.cap + ci] > cut)) { ++nsurv; only = a.perm[a.cand[row * a.cap + ci]]; }
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint32_t on = (uint32_t)__shfl_xor((int)nsurv, off, 64), oo = (uint32_t)__shfl_xor((int)only, off, 64);
+        only = nsurv ? only : oo;          // (meaningful only when the total is 1)
+        nsurv += on;
+    }
+    const bool exact = live && (all || nsurv != 1u);
+    if (all) cnt = a.kc;
+    if (!exact) cnt = 0;
+    const uint32_t G = dim >> 2;
+    uint64_t best = KEY_EMPTY;
+    uint32_t n_eval = 0;
+    for (uint32_t t = 0;; ++t) {
+        const uint32_t ci = 4 * t + cl;
+        bool act = ci < cnt;
+        uint32_t j = 0u;
+        if (act) {
+            if (all) j = ci;
+            else { j = a.perm[a.cand[row * a.cap + ci]]; act = !(a.cand_t[row * a.cap + ci] > cut); }
+        }
+        if (__ballot(ci < cnt) == 0) break;
+        const uint64_t mask = __ballot(act);
+        if (mask == 0) continue;
+        n_eval += act ? 1u : 0u;
+        float sum = 0.0f;
+        for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+            const uint32_t ng = (G - g0 < 64u) ? (G - g0) : 64u;
+            const bool gv = (uint32_t)lane < ng;
+            const uint32_t goff = (g0 + (gv ? (uint32_t)lane : 0u)) * 4;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m4 = (uint32_t)(mask >> (4 * r)) & 0xFu;     // wave-uniform
+                if (m4 == 0) continue;
+                const float4 xv = load4<true>(rows + (wave_row0 + (uint32_t)r) * dim + goff);
+                float4 cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t jp = readlane_u32(j, 4 * r + u);
+                    cv[u] = load4<true>(centroids + (uint64_t)jp * dim + goff);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d0 = xv.x - cv[u].x, d1 = xv.y - cv[u].y, d2 = xv.z - cv[u].z, d3 = xv.w - cv[u].w;
+                    float tt = d0 * d0 + d1 * d1;
+                    tt = tt + d2 * d2;
+                    tt = tt + d3 * d3;
+                    if (gv) lds[lane * 65 + 4 * r + u] = tt;
+                }
+            }
+            wave_lds_fence();
+            uint32_t e = 0;
+            for (; e + 8 <= ng; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = lds[(e + u) * 65 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; e < ng; ++e) sum = sum + lds[e * 65 + lane];
+            wave_lds_fence();
+        }
+        if (act) {
+            const uint64_t key = ((uint64_t)__float_as_uint(sum) << 32) | j;
+            best = key < best ? key : best;
+        }
+    }
+    // the row's four lanes: smallest (distance bits, index) = strict '<' in ascending centroid order (index.rs:408-415)
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const uint64_t o = shfl_u64(best, lane ^ off);
+        best = o < best ? o : best;
+    }
+    if (live && cl == 0) cluster[row] = exact ? (best == KEY_EMPTY ? 0u : (uint32_t)best) : only;
+    if (stats) {
+        const unsigned long long rows_x = (unsigned long long)__popcll(__ballot(exact && cl == 0));
+        uint32_t ev = n_eval;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ev += (uint32_t)__shfl_xor((int)ev, off, 64);
+        if (lane == 0 && (rows_x || ev)) { atomicAdd(&stats[0], rows_x); atomicAdd(&stats[1], (unsigned long long)ev); }
+    }
+}
+hipError_t launch_assign_resolve(const AssignWideArgs &a, const float *rows, const float *centroids, uint32_t dim, uint32_t *cluster,
+                                 unsigned long long *stats, hipStream_t s) {
+    if (a.m == 0) return hipSuccess;
+    if ((dim % 4) != 0) return hipErrorInvalidValue;
+    const uint64_t wblocks = (a.m + 31) / 32;
+    if (wblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assign_resolve_kernel, dim3((uint32_t)wblocks), dim3(128), 0, s, a, rows, centroids, dim, cluster, stats);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// k-means++ rounds with an int8 screen (kernels.h: MinUpdScreenArgs).  One wave per 16-row tile.
+//   screen   A = the picked row's image (every M row the same: an LDS broadcast), B = the tile's images straight from global
+//            memory (one contiguous 1 KiB per K step of 64 dims): lane (l15, kk) ends with the image dot product of row l15 in
+//            every accumulator register; |xi - ci|^2 = Nx + Nc - 2 dot is exact, and
+//                ref(x, c) >= (max(0, sqrt(|xi - ci|^2) / S - rx - rc))^2 (1 - cm)          (block_rows_i8_kernel's residual bounds)
+//   exact    rows the bound cannot rule out: the wave reads such a row 1 KiB at a time, lane g forms the 4-group term of group
+//            g (index.rs:466-472), parks it in LDS [group][row slot], and lane `slot` adds its row's terms in ascending group
+//            order -- the reference's chain, as in stream_kernel.
+// ------------------------------------------------------------------------------------
+// one 16-row tile of a round: screen + exact evaluation of what it cannot rule out
+__device__ __forceinline__ void minupd_screen_tile(const MinUpdScreenArgs &a, uint64_t pick, uint64_t T, const float4 *cimg, float *terms, int lane) {
+    const uint32_t dim = a.dim, G16 = dim >> 4, G = dim >> 2;
+    const int l15 = lane & 15, kk = lane >> 4;
+    // ---- screen: image dot products of the tile's 16 rows with the picked row
+    const float4 *tb = a.img + T * G16 * 16;
+    i32x4_acc acc = {0, 0, 0, 0};
+    const uint32_t nks = G16 >> 2;                   // K steps of 64 dims
+    constexpr int NB = 12;                           // operand loads in flight
+    for (uint32_t k0 = 0; k0 < nks; k0 += NB) {
+        float4 xb[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const uint32_t ks = k0 + u < nks ? k0 + u : nks - 1;
+            xb[u] = tb[ks * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (k0 + u < nks) mfma_step<OP_I8>(acc, cimg[4 * (k0 + u) + kk], xb[u]);
+    }
+    const uint64_t row = T * 16 + (uint32_t)l15;
+    const bool live = row < a.n;
+    const int nc = a.n2i[pick];
+    const float rc = a.res[pick];
+    const int nx = live ? a.n2i[row] : 0;
+    const float rx = live ? a.res[row] : 0.0f;
+    const float old = live ? a.min_d[row] : 0.0f;
+    // |xi - ci|^2: exact in int32 (<= 4 * 127^2 dim); its f32 image and square root are rounded DOWNWARD by the factors below
+    const int di = nx + nc - 2 * acc[0];
+    const float dn = sqrtf((float)(di > 0 ? di : 0)) * 0.999999f * a.inv_s;
+    const float g = fmaxf(dn * 0.999999f - (rx + rc) * 1.000001f, 0.0f);
+    const float lb = g * g * 0.999999f * (1.0f - a.cm);
+    const bool need = live && kk == 0 && !(lb > old);       // (a NaN bound is never a reason to skip)
+    const uint64_t mask = __ballot(need);                    // bits 0..15: rows of the tile to evaluate exactly
+    if (mask == 0) return;
+    // ---- exact distances of the flagged rows, the reference's order
+    const float *crow = a.rows + pick * dim;
+    float sum = 0.0f;
+    for (uint32_t c0 = 0; c0 < G; c0 += 64) {
+        const uint32_t ng = G - c0 < 64u ? G - c0 : 64u;
+        const bool gv = (uint32_t)lane < ng;
+        const uint32_t goff = (c0 + (gv ? (uint32_t)lane : 0u)) * 4;
+        const float4 qq = load4<true>(crow + goff);
+        uint64_t todo = mask;
+        while (todo) {
+            // up to four rows' loads in flight
+            int sl[4];
+            float4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sl[u] = todo ? __builtin_ctzll(todo) : -1;
+                if (todo) todo &= todo - 1;
+                if (sl[u] >= 0) xv[u] = load4<true>(a.rows + (T * 16 + (uint32_t)sl[u]) * dim + goff);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (sl[u] < 0) continue;
+                const float d0 = qq.x - xv[u].x, d1 = qq.y - xv[u].y, d2 = qq.z - xv[u].z, d3 = qq.w - xv[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                if (gv) terms[lane * 17 + sl[u]] = t;
+            }
+        }
+        wave_lds_fence();
+        if (need) {
+            uint32_t e = 0;
+            for (; e + 8 <= ng; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = terms[(e + u) * 17 + l15];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; e < ng; ++e) sum = sum + terms[e * 17 + l15];
+        }
+        wave_lds_fence();
+    }
+    if (need && sum < old) {                                 // index.rs:363-365
+        a.min_d[row] = sum;
+        if (a.mirror) a.mirror[row] = sum;
+        if (a.mirror_t) a.mirror_t[(row % a.mirror_chunk) * a.mirror_stride + row / a.mirror_chunk] = sum;
+    }
+}
+__global__ __launch_bounds__(256) void minupd_screen_kernel(const MinUpdScreenArgs a) {
+    extern __shared__ float4 mus_lds[];              // [G16] the picked row's image, then per wave [64][17] floats of chain terms
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t G16 = a.dim >> 4;
+    float4 *cimg = mus_lds;
+    float *terms = reinterpret_cast<float *>(mus_lds + G16) + wave * (64 * 17);
+    {
+        const uint64_t Tp = a.pick >> 4, jp = a.pick & 15;
+        for (uint32_t cc = threadIdx.x; cc < G16; cc += 256) cimg[cc] = a.img[(Tp * G16 + cc) * 16 + jp];
+    }
+    __syncthreads();
+    const uint64_t n_tiles = (a.n + 15) >> 4;
+    const uint64_t T = (uint64_t)blockIdx.x * 4 + (uint32_t)wave;
+    if (T < n_tiles) minupd_screen_tile(a, a.pick, T, cimg, terms, lane);
+}
+hipError_t launch_minupd_screen(const MinUpdScreenArgs &a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    if ((a.dim % 64) != 0 || a.pick >= a.n) return hipErrorInvalidValue;
+    const uint64_t n_tiles = (a.n + 15) / 16, blocks = (n_tiles + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.dim / 16) * 16 + 4 * 64 * 17 * sizeof(float);
+    if (lds > 65536) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(minupd_screen_kernel, dim3((uint32_t)blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 // |row - mu|^2 and 1 / |row - mu| per row, and the f16 image of (row - mu) / |row - mu| * 2^8 zero-padded to dim_p:
 // one wave per row (mu == nullptr: no centring).  pad_to rows beyond n are written as zero rows (the centroid table is
 // padded to a multiple of 256 rows).
 __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *__restrict__ rows, const float *__restrict__ mu, uint64_t n,
                                                                   uint64_t n_pad, uint32_t dim, uint32_t dim_p, float *__restrict__ out_n2,
-                                                                  uint16_t *__restrict__ out) {
+                                                                  uint16_t *__restrict__ out, float fixed_scale, const uint32_t *__restrict__ idx) {
     const int lane = threadIdx.x & 63;
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nw = (uint64_t)gridDim.x * 4;
@@ -331,7 +756,7 @@ __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *
             for (uint32_t e = lane; e < dim_p; e += 64) out[r * dim_p + e] = 0;
             continue;
         }
-        const float *p = rows + r * dim;
+        const float *p = rows + (idx ? (uint64_t)idx[r] : r) * dim;
         float acc = 0.0f;
         if ((dim & 7u) == 0 && dim <= 2048) {
             // 8 values (two 16-byte loads) per lane and step, kept in registers between the norm and the scaling pass
@@ -356,7 +781,7 @@ __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
             if (lane == 0) out_n2[r] = acc;
-            const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+            const float sc = fixed_scale > 0.0f ? fixed_scale : acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
             auto cl = [&](float x) { return fminf(fmaxf(x * sc, -65504.0f), 65504.0f); };
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -376,7 +801,7 @@ __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) out_n2[r] = acc;
-        const float sc = acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
+        const float sc = fixed_scale > 0.0f ? fixed_scale : acc > 0.0f ? 256.0f / sqrtf(acc) : 0.0f;
         for (uint32_t e = lane; e < dim_p; e += 64) {
             float v = e < dim ? (p[e] - (mu ? mu[e] : 0.0f)) * sc : 0.0f;
             v = fminf(fmaxf(v, -65504.0f), 65504.0f);
@@ -386,12 +811,12 @@ __global__ __launch_bounds__(256) void center_normalize_f16_kernel(const float *
     }
 }
 hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint64_t n, uint64_t n_pad, uint32_t dim, uint32_t dim_p,
-                                       float *out_n2, void *out, hipStream_t s) {
+                                       float *out_n2, void *out, hipStream_t s, float fixed_scale, const uint32_t *idx) {
     if (n_pad == 0) return hipSuccess;
     uint64_t blocks = (n_pad + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(center_normalize_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, rows, mu, n, n_pad, dim, dim_p, out_n2,
-                       static_cast<uint16_t *>(out));
+                       static_cast<uint16_t *>(out), fixed_scale, idx);
     return hipGetLastError();
 }
 // mu[d] = mean over the k rows of m[., d]: one block per 64 columns, four row slices per column reduced through LDS

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs a) {
                 if (sum < old) {                       // index.rs:363-365
                     a.out_f32[pos] = sum;
                     if (a.mirror_f32) a.mirror_f32[pos] = sum;
+                    if (a.mirror_t) a.mirror_t[(pos % a.mirror_chunk) * a.mirror_stride + pos / a.mirror_chunk] = sum;
                 }
             }
         } else {

@@ -108,13 +108,32 @@ class RcclShardComm:
 
     @classmethod
     def create_collective(cls, rank, world, device_index):
-        """Every rank of the torch process group calls this together.  Returns (comm or None, reason): whatever fails
-        on whichever rank, every rank takes the same number of collectives, so a failure never leaves ranks waiting
-        for each other."""
+        """Every rank of the torch process group calls this together.  Returns (comm or None, reason).
+
+        A rank that cannot even reach ncclCommInitRank (librccl not resolvable, bad device index) would leave the others
+        blocked inside it, so a NON-collective pre-flight runs first on every rank (the library resolves RCCL and selects
+        the device) and its result is all-reduced: the collective initialisation starts only if every rank passed.
+        Failures before and after the initialisation take the same number of torch collectives on every rank; a failure
+        INSIDE ncclCommInitRank itself (a rank dying mid-rendezvous) is RCCL's to time out."""
         import ctypes as C
         from . import _ffi
         dev = torch.device("cuda", device_index)
         on_gpu = world > 1 and dist.get_backend() == "nccl"
+        pre_ok, pre_why = 1, ""
+        try:
+            if not _ffi.lib().pqv_shard_rccl_path():
+                pre_ok, pre_why = 0, "librccl could not be resolved on this rank: " + _ffi.lib().pqv_last_error().decode()
+            elif not (0 <= device_index < max(1, _ffi.lib().pqv_device_count())):
+                pre_ok, pre_why = 0, f"device index {device_index} out of range on this rank"
+        except Exception as e:
+            pre_ok, pre_why = 0, str(e)
+        if world > 1:
+            okt = torch.tensor([pre_ok], dtype=torch.int32, device=dev if on_gpu else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) != 1:
+                return None, pre_why or "the RCCL pre-flight failed on another rank"
+        elif not pre_ok:
+            return None, pre_why
         msg = torch.zeros(129, dtype=torch.uint8)
         reason = ""
         if rank == 0:
@@ -149,6 +168,13 @@ class RcclShardComm:
         writes out_d f32 / out_r i64 [nq, k] on `stream` (default: torch's current stream)."""
         from . import _ffi
         nq, k = local_dist.shape
+        # raw pointers cross the ABI below: a sliced view, a wrong dtype or a host tensor would be read as garbage, silently
+        for name, t, dt, shape in (("local_dist", local_dist, torch.float32, (nq, k)), ("local_rows_i32", local_rows_i32, torch.int32, (nq, k)),
+                                   ("row_bases_i64", row_bases_i64, torch.int64, (self.world,)), ("out_d", out_d, torch.float32, (nq, k)),
+                                   ("out_r", out_r, torch.int64, (nq, k))):
+            if not (t.is_cuda and t.device.index == self.device_index and t.is_contiguous() and t.dtype == dt and tuple(t.shape) == shape):
+                raise ValueError(f"{name}: expected a contiguous {dt} tensor of shape {shape} on cuda:{self.device_index}, got "
+                                 f"{t.dtype} {tuple(t.shape)} on {t.device}{'' if t.is_contiguous() else ' (non-contiguous)'}")
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _rc(_ffi.lib().pqv_shard_exchange(self._h, _ffi.vp(local_dist.data_ptr()), _ffi.vp(local_rows_i32.data_ptr()),
                                           _ffi.vp(row_bases_i64.data_ptr()), nq, k, _ffi.vp(out_d.data_ptr()),

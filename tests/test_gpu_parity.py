@@ -271,6 +271,11 @@ def test_rerank_f64_batches_are_narrowed_like_the_reference(pqv, oracle):
     (3000, 30, 12, 3),       # unaligned dim
     (60000, 8, 25, 8),       # sample 3000, init subset == sample
     (1200, 768, 6, 5),
+    (40000, 128, 24, 8),     # sample 2000 rows of a multiple of 64 dims: the k-means++ rounds take the f16-screened min-update
+    (30000, 192, 12, 3),
+    (40000, 128, 24, 40),    # 40 chunk chains: the chunk-transposed mirror of the minima (vector lanes = chunks)
+    (50000, 64, 30, 256),    # the GPU box's own worker count: chunks of 10 minima
+    (24000, 256, 140, 8),    # ... and >= 128 centroids: the 256 x 256-tile f16 assignment + resolve pass
 ])
 def test_index_build_matches_oracle(pqv, oracle, n, dim, kc, workers):
     rng = np.random.default_rng(n + dim)
@@ -285,6 +290,29 @@ def test_index_build_matches_oracle(pqv, oracle, n, dim, kc, workers):
     assert (_bits(index.centroids) == _bits(oidx.centroids)).all(), "centroids differ"
     assert (index.list_offsets == oidx.list_off).all()
     assert (index.list_rows == oidx.list_rows).all()
+    assert index.to_bytes() == oidx.to_bytes()
+
+
+@pytest.mark.parametrize("kind", ["offset", "scales", "duplicates"])
+def test_kmeans_pp_screen_and_wide_assignment_on_hostile_data(pqv, oracle, kind):
+    """The f16 screens of the build (k-means++ min-update, 256 x 256-tile assignment) are bounds, never answers: data far from
+    the origin (the centring must carry the bound), rows of wildly different norms, and exact duplicates (zero distances, ties
+    at the minimum) must give the oracle's blob."""
+    rng = np.random.default_rng(31)
+    n, dim, kc = 26000, 128, 130
+    if kind == "offset":
+        data = (np.float32(-1000.0) + np.float32(0.01) * rng.standard_normal((n, dim), dtype=np.float32)).astype(np.float32)
+    elif kind == "scales":
+        data = rng.standard_normal((n, dim), dtype=np.float32)
+        data[::7] *= np.float32(1.0e4)
+        data[3::11] *= np.float32(1.0e-4)
+    else:
+        base = rng.random((n // 40, dim), dtype=np.float32)
+        data = np.repeat(base, 40, axis=0)[:n].copy()
+        data[::3] += np.float32(1.0e-3) * rng.random((len(data[::3]), dim), dtype=np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=8)
+    index = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).workers(8).build()
+    assert (_bits(index.centroids) == _bits(oidx.centroids)).all(), "centroids differ"
     assert index.to_bytes() == oidx.to_bytes()
 
 
