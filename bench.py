@@ -341,6 +341,94 @@ def ivf_config(args, pqv, torch, dev, local_rank, name, k, data="uniform", parit
     return rec
 
 
+def from_parquet_config(args, pqv, torch, dev, local_rank, name="refbench", k=100, n_queries=20):
+    """The reference's own end-to-end benches on its own shape (benches/index_build.rs:43-50: IndexBuilder::new(path, "embedding")
+    .build_inplace(); benches/query.rs: TopkBuilder over the indexed file): the synthetic column is written as List<f32> with an
+    Int32 id column in ONE row group (what ArrowWriter's defaults give benches/bench_util.rs:12-58 for 1 M rows), then
+      build_inplace   = Parquet column -> HBM (N1: reader threads + pinned staging + async DMA) + index build + blob appended to the file
+      first search    = read the blob back, load the column, create the searcher, answer one query
+      warm searches   = the cached resident searcher (the reference re-reads blob and candidate rows on every call, search.rs:89-110)
+    next to the CPU oracle on the same host (its k-means / assignment threads = the reference's worker chunks), whose blob and
+    answers the GPU's must equal."""
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n, dim, kc, nprobe, _ = WORKLOADS[name]
+    t_all = time.perf_counter()
+    corpus_t = synth(torch, dev, 1234, n, dim)
+    q_t = synth(torch, dev, 7, n_queries, dim)
+    host = corpus_t.cpu().numpy()
+    qs = q_t.cpu().numpy()
+    del corpus_t
+    torch.cuda.empty_cache()
+    tmp = tempfile.mkdtemp(prefix="pqv_bench_")
+    path = os.path.join(tmp, "bench.parquet")
+    t0 = time.perf_counter()
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int64 if (n + 1) * dim > 2**31 - 1 else np.int32)),
+                                   pa.array(host.reshape(-1)))
+    if pa.types.is_large_list(col.type):
+        col = col.cast(pa.list_(pa.field("item", pa.float32())))
+    table = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "embedding": col})
+    pq.write_table(table, path, row_group_size=max(n, 1 << 20), compression="NONE", use_dictionary=False)
+    write_s = time.perf_counter() - t0
+    del table, col
+    file_bytes = os.path.getsize(path)
+    rec = {"config": f"{name}: {n}x{dim} uniform f32 as List<f32> 'embedding' + Int32 'id', {pq.ParquetFile(path).metadata.num_row_groups} row group(s), "
+                     f"uncompressed; default n_clusters, max_iters 20, seed 42; k {k}, nprobe {nprobe}",
+           "file_bytes": file_bytes, "synthetic_file_write_s": write_s}
+    try:
+        b = pqv.IndexBuilder(path, "embedding", device=local_rank).workers(os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        index = b.build_inplace()
+        total = time.perf_counter() - t0
+        st = b.last_stats
+        rec["build_inplace"] = {"seconds": total, "vectors_per_s": n / total, "load_s": st["load_s"], "build_s": st["build_s"], "append_s": st["write_s"],
+                                "loader": st["load"], "pcie_peak_GBps": 63.0,
+                                "loader_note": "Parquet decode (pyarrow, one thread per row group up to 8) -> pinned staging -> hipMemcpyAsync; GB/s counts the f32 payload"}
+        blob = index.to_bytes()
+        t0 = time.perf_counter()
+        first = pqv.TopkBuilder(path, qs[0], device=local_rank).k(k).nprobe(nprobe).search()
+        first_s = time.perf_counter() - t0
+        lat, answers = [], [first]
+        for i in range(1, n_queries):
+            t1 = time.perf_counter()
+            answers.append(pqv.TopkBuilder(path, qs[i], device=local_rank).k(k).nprobe(nprobe).search())
+            lat.append(time.perf_counter() - t1)
+        rec["topk_builder"] = {"first_search_s": first_s, "warm_p50_us": float(np.percentile(np.array(lat) * 1e6, 50)),
+                               "warm_calls": len(lat), "k": k, "nprobe": nprobe,
+                               "note": "first = read_index_from_parquet + column load + searcher creation + the query; warm = the resident searcher, one query per call"}
+        if not args.no_cpu:
+            from oracle_binding import Oracle, build_oracle
+            build_oracle("native")
+            o = Oracle(native=True)
+            t0 = time.perf_counter()
+            oidx = o.build_index(host, n_clusters=0, max_iters=20, seed=42, workers=os.cpu_count() or 1)
+            cpu_build = time.perf_counter() - t0
+            same_blob = oidx.to_bytes() == blob
+            t0 = time.perf_counter()
+            ok = True
+            for i in range(n_queries):
+                orows, odist, onf, _ = oidx.topk_batch(host, qs[i:i + 1], k, nprobe)
+                got = answers[i]
+                ok &= len(got) == int(onf[0]) and all(got[j].row_idx == int(orows[0, j]) for j in range(len(got))) and \
+                    all(np.float32(got[j].distance).view(np.uint32) == odist[0, j].view(np.uint32) for j in range(len(got)))
+            cpu_q = (time.perf_counter() - t0) / n_queries
+            rec["cpu_oracle"] = {"build_s_in_memory": cpu_build, "build_threads": os.cpu_count(), "query_s_in_memory_1_thread": cpu_q,
+                                 "note": "the oracle on the in-memory column (no Parquet I/O on its side): build with the reference's worker-chunk threads, "
+                                         "one query on one thread (search.rs:115)"}
+            rec["parity"] = {"checker": "CPU oracle at full size", "index_blob_identical": bool(same_blob), "queries_checked": n_queries,
+                             "topk_rows_and_distance_bits_identical": bool(ok), "ok": bool(same_blob and ok)}
+    finally:
+        try:
+            os.remove(path); os.rmdir(tmp)
+        except OSError:
+            pass
+        from pq_vector_amd import api as _api
+        _api._PATH_SEARCHERS.clear()
+    rec["seconds"] = time.perf_counter() - t_all
+    return rec
+
+
 def build_record(n, dim, kc, build_s):
     """Phases of the last index build (pqv_index_build_stats) and the roofline of its dominant step, the final
     assignment of every row (src/ivf/index.rs:189-206): a dense n x n_clusters x dim contraction, SURVEY 8(d):
@@ -427,6 +515,11 @@ def main():
                          "always on for --force-dist with one rank, opt-in beyond (a second communicator that has never met real "
                          "multi-GPU hardware must not be able to cost a scaling run its line)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Gaussian-mixture pass that follows the default C3 run")
+    ap.add_argument("--rows-per-rank", type=int, default=0,
+                    help="c4 only: rows of every rank's shard (default 12 500 000; a smaller shard makes a quick multi-rank path check)")
+    ap.add_argument("--from-parquet", action="store_true",
+                    help="only the reference's end-to-end benches (IndexBuilder(path).build_inplace(), TopkBuilder(path).search()) on a synthetic "
+                         "Parquet file of its own bench shape; prints that record as the line")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / refbench / c4-shard / c5 passes that follow the default C3 run")
     ap.add_argument("--parity-queries", type=int, default=64, help="queries of the step checked bit for bit against the CPU oracle")
     ap.add_argument("--recall", type=int, default=32, help="queries checked against an exact brute force (0 disables)")
@@ -468,9 +561,20 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.from_parquet:
+        rec = from_parquet_config(args, pqv, torch, dev, local_rank)
+        bi = rec.get("build_inplace", {})
+        line = {"metric": "index_build_vectors_per_s_from_parquet", "value": bi.get("vectors_per_s"), "unit": "vectors/s", "n_gpus": 1,
+                "steps": 1, "warmup": 0, "ms_per_step": (bi.get("seconds") or 0.0) * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": rec["config"]}}
+        line.update(rec)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        sys.exit(0 if rec.get("parity", {}).get("ok", True) else 3)
     if args.workload is None:
         args.workload = "c3" if world == 1 else "c4"
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
+    if args.workload == "c4" and args.rows_per_rank > 0:
+        n_total = args.rows_per_rank
     nq = args.nq or nq_default
     from pq_vector_amd.sharding import ShardExchange, shard_range
     weak = args.workload == "c4"           # per-rank shard size fixed: N ranks hold N x rows
@@ -578,6 +682,7 @@ def main():
     # (`repeats`; every rank runs the same count: the decision is taken on the all-reduced time of the first block).
     searcher.set_timing(not args.no_timing)
     block_s = []
+    rank_block_s = []          # per block: every rank's own wall time (the line reports the spread)
     repeats = 1
     while len(block_s) < repeats:
         t0 = time.perf_counter()
@@ -586,6 +691,10 @@ def main():
         barrier()
         el_b = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if use_dist:
+            mine = el_b.clone()
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_block_s.append([float(x.item()) for x in every])
             dist.all_reduce(el_b, op=dist.ReduceOp.MAX)
         block_s.append(float(el_b.item()))
         if len(block_s) == 1 and args.steps > 0:
@@ -734,6 +843,11 @@ def main():
                       "frac": (mf / (k_ms * 1e-3) / 1e12 / (5000.0 if i8 else 2500.0 if f16 else 157.3)) if k_ms else 0.0} if screened else None,
     }
     result["counters"] = ctr
+    if rank_block_s:
+        med = int(np.argsort(block_s)[len(block_s) // 2])
+        per = [t / steps * 1e3 for t in rank_block_s[med]]
+        result["per_rank_ms_per_step"] = {"min": min(per), "max": max(per), "ranks": per,
+                                          "note": "every rank's own wall time of the median block / steps; the line's ms_per_step is the maximum"}
     if exchange and xchg.fast:
         # the library merge kernel against the torch stable-sort merge of the same gathered lists
         lane = (step_no[0] - 1) % n_lanes if step_no[0] else 0
@@ -750,8 +864,9 @@ def main():
         for _ in range(10):
             xchg_l[0].exchange_u32(dist_l[0], rows_l[0])
         torch.cuda.synchronize()
+        xms = (time.perf_counter() - t1) / 10 * 1e3
         result["exchange"] = {"ranks": world, "backend": "RCCL" if args.backend == "nccl" else args.backend,
-                              "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
+                              "ms_per_step": xms, "share_of_step": xms / (elapsed / steps * 1e3),
                               "bytes_per_rank_per_step": nq * K * 8,
                               "collective": "one all_gather_into_tensor of packed {f32 distance, u32 row} pairs + shard_merge_kernel"}
         if args.backend == "nccl" and (args.cabi_check or world == 1):
@@ -793,13 +908,17 @@ def main():
         for _ in range(10):
             xchg_l[0].exchange(dist_l[0], rows_l[0].to(torch.int64) & 0xFFFFFFFF, lo)
         torch.cuda.synchronize()
-        result["exchange"] = {"ranks": world, "backend": args.backend, "ms_per_step": (time.perf_counter() - t1) / 10 * 1e3,
+        xms = (time.perf_counter() - t1) / 10 * 1e3
+        result["exchange"] = {"ranks": world, "backend": args.backend, "ms_per_step": xms, "share_of_step": xms / (elapsed / steps * 1e3),
                               "bytes_per_rank_per_step": nq * K * 16,
                               "collective": "one all_gather_into_tensor of packed {f32 distance bits, i64 global row} pairs + stable-sort merge"}
 
     # ---- N > 1: the other multi-GPU mode on the same hardware, as a secondary object -------------------------
     if world > 1 and not replica and not args.force_dist and args.multi == "auto":
-        result["replicas"] = replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps=max(20, min(steps, 200)))
+        try:        # a secondary object: whatever goes wrong in it (on every rank alike: an allocation, a build) must not cost the headline its line
+            result["replicas"] = replica_pass(args, pqv, torch, dist, dev, local_rank, rank, world, nq, steps=max(20, min(steps, 200)))
+        except Exception as e:
+            result["replicas"] = {"error": str(e)[:300]}
 
     # ---- latency mode: one query per call through the same device API ------------
     if args.single and rank == 0 and world == 1:
@@ -884,6 +1003,7 @@ def main():
             cfg["refbench"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "refbench", 100, parity_queries=64))
             cfg["c4_shard_1rank_rccl"] = guarded(lambda: ivf_config(args, pqv, torch, dev, local_rank, "c4", 10, parity_queries=64, rccl=True))
             cfg["c5"] = guarded(lambda: brute_measure(args, pqv, torch, dev, local_rank, "c5", 10, steps=5))
+            cfg["refbench_from_parquet"] = guarded(lambda: from_parquet_config(args, pqv, torch, dev, local_rank))
             result["configs"] = cfg
             result["configs_note"] = ("BASELINE.json configs[1] (c2), the reference's own bench shape benches/query.rs:27-31 (refbench: 1 M x 1024, "
                                       "default n_clusters, K 100, nprobe 16), one configs[3] shard on one rank with the RCCL exchange in every step "

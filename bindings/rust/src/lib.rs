@@ -88,6 +88,29 @@ impl Corpus {
         check(unsafe { sys::pqv_corpus_append_f64(self.raw, rows.as_ptr(), (rows.len() / dim) as u64) })
     }
 
+    /// Streaming upload (`src/ivf/parquet.rs:262-286` batch by batch): rows `[row_offset, row_offset + rows.len() / dim)` are
+    /// staged in pinned memory and DMA'd asynchronously; batches may come in any order, from several threads (`&self`).
+    pub fn write_rows(&self, row_offset: usize, rows: &[f32]) -> Result<()> {
+        let dim = self.dim();
+        if rows.len() % dim != 0 {
+            return Err("Embedding data length must be a multiple of dimension".into());
+        }
+        check(unsafe { sys::pqv_corpus_write_rows(self.raw, row_offset as u64, rows.as_ptr(), (rows.len() / dim) as u64) })
+    }
+
+    pub fn write_rows_f64(&self, row_offset: usize, rows: &[f64]) -> Result<()> {
+        let dim = self.dim();
+        if rows.len() % dim != 0 {
+            return Err("Embedding data length must be a multiple of dimension".into());
+        }
+        check(unsafe { sys::pqv_corpus_write_rows_f64(self.raw, row_offset as u64, rows.as_ptr(), (rows.len() / dim) as u64) })
+    }
+
+    /// Waits for every upload and sets the row count.
+    pub fn finish(&mut self, n_rows: usize) -> Result<()> {
+        check(unsafe { sys::pqv_corpus_finish(self.raw, n_rows as u64) })
+    }
+
     pub fn rows(&self) -> usize {
         unsafe { sys::pqv_corpus_rows(self.raw) as usize }
     }

@@ -87,6 +87,15 @@ int pqv_corpus_create(int device, uint64_t capacity_rows, uint32_t dim, pqv_corp
 int pqv_corpus_append(pqv_corpus *corpus, const float *rows, uint64_t n_rows);
 /* Same, narrowing a Float64 column to f32 first (src/ivf/parquet.rs:246-256). */
 int pqv_corpus_append_f64(pqv_corpus *corpus, const double *rows, uint64_t n_rows);
+/* Streaming upload for a loader that decodes row groups on several threads (N1; src/ivf/parquet.rs:216-305 materialises the
+ * column batch by batch, :262-286): rows [row_offset, row_offset + n_rows) of a corpus made by pqv_corpus_create are written from
+ * `rows`.  The call copies them into one of the corpus' PINNED staging buffers and enqueues the DMA (hipMemcpyAsync); it returns
+ * as soon as the caller's buffer may be reused, so decoding the next batch overlaps the upload of this one.  Batches may arrive
+ * in any order and from several threads.  _f64 narrows `as f32` on the device (:246-256).  pqv_corpus_finish waits for every
+ * DMA and sets the row count to n_rows (<= capacity); until then the corpus must not be used by anything else. */
+int pqv_corpus_write_rows(pqv_corpus *corpus, uint64_t row_offset, const float *rows, uint64_t n_rows);
+int pqv_corpus_write_rows_f64(pqv_corpus *corpus, uint64_t row_offset, const double *rows, uint64_t n_rows);
+int pqv_corpus_finish(pqv_corpus *corpus, uint64_t n_rows);
 /* Adopt an existing device buffer [n, dim] f32 on `device` (borrowed; caller keeps it
  * alive and frees it). */
 int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,

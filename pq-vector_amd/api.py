@@ -74,6 +74,20 @@ class Corpus:
             r = _f32(rows)
             _check(_ffi.lib().pqv_corpus_append(self._h, r.ctypes.data_as(f32p), r.shape[0]))
 
+    def write_rows(self, row_offset, rows):
+        """Streaming upload (pqv_corpus_write_rows): rows [row_offset, row_offset + len(rows)) from a [m, dim] f32 / f64 array,
+        staged in pinned memory and DMA'd asynchronously.  Thread-safe; batches may arrive in any order.  finish() completes."""
+        rows = np.asarray(rows)
+        if rows.dtype == np.float64:
+            r = np.ascontiguousarray(rows)
+            _check(_ffi.lib().pqv_corpus_write_rows_f64(self._h, row_offset, r.ctypes.data_as(f64p), r.shape[0]))
+        else:
+            r = _f32(rows)
+            _check(_ffi.lib().pqv_corpus_write_rows(self._h, row_offset, r.ctypes.data_as(f32p), r.shape[0]))
+
+    def finish(self, n_rows):
+        _check(_ffi.lib().pqv_corpus_finish(self._h, n_rows))
+
     @classmethod
     def from_device_ptr(cls, ptr, n, dim, device=0, keepalive=None):
         """Adopt a device buffer (e.g. a torch tensor's data_ptr()); `keepalive` pins its owner."""
@@ -275,21 +289,33 @@ class IndexBuilder:
         from . import parquet_io
         self._config()                       # build_config() runs first (parquet.rs:58,72)
         self._require_column()
-        return parquet_io.load_embedding_column(self._source, self._embedding_column, self._device)
+        self.last_stats = {"load": {}}
+        return parquet_io.load_embedding_column(self._source, self._embedding_column, self._device, stats=self.last_stats["load"])
+
+    def _timed_build(self, write):
+        """load -> build -> write, with the wall time of each in self.last_stats (the reference's benches/index_build.rs times
+        the three together)."""
+        import time
+        t0 = time.perf_counter()
+        corpus = self._load_parquet()
+        t1 = time.perf_counter()
+        index = self._build_on(corpus)
+        t2 = time.perf_counter()
+        write(index)
+        t3 = time.perf_counter()
+        self.last_stats.update({"load_s": t1 - t0, "build_s": t2 - t1, "write_s": t3 - t2, "total_s": t3 - t0})
+        corpus.close()
+        return index
 
     def build_inplace(self):
         """Build and append the index to the source file (src/ivf/parquet.rs:57-69)."""
         from . import parquet_io
-        index = self._build_on(self._load_parquet())
-        parquet_io.append_index_inplace(self._source, index, self._embedding_column)
-        return index
+        return self._timed_build(lambda index: parquet_io.append_index_inplace(self._source, index, self._embedding_column))
 
     def build_new(self, output):
         """Build and write a new file that carries the index (src/ivf/parquet.rs:71-86)."""
         from . import parquet_io
-        index = self._build_on(self._load_parquet())
-        parquet_io.write_parquet_with_index(self._source, output, index, self._embedding_column)
-        return index
+        return self._timed_build(lambda index: parquet_io.write_parquet_with_index(self._source, output, index, self._embedding_column))
 
     def build(self):
         """In-memory form: returns the Index without touching any file."""
@@ -471,7 +497,8 @@ def searcher_for_parquet(path, device=0):
     if hit is None:
         index, column = parquet_io.read_index_from_parquet(path)
         corpus = parquet_io.load_embedding_column(path, column, device)
-        hit = Searcher(index, corpus, _ffi.PQV_LAYOUT_IVF_ORDERED | _ffi.PQV_RELEASE_ROW_ORDER)
+        # (the images-only IVF layout keeps ONE f32 copy -- the column as loaded -- next to the list-ordered screen images)
+        hit = Searcher(index, corpus, _ffi.PQV_LAYOUT_IVF_ORDERED)
         _PATH_SEARCHERS.clear()          # one resident file at a time by default
         _PATH_SEARCHERS[key] = hit
     return hit

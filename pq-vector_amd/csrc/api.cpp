@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -152,6 +154,28 @@ struct pqv_index {
     std::vector<uint32_t> list_rows;  // concatenated inverted lists
 };
 
+// pinned staging buffers of the streaming upload (pqv_corpus_write_rows): a buffer is free, being filled by a caller, or in
+// flight behind its event
+struct UploadStage {
+    static constexpr int N = 4;
+    static constexpr size_t BYTES = 32u << 20;
+    std::mutex mu;
+    std::condition_variable cv;
+    void *pin[N] = {nullptr, nullptr, nullptr, nullptr};
+    void *dev64[N] = {nullptr, nullptr, nullptr, nullptr};      // f64 batches: device-side landing area of the same size (made on first use)
+    hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};
+    int state[N] = {0, 0, 0, 0};                                // 0 free, 1 claimed, 2 in flight
+    hipStream_t copy_stream = nullptr;
+    ~UploadStage() {
+        for (int i = 0; i < N; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (dev64[i]) (void)hipFree(dev64[i]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
+
 struct pqv_corpus {
     int device = 0;
     uint32_t dim = 0;
@@ -160,6 +184,8 @@ struct pqv_corpus {
     float *d_rows = nullptr;  // [capacity, dim]
     bool owned = true;
     hipStream_t stream = nullptr;
+    std::unique_ptr<UploadStage> upload;       // made by the first pqv_corpus_write_rows
+    std::mutex upload_mu;
     // lazily computed per-row auxiliaries of pqv_brute_topk: 1/|v| and |v|^2
     mutable std::mutex aux_mu;
     mutable DevBuf aux_rnorm, aux_norm2, aux_v16;      // aux_v16: L2-normalised f16 images [n, dim_p] (the f16 screen of pqv_brute_topk)
@@ -402,6 +428,98 @@ static int pqv_corpus_append_f64_impl(pqv_corpus *c, const double *rows, uint64_
 }
 extern "C" int pqv_corpus_append_f64(pqv_corpus *c, const double *rows, uint64_t n_rows) {
     return guard([&] { return pqv_corpus_append_f64_impl(c, rows, n_rows); });
+}
+
+// ---- streaming upload (N1) ----------------------------------------------------------------
+namespace {
+int upload_stage_of(pqv_corpus *c, UploadStage **out) {
+    std::lock_guard<std::mutex> lock(c->upload_mu);
+    if (!c->upload) {
+        std::unique_ptr<UploadStage> u(new UploadStage());
+        HIP_TRY(hipStreamCreateWithFlags(&u->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < UploadStage::N; ++i) {
+            HIP_TRY(hipHostMalloc(&u->pin[i], UploadStage::BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&u->ev[i], hipEventDisableTiming));
+        }
+        c->upload = std::move(u);
+    }
+    *out = c->upload.get();
+    return PQV_OK;
+}
+// a staging buffer nobody else is filling: a free one, else the in-flight one whose DMA ends first (waited for outside the lock)
+int upload_claim(UploadStage *u, int *slot) {
+    std::unique_lock<std::mutex> lock(u->mu);
+    for (;;) {
+        for (int i = 0; i < UploadStage::N; ++i) if (u->state[i] == 0) { u->state[i] = 1; *slot = i; return PQV_OK; }
+        for (int i = 0; i < UploadStage::N; ++i)
+            if (u->state[i] == 2) {
+                u->state[i] = 1;                       // ours; its previous DMA still has to finish
+                lock.unlock();
+                const hipError_t e = hipEventSynchronize(u->ev[i]);
+                if (e != hipSuccess) { lock.lock(); u->state[i] = 0; u->cv.notify_one(); lock.unlock(); HIP_TRY(e); }
+                *slot = i;
+                return PQV_OK;
+            }
+        u->cv.wait(lock);                              // every buffer is being filled by another thread
+    }
+}
+void upload_release(UploadStage *u, int slot, bool in_flight) {
+    { std::lock_guard<std::mutex> lock(u->mu); u->state[slot] = in_flight ? 2 : 0; }
+    u->cv.notify_one();
+}
+template <class T>
+int corpus_write_rows(pqv_corpus *c, uint64_t row_offset, const T *rows, uint64_t n_rows) {
+    if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+    if (!c->owned) return fail(PQV_ERR_INVALID, "cannot write into a borrowed device buffer");
+    if (n_rows == 0) return PQV_OK;
+    if (!rows) return fail(PQV_ERR_INVALID, "rows must not be NULL");
+    if (row_offset > c->capacity || n_rows > c->capacity - row_offset) return fail(PQV_ERR_INVALID, "corpus capacity exceeded");
+    if (int rc = use_device(c->device)) return rc;
+    UploadStage *u = nullptr;
+    if (int rc = upload_stage_of(c, &u)) return rc;
+    const uint64_t row_bytes = static_cast<uint64_t>(c->dim) * sizeof(T);
+    const uint64_t rows_per_piece = std::max<uint64_t>(1, UploadStage::BYTES / row_bytes);
+    if (row_bytes > UploadStage::BYTES) return fail(PQV_ERR_INVALID, "a row exceeds the staging buffer");
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += rows_per_piece) {
+        const uint64_t m = std::min<uint64_t>(rows_per_piece, n_rows - r0);
+        int slot = -1;
+        if (int rc = upload_claim(u, &slot)) return rc;
+        std::memcpy(u->pin[slot], rows + r0 * c->dim, m * row_bytes);
+        float *dst = c->d_rows + (row_offset + r0) * c->dim;
+        hipError_t e = hipSuccess;
+        if (std::is_same<T, float>::value) {
+            e = hipMemcpyAsync(dst, u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, u->copy_stream);
+        } else {
+            if (!u->dev64[slot]) e = hipMalloc(&u->dev64[slot], UploadStage::BYTES);
+            if (e == hipSuccess) e = hipMemcpyAsync(u->dev64[slot], u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, u->copy_stream);
+            if (e == hipSuccess) e = pqv::launch_narrow_f64(static_cast<const double *>(u->dev64[slot]), m * c->dim, dst, u->copy_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(u->ev[slot], u->copy_stream);
+        upload_release(u, slot, e == hipSuccess);
+        HIP_TRY(e);
+    }
+    return PQV_OK;
+}
+}  // namespace
+extern "C" int pqv_corpus_write_rows(pqv_corpus *c, uint64_t row_offset, const float *rows, uint64_t n_rows) {
+    return guard([&] { return corpus_write_rows<float>(c, row_offset, rows, n_rows); });
+}
+extern "C" int pqv_corpus_write_rows_f64(pqv_corpus *c, uint64_t row_offset, const double *rows, uint64_t n_rows) {
+    return guard([&] { return corpus_write_rows<double>(c, row_offset, rows, n_rows); });
+}
+extern "C" int pqv_corpus_finish(pqv_corpus *c, uint64_t n_rows) {
+    return guard([&]() -> int {
+        if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+        if (n_rows > c->capacity) return fail(PQV_ERR_INVALID, "corpus capacity exceeded");
+        if (int rc = use_device(c->device)) return rc;
+        if (c->upload) {
+            HIP_TRY(hipStreamSynchronize(c->upload->copy_stream));
+            std::lock_guard<std::mutex> lock(c->upload_mu);
+            c->upload.reset();                     // the pinned buffers go back: a resident corpus does not keep 128 MB of them
+        }
+        c->n = n_rows;
+        return PQV_OK;
+    });
 }
 
 static int pqv_corpus_upload_impl(int device, const float *rows, uint64_t n, uint32_t dim,

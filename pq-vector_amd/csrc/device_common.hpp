@@ -79,6 +79,9 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
 #ifndef PQV_NS_WIDE
 #define PQV_NS_WIDE 2          // operand stages in flight, 8-wave blocks of <= 96 queries
 #endif
+#ifndef PQV_NS_REG
+#define PQV_NS_REG 2           // ... of the 4-wave int8 instances (two blocks per CU)
+#endif
 #ifndef PQV_NS_TS2
 #define PQV_NS_TS2 2           // ... of the wide-quad instance (32-row tiles): 3 / 4 / 6 measured no faster, 4 and 6 spill
 #endif

@@ -1682,7 +1682,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifndef PQV_XPF
 #define PQV_XPF 1
 #endif
-    constexpr int NS = TS == 2 ? PQV_NS_TS2 : (OP != OP_F32 && QLDS && !PF && NG <= 6 && NW == 8) ? PQV_NS_WIDE : 2;      // operand stages in flight
+    constexpr int NS = TS == 2 ? PQV_NS_TS2 : (OP != OP_F32 && QLDS && !PF && NG <= 6 && NW == 8) ? PQV_NS_WIDE
+                       : (OP == OP_I8 && QLDS && !PF && NW == 4) ? PQV_NS_REG : 2;      // operand stages in flight
     constexpr bool XPF = PQV_XPF;          // the next tile's first stages are requested before this tile's screen
     float4 xs[NS][TS];
     auto tile_desc = [&](uint64_t tn, uint32_t (&so)[TS]) {

@@ -356,12 +356,8 @@ def write_parquet_with_index(source, output, index, embedding_column):
 # ---------------------------------------------------------------------------------------
 # N1: embedding column -> HBM
 # ---------------------------------------------------------------------------------------
-def _column_chunks(path, column, batch_rows=1 << 16):
-    """Yields validated [rows, dim] float arrays (f32 or f64) of the column, batch by batch,
-    with the reference's checks and messages (src/ivf/parquet.rs:231-280)."""
+def _check_column_type(pf, column):
     import pyarrow as pa
-    import pyarrow.parquet as pq
-    pf = pq.ParquetFile(path)
     if column not in pf.schema_arrow.names:
         raise _err(f"Column '{column}' not found")
     typ = pf.schema_arrow.field(column).type
@@ -369,46 +365,109 @@ def _column_chunks(path, column, batch_rows=1 << 16):
         raise _err("Embedding column is not a list array")
     if not (pa.types.is_float32(typ.value_type) or pa.types.is_float64(typ.value_type)):
         raise _err("Embedding values are not float32/float64")
-    dim = None
-    for batch in pf.iter_batches(batch_size=batch_rows, columns=[column]):
-        arr = batch.column(0)
-        if arr.null_count > 0:
-            raise _err("Embedding column contains null rows")
-        n = len(arr)
-        if n == 0:
-            continue
-        flat = arr.flatten()                      # honours the slice offsets
-        if flat.null_count > 0:
-            raise _err("Embedding values contain nulls")
-        if pa.types.is_fixed_size_list(typ):
-            lens = np.full(n, typ.list_size, dtype=np.int64)
-        else:
-            off = arr.offsets.to_numpy()
-            lens = np.diff(off)
-        if (lens == 0).any():
-            raise _err("Embedding row has zero length")
-        if dim is None:
-            dim = int(lens[0])
-        if (lens != dim).any():
-            raise _err("Embedding vectors have inconsistent dimensions")
-        vals = flat.to_numpy(zero_copy_only=False)
-        yield vals.reshape(n, dim)
+    return typ
+
+
+def _batch_rows(arr, typ, dim):
+    """One decoded batch of the column -> ([rows, dim] float array, dim), with the reference's checks and messages
+    (src/ivf/parquet.rs:231-280); `dim` is None until the first batch has fixed it."""
+    import pyarrow as pa
+    if arr.null_count > 0:
+        raise _err("Embedding column contains null rows")
+    n = len(arr)
+    flat = arr.flatten()                      # honours the slice offsets
+    if flat.null_count > 0:
+        raise _err("Embedding values contain nulls")
+    if pa.types.is_fixed_size_list(typ):
+        lens = np.full(n, typ.list_size, dtype=np.int64)
+    else:
+        lens = np.diff(arr.offsets.to_numpy())
+    if (lens == 0).any():
+        raise _err("Embedding row has zero length")
     if dim is None:
-        raise _err("Embedding column has no rows")
+        dim = int(lens[0])
+    if (lens != dim).any():
+        raise _err("Embedding vectors have inconsistent dimensions")
+    return flat.to_numpy(zero_copy_only=False).reshape(n, dim), dim
 
 
-def load_embedding_column(path, column, device=0):
-    """Stream the column row-group-sized batch by batch into one resident [n, dim] f32 matrix
-    (Float64 values are narrowed on the device, parquet.rs:246-256).  Nothing larger than one
-    batch is ever materialised on the host, unlike the reference's Vec<f32> of the whole
-    column (:226)."""
+def _column_chunks(path, column, batch_rows=1 << 16, row_groups=None):
+    """Yields validated [rows, dim] float arrays (f32 or f64) of the column, batch by batch."""
     import pyarrow.parquet as pq
-    n_rows = pq.ParquetFile(path).metadata.num_rows
-    corpus = None
-    for chunk in _column_chunks(path, column):
-        if corpus is None:
-            corpus = Corpus.create(n_rows, chunk.shape[1], device)
-        corpus.append(chunk)
-    if corpus is None:
+    pf = pq.ParquetFile(path)
+    typ = _check_column_type(pf, column)
+    dim = None
+    for batch in pf.iter_batches(batch_size=batch_rows, columns=[column], row_groups=row_groups):
+        arr = batch.column(0)
+        if len(arr) == 0:
+            continue
+        vals, dim = _batch_rows(arr, typ, dim)
+        yield vals
+    if dim is None and row_groups is None:
         raise _err("Embedding column has no rows")
+
+
+def load_embedding_column(path, column, device=0, readers=None, stats=None):
+    """The column -> one resident [n, dim] f32 matrix (src/ivf/parquet.rs:216-305; Float64 values are narrowed on the device,
+    :246-256).  Row groups are decoded by `readers` threads (pyarrow releases the GIL while it decodes), each with its own file
+    handle; every decoded batch goes through the corpus' pinned staging buffers as an asynchronous DMA (pqv_corpus_write_rows)
+    at its row offset, so decoding batch i + 1 overlaps the upload of batch i and nothing larger than a batch is ever
+    materialised on the host -- unlike the reference's Vec<f32> of the whole column (:226).  `stats` (a dict) receives rows,
+    bytes, seconds and GB/s."""
+    import os
+    import threading
+    import time
+    import pyarrow.parquet as pq
+    t0 = time.perf_counter()
+    pf = pq.ParquetFile(path)
+    typ = _check_column_type(pf, column)
+    meta = pf.metadata
+    n_rows, n_rg = meta.num_rows, meta.num_row_groups
+    rg_off = np.zeros(n_rg + 1, dtype=np.int64)
+    for i in range(n_rg):
+        rg_off[i + 1] = rg_off[i] + meta.row_group(i).num_rows
+    if n_rows == 0:
+        raise _err("Embedding column has no rows")
+    # the first batch fixes the dimension (and is uploaded like any other)
+    first = next(_column_chunks(path, column, batch_rows=4096), None)
+    if first is None:
+        raise _err("Embedding column has no rows")
+    dim = first.shape[1]
+    corpus = Corpus.create(n_rows, dim, device)
+    nthr = max(1, min(readers or min(8, os.cpu_count() or 1), n_rg))
+    errors, lock = [], threading.Lock()
+    nbytes = [0]
+
+    def work(t):
+        try:
+            for rg in range(t, n_rg, nthr):
+                at = int(rg_off[rg])
+                for vals in _column_chunks(path, column, row_groups=[rg]):
+                    if vals.shape[1] != dim:
+                        raise _err("Embedding vectors have inconsistent dimensions")
+                    corpus.write_rows(at, vals)
+                    at += vals.shape[0]
+                    with lock:
+                        nbytes[0] += vals.nbytes
+                    if errors:
+                        return
+                if at != int(rg_off[rg + 1]):
+                    raise _err("Embedding column row count does not match the file metadata")
+        except Exception as e:          # the first error wins; the other readers stop at their next batch
+            with lock:
+                errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,), daemon=True) for t in range(nthr)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        corpus.close()
+        raise errors[0]
+    corpus.finish(n_rows)
+    if stats is not None:
+        el = time.perf_counter() - t0
+        stats.update({"rows": int(n_rows), "dim": int(dim), "bytes": int(nbytes[0]), "seconds": el, "GBps": nbytes[0] / el / 1e9,
+                      "row_groups": int(n_rg), "reader_threads": nthr})
     return corpus

@@ -105,6 +105,24 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["shards"] == 2 and rec["value"] > 0
 
 
+def test_bench_c4_two_ranks_with_a_small_shard():
+    """BASELINE configs[3]'s code path -- one shard and one index per rank, the whole batch searched on every shard, one exchange
+    per step -- with two ranks of 1 M rows each on this box's one GPU (gloo): the line must carry both ranks' step times and the
+    exchange's share.  (No multi-GPU hardware has run this yet: the 1 -> 8 curve is the driver's to measure.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c4",
+                        "--rows-per-rank", "1000000", "--steps", "5", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["shards"] == 2 and rec["config"]["rows_per_gpu"] == 1000000 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and len(rec["per_rank_ms_per_step"]["ranks"]) == 2
+    assert rec["per_rank_ms_per_step"]["max"] <= rec["ms_per_step"] * 1.5 + 1.0
+    assert rec["exchange"]["ranks"] == 2 and 0.0 < rec["exchange"]["share_of_step"]
+
+
 @pytest.mark.parametrize("k,nprobe", [(1024, 4), (1500, 6), (3000, 3), (10, 1500)])
 def test_topk_beyond_the_kernel_list_capacity(pqv, oracle, k, nprobe):
     """search.rs:56-81 accepts any NonZeroUsize for k and nprobe.  k >= 1024 (no runner-up slot in the kernels' lists) and

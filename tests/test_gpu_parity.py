@@ -504,6 +504,50 @@ def test_parquet_build_inplace_and_topk(pqv, oracle, tmp_path):
     assert hits2[0].row_idx == 17 and hits2[0].distance == 0.0
 
 
+@pytest.mark.parametrize("value_type,list_kind", [("f32", "list"), ("f64", "list"), ("f32", "fixed")])
+def test_streamed_parquet_loader_places_every_row_group(pqv, tmp_path, value_type, list_kind):
+    """N1 (src/ivf/parquet.rs:216-305): row groups of unequal sizes decoded by several reader threads, every batch uploaded
+    through the pinned staging buffers at its row offset (pqv_corpus_write_rows, any order) -- the resident matrix must be the
+    column, row for row, and a float64 column narrowed `as f32` (:246-256).  Batches larger than a staging buffer are split."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from pq_vector_amd import parquet_io
+    rng = np.random.default_rng(3)
+    dim = 96
+    sizes = [70000, 1, 33333, 5000, 90000, 12]
+    n = sum(sizes)
+    vecs = rng.standard_normal((n, dim)).astype(np.float64 if value_type == "f64" else np.float32)
+    vt = pa.float64() if value_type == "f64" else pa.float32()
+    typ = pa.list_(pa.field("item", vt), dim) if list_kind == "fixed" else pa.list_(pa.field("item", vt))
+    path = str(tmp_path / "col.parquet")
+    writer = None
+    at = 0
+    for m in sizes:
+        flat = pa.array(vecs[at:at + m].reshape(-1), type=vt)
+        if list_kind == "fixed":
+            col = pa.FixedSizeListArray.from_arrays(flat, dim)
+        else:
+            col = pa.ListArray.from_arrays(pa.array(np.arange(0, (m + 1) * dim, dim, dtype=np.int32)), flat)
+        t = pa.table({"id": pa.array(np.arange(at, at + m, dtype=np.int32)), "emb": col.cast(typ)})
+        if writer is None:
+            writer = pq.ParquetWriter(path, t.schema)
+        writer.write_table(t, row_group_size=m)
+        at += m
+    writer.close()
+    assert pq.ParquetFile(path).metadata.num_row_groups == len(sizes)
+    stats = {}
+    corpus = parquet_io.load_embedding_column(path, "emb", readers=3, stats=stats)
+    assert corpus.rows == n and corpus.dim == dim and stats["rows"] == n and stats["reader_threads"] == 3
+    want = vecs.astype(np.float32)
+    sel = np.concatenate([np.arange(0, n, 997), np.cumsum(sizes)[:-1], np.cumsum(sizes)[:-1] - 1, [0, n - 1]]).astype(np.uint32)
+    got = corpus.fetch_rows(sel)
+    assert np.array_equal(got.view(np.uint32), want[sel].view(np.uint32))
+    # the whole matrix, through the device
+    import torch
+    full = corpus.fetch_rows(np.arange(n, dtype=np.uint32))
+    assert np.array_equal(full.view(np.uint32), want.view(np.uint32))
+
+
 def test_parquet_build_new_reference_fixture(pqv, tmp_path):
     """src/df_vector/tests.rs:16-104 data through build_new: 6 rows x 2-D, default clusters."""
     import pyarrow as pa
