@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r02}; wl=${2:-c3}; shift 2
 O=$R/gpurun_out/prof_$tag; mkdir -p $O
-B="python $R/bench.py --workload $wl --no-cpu --no-secondary --single 0 --recall 0 $*"
+B="python $R/bench.py --workload $wl --no-cpu --no-secondary --no-configs --single 0 --recall 0 $*"
 rocprofv3 --kernel-trace --stats -d $O/kt -- $B --steps 20 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find $O/kt -name "*.db" | head -1) --match pqv > $O/${tag}_${wl}_kernel_trace.txt
 for c in FETCH_SIZE WRITE_SIZE; do
