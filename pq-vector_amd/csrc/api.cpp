@@ -190,7 +190,7 @@ struct pqv_corpus {
     mutable std::mutex aux_mu;
     mutable DevBuf aux_rnorm, aux_norm2, aux_v16;      // aux_v16: L2-normalised f16 images [n, dim_p] (the f16 screen of pqv_brute_topk)
     mutable uint64_t aux_rnorm_rows = 0, aux_norm2_rows = 0, aux_v16_rows = 0;
-    mutable DevBuf aux_v8_max;                         // [4] maxima over the rows (kernels.h: BruteF16Args::row_max)
+    mutable DevBuf aux_v8_max;                         // [12, nine used] maxima over the rows (kernels.h: BruteF16Args::row_max)
     mutable DevBuf aux_v8, aux_v8_sr, aux_v8_n;        // int8 images [n, dim_p8] + {1 / S, residual, mid-range, sum} + norm per row (the int8 screen of pqv_brute_topk)
     mutable uint64_t aux_v8_rows = 0;
     ~pqv_corpus() {
@@ -3140,8 +3140,8 @@ static int pqv_brute_topk_impl(const pqv_corpus *c, const float *queries, uint32
             HIP_TRY(c->aux_v8.alloc(std::max<uint64_t>(1, n) * dim_p));
             HIP_TRY(c->aux_v8_sr.alloc(std::max<uint64_t>(1, n) * sizeof(float4)));
             HIP_TRY(c->aux_v8_n.alloc(std::max<uint64_t>(1, n) * sizeof(float)));
-            HIP_TRY(c->aux_v8_max.alloc(4 * sizeof(float)));
-            HIP_TRY(hipMemsetAsync(c->aux_v8_max.p, 0, 4 * sizeof(float), stream));
+            HIP_TRY(c->aux_v8_max.alloc(12 * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->aux_v8_max.p, 0, 12 * sizeof(float), stream));
             HIP_TRY(launch_normalize_i8(c->d_rows, c->aux_rnorm.as<float>(), n, dim, dim_p, c->aux_v8.p, c->aux_v8_sr.p, c->aux_v8_n.as<float>(),
                                         c->aux_v8_max.as<float>(), stream));
             HIP_TRY(hipStreamSynchronize(stream));

@@ -379,7 +379,8 @@ struct BruteF16Args {
     const int8_t   *v8, *q8;
     const float4   *row_sr, *query_sr;
     const float    *row_n, *query_n;
-    const float    *row_max;  // [4] corpus-wide maxima of |sum - mid-range dim|, norm + 3 residual, |mid-range|, residual (the epilogue's quick screen)
+    const float    *row_max;  // [9] corpus-wide maxima of |sum - mid-range dim|, norm + 3 residual, |mid-range|, residual, 1 / S, and -- as
+                              // sortable_bits keys -- of C, -C, A, -A (C = mid-range, A = sum - mid-range dim): the epilogue's screens
     float           dim_f, eps_sum;
     const float *row_aux;      // [n]  |v|^2 (l2 only)
     const float *query_aux;    // [nq] |q|^2 (l2 only)
@@ -446,7 +447,7 @@ hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint6
 hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s);
 hipError_t launch_normalize_f16(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, hipStream_t s);
 hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm,
-                               float *maxima /* [4], zeroed by the caller; nullptr: not wanted */, hipStream_t s);
+                               float *maxima /* [9], zeroed by the caller; nullptr: not wanted */, hipStream_t s);
 hipError_t launch_brute_rescore(const BruteArgs &a, const uint32_t *first, hipStream_t s);
 // per-row auxiliary values: mode 0 = 1/sqrt(sum x^2) (0 for a zero row), mode 1 = sum x^2, mode 2 = max |x_i|
 hipError_t launch_row_norms(const float *rows, uint64_t n, uint32_t dim, int mode, float *out, hipStream_t s);

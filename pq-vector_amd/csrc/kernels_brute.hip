@@ -232,6 +232,9 @@ hipError_t launch_brute_mfma(const BruteArgs &a, hipStream_t s) {
 // registers: three stages are in flight while one is contracted, the loads stay outstanding ACROSS the per-stage barrier
 // (counted s_waitcnt vmcnt + a raw s_barrier; the operand reads are inline asm so that the compiler does not drain the
 // load queue in front of them) -- with one 8-wave block per CU nothing else hides the L2 / HBM latency of a stage.
+// (Round 4, measured and dropped: PING-PONG of the two M groups on the ring form -- a K step as [operand reads] barrier [8 MFMAs]
+//  barrier with group 1 one barrier behind group 0, so that one wave of a SIMD contracts while the other reads: 24.7 against
+//  24.0 ms on C5.  The matrix pipe does not idle for lack of stagger.)
 template <int NWM, int NWN, int TM, int TN, bool I8, int ST, int RING = 0>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_f16_kernel(const BruteF16Args a) {
     constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN, NT = 64 * NWM * NWN;
@@ -464,18 +467,28 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
         if constexpr (I8) { if (jvs[j]) { vsrs[j] = a.row_sr[vjs[j]]; vns[j] = a.row_n[vjs[j]]; } }
     }
     // the exact test of one pair: lower bound of its distance against the query's threshold key
-    auto exact = [&](int ml, int j, auto accv) {
+    // The exact test of one pair: lower bound of its distance against the query's threshold key.  It is instantiated ONCE per
+    // query tile row (below), in a rolled loop over the pairs the screen queued -- inlined at every pair, 128 copies made the
+    // kernel 80 KB of code and its epilogue a quarter of the run time (round 4: ablation, 18.5 -> 13.9 ms without it).
+    auto exact = [&](int ml, int j, uint32_t bits) {
         const uint32_t qi = m0 + ml;
-        const float vaux = vauxs[j];
+        auto pick = [&](const auto &arr) { auto v = arr[0];
+#pragma unroll
+            for (int jj = 1; jj < TN; ++jj) v = j == jj ? arr[jj] : v;
+            return v; };
+        const float vaux = pick(vauxs);
+        const uint64_t vj = pick(vjs);
+        const bool jv = pick(jvs);
         float sc, eps;
         if constexpr (I8) {
-            const float4 qsr = qsr_s[ml], vsr = vsrs[j];
-            sc = ((float)accv * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
+            const float4 qsr = qsr_s[ml], vsr = pick(vsrs);
+            const float vn = pick(vns);
+            sc = ((float)(int)bits * qsr.x) * vsr.x + (vsr.z * qsr.w + qsr.z * (vsr.w - vsr.z * a.dim_f));
             // n_q r_v + n_v r_q + 3 r_q r_v, rounded up, + the f32 roundings of both sides (a.eps) and of the two
             // component sums (a.eps_sum per unit of |a| + |b|)
-            eps = (qn_s[ml] * vsr.y + qsr.y * (vns[j] + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
+            eps = (qn_s[ml] * vsr.y + qsr.y * (vn + 3.0f * vsr.y)) * 1.00001f + a.eps + a.eps_sum * (fabsf(qsr.z) + fabsf(vsr.z));
         } else {
-            sc = accv * inv; eps = a.eps;
+            sc = __uint_as_float(bits) * inv; eps = a.eps;
         }
         float lb;
         if (a.metric == BRUTE_COSINE) lb = (1.0f - sc) - eps;
@@ -486,9 +499,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
         }
         // (a NaN bound sorts last, like a NaN distance in the f32 kernel)
         const bool keep = !((unsigned long long)sortable_bits(lb) > (thr_s[ml] >> 32));
-        if (jvs[j] && qi < a.nq && keep) {
+        if (jv && qi < a.nq && keep) {
             const uint32_t slot2 = atomicAdd(&a.cand_cnt[qi], 1u);
-            if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vjs[j];
+            if (slot2 < a.cap) a.cand[(uint64_t)qi * a.cap + slot2] = ((unsigned long long)sortable_bits(lb) << 32) | (uint32_t)vj;
         }
     };
     const bool quick = a.metric == BRUTE_COSINE;
@@ -497,8 +510,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
 #pragma unroll
         for (int j = 0; j < TN; ++j) { rowI[j] = vsrs[j].x; rowC[j] = vsrs[j].z; rowA[j] = vsrs[j].w - vsrs[j].z * a.dim_f; }
     }
+    // per-thread queue of the pairs that pass the quick screen, in the (now free) stage buffers: entry c of thread t at
+    // [c][t] -- consecutive lanes, consecutive addresses; a tile row holds at most 16 x TN = 32 pairs per thread
+    uint2 *const pq = reinterpret_cast<uint2 *>(brute_lds);
+    constexpr size_t LDSB = RING != 0 ? (size_t)RING * (BM + BN) * 64 : (size_t)2 * (BM + BN) * ST * 16;
+    constexpr int CAP = (int)(LDSB / ((size_t)NT * sizeof(uint2)));      // entries per thread the stage buffers hold
+    constexpr int RB = CAP / TN >= 16 ? 16 : CAP / TN;                    // tile rows (r) queued between two drains
+    static_assert(RB >= 1, "queue fits the stage buffers");
+    auto drain = [&](int i, uint32_t &cnt) {
+#pragma unroll 1
+        for (uint32_t c = 0; c < cnt; ++c) {
+            const uint2 e = pq[c * NT + tid];
+            const int r = (int)(e.x / TN), j = (int)(e.x % TN);
+            exact(wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, j, e.y);
+        }
+        cnt = 0;
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        uint32_t cnt = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -510,8 +540,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void brute_
                     if constexpr (I8) pass = !(__builtin_fmaf((float)acc[i][j][r], rowI[j], __builtin_fmaf(qk.x, rowA[j], __builtin_fmaf(qk.y, rowC[j], qk.z))) < 0.0f);
                     else pass = !(acc[i][j][r] < qk.x);
                 }
-                if (pass) exact(ml, j, acc[i][j][r]);
+                if (pass) {
+                    uint32_t bits;
+                    if constexpr (I8) bits = (uint32_t)acc[i][j][r]; else bits = __float_as_uint(acc[i][j][r]);
+                    pq[cnt * NT + tid] = make_uint2((uint32_t)(r * TN + j), bits);
+                    ++cnt;
+                }
             }
+            if ((r + 1) % RB == 0 || r == 15) drain(i, cnt);
         }
     }
 }
@@ -569,6 +605,8 @@ __global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restri
     const int lane = threadIdx.x & 63;
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nw = (uint64_t)gridDim.x * 4;
+    float mxI = 0.0f;
+    uint32_t kC = 0, kNC = 0, kA = 0, kNA = 0;                  // sortable keys of max C, max -C, max A, max -A
     float mxA = 0.0f, mxB = 0.0f, mxC = 0.0f, mxE = 0.0f;       // corpus-wide maxima of |sum - b dim|, n + 3 r, |b|, r (brute_f16_kernel's quick screen)
     for (uint64_t r = w; r < n; r += nw) {
         const float *p = rows + r * dim;
@@ -607,10 +645,18 @@ __global__ __launch_bounds__(256) void normalize_i8_kernel(const float *__restri
         }
         mxA = fmaxf(mxA, bad ? __builtin_inff() : fabsf(sum - b * (float)dim) * 1.00001f);
         mxB = fmaxf(mxB, (nn + 3.0f * rr) * 1.00001f); mxC = fmaxf(mxC, fabsf(b)); mxE = fmaxf(mxE, rr * 1.00001f);
+        mxI = fmaxf(mxI, invS);
+        if (!bad) {
+            const float Aj = sum - b * (float)dim;
+            const uint32_t c1 = sortable_bits(b), c2 = sortable_bits(-b), a1 = sortable_bits(Aj), a2 = sortable_bits(-Aj);
+            kC = c1 > kC ? c1 : kC; kNC = c2 > kNC ? c2 : kNC; kA = a1 > kA ? a1 : kA; kNA = a2 > kNA ? a2 : kNA;
+        }
     }
     if (maxima && lane == 0) {        // non-negative floats (or +inf): their bit patterns order like the values
         atomicMax(&maxima[0], __float_as_uint(mxA)); atomicMax(&maxima[1], __float_as_uint(mxB));
         atomicMax(&maxima[2], __float_as_uint(mxC)); atomicMax(&maxima[3], __float_as_uint(mxE));
+        atomicMax(&maxima[4], __float_as_uint(mxI));
+        atomicMax(&maxima[5], kC); atomicMax(&maxima[6], kNC); atomicMax(&maxima[7], kA); atomicMax(&maxima[8], kNA);
     }
 }
 hipError_t launch_normalize_i8(const float *rows, const float *rnorm, uint64_t n, uint32_t dim, uint32_t dim_p, void *out, void *sr, float *nrm, float *maxima, hipStream_t s) {
