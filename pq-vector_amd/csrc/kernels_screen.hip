@@ -539,12 +539,15 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
     PQV_STAMP_MIN(8);
     uint32_t bx, by;
     quad_xcd_remap(bx, by, a.xcd_swizzle, *a.n_quads);
-    if (by >= *a.n_quads) { if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); } return; }
+    // (one pass of a loop, so that a block with nothing to sample leaves through `break` and the one-query tail below is
+    //  instantiated ONCE: inlined at three exits it made this kernel 143 KB of code, more than the instruction cache)
+    for (int once = 0; once < 1; ++once) {
+    if (by >= *a.n_quads) break;
     const uint4 quad = a.quads[by];
     // a quad wider than this kernel's 16 NG queries (the 8-wave filter kernel takes up to 128) is sampled in
     // slices of 16 NG: blockIdx.z
     const uint32_t sub = blockIdx.z * NQ;
-    if (sub >= quad.z) { if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); } return; }
+    if (sub >= quad.z) break;
     const uint32_t c = quad.x, p0 = quad.y + sub, cnt = quad.z - sub < NQ ? quad.z - sub : NQ;
     const uint32_t ng = ONE ? 1u : (cnt + 15) >> 4;
     const int lane = threadIdx.x & 63;
@@ -778,6 +781,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(const TileArgs a) {
         }
     }
     PQV_STAMP_MAX(11);
+    }
     if constexpr (U > 1) { if (a.seed_tail.enable) seed_tail_finish(a); }
 }
 

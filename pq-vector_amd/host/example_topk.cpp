@@ -5,7 +5,7 @@
 
 #include "pqv.hpp"
 
-int main() {
+int main(int argc, char **argv) {
     try {
         const uint64_t n = 20000; const uint32_t dim = 64;
         std::mt19937 gen(1234);
@@ -20,6 +20,20 @@ int main() {
         std::printf("index: dim %u, %u clusters, blob %zu bytes\n", index.dim(), index.n_clusters(),
                     index.to_bytes().size());
         for (auto &h : hits) std::printf("row %u distance %.6f\n", h.row_idx, h.distance);
+        if (argc > 1) {
+            // tests/test_gpu_exchange_and_limits.py: inputs, index blob and answers as raw little-endian arrays, so that the CPU
+            // oracle can be run on exactly this data
+            std::FILE *f = std::fopen(argv[1], "wb");
+            if (!f) return 3;
+            const uint64_t head[4] = {n, dim, index.to_bytes().size(), hits.size()};
+            std::fwrite(head, sizeof head, 1, f);
+            std::fwrite(data.data(), sizeof(float), data.size(), f);
+            std::fwrite(query.data(), sizeof(float), query.size(), f);
+            const auto blob = index.to_bytes();
+            std::fwrite(blob.data(), 1, blob.size(), f);
+            for (auto &h : hits) { std::fwrite(&h.row_idx, 4, 1, f); std::fwrite(&h.distance, 4, 1, f); }
+            std::fclose(f);
+        }
         return hits.size() == 5 ? 0 : 1;
     } catch (const pqv::Error &e) {
         std::fprintf(stderr, "pqv error %d: %s\n", e.code, e.what());

@@ -105,6 +105,29 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["shards"] == 2 and rec["value"] > 0
 
 
+def test_cpp_host_mirror_example_matches_the_oracle(oracle, tmp_path):
+    """pq-vector_amd/host/pqv.hpp (the header-only C++ mirror of IndexBuilder / TopkBuilder over the C ABI) through its example
+    program: the index it builds and the answers it prints must be the oracle's on the same data."""
+    exe = os.path.join(ROOT, "pq-vector_amd", "host", "example_topk")
+    assert os.path.exists(exe), "built by make -C pq-vector_amd/csrc (__graft_entry__.build)"
+    out = str(tmp_path / "example.bin")
+    p = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    raw = open(out, "rb").read()
+    n, dim, blob_len, n_hits = np.frombuffer(raw, dtype=np.uint64, count=4)
+    n, dim, blob_len, n_hits = int(n), int(dim), int(blob_len), int(n_hits)
+    off = 32
+    data = np.frombuffer(raw, dtype=np.float32, count=n * dim, offset=off).reshape(n, dim); off += n * dim * 4
+    query = np.frombuffer(raw, dtype=np.float32, count=dim, offset=off); off += dim * 4
+    blob = raw[off:off + blob_len]; off += blob_len
+    hits = np.frombuffer(raw, dtype=np.uint32, count=2 * n_hits, offset=off).reshape(n_hits, 2)
+    oidx = oracle.build_index(np.ascontiguousarray(data), n_clusters=16, workers=os.cpu_count() or 1)     # the example builds with workers = 0: this host's CPUs
+    assert oidx.to_bytes() == blob
+    orows, odist, onf, _ = oidx.topk_batch(np.ascontiguousarray(data), query.reshape(1, -1).copy(), 5, 4)
+    assert int(onf[0]) == n_hits == 5
+    assert (hits[:, 0] == orows[0]).all() and (hits[:, 1] == odist[0].view(np.uint32)).all()
+
+
 def test_bench_c4_two_ranks_with_a_small_shard():
     """BASELINE configs[3]'s code path -- one shard and one index per rank, the whole batch searched on every shard, one exchange
     per step -- with two ranks of 1 M rows each on this box's one GPU (gloo): the line must carry both ranks' step times and the
