@@ -384,7 +384,7 @@ def from_parquet_config(args, pqv, torch, dev, local_rank, name="refbench", k=10
         st = b.last_stats
         rec["build_inplace"] = {"seconds": total, "vectors_per_s": n / total, "load_s": st["load_s"], "build_s": st["build_s"], "append_s": st["write_s"],
                                 "loader": st["load"], "pcie_peak_GBps": 63.0,
-                                "loader_note": "Parquet decode (pyarrow, one thread per row group up to 8) -> pinned staging -> hipMemcpyAsync; GB/s counts the f32 payload"}
+                                "loader_note": "data pages walked in the memory-mapped file (level runs checked, PLAIN values copied from the page cache) -> pinned staging -> hipMemcpyAsync, 8 threads; anything else through pyarrow record batches; GB/s counts the f32 payload"}
         blob = index.to_bytes()
         t0 = time.perf_counter()
         first = pqv.TopkBuilder(path, qs[0], device=local_rank).k(k).nprobe(nprobe).search()

@@ -96,6 +96,22 @@ int pqv_corpus_append_f64(pqv_corpus *corpus, const double *rows, uint64_t n_row
 int pqv_corpus_write_rows(pqv_corpus *corpus, uint64_t row_offset, const float *rows, uint64_t n_rows);
 int pqv_corpus_write_rows_f64(pqv_corpus *corpus, uint64_t row_offset, const double *rows, uint64_t n_rows);
 int pqv_corpus_finish(pqv_corpus *corpus, uint64_t n_rows);
+/* Host-side helpers of the page-level Parquet reader (N1: parquet_io.py walks the data pages of the embedding leaf itself where
+ * it can -- uncompressed or codec-decompressed v1 pages, PLAIN or dictionary-encoded -- instead of materialising Arrow lists):
+ *   pqv_parquet_levels_check  decodes an RLE / bit-packed hybrid level run (Parquet "RLE" encoding without the length prefix)
+ *                             of n_values levels and checks it WITHOUT storing it: mode 0 -- every level == expect (definition
+ *                             levels of a column without nulls); mode 1 -- repetition levels of equal-length lists: level 0 at
+ *                             every multiple of `expect` (the list length), 1 elsewhere, the page starting a row.
+ *                             0 = as expected, 1 = something else (the caller falls back to the Arrow reader and its messages),
+ *                             PQV_ERR_INVALID = malformed run.
+ *   pqv_parquet_dict_decode   hybrid-encoded dictionary indices (bit width in the first byte, as in a RLE_DICTIONARY data page)
+ *                             -> out[i] = dict[index_i], elem_size 4 or 8 bytes per value.
+ * No device is touched. */
+int pqv_parquet_levels_check(const uint8_t *buf, uint64_t len, uint32_t bit_width, uint64_t n_values, int mode, uint64_t expect,
+                             uint64_t *period_out /* mode 1 with expect == 0: the list length is DISCOVERED (the position of the
+                                                     second level 0, or n_values if there is none), written here, then checked */);
+int pqv_parquet_dict_decode(const uint8_t *buf, uint64_t len, const void *dict, uint64_t dict_n, uint32_t elem_size,
+                            uint64_t n_values, void *out);
 /* Adopt an existing device buffer [n, dim] f32 on `device` (borrowed; caller keeps it
  * alive and frees it). */
 int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,

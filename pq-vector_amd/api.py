@@ -85,6 +85,11 @@ class Corpus:
             r = _f32(rows)
             _check(_ffi.lib().pqv_corpus_write_rows(self._h, row_offset, r.ctypes.data_as(f32p), r.shape[0]))
 
+    def write_rows_ptr(self, row_offset, address, n_rows, f64=False):
+        """write_rows from a raw host address (a page inside a memory-mapped file: no intermediate array)."""
+        fn = _ffi.lib().pqv_corpus_write_rows_f64 if f64 else _ffi.lib().pqv_corpus_write_rows
+        _check(fn(self._h, row_offset, C.cast(C.c_void_p(address), f64p if f64 else f32p), n_rows))
+
     def finish(self, n_rows):
         _check(_ffi.lib().pqv_corpus_finish(self._h, n_rows))
 

@@ -157,14 +157,14 @@ struct pqv_index {
 // pinned staging buffers of the streaming upload (pqv_corpus_write_rows): a buffer is free, being filled by a caller, or in
 // flight behind its event
 struct UploadStage {
-    static constexpr int N = 4;
-    static constexpr size_t BYTES = 32u << 20;
+    static constexpr int N = 16;                  // (a page-level reader hands over ~1 MB pages from eight threads: many small buffers)
+    static constexpr size_t BYTES = 8u << 20;
     std::mutex mu;
     std::condition_variable cv;
-    void *pin[N] = {nullptr, nullptr, nullptr, nullptr};
-    void *dev64[N] = {nullptr, nullptr, nullptr, nullptr};      // f64 batches: device-side landing area of the same size (made on first use)
-    hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};
-    int state[N] = {0, 0, 0, 0};                                // 0 free, 1 claimed, 2 in flight
+    void *pin[N] = {};
+    void *dev64[N] = {};                          // f64 batches: device-side landing area of the same size (made on first use)
+    hipEvent_t ev[N] = {};
+    int state[N] = {};                            // 0 free, 1 claimed, 2 in flight
     hipStream_t copy_stream = nullptr;
     ~UploadStage() {
         for (int i = 0; i < N; ++i) {
@@ -519,6 +519,113 @@ extern "C" int pqv_corpus_finish(pqv_corpus *c, uint64_t n_rows) {
         }
         c->n = n_rows;
         return PQV_OK;
+    });
+}
+
+// ---- Parquet page helpers (N1; host only) ---------------------------------------------------
+namespace {
+// One run of the RLE / bit-packed hybrid at a time: fn(value, count) for an RLE run, fn(values...) one by one for a bit-packed
+// group.  Returns false on a malformed stream.  `want` values are consumed (a final bit-packed group may hold padding).
+template <class F>
+bool hybrid_runs(const uint8_t *p, uint64_t len, uint32_t bw, uint64_t want, F &&fn) {
+    if (bw > 32) return false;
+    const uint8_t *end = p + len;
+    const uint32_t vbytes = (bw + 7) / 8;
+    const uint64_t mask = bw == 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1ull);
+    uint64_t got = 0;
+    while (got < want) {
+        uint64_t h = 0;
+        for (uint32_t shift = 0;; shift += 7) {
+            if (p >= end || shift > 56) return false;
+            const uint8_t b = *p++;
+            h |= static_cast<uint64_t>(b & 0x7F) << shift;
+            if (!(b & 0x80)) break;
+        }
+        if (h & 1) {                                     // bit-packed: (h >> 1) groups of 8 values
+            const uint64_t nvals = (h >> 1) * 8, nbytes = (h >> 1) * bw;
+            if (nvals == 0 || static_cast<uint64_t>(end - p) < nbytes) return false;
+            const uint64_t use = std::min<uint64_t>(nvals, want - got);
+            uint64_t acc = 0; uint32_t nb = 0; const uint8_t *q = p;
+            for (uint64_t i = 0; i < use; ++i) {
+                while (nb < bw) { acc |= static_cast<uint64_t>(*q++) << nb; nb += 8; }
+                if (!fn(static_cast<uint32_t>(acc & mask), 1ull)) return true;       // the callback has its answer
+                acc >>= bw; nb -= bw;
+            }
+            p += nbytes; got += use;
+        } else {                                         // RLE: count, value in ceil(bw / 8) bytes
+            const uint64_t cnt = h >> 1;
+            if (cnt == 0 || static_cast<uint64_t>(end - p) < vbytes) return false;
+            uint32_t v = 0;
+            for (uint32_t i = 0; i < vbytes; ++i) v |= static_cast<uint32_t>(p[i]) << (8 * i);
+            p += vbytes;
+            const uint64_t use = std::min<uint64_t>(cnt, want - got);
+            if (!fn(v, use)) return true;
+            got += use;
+        }
+    }
+    return true;
+}
+}  // namespace
+extern "C" int pqv_parquet_levels_check(const uint8_t *buf, uint64_t len, uint32_t bit_width, uint64_t n_values, int mode, uint64_t expect,
+                                        uint64_t *period_out) {
+    return guard([&]() -> int {
+        if (n_values == 0) return 0;
+        if (!buf) return fail(PQV_ERR_INVALID, "buf must not be NULL");
+        if (mode == 1 && expect == 0) {
+            // discover the list length: the position of the second level 0 (the first must be at position 0)
+            if (!period_out) return fail(PQV_ERR_INVALID, "list length must be > 0");
+            uint64_t at = 0, zeros = 0, second = 0;
+            const bool w0 = hybrid_runs(buf, len, bit_width, n_values, [&](uint32_t v, uint64_t cnt) {
+                if (v == 0) {
+                    if (zeros == 0 && at != 0) { zeros = 99; return false; }          // the page starts inside a row
+                    if (zeros == 0 && cnt >= 2) { second = 1; zeros = 2; return false; }
+                    if (zeros == 1) { second = at; zeros = 2; return false; }
+                    zeros = 1;
+                }
+                at += cnt;
+                return true;
+            });
+            if (!w0) return fail(PQV_ERR_INVALID, "malformed RLE / bit-packed level run");
+            if (zeros == 99 || zeros == 0) return 1;
+            expect = zeros == 2 ? second : n_values;
+            *period_out = expect;
+            if (expect == 0) return 1;
+        }
+        bool ok = true;
+        uint64_t pos = 0;                                // mode 1: position inside the page, in values
+        const bool well = hybrid_runs(buf, len, bit_width, n_values, [&](uint32_t v, uint64_t cnt) {
+            if (mode == 0) { ok = v == expect; return ok; }
+            // repetition levels: 0 exactly at the multiples of `expect`
+            const uint64_t ph = pos % expect;
+            if (v == 0) ok = ph == 0 && (cnt == 1 || expect == 1);
+            else ok = v == 1 && ph != 0 && ph + cnt <= expect;
+            pos += cnt;
+            return ok;
+        });
+        if (!well) return fail(PQV_ERR_INVALID, "malformed RLE / bit-packed level run");
+        if (ok && mode == 1 && pos % expect != 0) ok = false;     // the page ends inside a row
+        return ok ? 0 : 1;
+    });
+}
+extern "C" int pqv_parquet_dict_decode(const uint8_t *buf, uint64_t len, const void *dict, uint64_t dict_n, uint32_t elem_size,
+                                       uint64_t n_values, void *out) {
+    return guard([&]() -> int {
+        if (n_values == 0) return 0;
+        if (!buf || !dict || !out || len < 1 || (elem_size != 4 && elem_size != 8)) return fail(PQV_ERR_INVALID, "bad arguments");
+        const uint32_t bw = buf[0];
+        uint64_t at = 0;
+        bool in_range = true;
+        auto put = [&](uint32_t idx, uint64_t cnt) {
+            if (idx >= dict_n) { in_range = false; return false; }
+            if (elem_size == 4) { const uint32_t v = static_cast<const uint32_t *>(dict)[idx]; uint32_t *o = static_cast<uint32_t *>(out) + at; for (uint64_t i = 0; i < cnt; ++i) o[i] = v; }
+            else { const uint64_t v = static_cast<const uint64_t *>(dict)[idx]; uint64_t *o = static_cast<uint64_t *>(out) + at; for (uint64_t i = 0; i < cnt; ++i) o[i] = v; }
+            at += cnt;
+            return true;
+        };
+        if (bw == 0) { put(0, n_values); return in_range ? 0 : fail(PQV_ERR_INVALID, "dictionary index out of range"); }
+        const bool well = hybrid_runs(buf + 1, len - 1, bw, n_values, put);
+        if (!well || !in_range || at != n_values) return fail(PQV_ERR_INVALID, "malformed dictionary-encoded page");
+        return 0;
     });
 }
 

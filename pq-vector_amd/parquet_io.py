@@ -407,6 +407,224 @@ def _column_chunks(path, column, batch_rows=1 << 16, row_groups=None):
         raise _err("Embedding column has no rows")
 
 
+# ---------------------------------------------------------------------------------------
+# N1 fast path: the data pages of the embedding leaf, walked directly
+# ---------------------------------------------------------------------------------------
+_CODECS = {"UNCOMPRESSED": None, "SNAPPY": "snappy", "ZSTD": "zstd", "LZ4": "lz4", "GZIP": "gzip", "BROTLI": "brotli"}
+
+
+def _i32_fields(raw):
+    """{field id: value} of a Thrift struct's integer fields, {field id: raw bytes} of its struct fields."""
+    ints, structs = {}, {}
+    for fid, ttype, val in _struct_fields(raw):
+        if ttype in (T_I16, T_I32, T_I64):
+            ints[fid] = _zigzag_decode(_varint(val, 0)[0])
+        elif ttype == T_STRUCT:
+            structs[fid] = val
+    return ints, structs
+
+
+class _PagePlan:
+    """What _plan_pages found: the list length, the value type and one task per data page."""
+    __slots__ = ("dim", "f64", "esz", "max_def", "def_bw", "tasks", "mm", "n_rows")
+
+
+def _page_levels(L, addr, blen, nv, dim, max_def, def_bw):
+    """Check the two level runs at the head of a v1 data page body; returns the offset of the values, or None."""
+    import ctypes
+    p = 0
+    for bw, mode, expect in ((1, 1, dim), (def_bw, 0, max_def)):
+        if p + 4 > blen:
+            return None
+        n = int.from_bytes(ctypes.string_at(addr + p, 4), "little")
+        if p + 4 + n > blen:
+            return None
+        if L.pqv_parquet_levels_check(ctypes.cast(ctypes.c_void_p(addr + p + 4), _ffi.u8p), n, bw, nv, mode, expect, None) != 0:
+            return None
+        p += 4 + n
+    return p
+
+
+def _plan_pages(path, column, n_threads, on_page=None):
+    """Walk the data pages of the embedding leaf in the memory-mapped file WITHOUT touching a device: a no-null `List<f32|f64>`
+    leaf stores its values contiguously behind the page's two level runs.  The level runs are CHECKED, not trusted
+    (pqv_parquet_levels_check: every definition level at its maximum -- no null row, no null value, no empty list -- and a
+    repetition level 0 exactly every `dim` values, `dim` discovered from the first page); uncompressed pages are all checked
+    here, of a compressed chunk the first page (the others when they are decompressed for the upload).  Returns None -- the
+    caller takes the Arrow path, which owns the reference's error messages -- for anything it does not handle: v2 pages, other
+    encodings, pages that end inside a row, levels that differ."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    pf = pq.ParquetFile(path)
+    meta, schema = pf.metadata, pf.schema
+    leaves = [j for j in range(meta.num_columns) if schema.column(j).path.split(".")[0] == column]
+    if len(leaves) != 1 or meta.num_rows == 0:
+        return None
+    leaf = leaves[0]
+    cs = schema.column(leaf)
+    if cs.physical_type not in ("FLOAT", "DOUBLE") or cs.max_repetition_level != 1 or cs.max_definition_level < 1:
+        return None
+    plan = _PagePlan()
+    plan.f64 = cs.physical_type == "DOUBLE"
+    plan.esz = 8 if plan.f64 else 4
+    plan.max_def, plan.def_bw = cs.max_definition_level, int(cs.max_definition_level).bit_length()
+    plan.mm = mm = np.memmap(path, dtype=np.uint8, mode="r")
+    plan.n_rows = meta.num_rows
+    base = mm.ctypes.data
+    L = _ffi.lib()
+    plan.dim = None
+    tasks = []            # [first value position in values, file offset of the page body, body bytes, uncompressed bytes, n_values, encoding, dictionary, codec, value offset | None]
+    values_before = 0
+    for rg in range(meta.num_row_groups):
+        cm = meta.row_group(rg).column(leaf)
+        codec = _CODECS.get(cm.compression, "?")
+        if codec == "?":
+            return None
+        start = cm.dictionary_page_offset if cm.has_dictionary_page and cm.dictionary_page_offset else cm.data_page_offset
+        pos, end = int(start), int(start) + int(cm.total_compressed_size)
+        left = int(cm.num_values)
+        dictionary = None
+        while pos < end and left > 0:
+            win = 4096
+            while True:                              # (a page header is tens of bytes; statistics can make it longer)
+                hdr = bytes(mm[pos:min(end, pos + win)])
+                try:
+                    hlen = _skip(hdr, 0, T_STRUCT)
+                    break
+                except IndexError:
+                    if pos + win >= end:
+                        return None
+                    win *= 8
+            hend = pos + hlen
+            ints, structs = _i32_fields(hdr[:hlen])
+            ptype, usize, csize = ints.get(1), ints.get(2), ints.get(3)
+            if ptype is None or usize is None or csize is None or csize < 0 or hend + csize > end:
+                return None
+            if ptype == 2:                       # dictionary page: PLAIN values
+                di, _ = _i32_fields(structs.get(7, b"\x00"))
+                if di.get(2) not in (0, 2):
+                    return None
+                body = bytes(mm[hend:hend + csize])
+                if codec:
+                    body = pa.Codec(codec).decompress(body, decompressed_size=usize).to_pybytes()
+                dictionary = np.frombuffer(body, dtype="<f8" if plan.f64 else "<f4", count=di.get(1, 0)).copy()
+            elif ptype == 0:                     # data page v1
+                dh, _ = _i32_fields(structs.get(5, b"\x00"))
+                nv, enc = dh.get(1), dh.get(2)
+                if nv is None or nv <= 0 or dh.get(3) != 3 or dh.get(4) != 3 or enc not in (0, 2, 8) or (enc != 0 and dictionary is None):
+                    return None
+                voff = None
+                if plan.dim is None:             # the first data page fixes the list length (and is checked right here)
+                    if codec:
+                        buf = pa.Codec(codec).decompress(pa.py_buffer(mm[hend:hend + csize]), decompressed_size=usize)
+                        addr, blen = buf.address, buf.size
+                    else:
+                        addr, blen = base + hend, csize
+                    period = ctypes.c_uint64(0)
+                    n = int.from_bytes(ctypes.string_at(addr, 4), "little") if blen >= 4 else -1
+                    if n < 0 or 4 + n > blen:
+                        return None
+                    if L.pqv_parquet_levels_check(ctypes.cast(ctypes.c_void_p(addr + 4), _ffi.u8p), n, 1, nv, 1, 0, ctypes.byref(period)) != 0:
+                        return None
+                    plan.dim = int(period.value)
+                    voff = _page_levels(L, addr, blen, nv, plan.dim, plan.max_def, plan.def_bw)
+                    if voff is None:
+                        return None
+                if nv % plan.dim:
+                    return None
+                tasks.append([values_before, hend, csize, usize, nv, enc, dictionary, codec, voff])
+                if on_page is not None:          # pipelined: the caller uploads (and checks) this page while the walk goes on
+                    on_page(plan, tasks[-1])
+                values_before += nv
+                left -= nv
+            else:                                # v2 data pages, index pages: the Arrow path
+                return None
+            pos = hend + csize
+        if left != 0:
+            return None
+    if plan.dim is None or values_before != plan.n_rows * plan.dim:
+        return None
+
+    def check(t):                                # uncompressed pages: their level runs now
+        if t[7] or t[8] is not None:
+            return True
+        t[8] = _page_levels(L, base + t[1], t[2], t[4], plan.dim, plan.max_def, plan.def_bw)
+        if t[8] is None or (t[5] == 0 and t[2] - t[8] != t[4] * plan.esz):
+            return False
+        return True
+
+    if on_page is None:
+        with ThreadPoolExecutor(max_workers=max(1, n_threads)) as ex:
+            if not all(ex.map(check, tasks)):
+                return None
+    plan.tasks = tasks
+    return plan
+
+
+def _page_uploader(plan, corpus):
+    """One planned page -> the corpus: a PLAIN page goes from the page cache straight into the pinned staging buffers
+    (pqv_corpus_write_rows from the mapped address), dictionary pages through pqv_parquet_dict_decode, compressed pages through
+    pyarrow's codecs; level runs not checked by the plan are checked here.  Returns the payload bytes, or False: something did
+    not check out, the Arrow path re-reads the column."""
+    import ctypes
+    import pyarrow as pa
+    L = _ffi.lib()
+    mm, base, esz, f64 = plan.mm, plan.mm.ctypes.data, plan.esz, plan.f64
+
+    def do_page(t):
+        first, off, csize, usize, nv, enc, dictionary, codec, voff = t
+        dim = plan.dim
+        buf = None
+        if codec:
+            buf = pa.Codec(codec).decompress(pa.py_buffer(mm[off:off + csize]), decompressed_size=usize)
+            addr, blen = buf.address, buf.size
+            voff = None
+        else:
+            addr, blen = base + off, csize
+        if voff is None:
+            voff = _page_levels(L, addr, blen, nv, dim, plan.max_def, plan.def_bw)
+            if voff is None:
+                return False
+        row = first // dim
+        if enc == 0:
+            if blen - voff != nv * esz:
+                return False
+            corpus.write_rows_ptr(row, addr + voff, nv // dim, f64)
+        else:
+            out = np.empty(nv, dtype=np.float64 if f64 else np.float32)
+            rc = L.pqv_parquet_dict_decode(ctypes.cast(ctypes.c_void_p(addr + voff), _ffi.u8p), blen - voff, dictionary.ctypes.data_as(_ffi.vp),
+                                           dictionary.size, esz, nv, out.ctypes.data_as(_ffi.vp))
+            if rc != 0:
+                return False
+            corpus.write_rows_ptr(row, out.ctypes.data, nv // dim, f64)
+        del buf
+        return nv * esz
+
+    return do_page
+
+
+def _upload_pages(plan, corpus, n_threads, counters):
+    """Every planned page through _page_uploader on `n_threads` threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, n_threads)) as ex:
+        for r in ex.map(_page_uploader(plan, corpus), plan.tasks):
+            if r is False:
+                return False
+            counters[0] += r
+    counters[1] = len(plan.tasks)
+    return True
+
+
+def _load_pages(path, column, corpus, dim, rg_off, n_threads, counters):
+    """plan + upload (tests drive the walker through this with a stand-in corpus)."""
+    plan = _plan_pages(path, column, n_threads)
+    if plan is None or plan.dim != dim:
+        return False
+    return _upload_pages(plan, corpus, n_threads, counters)
+
+
 def load_embedding_column(path, column, device=0, readers=None, stats=None):
     """The column -> one resident [n, dim] f32 matrix (src/ivf/parquet.rs:216-305; Float64 values are narrowed on the device,
     :246-256).  Row groups are decoded by `readers` threads (pyarrow releases the GIL while it decodes), each with its own file
@@ -428,15 +646,85 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
         rg_off[i + 1] = rg_off[i] + meta.row_group(i).num_rows
     if n_rows == 0:
         raise _err("Embedding column has no rows")
-    # the first batch fixes the dimension (and is uploaded like any other)
-    first = next(_column_chunks(path, column, batch_rows=4096), None)
-    if first is None:
-        raise _err("Embedding column has no rows")
-    dim = first.shape[1]
-    corpus = Corpus.create(n_rows, dim, device)
-    nthr = max(1, min(readers or min(8, os.cpu_count() or 1), n_rg))
+    nthr_pages = max(1, readers or min(8, os.cpu_count() or 1))
+    # the page-level walk first (PQV_PARQUET_PAGES=0: the Arrow reader only).  Its first data page fixes the dimension and is
+    # checked before any device is touched; from then on every page is handed to the upload threads while the walk goes on.
+    # Whatever the walk cannot take -- or does not like -- goes through pyarrow below, which validates its first batch (before a
+    # device is touched, if the walk stopped at the first page) and raises the reference's messages.
+    from concurrent.futures import ThreadPoolExecutor
+    corpus, plan, futures, ex, t_first, t_create = None, None, [], None, None, 0.0
+    pages = [0, 0]
+    fast = False
+    if os.environ.get("PQV_PARQUET_PAGES", "1") != "0":
+        state = {}
+
+        def on_page(pl, task):
+            nonlocal corpus, ex, t_first, t_create
+            if corpus is None:
+                t_first = time.perf_counter() - t0
+                corpus = Corpus.create(n_rows, pl.dim, device)
+                t_create = time.perf_counter() - t0 - t_first
+                state["do"] = _page_uploader(pl, corpus)
+                ex = ThreadPoolExecutor(max_workers=nthr_pages)
+            futures.append(ex.submit(state["do"], task))
+
+        try:
+            try:
+                plan = _plan_pages(path, column, nthr_pages, on_page)
+            except PqvError:
+                raise
+            except Exception:
+                plan = None
+            fast = plan is not None
+            for f in futures:
+                try:
+                    r = f.result()
+                except PqvError:
+                    raise
+                except Exception:
+                    r = False
+                if r is False:
+                    fast = False
+                else:
+                    pages[0] += r
+            pages[1] = len(futures)
+        except PqvError:                       # a device error: nothing to fall back to
+            if ex is not None:
+                ex.shutdown(wait=True)
+            if corpus is not None:
+                corpus.close()
+            raise
+        if ex is not None:
+            ex.shutdown(wait=True)
+    if not fast:
+        try:
+            first = next(_column_chunks(path, column, batch_rows=4096), None)      # the first batch fixes the dimension
+            if first is None:
+                raise _err("Embedding column has no rows")
+        except Exception:
+            if corpus is not None:
+                corpus.close()
+            raise
+        dim = first.shape[1]
+        if corpus is None or plan is None or plan.dim != dim:                      # (else the walk's corpus is overwritten)
+            if corpus is not None:
+                corpus.close()
+            t_first = time.perf_counter() - t0
+            corpus = Corpus.create(n_rows, dim, device)
+            t_create = time.perf_counter() - t0 - t_first
+    else:
+        dim = plan.dim
+    nthr = max(1, min(nthr_pages, n_rg))
     errors, lock = [], threading.Lock()
     nbytes = [0]
+    if fast:
+        corpus.finish(n_rows)
+        if stats is not None:
+            el = time.perf_counter() - t0
+            stats.update({"rows": int(n_rows), "dim": int(dim), "bytes": int(pages[0]), "seconds": el, "GBps": pages[0] / el / 1e9,
+                          "row_groups": int(n_rg), "reader_threads": nthr_pages, "path": "data pages walked in the mapped file", "pages": pages[1],
+                          "first_page_s": t_first, "corpus_create_s": t_create})
+        return corpus
 
     def work(t):
         try:
@@ -469,5 +757,5 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
     if stats is not None:
         el = time.perf_counter() - t0
         stats.update({"rows": int(n_rows), "dim": int(dim), "bytes": int(nbytes[0]), "seconds": el, "GBps": nbytes[0] / el / 1e9,
-                      "row_groups": int(n_rg), "reader_threads": nthr})
+                      "row_groups": int(n_rg), "reader_threads": nthr, "path": "pyarrow record batches"})
     return corpus

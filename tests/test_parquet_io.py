@@ -262,3 +262,114 @@ def test_footer_offset_is_parsed_like_rust_u64_and_corrupt_footers_raise_pqv_err
     open(cut, "wb").write(bytes(raw[:len(raw) - 8 - flen]) + b"\x19\xfc\xff\xff" + struct.pack("<I", 4) + b"PAR1")
     with pytest.raises(pqv.PqvError):
         pqv.read_index_from_parquet(cut)
+
+
+# ---------------------------------------------------------------------------------------
+# N1 fast path: the page walker and its two host helpers (no GPU: a stand-in corpus collects what would be uploaded)
+# ---------------------------------------------------------------------------------------
+class _CollectingCorpus:
+    def __init__(self, n, dim):
+        self.a = np.full((n, dim), np.nan, np.float32)
+
+    def write_rows_ptr(self, row, addr, m, f64=False):
+        import ctypes
+        dim = self.a.shape[1]
+        src = np.frombuffer(ctypes.string_at(addr, m * dim * (8 if f64 else 4)), dtype=np.float64 if f64 else np.float32)
+        self.a[row:row + m] = src.reshape(m, dim).astype(np.float32)
+
+
+def _rg_offsets(path):
+    meta = pq.ParquetFile(path).metadata
+    off = np.zeros(meta.num_row_groups + 1, dtype=np.int64)
+    for i in range(meta.num_row_groups):
+        off[i + 1] = off[i] + meta.row_group(i).num_rows
+    return off
+
+
+@pytest.mark.parametrize("value_type,codec,dictionary", [("f32", "NONE", False), ("f32", "SNAPPY", True), ("f64", "ZSTD", False),
+                                                         ("f32", "NONE", True), ("f64", "GZIP", True)])
+def test_page_walker_uploads_exactly_the_column(pqv, tmp_path, value_type, codec, dictionary):
+    """src/ivf/parquet.rs:216-305 through the data pages themselves: PLAIN and dictionary-encoded pages, compressed or not,
+    f32 and f64, several row groups and many pages per chunk -- what reaches the corpus is the column, row for row."""
+    from pq_vector_amd import parquet_io
+    rng = np.random.default_rng(5)
+    n, dim = 30000, 24
+    dt = np.float64 if value_type == "f64" else np.float32
+    vec = rng.integers(0, 40, (n, dim)).astype(dt) if dictionary else rng.standard_normal((n, dim)).astype(dt)
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(vec.reshape(-1)))
+    path = str(tmp_path / "c.parquet")
+    pq.write_table(pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "emb": col}), path, row_group_size=11000,
+                   compression=codec, use_dictionary=dictionary, data_page_size=64 * 1024)
+    c, counters = _CollectingCorpus(n, dim), [0, 0]
+    assert parquet_io._load_pages(path, "emb", c, dim, _rg_offsets(path), 4, counters) is True
+    assert counters[1] > 3 and counters[0] == n * dim * (8 if value_type == "f64" else 4)
+    assert np.array_equal(c.a.view(np.uint32), vec.astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("lists", [[[1.0, 2.0], [3.0], [4.0, 5.0]], [[1.0, None], [3.0, 4.0]], [[1.0, 2.0], None, [3.0, 4.0]],
+                                   [[1.0, 2.0], [], [3.0, 4.0]]])
+def test_page_walker_refuses_what_the_reference_rejects(pqv, tmp_path, lists):
+    """Ragged lists, null values, null rows, empty lists (parquet.rs:231-280): the level runs give them away, the walker
+    returns False and load_embedding_column's Arrow path raises the reference's message."""
+    from pq_vector_amd import parquet_io
+    path = str(tmp_path / "bad.parquet")
+    pq.write_table(pa.table({"emb": pa.array(lists, type=pa.list_(pa.float32()))}), path)
+    assert parquet_io._load_pages(path, "emb", _CollectingCorpus(len(lists), 2), 2, _rg_offsets(path), 2, [0, 0]) is False
+    assert parquet_io._plan_pages(path, "emb", 2) is None               # ... and the plan says so before any device is touched
+
+
+def test_page_plan_discovers_the_list_length_without_a_device(pqv, tmp_path):
+    from pq_vector_amd import parquet_io
+    rng = np.random.default_rng(6)
+    for dim, n in ((1, 700), (7, 9000), (768, 300)):
+        vec = rng.standard_normal((n, dim)).astype(np.float32)
+        col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(vec.reshape(-1)))
+        path = str(tmp_path / f"d{dim}.parquet")
+        pq.write_table(pa.table({"emb": col}), path, compression="NONE", use_dictionary=False, data_page_size=32 * 1024)
+        plan = parquet_io._plan_pages(path, "emb", 2)
+        assert plan is not None and plan.dim == dim and plan.n_rows == n and not plan.f64
+        assert sum(t[4] for t in plan.tasks) == n * dim and all(t[8] is not None for t in plan.tasks)
+
+
+def test_level_run_and_dictionary_helpers(pqv):
+    import ctypes as C
+    from pq_vector_amd import _ffi
+    L = _ffi.lib()
+
+    def check(buf, bw, n, mode, expect):
+        b = (C.c_uint8 * len(buf)).from_buffer_copy(bytes(buf))
+        return L.pqv_parquet_levels_check(b, len(buf), bw, n, mode, expect, None)
+    # definition levels: one RLE run of 1000 x 2
+    assert check([2000 & 0x7F | 0x80, 2000 >> 7, 2], 2, 1000, 0, 2) == 0
+    assert check([2000 & 0x7F | 0x80, 2000 >> 7, 1], 2, 1000, 0, 2) == 1
+    # repetition levels of lists of 4: bit-packed groups 0111 0111 (lsb first: 0xEE)
+    assert check([(2 << 1) | 1, 0xEE, 0xEE], 1, 16, 1, 4) == 0
+    assert check([(2 << 1) | 1, 0xEE, 0xEE], 1, 16, 1, 8) == 1
+    assert check([(2 << 1) | 1, 0xEE, 0xEF], 1, 16, 1, 4) == 1          # a list of length 5 ... 3
+    assert check([(2 << 1) | 1, 0xEE], 1, 16, 1, 4) < 0                  # truncated
+    # lists of 12: a bit-packed group holding the 0, then an RLE run of ones that must not cross the next row start
+    assert check([(1 << 1) | 1, 0xFE, (4 << 1), 1], 1, 12, 1, 12) == 0
+    assert check([(1 << 1) | 1, 0xFE, (5 << 1), 1], 1, 13, 1, 12) == 1
+    # discovery (expect 0 + an out pointer): the second level 0 gives the list length, then the run is checked against it
+    period = C.c_uint64(0)
+
+    def discover(buf, n):
+        b = (C.c_uint8 * len(buf)).from_buffer_copy(bytes(buf))
+        period.value = 0
+        return L.pqv_parquet_levels_check(b, len(buf), 1, n, 1, 0, C.byref(period)), period.value
+    assert discover([(2 << 1) | 1, 0xEE, 0xEE], 16) == (0, 4)
+    assert discover([(1 << 1) | 1, 0xFE, (4 << 1), 1], 12) == (0, 12)    # one row in the page: the whole page is the list
+    assert discover([(8 << 1), 0], 8) == (0, 1)                          # RLE run of zeros: lists of one value
+    assert discover([(2 << 1) | 1, 0xEE, 0xEF], 16)[0] == 1
+    assert discover([(2 << 1) | 1, 0xEF, 0xEE], 16)[0] == 1              # the page starts inside a row
+    assert check([(2 << 1) | 1, 0xEE, 0xEE], 1, 16, 1, 0) < 0            # expect 0 without the out pointer
+    # dictionary indices, bit width 2: 0 1 2 3 | RLE 3 x index 1
+    dict32 = np.array([10.0, 11.0, 12.0, 13.0], np.float32)
+    out = np.zeros(11, np.float32)
+    enc = bytes([2, (1 << 1) | 1, 0b11100100, 0b11100100, (3 << 1), 1])
+    b = (C.c_uint8 * len(enc)).from_buffer_copy(enc)
+    assert L.pqv_parquet_dict_decode(b, len(enc), dict32.ctypes.data_as(_ffi.vp), 4, 4, 11, out.ctypes.data_as(_ffi.vp)) == 0
+    assert out.tolist() == [10, 11, 12, 13, 10, 11, 12, 13, 11, 11, 11]
+    enc_bad = bytes([3, (1 << 1) | 1, 0xFF, 0xFF, 0xFF])                  # index 7 of a 4-entry dictionary
+    b = (C.c_uint8 * len(enc_bad)).from_buffer_copy(enc_bad)
+    assert L.pqv_parquet_dict_decode(b, len(enc_bad), dict32.ctypes.data_as(_ffi.vp), 4, 4, 8, out.ctypes.data_as(_ffi.vp)) < 0
