@@ -204,7 +204,7 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_ticket, s_ticket2, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_qresu, s_pair_lb, s_part_flags, s_qpad;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_qresu, s_pair_lb, s_part_flags, s_qpad, s_cand_lb, s_pendv, s_work, s_nwork;
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -278,6 +278,7 @@ struct pqv_searcher {
         uint32_t wide_rows = 0;            // rows per block of the wide kernel (0 = by rule)
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
         int running_thr = 1;               // running thresholds of the wide kernel
+        int defer = 1;                     // wide kernel: survivors are appended with their bounds, the final merge evaluates the few that matter
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
         int single_bucket = 1;             // one query: the probe merge writes the bucketing, no pair-sort launches
         int seed_refine = 1;               // exact distances behind the k selected seed bounds tighten the first threshold (k <= 16)
@@ -1744,6 +1745,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.wide_rows = static_cast<uint32_t>(num("PQV_WIDE_ROWS", o.wide_rows));
     o.tile_rows = static_cast<uint32_t>(num("PQV_TILE_ROWS", o.tile_rows));
     o.running_thr = num("PQV_RUNNING_THR", o.running_thr) != 0;
+    o.defer = static_cast<int>(num("PQV_DEFER", o.defer));
     o.quad_xcd = static_cast<int>(num("PQV_QUAD_XCD", o.quad_xcd));
     o.wide_waves = static_cast<int>(num("PQV_WIDE_WAVES", o.wide_waves));
     o.item_grid = static_cast<int>(num("PQV_ITEM_GRID", o.item_grid));
@@ -2065,6 +2067,13 @@ struct TopkPlan {
 static uint32_t cand_cap_for(const pqv_searcher *s, uint32_t k) {
     return std::max<uint32_t>(s->opt.cand_cap ? s->opt.cand_cap : (k > 32 ? 8192u : 2048u), k);
 }
+// Deferred exact evaluation (TileArgs::cand_lb): pays where the exact evaluations are most of the screen kernel's time -- long
+// lists of survivors, i.e. large k (the reference's bench shape, 1 M x 1024 at K = 100: 1226 evaluations per query in the
+// filter -> 633 after it, screen kernel 2.14 -> 0.95 ms); at k = 10 the streaming waves hide their evaluations behind each
+// other and the extra launches cost more than they save (C3: 1.08 + 0.73 ms of screen either way).  2 = always.
+static bool defer_on(const pqv_searcher *s, uint32_t k) {
+    return s->opt.defer == 2 || (s->opt.defer == 1 && k > 32);
+}
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
     (void)nq;
     return s->opt.seed_refine && (!s->d_row_of || s->images_only) && (s->sdim % 32) == 0 && k <= 16 && (s->opt.seed_refine > 1 || s->sdim >= 256);
@@ -2177,7 +2186,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // the 8-wave blocks (one per CU) measured best at 3072 on C3 (2.60 -> 2.51 ms against 4608)
                 // the two-block int8 form is flat between 1280 and 5120 on the item grid (C3: 2.19 / 2.20 / 2.16 ms at 1280 /
                 // 1792 / 3072; C4 shard: 2.77 / 2.69 / 2.71)
-                const uint64_t wide_rows = o.wide_rows >= 256 ? o.wide_rows / 256 * 256
+                const uint64_t wide_rows = o.wide_rows >= 256 ? std::min<uint64_t>(o.wide_rows, 1u << 22) / 256 * 256
                                            : (p.block_waves == 8 || p.i8 || p.quad_width == 96) ? 3072ull : 2304ull;
                 const uint64_t est_quads = std::max<uint64_t>(1, pairs / p.quad_width);
                 const uint64_t min_blocks = o.min_blocks ? o.min_blocks : (p.block_waves == 8 ? 1024 : 2048);
@@ -2195,7 +2204,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && o.item_grid >= 1 && 160ull * s->sdim <= 122880 &&
                     pairs >= 16ull * s->n_clusters) {
                     p.wide_width = 160;
-                    const uint64_t wr = o.wide_quad_rows >= 512 ? o.wide_quad_rows / 256 * 256 : 6144ull;
+                    const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 6144ull;
                     p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
                     p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
                     p.slots_per_pair = std::max(p.slots_per_pair, 8 * p.wide_bpl);
@@ -2378,6 +2387,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
+    bool use_defer = false;    // ... and resolves deferred evaluations first
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
         uint32_t *u = pair_u32;
@@ -2474,6 +2484,17 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(sc.s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
             ta.cand_keys = sc.s_cand_keys.as<uint64_t>(); ta.cand_vals = sc.s_cand_vals.as<uint32_t>();
             ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = sc.s_spilled.as<uint32_t>();
+            if (defer_on(s, k) && ccap <= 8192) {
+                // deferred exact evaluation: bounds per appended pair, and the queues' raw scores (a strip per wave of every block)
+                HIP_TRY(sc.s_cand_lb.ensure(static_cast<size_t>(nq) * ccap * sizeof(float)));
+                const size_t blocks_r = items ? max_items : static_cast<size_t>(p.filter_bpl | 1u) * p.max_quads;
+                const size_t words_r = blocks_r * p.block_waves * pqv::wide_filter_pend(p.quad_width, p.block_waves);
+                const size_t words_w = wide ? static_cast<size_t>(wide_max_items) * 8 * pqv::wide_filter_pend(p.wide_width, 8) : 0;
+                HIP_TRY(sc.s_pendv.ensure((words_r + words_w) * sizeof(uint32_t)));
+                ta.cand_lb = sc.s_cand_lb.as<float>();
+                ta.pendv = sc.s_pendv.as<uint32_t>(); ta.pendv_wide = ta.pendv + words_r;
+                use_defer = true;
+            }
             // thresholds: upper bounds of the first seed_rows rows of every probed list
             TileArgs seed = ta;
             if (wide) seed.quad_width = p.wide_width;      // (the seed kernel samples a quad in slices of its own 64 queries)
@@ -2565,6 +2586,18 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = cand_cap_for(s, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
         fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
+        if (use_defer) {
+            fm.cand_lb = sc.s_cand_lb.as<float>(); fm.cand_keys_rw = sc.s_cand_keys.as<uint64_t>();
+            fm.mat = s->d_mat; fm.queries = d_queries_s; fm.dim = s->sdim;
+            fm.resolve_stats = s->d_stats.as<unsigned long long>();
+            if (nq >= 8) {          // a batch: selection per query, then all band entries at once on the whole chip; the merge sees exact keys
+                HIP_TRY(sc.s_work.ensure(static_cast<size_t>(nq) * fm.cand_cap * sizeof(uint32_t) * 2));
+                HIP_TRY(sc.s_nwork.ensure(sizeof(uint32_t)));
+                HIP_TRY(launch_resolve(fm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), stream));
+                fm.cand_lb = nullptr;
+                s->counters.kernel_launches += 2;
+            }
+        }
     }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
@@ -2905,6 +2938,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "wide_rows") o.wide_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "tile_rows") o.tile_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "running_thr") o.running_thr = value != 0;
+    else if (n == "defer") o.defer = static_cast<int>(value);
     else if (n == "quad_xcd") o.quad_xcd = static_cast<int>(value);
     else if (n == "wide_waves") o.wide_waves = static_cast<int>(value);
     else if (n == "single_bucket") o.single_bucket = static_cast<int>(value);      // 2 = bucketing in the merge, separate probe launch

@@ -103,6 +103,13 @@ struct MergeArgs {
     const uint32_t *cand_cnt;    // [nq]
     uint32_t        cand_cap;
     const uint32_t *spilled;     // [nq] or nullptr
+    // deferred exact evaluation (TileArgs::cand_lb): the merge first RESOLVES the query's buffer -- T = the k-th smallest upper
+    // bound; entries with lower bound <= T are evaluated in the reference's order (index.rs:461-480) against `mat`, the others
+    // dropped -- and then merges exact keys as before.  256 threads per query.
+    float          *cand_lb;     // [nq][cand_cap] or nullptr
+    uint64_t       *cand_keys_rw;
+    const float    *mat;         // row-major f32 rows, `dim` values each; cand_vals are row numbers in it
+    unsigned long long *resolve_stats;   // optional: the statistics block (slot q % STATS_SLOTS, word 1 += exact evaluations)
     uint32_t       *tie_flag;    // [nq] or nullptr: 1 iff two of the first k_out+1 merged entries
                                  // (k_out entries + the runner-up) have equal OUTPUT distance --
                                  // then the reference's order/survivors depend on heap history
@@ -146,6 +153,8 @@ struct MergeArgs {
     uint32_t        dim;
 };
 hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s);
+// deferred evaluations of a BATCH, ahead of launch_merge_final (which then gets cand_lb = nullptr): work = nq * cand_cap uint2 of scratch
+hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, hipStream_t s);
 hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 
 // ---- batched re-rank: cluster-major tiles ------------------------------------------------
@@ -306,6 +315,14 @@ struct TileArgs {
     uint32_t       *cand_cnt;    // [nq] appended so far (may exceed cand_cap: the excess went to the wave lists)
     uint32_t        cand_cap;
     uint32_t       *spilled;     // [nq] set to 1 when a query overflowed its buffer
+    // DEFERRED exact evaluation (optional): a survivor of the screen is appended with the BOUNDS its screen score gives --
+    // key = (upper bound of the reference distance << 32 | position), cand_lb = lower bound -- instead of being evaluated by
+    // the streaming wave; the final merge evaluates only the entries whose lower bound does not exceed the k-th smallest upper
+    // bound of the query (MergeArgs::cand_lb).  cand_lb < 0 marks an entry whose key already holds the exact distance (pairs
+    // without usable bounds: non-finite data, f16 range overflow, a tile with too many survivors for one expansion pass).
+    float          *cand_lb;     // [nq][cand_cap] or nullptr (evaluate in the filter)
+    uint32_t       *pendv;       // scratch [blocks][waves][wide_filter_pend()]: raw screen scores of the queued survivors
+    uint32_t       *pendv_wide;  // ... of the wide-quad instance's launch
     // wide_seed_kernel: upper bounds [nq][nprobe][seed_sw][16], seed_sw = 4 * gridDim.x of the seed launch
     float          *seed_ub;
     SeedTail        seed_tail;   // wide_seed_kernel, one query: select + refine in the same launch
@@ -324,6 +341,8 @@ struct TileArgs {
 // PQV_L2SQ_REF4 only, k <= 256.  The caller presets the whole partial-list buffer to EMPTY (0xFF bytes:
 // KEY_EMPTY keys, 0xFFFFFFFF values); a wave touches its slots only when a candidate is admitted.
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
+// entries of a wave's survivor queue in wide_filter_kernel<NG = quad_width / 16, NW = waves> (TileArgs::pendv is sized with it)
+inline uint32_t wide_filter_pend(uint32_t quad_width, uint32_t waves) { return (waves == 8 ? 256u : quad_width == 96 ? 128u : 512u) + 64u; }
 // Same contract, but every (row, query) pair is first screened with an MFMA lower bound of its
 // distance; only pairs that could still beat the query's admission threshold are evaluated in
 // the reference's exact order.  Needs thresholds seeded by a prior launch_tile_rerank window.

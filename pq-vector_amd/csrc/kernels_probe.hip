@@ -501,11 +501,221 @@ __device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q,
     if (norms) probe_query_norms(a, q, lane);
 }
 
+// ------------------------------------------------------------------------------------
+// Deferred exact evaluation (TileArgs::cand_lb, wide_filter_kernel): the query's candidate buffer holds survivors of the screen
+// with their distance BOUNDS -- key = (upper bound << 32 | position), cand_lb = lower bound, or cand_lb < 0 and an exact key.
+// The whole block (256 threads) resolves it before wave 0 merges:
+//   1. T = the k-th smallest upper bound (4-pass radix select over the bound bits; +inf with fewer than k entries).  k rows
+//      have a reference distance <= T, so the k-th smallest reference distance is <= T.
+//   2. an entry whose lower bound exceeds T cannot be among the k nearest (not even tied with the k-th): dropped.
+//   3. the others are evaluated in the reference's order -- chunks of 4 values, ((d0^2 + d1^2) + d2^2) + d3^2 added to ONE
+//      running sum in chunk order (index.rs:461-480); L lanes share a row, the sum passes through them in order -- and their
+//      keys become exact.  The merge below then sees what the in-filter evaluation would have left, minus rows that cannot matter.
+// ------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void resolve_exact(const MergeArgs &a, uint32_t q, const uint16_t *band, uint32_t m, uint64_t *ck, const uint32_t *cv,
+                                              int lane, int wave, uint32_t lg) {
+    const uint32_t Gx = a.dim >> 2;
+    const uint32_t L = 1u << lg, per_wave = 64u >> lg;
+    const uint32_t pl = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);
+    const uint32_t first = (uint32_t)lane & ~(L - 1u);
+    const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)q * a.dim);
+    for (uint32_t p0 = (uint32_t)wave * per_wave; p0 < m; p0 += 4u * per_wave) {
+        const uint32_t pi = p0 + pl;
+        const bool valid = pi < m;
+        const uint32_t idx = band[valid ? pi : p0];
+        const float *x = a.mat + (uint64_t)cv[idx] * a.dim;
+        float sum = 0.0f;
+        for (uint32_t g0 = 0; g0 < Gx; g0 += NB * L) {
+            const uint32_t g = g0 + NB * pj;
+            float4 xv[NB], qv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t gu = g + u < Gx ? g + u : Gx - 1;          // (L == 1: Gx need not be a multiple of NB)
+                xv[u] = load4<true>(x + gu * 4); qv[u] = qg[gu];
+            }
+            float tt[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y, d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                float w = d0 * d0 + d1 * d1;
+                w = w + d2 * d2;
+                tt[u] = w + d3 * d3;
+            }
+            if (L == 1u) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) if (g + u < Gx) sum = sum + tt[u];
+            } else {
+                for (uint32_t sl = 0; sl < L; ++sl) {
+                    float sn = sum;
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) sn = sn + tt[u];
+                    sum = __shfl(pj == sl ? sn : sum, (int)(first + sl), 64);
+                }
+            }
+        }
+        if (valid && pj == 0u) ck[idx] = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)ck[idx];
+    }
+}
+// work != nullptr: the band goes to a batch-wide work list {query, entry} for resolve_exact_kernel instead of being evaluated here
+__device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t q, uint2 *work = nullptr, uint32_t *n_work = nullptr) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_sel[4];            // {prefix, remaining rank, band count}
+    __shared__ uint16_t s_band[8192];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t n = a.cand_cnt[q];
+    if (n > a.cand_cap) n = a.cand_cap;
+    uint64_t *ck = a.cand_keys_rw + (uint64_t)q * a.cand_cap;
+    const uint32_t *cv = a.cand_vals + (uint64_t)q * a.cand_cap;
+    float *cl = a.cand_lb + (uint64_t)q * a.cand_cap;
+    if (n == 0) return;
+    // 1. the k-th smallest upper bound (bounds are >= 0: their bits order like unsigned integers)
+    uint32_t T = 0x7F800000u;
+    if (n >= a.k) {
+        uint32_t prefix = 0, mask = 0, rank = a.k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                const uint32_t u = (uint32_t)(ck[i] >> 32);
+                if ((u & mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // 4 bins per lane, inclusive scan over the lanes, the digit whose cumulative count reaches `rank`
+                uint32_t c4[4], tot = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { c4[j] = s_hist[4 * lane + j]; tot += c4[j]; }
+                const uint32_t incl = wave_incl_scan_u32(tot);
+                uint32_t before = incl - tot;
+                int digit = -1;
+                uint32_t below = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (digit < 0 && before < rank && rank <= before + c4[j]) { digit = 4 * lane + j; below = before; }
+                    before += c4[j];
+                }
+                const unsigned long long hit = __ballot(digit >= 0);
+                const int src = __builtin_ctzll(hit ? hit : 1ull);
+                const uint32_t d = (uint32_t)__shfl(digit, src, 64), bl = (uint32_t)__shfl((int)below, src, 64);
+                if (lane == 0) { s_sel[0] = prefix | (d << shift); s_sel[1] = rank - bl; }
+            }
+            __syncthreads();
+            prefix = s_sel[0]; rank = s_sel[1];
+            mask |= 0xFFu << shift;
+        }
+        T = prefix;
+    }
+    // 2. the band: deferred entries whose lower bound does not exceed T; exact entries beyond T and deferred ones outside the
+    //    band leave (KEY_EMPTY)
+    if (threadIdx.x == 0) s_sel[2] = 0;
+    __syncthreads();
+    const float Tf = __uint_as_float(T);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const float lb = cl[i];
+        const uint32_t ub = (uint32_t)(ck[i] >> 32);
+        if (lb < 0.0f) {
+            if (ub > T) ck[i] = KEY_EMPTY;
+        } else if (lb <= Tf) {
+            s_band[atomicAdd(&s_sel[2], 1u)] = (uint16_t)i;
+        } else {
+            ck[i] = KEY_EMPTY;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = s_sel[2];
+    if (work) {
+        if (m) {
+            if (threadIdx.x == 0) s_sel[3] = atomicAdd(n_work, m);
+            __syncthreads();
+            const uint32_t base = s_sel[3];
+            for (uint32_t i = threadIdx.x; i < m; i += 256) work[base + i] = make_uint2(q, (uint32_t)s_band[i]);
+            if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
+        }
+        return;
+    }
+    // 3. exact keys for the band
+    if (m) {
+        const uint32_t Gx = a.dim >> 2;
+        const uint32_t per = (m + 3u) / 4u;                    // pairs per wave
+        uint32_t lg = 0;
+        if ((Gx % 64u) == 0u) {
+            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
+            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, lg);
+        } else if ((Gx % 16u) == 0u) {
+            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
+            resolve_exact<2>(a, q, s_band, m, ck, cv, lane, wave, lg);
+        } else {
+            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, 0u);
+        }
+        if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void resolve_select_kernel(const MergeArgs a, uint2 *work, uint32_t *n_work) {
+    resolve_candidates(a, blockIdx.x, work, n_work);
+}
+// the batch's band entries, 8 lanes per pair (Gx % 16 == 0: every path that defers has dim % 64 == 0), grid-stride
+template <int NB>
+__global__ __launch_bounds__(256) void resolve_exact_kernel(const MergeArgs a, const uint2 *work, const uint32_t *n_work) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
+    const uint32_t m = *n_work;
+    const uint32_t Gx = a.dim >> 2;
+    const uint32_t pl = (uint32_t)lane >> 3, pj = (uint32_t)lane & 7u, first = (uint32_t)lane & ~7u;
+    for (uint32_t p0 = gw * 8u; p0 < m; p0 += nw * 8u) {
+        const uint32_t pi = p0 + pl;
+        const bool valid = pi < m;
+        const uint2 w = work[valid ? pi : p0];
+        uint64_t *ck = a.cand_keys_rw + (uint64_t)w.x * a.cand_cap + w.y;
+        const float *x = a.mat + (uint64_t)a.cand_vals[(uint64_t)w.x * a.cand_cap + w.y] * a.dim;
+        const float4 *qg = reinterpret_cast<const float4 *>(a.queries + (uint64_t)w.x * a.dim);
+        float sum = 0.0f;
+        for (uint32_t g0 = 0; g0 < Gx; g0 += NB * 8) {
+            const uint32_t g = g0 + NB * pj;
+            float4 xv[NB], qv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { xv[u] = load4<true>(x + (g + u) * 4); qv[u] = qg[g + u]; }
+            float tt[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d0 = qv[u].x - xv[u].x, d1 = qv[u].y - xv[u].y, d2 = qv[u].z - xv[u].z, d3 = qv[u].w - xv[u].w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                tt[u] = t + d3 * d3;
+            }
+            for (uint32_t sl = 0; sl < 8u; ++sl) {            // the reference's one running sum passes through the pair's lanes in order
+                float sn = sum;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) sn = sn + tt[u];
+                sum = __shfl(pj == sl ? sn : sum, (int)(first + sl), 64);
+            }
+        }
+        if (valid && pj == 0u) *ck = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)*ck;
+    }
+}
+// Resolve a batch's deferred evaluations in two launches (selection per query, then every band entry of the batch on the
+// whole chip); the final merge then runs without a.cand_lb.  n_work: one u32, zeroed here.
+hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, hipStream_t s) {
+    if (a.nq == 0) return hipSuccess;
+    if (!a.cand_lb || a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 64) != 0 || !work || !n_work) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(n_work, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resolve_select_kernel, dim3(a.nq), dim3(256), 0, s, a, static_cast<uint2 *>(work), n_work);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)a.nq * 64 + 31) / 32 + 256);
+    if ((a.dim % 256) == 0) hipLaunchKernelGGL(resolve_exact_kernel<8>, dim3(blocks), dim3(256), 0, s, a, static_cast<const uint2 *>(work), n_work);
+    else hipLaunchKernelGGL(resolve_exact_kernel<2>, dim3(blocks), dim3(256), 0, s, a, static_cast<const uint2 *>(work), n_work);
+    return hipGetLastError();
+}
+
 template <int S, bool PROBE>
 __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if constexpr (!PROBE) PQV_STAMP_MIN(24);
+    if constexpr (!PROBE) { if (a.cand_lb) resolve_candidates(a, q); }
     if (threadIdx.x >= 64) {
         // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
         if constexpr (PROBE) probe_merge_helpers(a, q);
@@ -834,7 +1044,9 @@ hipError_t launch_probe_single(const ProbeRowsArgs &pr, const MergeArgs &a, uint
 template <bool PROBE>
 static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
-    dim3 grid(a.nq), block(PROBE && (a.preset_keys || a.preset_flags) ? 256 : 64);       // probe merge with a preset: three helper waves
+    // (probe merge with a preset: three helper waves; final merge with deferred evaluation: the block resolves the buffer)
+    dim3 grid(a.nq), block(((PROBE && (a.preset_keys || a.preset_flags)) || (!PROBE && a.cand_lb)) ? 256 : 64);
+    if (!PROBE && a.cand_lb && (a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 4) != 0)) return hipErrorInvalidValue;
     if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);

@@ -1247,6 +1247,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     constexpr int NWD = (NG + (int)GPW - 1) / (int)GPW;
     constexpr uint32_t NQ = 16 * NG;
     constexpr uint32_t QSH = NQ > 128 ? 24 : 25;   // queue entry = (query index << QSH) | row offset from the wave's r0
+    constexpr uint32_t QCNT = 1u << (QSH - 1);     // ... | QCNT: "already counted in the running-threshold bins" (deferred pass -> exact pass);
+                                                   // row offsets stay below 2^23 (launch_wide checks rows_per_block)
     constexpr int QS = (NQ + 63) / 64;        // state slots per lane
     // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
     // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
@@ -1314,6 +1316,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     extern __shared__ float4 qs[];                   // [NQ][dim / 4], column ch of query q at ch ^ (q & 15)
     __shared__ uint32_t pend_all[NW * PEND];         // (query index << QSH) | row offset from the wave's r0
     uint32_t *pend = pend_all + wave * PEND;
+    // deferred evaluation (TileArgs::cand_lb): the queue entry's raw screen score lives in the wave's strip of a global
+    // scratch (written at expansion, read back when the entry is appended: one wave, program order; no LDS to spare)
+    const bool defer = a.cand_lb != nullptr;
+    uint32_t *pv = defer ? a.pendv + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + (uint32_t)wave) * PEND : nullptr;
+    constexpr uint32_t NOVAL = I8 ? 0x80000000u : 0x7FC00000u, NOVAL_NOHIST = I8 ? 0x80000001u : 0x7FC00001u;
     __shared__ __attribute__((aligned(16))) float aq_all[NW * NQ];   // per-wave, per-query screen terms
     float *aq = aq_all + wave * NQ;
 
@@ -1455,10 +1462,155 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint64_t cur_gthr[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    auto eval = [&](uint32_t start, uint32_t count) {
+    // Running threshold + append of one lane's pair (deferred: the UPPER bound stands for the distance -- a pair counted in a
+    // bin is truly at or below the bin's edge -- and lbv >= 0 is its lower bound; exact: lbv = -1).  Returns false when the
+    // query's buffer is full.
+    auto append_pair = [&](bool pass, uint32_t qrow, float dval, uint64_t key, uint32_t srow, float lbv, bool count_hist) -> bool {
+        // k == 1: the distance itself.  Otherwise the query has 12 bins below its
+        // seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one 8-bit
+        // counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER: word 0 = bins 8..1,
+        // word 1 = bins 12..9, the NEARER bin in the LOWER byte.  An append adds 1 to the counters of bins
+        // 1..b with one returning atomic per word -- issued together with the append's own counter, one round
+        // trip in all -- and the returned word says whether this add took some counter to k: then that bin's
+        // upper edge (+ the rounding pad of the bin arithmetic) bounds the final k-th distance, and exactly one
+        // lane publishes it.  A counter that wraps (> 255 pairs) carries into the next byte, the counter of a
+        // FARTHER bin, which truly holds at least as many pairs (>= 256 > k): every value the bytes can show
+        // is either an under-count or the count of a bin that does hold k pairs.  No look-up, no extra loads.
+        int hb_bin = 0;
+        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pass && count_hist && k > 1u && a.thr_hist) {
+            hb = a.thr_bins[qrow];
+            hb_bin = hb.z > 0.0f ? (int)fminf(fmaxf((hb.x - dval) * hb.z, 0.0f), 12.0f) : 0;
+        }
+        bool full = false;
+        if (pass) {
+            const unsigned long long ones = 0x0101010101010101ull;
+            unsigned long long w0 = 0ull, w1 = 0ull;
+            unsigned long long *h2 = reinterpret_cast<unsigned long long *>(a.thr_hist) + (uint64_t)qrow * 2;
+            const int b = hb_bin;
+            // byte j of word 0 = bin 8 - j: bins <= b are bytes j >= 8 - b;  byte j of word 1 = bin 12 - j
+            const unsigned long long add0 = b >= 8 ? ones : b >= 1 ? ones << (8 * (8 - b)) : 0ull;
+            const unsigned long long add1 = b >= 9 ? (ones & 0xFFFFFFFFull) << (8 * (12 - b)) & 0xFFFFFFFFull : 0ull;
+            if (add1) w1 = atomicAdd(h2 + 1, add1) + add1;
+            if (add0) w0 = atomicAdd(h2, add0) + add0;
+            const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
+            if (idx < a.cand_cap) {
+                a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = key;
+                a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = srow;
+                if (defer) a.cand_lb[(uint64_t)qrow * a.cand_cap + idx] = lbv;
+            } else {
+                full = true;           // buffer full: fall back to this wave's sorted list (slow, exact)
+                a.spilled[qrow] = 1u;
+            }
+            if (k == 1u) {
+                atomicMin(a.gthr + qrow, (unsigned long long)(key | 0xFFFFFFFFull));
+            } else if (b > 0) {
+                // the nearest bin <= b whose counter shows exactly k after this add
+                int bsel = 0;
+#pragma unroll
+                for (int jj = 7; jj >= 0; --jj) {            // far -> near: the last match is the nearest
+                    const int bin = 8 - jj;
+                    if (bin <= b && (uint32_t)((w0 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
+                }
+#pragma unroll
+                for (int jj = 3; jj >= 0; --jj) {
+                    const int bin = 12 - jj;
+                    if (bin <= b && (uint32_t)((w1 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
+                }
+                if (bsel > 0) {
+                    const float e = hb.x - (float)bsel * hb.y + hb.w;
+                    if (e < hb.x && e >= 0.0f)
+                        atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
+                }
+            }
+        }
+        return !full;
+    };
+    uint32_t n_defer = 0;
+    // Deferred pass over queue entries [start, start + count), a lane per entry: the entry's screen score gives a lower and an
+    // upper bound of the reference distance (the screen's own inequality, and wide_seed_kernel's); the pair is appended with
+    // both and the streaming wave is done with it.  Entries without usable bounds -- or whose query's buffer is full -- are
+    // compacted to the front of the segment for the exact evaluation below; returns how many.
+    auto defer_pass = [&](uint32_t start, uint32_t count) -> uint32_t {
+        wave_lds_fence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool valid = (uint32_t)lane < count;
+        const uint32_t pe = pend[start + (valid ? (uint32_t)lane : 0u)];
+        const uint32_t raw = valid ? pv[start + (uint32_t)lane] : NOVAL;
+        const uint32_t qsl = pe >> QSH;
+        const uint64_t roff = r0 + (pe & (QCNT - 1u));
+        const uint64_t lpos = lbeg + roff;
+        const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
+        const uint32_t qrow = qsel_u32<QS>(my_qrow, qsl);
+        uint64_t my_thr[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+        const uint64_t pair_thr = qsel_u64<QS>(my_thr, qsl);
+        const float thr_d = __uint_as_float((uint32_t)(pair_thr >> 32));
+        uint64_t pos;
+        if constexpr (LST) pos = qst_cbase[qsl] + roff; else pos = qsel_u64<QS>(my_cbase, qsl) + roff;
+        float lb = 0.0f, ub = INFINITY;
+        bool ok = valid && raw != NOVAL && raw != NOVAL_NOHIST;
+        if constexpr (I8) {
+            // |vi - xi|^2 = Nq + Nx - 2 dot EXACTLY; the accumulator started at -(Nx >> 1)
+            const uint32_t img = qsel_u32<QS>(my_pairi, qsl);
+            const int xn2 = a.row_n2i[lpos];
+            const float rx = a.row_res[lpos];
+            const int n = qst_n2i[qsl] + (xn2 & 1) - 2 * (int)raw;
+            const float rq = qst_res[qsl], rqu = a.q_resu[img];
+            const float nf = fmaxf((float)n, 0.0f), inv_s = 1.0f / lscale;
+            const float du = sqrtf(nf * 1.000001f + 2.0f) * 1.000001f * inv_s + rqu + rx;          // wide_seed_kernel's bound
+            ub = du * du * (1.0f + 4.0f * cmargin) * 1.000002f;
+            const float dl = sqrtf(nf) * 0.999998f * inv_s - rq - rx;                              // the screen's bound, this row's residual
+            lb = dl > 0.0f ? dl * dl * (1.0f / (1.0f + 4.0f * cmargin)) * 0.999997f : 0.0f;
+            ok = ok && rq <= 3.0e38f && rqu <= 3.0e38f && rx <= 3.0e38f;
+        } else {
+            float qn;
+            bool noskip;
+            if constexpr (LST) { qn = qst_qn[qsl]; noskip = !(qn == qn); }
+            else {
+                uint32_t qnb[QS], nsk[QS];
+#pragma unroll
+                for (int s = 0; s < QS; ++s) { qnb[s] = __float_as_uint(my_qn[s]); nsk[s] = my_noskip[s] ? 1u : 0u; }
+                qn = __uint_as_float(qsel_u32<QS>(qnb, qsl));
+                noskip = qsel_u32<QS>(nsk, qsl) != 0u;
+            }
+            const float sv = __uint_as_float(raw);
+            const float nn = qn + a.row_norm2[lpos];
+            const float dt = nn - 2.0f * (sv * (1.0f / sc2));
+            ub = dt + cmargin * (2.0f * nn + fabsf(dt)) + c16 * nn;                                 // wide_seed_kernel's bound
+            lb = fmaxf(((1.0f - cmargin) * dt - (2.0f * cmargin + c16) * nn) * 0.999999f - nn * 1.0e-7f, 0.0f);   // skip <=> lb > thr, with a pad
+            ok = ok && !noskip && sv == sv && nn <= 3.0e38f;
+        }
+        ok = ok && ub >= 0.0f && ub <= 3.0e38f && lb <= ub;
+        const bool in_cap = valid && pos < a.max_pos;
+        // (the threshold may have tightened since the screen; an unset one is NaN: never dropped)
+        const bool dpass = ok && in_cap && !(lb > thr_d);
+        const uint64_t dkey = ((uint64_t)__float_as_uint(ub) << 32) | (uint64_t)(uint32_t)pos;
+        const bool appended = append_pair(dpass, qrow, ub, dkey, srow, lb, true);
+        n_defer += (uint32_t)__popcll(__ballot(dpass && appended));
+        // what is left for the exact evaluation: no bounds, or no room
+        const bool need = in_cap && (!ok || (dpass && !appended));
+        const unsigned long long nm = __ballot(need);
+        const uint32_t rank = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        wave_lds_fence();
+        if (need) pend[start + rank] = pe | ((dpass && !appended) ? QCNT : 0u);       // (counted in the bins already)
+        wave_lds_fence();
+        return (uint32_t)__popcll(nm);
+    };
+    auto eval = [&](uint32_t start, uint32_t count) -> uint32_t {
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_e0 = __builtin_amdgcn_s_memtime();
 #endif
+        if (defer) {
+            count = defer_pass(start, count);
+            if (count == 0) {
+#ifdef PQV_PROFILE_PHASES
+                ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
+#endif
+                return 0u;
+            }
+        }
         wave_lds_fence();
         // A batch that does not fill the wave (the last one of every wave; most batches of long rows) gives each
         // pair L = 2, 4 or 8 lanes: per round the L lanes of a pair fetch L x 8 consecutive row chunks -- the
@@ -1476,7 +1628,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const bool have = valid && pj == 0u;
         const uint32_t pe = pend[start + (valid ? pi : 0)];
         const uint32_t qsl = pe >> QSH;                       // query index in the quad
-        const uint64_t roff = r0 + (pe & ((1u << QSH) - 1u));  // row offset in the list
+        const uint64_t roff = r0 + (pe & (QCNT - 1u));         // row offset in the list
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const float *x = a.mat + (uint64_t)srow * dim;
@@ -1544,63 +1696,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // read-modify-write round trip per query, serially -- measured: half of the kernel).
         const uint64_t pair_thr = qsel_u64<QS>(my_thr, qsl);
         const bool pass = mykey_all < pair_thr;
-        bool spill = false;
-        // Running threshold.  k == 1: the exact distance itself.  Otherwise the query has 12 bins below its
-        // seed threshold thr0 (bin b = [thr0 - (b + 1) w, thr0 - b w), the last one open-ended) and one 8-bit
-        // counter per bin b >= 1 holding the number of appended pairs in bin b OR NEARER: word 0 = bins 8..1,
-        // word 1 = bins 12..9, the NEARER bin in the LOWER byte.  An append adds 1 to the counters of bins
-        // 1..b with one returning atomic per word -- issued together with the append's own counter, one round
-        // trip in all -- and the returned word says whether this add took some counter to k: then that bin's
-        // upper edge (+ the rounding pad of the bin arithmetic) bounds the final k-th distance, and exactly one
-        // lane publishes it.  A counter that wraps (> 255 pairs) carries into the next byte, the counter of a
-        // FARTHER bin, which truly holds at least as many pairs (>= 256 > k): every value the bytes can show
-        // is either an under-count or the count of a bin that does hold k pairs.  No look-up, no extra loads.
-        int hb_bin = 0;
-        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pass && k > 1u && a.thr_hist) {
-            hb = a.thr_bins[qrow];
-            hb_bin = hb.z > 0.0f ? (int)fminf(fmaxf((hb.x - sum) * hb.z, 0.0f), 12.0f) : 0;
-        }
-        if (pass) {
-            const unsigned long long ones = 0x0101010101010101ull;
-            unsigned long long w0 = 0ull, w1 = 0ull;
-            unsigned long long *h2 = reinterpret_cast<unsigned long long *>(a.thr_hist) + (uint64_t)qrow * 2;
-            const int b = hb_bin;
-            // byte j of word 0 = bin 8 - j: bins <= b are bytes j >= 8 - b;  byte j of word 1 = bin 12 - j
-            const unsigned long long add0 = b >= 8 ? ones : b >= 1 ? ones << (8 * (8 - b)) : 0ull;
-            const unsigned long long add1 = b >= 9 ? (ones & 0xFFFFFFFFull) << (8 * (12 - b)) & 0xFFFFFFFFull : 0ull;
-            if (add1) w1 = atomicAdd(h2 + 1, add1) + add1;
-            if (add0) w0 = atomicAdd(h2, add0) + add0;
-            const uint32_t idx = atomicAdd(a.cand_cnt + qrow, 1u);
-            if (idx < a.cand_cap) {
-                a.cand_keys[(uint64_t)qrow * a.cand_cap + idx] = mykey_all;
-                a.cand_vals[(uint64_t)qrow * a.cand_cap + idx] = srow;
-            } else {
-                spill = true;          // buffer full: fall back to this wave's sorted list (slow, exact)
-                a.spilled[qrow] = 1u;
-            }
-            if (k == 1u) {
-                atomicMin(a.gthr + qrow, (unsigned long long)(mykey_all | 0xFFFFFFFFull));
-            } else if (b > 0) {
-                // the nearest bin <= b whose counter shows exactly k after this add
-                int bsel = 0;
-#pragma unroll
-                for (int jj = 7; jj >= 0; --jj) {            // far -> near: the last match is the nearest
-                    const int bin = 8 - jj;
-                    if (bin <= b && (uint32_t)((w0 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
-                }
-#pragma unroll
-                for (int jj = 3; jj >= 0; --jj) {
-                    const int bin = 12 - jj;
-                    if (bin <= b && (uint32_t)((w1 >> (8 * jj)) & 0xFFu) == k) bsel = bin;
-                }
-                if (bsel > 0) {
-                    const float e = hb.x - (float)bsel * hb.y + hb.w;
-                    if (e < hb.x && e >= 0.0f)
-                        atomicMin(a.gthr + qrow, ((unsigned long long)__float_as_uint(e) << 32) | 0xFFFFFFFFull);
-                }
-            }
-        }
+        const bool counted = (pe & QCNT) != 0u;               // (deferred pass: in the bins already)
+        const bool spill = !append_pair(pass, qrow, sum, mykey_all, srow, -1.0f, !counted);
         unsigned long long todo = __ballot(spill);
         while (todo) {
             const uint32_t qq = readlane_u32(qsl, __builtin_ctzll(todo));
@@ -1628,12 +1725,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                     if ((uint32_t)(64 * s + lane) == qq) my_lkth[s] = nk;
             }
         }
+        return count;
     };
     auto drain = [&](uint32_t keep_below) {
         while (npend >= keep_below && npend > 0) {
             const uint32_t take = npend < 64 ? npend : 64;
-            eval(npend - take, take);
-            n_exact += take;
+            n_exact += eval(npend - take, take);
             npend -= take;
         }
         wave_lds_fence();
@@ -2158,6 +2255,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const bool last_tile = t0 + TROWS >= r1;
         if (one_pass) {
             uint32_t at = npend + incl_all - tot;
+            if (defer) {
+                // the raw scores of the survivors, in the order the expansion below numbers them (word, group, r, t): a static
+                // sweep over the accumulators, a group at a time and only where some lane has a survivor
+                uint32_t atv = at;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const uint32_t field = (vw[g / (int)GPW] >> (FW * (GPW - 1u - (uint32_t)(g % (int)GPW)))) & ((1u << FW) - 1u);
+                    if (__ballot(field != 0u) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                            for (int t = 0; t < TS; ++t) {
+                                if (field & (1u << (FW - 1u - (uint32_t)(TS * r + t)))) {
+                                    uint32_t rawv;
+                                    if constexpr (I8) rawv = (uint32_t)acc[g][t][r]; else rawv = __float_as_uint(acc[g][t][r]);
+                                    if constexpr (!I8) { if (rawv == NOVAL_NOHIST) rawv = NOVAL; }
+                                    pv[atv++] = rawv;
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
 #pragma unroll
             for (int ww = 0; ww < NWD; ++ww) {
                 uint32_t mm = vw[ww];
@@ -2201,6 +2322,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                     const uint32_t b = 31u - (uint32_t)__clz(mm);        // highest set bit first
                     mm &= ~(1u << b);
                     const uint32_t cc = FW - 1u - b;                     // cc = TS r + t
+                    if (defer) pv[at] = NOVAL;                           // (a tile with this many survivors: evaluated here)
                     pend[at++] = qb + ((cc / TS) << QSH) + rowbase + 16u * (cc % TS);
                 }
                 npend += readlane_u32(incl, 63);
@@ -2227,6 +2349,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         unsigned long long *st = a.stats + 8 + 16 * ((blockIdx.y * gridDim.x + blockIdx.x + (uint32_t)wave * 17u) % STATS_SLOTS);
         atomicAdd(&st[0], (unsigned long long)(r1 - r0) * cnt);
         atomicAdd(&st[1], (unsigned long long)n_exact);
+        if (n_defer) atomicAdd(&st[4], (unsigned long long)n_defer);
 #endif
 #ifdef PQV_PROFILE_PHASES
         {   // per-wave record: [start, prologue, kloop, screen, drain, end, rows, cnt] at stats[8 + 8 * wave id]
@@ -2287,6 +2410,7 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false, bool ONCE = false, int TS = 4>
 static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
     auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF, ONCE, TS>;
+    if (a.rows_per_block / NW + 64u >= (1u << 23)) return hipErrorInvalidValue;       // queue entries: 23 bits of row offset per wave
     if (lds > 65536) {          // raise the kernel's dynamic-LDS ceiling to what this launch needs (static + dynamic <= 160 KB)
         static std::atomic<size_t> allowed{65536};
         if (lds > allowed.load(std::memory_order_relaxed)) {
@@ -2335,7 +2459,7 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                         if (a.wide_width != 160 || !a.item_quad || !a.wide_item_quad || !a.wide_max_items || !a.wide_rows_per_block)
                             return hipErrorInvalidValue;
                         TileArgs w = a;
-                        w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0;
+                        w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0; w.pendv = a.pendv_wide;
                         w.item_quad = a.wide_item_quad; w.item_chunk = a.wide_item_chunk; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
                         w.rows_per_block = a.wide_rows_per_block;
                         // the regular instance first: most lists are its, so every query's thresholds have met most of its lists'
