@@ -278,7 +278,7 @@ struct pqv_searcher {
         uint32_t wide_rows = 0;            // rows per block of the wide kernel (0 = by rule)
         uint32_t tile_rows = 0;            // rows per block of the exact tile kernel (0 = 1536)
         int running_thr = 1;               // running thresholds of the wide kernel
-        int defer = 1;                     // wide kernel: survivors are appended with their bounds, the final merge evaluates the few that matter
+        int defer = 1;                     // wide kernel, k > 64: survivors are appended with their bounds, evaluated after the filter (0: in it)
         int quad_xcd = -1;                 // quad-to-XCD affinity of the wide kernels (-1 = by rule)
         int single_bucket = 1;             // one query: the probe merge writes the bucketing, no pair-sort launches
         int seed_refine = 1;               // exact distances behind the k selected seed bounds tighten the first threshold (k <= 16)
@@ -2069,10 +2069,11 @@ static uint32_t cand_cap_for(const pqv_searcher *s, uint32_t k) {
 }
 // Deferred exact evaluation (TileArgs::cand_lb): pays where the exact evaluations are most of the screen kernel's time -- long
 // lists of survivors, i.e. large k (the reference's bench shape, 1 M x 1024 at K = 100: 1226 evaluations per query in the
-// filter -> 633 after it, screen kernel 2.14 -> 0.95 ms); at k = 10 the streaming waves hide their evaluations behind each
-// other and the extra launches cost more than they save (C3: 1.08 + 0.73 ms of screen either way).  2 = always.
+// filter -> 633 after it, screen kernel 2.14 -> 0.95 ms).  At k = 10 the streaming waves hide their evaluations behind each
+// other and the extra launches cost more than they save (C3: 1.08 + 0.73 ms of screen either way), so the deferred form is
+// compiled into the k > 64 instances of the kernel only (S > 1) and those always use it (PQV_DEFER=0: never).
 static bool defer_on(const pqv_searcher *s, uint32_t k) {
-    return s->opt.defer == 2 || (s->opt.defer == 1 && k > 32);
+    return k > 64 && s->opt.defer != 0;         // (the kernels carry the deferred form in their k > 64 instances only)
 }
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
     (void)nq;

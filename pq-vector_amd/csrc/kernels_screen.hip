@@ -1318,7 +1318,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint32_t *pend = pend_all + wave * PEND;
     // deferred evaluation (TileArgs::cand_lb): the queue entry's raw screen score lives in the wave's strip of a global
     // scratch (written at expansion, read back when the entry is appended: one wave, program order; no LDS to spare)
-    const bool defer = a.cand_lb != nullptr;
+    // (compiled into the S > 1 instances only -- k > 64 -- so that the k <= 64 instances keep their registers: with a run-time
+    //  switch alone C3 lost 5 %)
+    const bool defer = S > 1 && a.cand_lb != nullptr;
     uint32_t *pv = defer ? a.pendv + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + (uint32_t)wave) * PEND : nullptr;
     constexpr uint32_t NOVAL = I8 ? 0x80000000u : 0x7FC00000u, NOVAL_NOHIST = I8 ? 0x80000001u : 0x7FC00001u;
     __shared__ __attribute__((aligned(16))) float aq_all[NW * NQ];   // per-wave, per-query screen terms

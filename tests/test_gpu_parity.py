@@ -748,8 +748,9 @@ def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, np
     query overflows into the per-wave sorted lists) and the one-group-per-block kernel must all
     reproduce the oracle bit for bit.  "deferred": survivors are appended with the bounds their screen score
     gives and the exact evaluations happen after the filter, for the entries the k-th smallest upper bound
-    leaves (the default for k > 32, forced here for every k); with a 16-entry buffer most of them overflow
-    and are evaluated by the streaming wave after all."""
+    leaves (what the library does for k > 64: these variants ask for 70 neighbours where the case has fewer);
+    with a 16-entry buffer (raised to k by the library) most of them overflow and are evaluated by the
+    streaming wave after all."""
     rng = np.random.default_rng(3 * n + dim + nq)
     data, oidx = _random_index(oracle, rng, n, dim, kc)
     queries = rng.random((nq, dim), dtype=np.float32)
@@ -762,8 +763,10 @@ def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, np
         monkeypatch.setenv("PQV_CAND_CAP", "16")
     if variant == "narrow":
         monkeypatch.setenv("PQV_FILTER_VARIANT", "1")
-    if variant != "default":                 # ("default": the library's own rule -- deferred for k > 32)
-        monkeypatch.setenv("PQV_DEFER", "2" if variant.startswith("deferred") else "0")
+    if variant.startswith("deferred"):
+        k = max(k, 70)
+    elif variant != "default":               # ("default": the library's own rule -- deferred for k > 64)
+        monkeypatch.setenv("PQV_DEFER", "0")
     s = pqv.Searcher(index, corpus)
     orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
     rows, dist, nf, nc = s.topk(queries, k, nprobe)
