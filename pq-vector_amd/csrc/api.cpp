@@ -1740,7 +1740,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.filter_variant = static_cast<int>(num("PQV_FILTER_VARIANT", o.filter_variant));
     o.cand_cap = static_cast<uint32_t>(std::max<long long>(0, num("PQV_CAND_CAP", o.cand_cap)));
     o.screen_f16 = num("PQV_SCREEN_F16", o.screen_f16) != 0;
-    o.screen_i8 = num("PQV_SCREEN_I8", o.screen_i8) != 0;
+    o.screen_i8 = static_cast<int>(num("PQV_SCREEN_I8", o.screen_i8));
     o.seed_rows = static_cast<uint32_t>(num("PQV_SEED_ROWS", o.seed_rows));
     o.wide_rows = static_cast<uint32_t>(num("PQV_WIDE_ROWS", o.wide_rows));
     o.tile_rows = static_cast<uint32_t>(num("PQV_TILE_ROWS", o.tile_rows));
@@ -1781,7 +1781,7 @@ bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && (
 // 2.44 against 3.85, K = 100 4.21 against 5.10; 1 M x 768 (976-row lists) K = 10 1.07 against 1.16.
 int screen_op(const pqv_searcher *s, uint32_t k = 1) {
     const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
-    const bool i8_pays = !(k > 32 && mean_len < 4096);
+    const bool i8_pays = !(k > 32 && mean_len < 4096) || s->opt.screen_i8 > 1;
     if (s->opt.screen_i8 && i8_pays && s->i8_ok && (s->sdim % 256) == 0 && s->sdim >= 256 && static_cast<uint64_t>(64) * s->sdim <= 147456) return 2;
     if (s->opt.screen_f16 && s->f16_ok && (s->sdim % 128) == 0 && s->sdim <= 1024) return 1;
     return 0;
@@ -2934,7 +2934,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "filter_variant") o.filter_variant = static_cast<int>(value);
     else if (n == "cand_cap") o.cand_cap = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "screen_f16") o.screen_f16 = value != 0;
-    else if (n == "screen_i8") o.screen_i8 = value != 0;
+    else if (n == "screen_i8") o.screen_i8 = static_cast<int>(value);
     else if (n == "seed_rows") o.seed_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "wide_rows") o.wide_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "tile_rows") o.tile_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));

@@ -233,6 +233,48 @@ struct WaveTopk {
 };
 
 // ------------------------------------------------------------------------------------
+// k-th smallest of n 32-bit values (1 <= k <= n), by the whole block: four 8-bit radix passes over a 256-bin LDS histogram;
+// get(i) returns value i (read four times).  Every thread of the block must call it; s_hist: 256 words, s_sel: 2 words.
+// ------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ uint32_t block_kth_u32(F get, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel) {
+    const int lane = threadIdx.x & 63;
+    uint32_t prefix = 0, mask = 0, rank = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t u = get(i);
+            if ((u & mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // 4 bins per lane, inclusive scan over the lanes, the digit whose cumulative count reaches `rank`
+            uint32_t c4[4], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c4[j] = s_hist[4 * lane + j]; tot += c4[j]; }
+            const uint32_t incl = wave_incl_scan_u32(tot);
+            uint32_t before = incl - tot;
+            int digit = -1;
+            uint32_t below = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (digit < 0 && before < rank && rank <= before + c4[j]) { digit = 4 * lane + j; below = before; }
+                before += c4[j];
+            }
+            const unsigned long long hit = __ballot(digit >= 0);
+            const int src = __builtin_ctzll(hit ? hit : 1ull);
+            const uint32_t d = (uint32_t)__shfl(digit, src, 64), bl = (uint32_t)__shfl((int)below, src, 64);
+            if (lane == 0) { s_sel[0] = prefix | (d << shift); s_sel[1] = rank - bl; }
+        }
+        __syncthreads();
+        prefix = s_sel[0]; rank = s_sel[1];
+        mask |= 0xFFu << shift;
+    }
+    return prefix;
+}
+
+// ------------------------------------------------------------------------------------
 // 16-byte row loads.  ALIGNED: dim % 4 == 0 so every row starts 16-B aligned.
 // ------------------------------------------------------------------------------------
 template <bool ALIGNED>

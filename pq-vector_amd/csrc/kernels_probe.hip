@@ -572,41 +572,7 @@ __device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t 
     if (n == 0) return;
     // 1. the k-th smallest upper bound (bounds are >= 0: their bits order like unsigned integers)
     uint32_t T = 0x7F800000u;
-    if (n >= a.k) {
-        uint32_t prefix = 0, mask = 0, rank = a.k;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            s_hist[threadIdx.x] = 0;
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += 256) {
-                const uint32_t u = (uint32_t)(ck[i] >> 32);
-                if ((u & mask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                // 4 bins per lane, inclusive scan over the lanes, the digit whose cumulative count reaches `rank`
-                uint32_t c4[4], tot = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { c4[j] = s_hist[4 * lane + j]; tot += c4[j]; }
-                const uint32_t incl = wave_incl_scan_u32(tot);
-                uint32_t before = incl - tot;
-                int digit = -1;
-                uint32_t below = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (digit < 0 && before < rank && rank <= before + c4[j]) { digit = 4 * lane + j; below = before; }
-                    before += c4[j];
-                }
-                const unsigned long long hit = __ballot(digit >= 0);
-                const int src = __builtin_ctzll(hit ? hit : 1ull);
-                const uint32_t d = (uint32_t)__shfl(digit, src, 64), bl = (uint32_t)__shfl((int)below, src, 64);
-                if (lane == 0) { s_sel[0] = prefix | (d << shift); s_sel[1] = rank - bl; }
-            }
-            __syncthreads();
-            prefix = s_sel[0]; rank = s_sel[1];
-            mask |= 0xFFu << shift;
-        }
-        T = prefix;
-    }
+    if (n >= a.k) T = block_kth_u32([&](uint32_t i) { return (uint32_t)(ck[i] >> 32); }, n, a.k, s_hist, s_sel);
     // 2. the band: deferred entries whose lower bound does not exceed T; exact entries beyond T and deferred ones outside the
     //    band leave (KEY_EMPTY)
     if (threadIdx.x == 0) s_sel[2] = 0;
@@ -710,19 +676,79 @@ hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, hipS
     return hipGetLastError();
 }
 
+// Final merge, k > 64, nothing spilled: the k smallest of a buffer of a few thousand exact keys.  Serial insertion into the
+// wave-distributed list costs ~3 k inserts of S ballots each (K = 100: 138 us); instead the block radix-selects the k-th
+// smallest DISTANCE, compacts the keys at or below it (k + ties) into LDS, ranks them against each other and wave 0 picks
+// them up in order.  false: more than 64 S keys at or below the k-th distance (a huge tie group) -- the caller inserts.
+template <int S>
+__device__ __forceinline__ bool merge_select_large(const MergeArgs &a, uint32_t q, WaveTopk<S> &tk) {
+    constexpr uint32_t CAPK = 64u * S;
+    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_s[4];
+    __shared__ uint64_t s_k[CAPK], s_k2[CAPK];
+    __shared__ uint32_t s_v[CAPK], s_v2[CAPK];
+    const int lane = threadIdx.x & 63;
+    uint32_t n = a.cand_cnt[q];
+    if (n > a.cand_cap) n = a.cand_cap;
+    const uint64_t *ck = a.cand_keys + (uint64_t)q * a.cand_cap;
+    const uint32_t *cv = a.cand_vals + (uint64_t)q * a.cand_cap;
+    if (threadIdx.x == 0) { s_s[2] = 0u; s_s[3] = 0u; }
+    __syncthreads();
+    uint32_t nv = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) nv += ck[i] != KEY_EMPTY ? 1u : 0u;
+    if (nv) atomicAdd(&s_s[3], nv);
+    __syncthreads();
+    const uint32_t nvalid = s_s[3];
+    uint32_t m = 0;
+    if (nvalid) {
+        const uint32_t kk = a.k < nvalid ? a.k : nvalid;
+        const uint32_t Td = block_kth_u32([&](uint32_t i) { return (uint32_t)(ck[i] >> 32); }, n, kk, s_h, s_s);     // (KEY_EMPTY sorts last)
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t key = ck[i];
+            if (key != KEY_EMPTY && (uint32_t)(key >> 32) <= Td) {
+                const uint32_t slot = atomicAdd(&s_s[2], 1u);
+                if (slot < CAPK) { s_k[slot] = key; s_v[slot] = cv[i]; }
+            }
+        }
+        __syncthreads();
+        m = s_s[2];
+        if (m > CAPK) return false;
+        for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) {          // keys are distinct (the position is part of them)
+            const uint64_t key = s_k[e];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; ++j) rank += s_k[j] < key ? 1u : 0u;
+            s_k2[rank] = key; s_v2[rank] = s_v[e];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t e = (uint32_t)(s * 64 + lane);
+            tk.key[s] = e < m ? s_k2[e] : KEY_EMPTY;
+            tk.val[s] = e < m ? s_v2[e] : 0xFFFFFFFFu;
+        }
+    }
+    return true;
+}
+
 template <int S, bool PROBE>
 __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if constexpr (!PROBE) PQV_STAMP_MIN(24);
-    if constexpr (!PROBE) { if (a.cand_lb) resolve_candidates(a, q); }
+    if constexpr (!PROBE && S > 1 && S <= 4) { if (a.cand_lb) resolve_candidates(a, q); }      // (deferred evaluation: k > 64, wide path k <= 128)
+    WaveTopk<S> tk;
+    tk.init();
+    [[maybe_unused]] bool preselected = false;
+    if constexpr (!PROBE && S > 1 && S <= 4) {
+        if (a.cand_keys && blockDim.x == 256 && a.spilled && a.spilled[q] == 0) preselected = merge_select_large<S>(a, q, tk);
+    }
     if (threadIdx.x >= 64) {
         // helper waves (probe mode with a preset only): the query's partial lists of the re-rank start EMPTY
         if constexpr (PROBE) probe_merge_helpers(a, q);
         return;
     }
-    WaveTopk<S> tk;
-    tk.init();
     const uint64_t total = (uint64_t)a.n_part * a.k_part;
     const uint64_t *pk = a.part_keys + (uint64_t)q * total;
     const uint32_t *pv = a.part_vals + (uint64_t)q * total;
@@ -734,7 +760,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     uint64_t cut = KEY_EMPTY;
     uint32_t ncand = 0;
     if (a.cand_keys) { ncand = a.cand_cnt[q]; if (ncand > a.cand_cap) ncand = a.cand_cap; }
-    bool folded = false;
+    bool folded = preselected;
     if constexpr (S == 1 && !PROBE) {
         // the usual final merge of the wide screened path: nothing spilled, up to 1024 candidates, k <= 64 -- keys and values
         // in ONE round trip (16 per lane), the k-th lane minimum as a cut, and the handful that pass it ordered by rank
@@ -1045,8 +1071,9 @@ template <bool PROBE>
 static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
     // (probe merge with a preset: three helper waves; final merge with deferred evaluation: the block resolves the buffer)
-    dim3 grid(a.nq), block(((PROBE && (a.preset_keys || a.preset_flags)) || (!PROBE && a.cand_lb)) ? 256 : 64);
-    if (!PROBE && a.cand_lb && (a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 4) != 0)) return hipErrorInvalidValue;
+    //  final merge of candidate buffers at k > 64: the block selects, merge_select_large)
+    dim3 grid(a.nq), block(((PROBE && (a.preset_keys || a.preset_flags)) || (!PROBE && (a.cand_lb || (a.cand_keys && a.k > 64 && a.k <= 256)))) ? 256 : 64);
+    if (!PROBE && a.cand_lb && (a.k <= 64 || a.k > 256 || a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 4) != 0)) return hipErrorInvalidValue;
     if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);
