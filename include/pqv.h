@@ -184,6 +184,9 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "screen_f16"    f16 screen operands where the data allows (default 1)
  *   "seed_rows", "wide_rows", "tile_rows"   rows sampled for thresholds / per block (0 = by rule)
  *   "running_thr"   running thresholds of the wide kernel (default 1)
+ *   "defer"         k > 64 on the wide screened path: survivors of the screen are appended with the distance bounds their
+ *                   screen score gives and evaluated after the filter, only where the k-th smallest upper bound leaves them
+ *                   (default 1; 0 = every survivor is evaluated by the streaming wave)
  *   "quad_xcd"      quad-to-XCD affinity of the wide kernels (-1 by rule)
  *   "wide_waves"    waves per block of the wide kernel: 0 by rule, 4 or 8
  *   "quad_width"    queries per quad of the wide kernel (0 by rule; a multiple of 32)

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r02}; wl=${2:-c3}
 O=$R/gpurun_out/prof_$tag; mkdir -p $O
-B="python $R/bench.py --workload $wl --no-cpu --recall 0 --steps 2 --warmup 1 --single 100"
+B="python $R/bench.py --workload $wl --no-cpu --no-secondary --no-configs --recall 0 --steps 2 --warmup 1 --single 100"
 : > $O/${tag}_${wl}_single_trace.txt; : > $O/${tag}_${wl}_single_pmc_FETCH_SIZE.txt
 for mode in rule stream; do
   echo "## PQV_RERANK_MODE=$mode (rule: screened dispatch, stream: stream_kernel per query)" | tee -a $O/${tag}_${wl}_single_trace.txt >> $O/${tag}_${wl}_single_pmc_FETCH_SIZE.txt
