@@ -53,6 +53,8 @@ WORKLOADS = {
     "c2s4": (250_000, 128, 100, 8, 1024),
     "c2s8": (125_000, 128, 100, 8, 1024),
     "c3s": (1_000_000, 768, 1024, 32, 1024),   # C3's parameters on 1 M rows (quick check)
+    "c3m": (2_500_000, 768, 1024, 32, 1024),   # C3's parameters on 2.5 M rows: 2441 rows per list
+    "c3l": (5_000_000, 768, 1024, 32, 1024),   # ... on 5 M rows: 4883 rows per list
     "c3h": (500_000, 768, 1024, 32, 1024),     # short lists: 488 rows per list (the reference's default n_clusters = ceil(sqrt(n)) regime)
     "c2d": (1_000_000, 128, 0, 8, 1024),       # C2's rows with the DEFAULT n_clusters = ceil(sqrt(n)) = 1000 (index.rs:161-167)
     "tiny": (20_000, 64, 16, 4, 64),       # plumbing check

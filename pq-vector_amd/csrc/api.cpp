@@ -2072,8 +2072,17 @@ static uint32_t cand_cap_for(const pqv_searcher *s, uint32_t k) {
 // filter -> 633 after it, screen kernel 2.14 -> 0.95 ms).  At k = 10 the streaming waves hide their evaluations behind each
 // other and the extra launches cost more than they save (C3: 1.08 + 0.73 ms of screen either way), so the deferred form is
 // compiled into the k > 64 instances of the kernel only (S > 1) and those always use it (PQV_DEFER=0: never).
-static bool defer_on(const pqv_searcher *s, uint32_t k) {
-    return k > 64 && s->opt.defer != 0;         // (the kernels carry the deferred form in their k > 64 instances only)
+// k <= 64: only where a wave's own evaluations are a large part of its short life -- lists of a few tiles per wave of long
+// rows (int8 images of >= 512 dims; the two-instance form of batches).  With 1024 lists of 768-dim rows and k = 10, q/s
+// deferred against in-filter: 488 rows per list 1.79 against 1.49 M, 976: 1.63 / 1.50 M, 2441: 1.29 / 1.20 M, 4883:
+// 0.83 / 0.91 M, 9766 (C3): equal at best -- hence mean list <= 3072 rows.  128-dim rows cost less to evaluate than to
+// defer (C2 7.8 -> 6.8 M, its 1000-list variant 5.9 -> 5.5 M).
+static bool defer_on(const pqv_searcher *s, uint32_t nq, uint32_t k, const TopkPlan &p) {
+    if (s->opt.defer == 0) return false;
+    if (k > 64) return true;                    // (the kernels carry the deferred form in their k > 64 instances ...)
+    const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
+    // (... and in the DEFP instances of the int8 two-blocks-per-CU form: launch_filter_s)
+    return nq >= 8 && p.i8 && p.block_waves == 4 && p.quad_width == 96 && s->sdim >= 512 && (s->opt.defer == 2 || mean_len <= 3072);
 }
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
     (void)nq;
@@ -2388,7 +2397,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
-    bool use_defer = false;    // ... and resolves deferred evaluations first
+    bool use_defer = false;    // ... whose entries carry bounds (deferred evaluation) ...
+    bool resolved = false;     // ... already resolved by launch_resolve
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
         uint32_t *u = pair_u32;
@@ -2485,7 +2495,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(sc.s_spilled.ensure(static_cast<size_t>(nq) * sizeof(uint32_t)));
             ta.cand_keys = sc.s_cand_keys.as<uint64_t>(); ta.cand_vals = sc.s_cand_vals.as<uint32_t>();
             ta.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); ta.cand_cap = ccap; ta.spilled = sc.s_spilled.as<uint32_t>();
-            if (defer_on(s, k) && ccap <= 8192) {
+            if (defer_on(s, nq, k, p) && ccap <= 8192) {
                 // deferred exact evaluation: bounds per appended pair, and the queues' raw scores (a strip per wave of every block)
                 HIP_TRY(sc.s_cand_lb.ensure(static_cast<size_t>(nq) * ccap * sizeof(float)));
                 const size_t blocks_r = items ? max_items : static_cast<size_t>(p.filter_bpl | 1u) * p.max_quads;
@@ -2546,6 +2556,19 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
+            if (use_defer && nq >= 8) {
+                // a batch: the k-th smallest upper bound per query, then every band entry of the batch on the whole chip; the
+                // merge then sees exact keys only.  (Part of the re-rank group: inside its timing events.)
+                pqv::MergeArgs rm{};
+                rm.nq = nq; rm.k = k; rm.cand_keys = ta.cand_keys; rm.cand_keys_rw = ta.cand_keys; rm.cand_vals = ta.cand_vals;
+                rm.cand_cnt = ta.cand_cnt; rm.cand_cap = ccap; rm.cand_lb = ta.cand_lb;
+                rm.mat = s->d_mat; rm.queries = d_queries_s; rm.dim = s->sdim; rm.resolve_stats = s->d_stats.as<unsigned long long>();
+                HIP_TRY(sc.s_work.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t) * 2));
+                HIP_TRY(sc.s_nwork.ensure(sizeof(uint32_t)));
+                HIP_TRY(launch_resolve(rm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), stream));
+                s->counters.kernel_launches += 2;
+                resolved = true;
+            }
         } else if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
             seed.row_offset = 0; seed.slot_base = 0; seed.grid_x = 1; seed.row_end = p.seed_rows;
@@ -2587,17 +2610,10 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = cand_cap_for(s, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
         fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
-        if (use_defer) {
+        if (use_defer && !resolved) {          // a handful of queries: the merge's block resolves the buffer itself
             fm.cand_lb = sc.s_cand_lb.as<float>(); fm.cand_keys_rw = sc.s_cand_keys.as<uint64_t>();
             fm.mat = s->d_mat; fm.queries = d_queries_s; fm.dim = s->sdim;
             fm.resolve_stats = s->d_stats.as<unsigned long long>();
-            if (nq >= 8) {          // a batch: selection per query, then all band entries at once on the whole chip; the merge sees exact keys
-                HIP_TRY(sc.s_work.ensure(static_cast<size_t>(nq) * fm.cand_cap * sizeof(uint32_t) * 2));
-                HIP_TRY(sc.s_nwork.ensure(sizeof(uint32_t)));
-                HIP_TRY(launch_resolve(fm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), stream));
-                fm.cand_lb = nullptr;
-                s->counters.kernel_launches += 2;
-            }
         }
     }
     HIP_TRY(launch_merge_final(fm, stream));
@@ -2997,6 +3013,12 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         std::snprintf(t + l, sizeof t - l, "; lists probed by %u..%u queries: one quad, 8 waves per block on 32-row tiles, %u rows per block",
                       p.quad_width + 1, p.wide_width, p.wide_rows_per_block);
     }
+    if (p.tile && p.filter && p.quad && defer_on(s, std::max<uint32_t>(1, nq), k, p) && cand_cap_for(s, k) <= 8192) {
+        const size_t l = std::strlen(t);
+        std::snprintf(t + l, sizeof t - l, "; exact evaluations deferred: survivors appended with their bounds, %s",
+                      nq >= 8 ? "resolve_select_kernel + resolve_exact_kernel evaluate what the k-th smallest upper bound leaves"
+                              : "resolved by the final merge's block");
+    }
     if (s->sdim != s->dim) {
         const size_t l = std::strlen(t);
         std::snprintf(t + l, sizeof t - l, "; rows stored zero-padded from %u to %u dims", s->dim, s->sdim);
@@ -3009,14 +3031,16 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         const bool pf = p.f16 && s->sdim <= 128 && p.block_waves == 4 && p.quad_width != 96;
         const int op = p.i8 ? 2 : p.f16 ? 1 : 0;
         const int seed_ng = p.i8 ? (64ull * s->sdim <= 49152 ? 4 : 2) : p.f16 ? ((64ull * s->sdim * 2 <= 32768 && p.quad_width % 64 == 0) ? 4 : 2) : static_cast<int>(p.quad_width / 16);
-        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4>; wide_seed_kernel<%d, %s, %d, %d>; seed_select_kernel<%d>@%u",
+        const bool defp = S == 1 && defer_on(s, std::max<uint32_t>(1, nq), k, p) && cand_cap_for(s, k) <= 8192;
+        std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4, %s>; wide_seed_kernel<%d, %s, %d, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
                       ((p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) || p.wide_width) ? "true" : "false",
-                      seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 64 && s->opt.single_bucket > 0) ? 12 : 1, S,
+                      defp ? "true" : "false", seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 64 && s->opt.single_bucket > 0) ? 12 : 1, S,
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
         if (p.wide_width) {
             const size_t l = std::strlen(kn);
-            std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, %s, 2>", p.wide_width / 16, S, wide_rows_nt(s) ? "true" : "false");
+            std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, %s, 2, %s>", p.wide_width / 16, S, wide_rows_nt(s) ? "true" : "false",
+                          defp ? "true" : "false");
         }
     }
     std::snprintf(buf, len, "%s; centroid probe: %s%s", t, p.probe_rows ? "probe_rows_kernel (a lane per centroid)" : "stream_kernel", kn);

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if constexpr (!PROBE) PQV_STAMP_MIN(24);
-    if constexpr (!PROBE && S > 1 && S <= 4) { if (a.cand_lb) resolve_candidates(a, q); }      // (deferred evaluation: k > 64, wide path k <= 128)
+    if constexpr (!PROBE && S > 1 && S <= 4) { if (a.cand_lb) resolve_candidates(a, q); }      // (calls of < 8 queries defer for k > 64 only; batches resolve through launch_resolve)
     WaveTopk<S> tk;
     tk.init();
     [[maybe_unused]] bool preselected = false;

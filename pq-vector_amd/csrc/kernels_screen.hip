@@ -1263,7 +1263,8 @@ __device__ __forceinline__ uint64_t qread_u64(const uint64_t (&v)[QS], uint32_t 
 // TS: 16-row sub-tiles per wave tile.  4 (64-row tiles) everywhere but the WIDE-QUAD instance <10, 8, .., TS = 2>: 32-row tiles
 // halve the accumulator registers per query group, so ONE block holds a quad of 160 queries (120 KB of int8 images) and a
 // list that 97..160 queries of the batch probe is streamed once instead of twice (launch_tile_filter, TileArgs::wide_*).
-template <int NG, int NW, int S, bool QLDS, int OP, bool PF, bool ONCE, int TS>
+// DEFP: the deferred-evaluation form (5.4b) also in a k <= 64 instance (the k > 64 instances always carry it)
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF, bool ONCE, int TS, bool DEFP>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS && OP != OP_F32)) ? 2 : 3) void wide_filter_kernel(const TileArgs a) {
     constexpr int ROW_AUX = ONCE ? 2 : PQV_ROW_AUX;
     constexpr bool F16 = OP == OP_F16, I8 = OP == OP_I8;
@@ -1347,9 +1348,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint32_t *pend = pend_all + wave * PEND;
     // deferred evaluation (TileArgs::cand_lb): the queue entry's raw screen score lives in the wave's strip of a global
     // scratch (written at expansion, read back when the entry is appended: one wave, program order; no LDS to spare)
-    // (compiled into the S > 1 instances only -- k > 64 -- so that the k <= 64 instances keep their registers: with a run-time
-    //  switch alone C3 lost 5 %)
-    const bool defer = S > 1 && a.cand_lb != nullptr;
+    // (compiled into the S > 1 instances -- k > 64 -- and the DEFP ones only, so that the others keep their registers: with a
+    //  run-time switch alone C3 lost 5 %)
+    const bool defer = (S > 1 || DEFP) && a.cand_lb != nullptr;
     uint32_t *pv = defer ? a.pendv + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + (uint32_t)wave) * PEND : nullptr;
     constexpr uint32_t NOVAL = I8 ? 0x80000000u : 0x7FC00000u, NOVAL_NOHIST = I8 ? 0x80000001u : 0x7FC00001u;
     __shared__ __attribute__((aligned(16))) float aq_all[NW * NQ];   // per-wave, per-query screen terms
@@ -2438,9 +2439,10 @@ hipError_t launch_seed_threshold(const uint64_t *part_keys, uint32_t nq, uint32_
 }
 
 // dynamic LDS beyond 64 KB has to be allowed per kernel once
-template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false, bool ONCE = false, int TS = 4>
+template <int NG, int NW, int S, bool QLDS, int OP, bool PF = false, bool ONCE = false, int TS = 4, bool DEFP = false>
 static hipError_t launch_wide(const TileArgs &a, size_t lds, hipStream_t s) {
-    auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF, ONCE, TS>;
+    auto kern = wide_filter_kernel<NG, NW, S, QLDS, OP, PF, ONCE, TS, DEFP>;
+    if (a.cand_lb && !(S > 1 || DEFP)) return hipErrorInvalidValue;      // this instance would ignore the request
     if (a.rows_per_block / NW + 64u >= (1u << 23)) return hipErrorInvalidValue;       // queue entries: 23 bits of row offset per wave
     if (lds > 65536) {          // raise the kernel's dynamic-LDS ceiling to what this launch needs (static + dynamic <= 160 KB)
         static std::atomic<size_t> allowed{65536};
@@ -2502,11 +2504,18 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                         // side by side and share its rows through the caches -- nt pays there only when such lists are rare: the
                         // caller decides from the previous batch's counts (TileArgs::wide_nt).  Measured, nt on regular / wide /
                         // both: C3 +0.5 / +3.5 / +4 %, mixture +2.5 / -6 / -4 %.
+                        if constexpr (S == 1) if (a.cand_lb) {       // short lists of long rows: the deferred form (defer_on decides)
+                            hipError_t e = launch_wide<6, 4, S, true, OP_I8, false, true, 4, true>(a, lds, s);
+                            if (e != hipSuccess) return e;
+                            return a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2, true>(w, (size_t)a.wide_width * a.dim, s)
+                                             : launch_wide<10, 8, S, true, OP_I8, false, false, 2, true>(w, (size_t)a.wide_width * a.dim, s);
+                        }
                         hipError_t e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
                         if (e != hipSuccess) return e;
                         return a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, s)
                                          : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s);
                     }
+                    if constexpr (S == 1) if (a.cand_lb) return launch_wide<6, 4, S, true, OP_I8, false, false, 4, true>(a, lds, s);
                     return launch_wide<6, 4, S, true, OP_I8>(a, lds, s);
                 }
                 return hipErrorInvalidValue;

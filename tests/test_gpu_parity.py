@@ -790,6 +790,35 @@ def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, np
         assert (_bits(d2[q, :len(order)]) == _bits(d[order])).all()
 
 
+def test_deferred_evaluation_rule_for_short_lists_of_long_rows(pqv, oracle, monkeypatch):
+    """k <= 64: batches on short lists of long rows (int8 images, >= 512 dims, mean list <= 3072 rows) defer their exact
+    evaluations behind the screen; one-query calls and PQV_DEFER=0 do not.  All three give the oracle's answer bit for bit."""
+    rng = np.random.default_rng(99)
+    n, dim, kc, k, nprobe, nq = 30000, 768, 24, 10, 6, 200
+    data, oidx = _random_index(oracle, rng, n, dim, kc)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    queries[::9] = data[rng.integers(0, n, size=len(queries[::9]))]
+    corpus = pqv.Corpus.upload(data)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    for env in ("1", "0"):
+        monkeypatch.setenv("PQV_DEFER", env)
+        s = pqv.Searcher(index, corpus)
+        text = s.describe(nq, k + 1, nprobe)
+        assert ("exact evaluations deferred" in text) == (env == "1"), text
+        assert "resolved by the final merge" not in s.describe(1, k + 1, nprobe) and "deferred" not in s.describe(1, k + 1, nprobe)
+        if env == "1":
+            assert "wide_filter_kernel<6, 4, 1, true, 2, false, true, 4, true>" in text
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all()
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+        r1, d1, n1, _ = s.topk(queries[3:4], k, nprobe)
+        _assert_topk_equal((r1, d1, n1), (orows[3:4], odist[3:4], onf[3:4]), k)
+        c = s.counters()
+        assert c["screen_survivors"] > 0
+        s.close() if hasattr(s, "close") else None
+
+
 def test_mfma_screen_under_cancellation(pqv, oracle, monkeypatch):
     """Rows = large common offset + tiny noise: |q|^2 + |x|^2 - 2 q.x cancels catastrophically,
     the screen's margin dwarfs every distance, so (nearly) all pairs must survive it and be
