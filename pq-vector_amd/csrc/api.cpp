@@ -2499,8 +2499,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 // deferred exact evaluation: bounds per appended pair, and the queues' raw scores (a strip per wave of every block)
                 HIP_TRY(sc.s_cand_lb.ensure(static_cast<size_t>(nq) * ccap * sizeof(float)));
                 const size_t blocks_r = items ? max_items : static_cast<size_t>(p.filter_bpl | 1u) * p.max_quads;
-                const size_t words_r = blocks_r * p.block_waves * pqv::wide_filter_pend(p.quad_width, p.block_waves);
-                const size_t words_w = wide ? static_cast<size_t>(wide_max_items) * 8 * pqv::wide_filter_pend(p.wide_width, 8) : 0;
+                const size_t words_r = blocks_r * p.block_waves * pqv::wide_filter_pend(p.quad_width, p.block_waves, p.f16);
+                const size_t words_w = wide ? static_cast<size_t>(wide_max_items) * 8 * pqv::wide_filter_pend(p.wide_width, 8, false) : 0;
                 HIP_TRY(sc.s_pendv.ensure((words_r + words_w) * sizeof(uint32_t)));
                 ta.cand_lb = sc.s_cand_lb.as<float>();
                 ta.pendv = sc.s_pendv.as<uint32_t>(); ta.pendv_wide = ta.pendv + words_r;

@@ -342,7 +342,9 @@ struct TileArgs {
 // KEY_EMPTY keys, 0xFFFFFFFF values); a wave touches its slots only when a candidate is admitted.
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s);
 // entries of a wave's survivor queue in wide_filter_kernel<NG = quad_width / 16, NW = waves> (TileArgs::pendv is sized with it)
-inline uint32_t wide_filter_pend(uint32_t quad_width, uint32_t waves) { return (waves == 8 ? 256u : quad_width == 96 ? 128u : 512u) + 64u; }
+constexpr uint32_t wide_filter_pend(uint32_t quad_width, uint32_t waves, bool f16) {
+    return (waves == 8 ? (quad_width == 64 && f16 ? 512u : 256u) : quad_width == 96 ? 128u : 512u) + 64u;
+}
 // Same contract, but every (row, query) pair is first screened with an MFMA lower bound of its
 // distance; only pairs that could still beat the query's admission threshold are evaluated in
 // the reference's exact order.  Needs thresholds seeded by a prior launch_tile_rerank window.

@@ -514,7 +514,7 @@ __device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q,
 // ------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void resolve_exact(const MergeArgs &a, uint32_t q, const uint16_t *band, uint32_t m, uint64_t *ck, const uint32_t *cv,
-                                              int lane, int wave, uint32_t lg) {
+                                              int lane, int wave, uint32_t lg, float *cl = nullptr /* marks the entry exact */) {
     const uint32_t Gx = a.dim >> 2;
     const uint32_t L = 1u << lg, per_wave = 64u >> lg;
     const uint32_t pl = (uint32_t)lane >> lg, pj = (uint32_t)lane & (L - 1u);
@@ -554,7 +554,10 @@ __device__ __forceinline__ void resolve_exact(const MergeArgs &a, uint32_t q, co
                 }
             }
         }
-        if (valid && pj == 0u) ck[idx] = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)ck[idx];
+        if (valid && pj == 0u) {
+            ck[idx] = ((uint64_t)__float_as_uint(sum) << 32) | (uint64_t)(uint32_t)ck[idx];
+            if (cl) cl[idx] = -1.0f;
+        }
     }
 }
 // work != nullptr: the band goes to a batch-wide work list {query, entry} for resolve_exact_kernel instead of being evaluated here
@@ -573,6 +576,42 @@ __device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t 
     // 1. the k-th smallest upper bound (bounds are >= 0: their bits order like unsigned integers)
     uint32_t T = 0x7F800000u;
     if (n >= a.k) T = block_kth_u32([&](uint32_t i) { return (uint32_t)(ck[i] >> 32); }, n, a.k, s_hist, s_sel);
+    auto exact_list = [&](uint32_t m, float *mark) {
+        const uint32_t Gx = a.dim >> 2;
+        const uint32_t per = (m + 3u) / 4u;                    // pairs per wave
+        uint32_t lg = 0;
+        if ((Gx % 64u) == 0u) {
+            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
+            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, lg, mark);
+        } else if ((Gx % 16u) == 0u) {
+            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
+            resolve_exact<2>(a, q, s_band, m, ck, cv, lane, wave, lg, mark);
+        } else {
+            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, 0u, mark);
+        }
+        if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
+    };
+    // 1b. (batches) the entries that DEFINE T -- the k smallest upper bounds, nearly the k nearest rows -- are evaluated right
+    //     here, and T is taken again over exact distances where they exist: it drops from "k-th distance + the bound's whole
+    //     width" to "+ what the k-th nearest row's own bound leaves", and the band below loses the entries whose lower bound
+    //     lies in between.  Skipped when a tie group makes that list long.
+    if (work && n >= a.k) {
+        if (threadIdx.x == 0) s_sel[2] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            if (cl[i] >= 0.0f && (uint32_t)(ck[i] >> 32) <= T) {
+                const uint32_t slot = atomicAdd(&s_sel[2], 1u);
+                if (slot < 8192u) s_band[slot] = (uint16_t)i;
+            }
+        __syncthreads();
+        const uint32_t mA = s_sel[2];
+        __syncthreads();
+        if (mA && mA <= 2u * a.k + 64u) {
+            exact_list(mA, cl);
+            __syncthreads();
+            T = block_kth_u32([&](uint32_t i) { return (uint32_t)(ck[i] >> 32); }, n, a.k, s_hist, s_sel);
+        }
+    }
     // 2. the band: deferred entries whose lower bound does not exceed T; exact entries beyond T and deferred ones outside the
     //    band leave (KEY_EMPTY)
     if (threadIdx.x == 0) s_sel[2] = 0;
@@ -602,21 +641,7 @@ __device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t 
         return;
     }
     // 3. exact keys for the band
-    if (m) {
-        const uint32_t Gx = a.dim >> 2;
-        const uint32_t per = (m + 3u) / 4u;                    // pairs per wave
-        uint32_t lg = 0;
-        if ((Gx % 64u) == 0u) {
-            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
-            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, lg);
-        } else if ((Gx % 16u) == 0u) {
-            while (lg < 3 && (per << (lg + 1)) <= 64u) ++lg;
-            resolve_exact<2>(a, q, s_band, m, ck, cv, lane, wave, lg);
-        } else {
-            resolve_exact<8>(a, q, s_band, m, ck, cv, lane, wave, 0u);
-        }
-        if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
-    }
+    if (m) exact_list(m, nullptr);
     __syncthreads();
 }
 

@@ -1283,7 +1283,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // survivors are expanded into the wave's queue a PASS at a time when a tile's do not fit at once: half a
     // group's pairs (queries r < 2 / r >= 2 of every lane: <= 512 entries) for the 4-wave blocks, a quarter
     // (<= 256) for the 8-wave blocks, whose LDS belongs to the staged queries
-    constexpr int PASS = NW == 8 ? 256 : NG == 6 ? 128 : 512;      // (96 int8 queries, two blocks per CU: 80 KB each)
+    // (64 f16 queries on 8 waves -- K = 100 on 1024-dim rows: a tile often has more than 192 survivors, and only what is expanded
+    //  in one pass can be deferred; its quad takes <= 128 KB, so the queues may have 18 KB)
+    constexpr int PASS = (int)wide_filter_pend(NQ, NW, OP == OP_F16) - 64;      // (96 int8 queries, two blocks per CU: 80 KB each)
     constexpr int PEND = PASS + 64;        // one pass + a partial batch
     constexpr int NT = 64 * NW;
 #ifdef PQV_PROFILE_PHASES
