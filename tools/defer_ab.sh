@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for wl in "$@"; do
   X=""; [ $wl = refbench ] && X="--k 100"
-  for d in 0 1; do
+  for d in ${DEFER_VALUES:-0 1}; do
     PQV_DEFER=$d python $R/bench.py --workload $wl $X --no-cpu --no-secondary --no-configs --single 0 --recall 0 --steps 200 2>/dev/null | python -c "
 import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=l['counters']
