@@ -112,6 +112,19 @@ int pqv_parquet_levels_check(const uint8_t *buf, uint64_t len, uint32_t bit_widt
                                                      second level 0, or n_values if there is none), written here, then checked */);
 int pqv_parquet_dict_decode(const uint8_t *buf, uint64_t len, const void *dict, uint64_t dict_n, uint32_t elem_size,
                             uint64_t n_values, void *out);
+/* The page headers of one column chunk, walked from its first byte (Thrift compact PageHeader, parquet.thrift): per page 8
+ * ints {type, header bytes, compressed_page_size, uncompressed_page_size, num_values, encoding, definition_level_encoding,
+ * repetition_level_encoding}, -1 where the header has no such field.  Stops at len, at max_pages, or once stop_values (> 0)
+ * values have been seen in data pages.  (The reference reads pages through the parquet crate: src/ivf/parquet.rs:216-230.) */
+/* A run of uncompressed PLAIN v1 data pages of the embedding leaf, from the mapped file to the corpus: per page body (at
+ * file_base + body_off[i], body_len[i] bytes) the repetition levels must start a row exactly every `dim` values and every
+ * definition level must be max_def (src/ivf/parquet.rs:231-280's checks, on the levels); the n_values[i] values behind the level
+ * runs go to rows first_value[i] / dim .. through the pinned staging buffers like pqv_corpus_write_rows (f64 != 0: Float64
+ * values, narrowed on the device).  Returns 0, a negative error, or 1 with *bad_page set when page i is not such a page. */
+int pqv_corpus_write_plain_pages(pqv_corpus *corpus, const uint8_t *file_base, const uint64_t *body_off, const uint32_t *body_len,
+                                 const uint64_t *first_value, const uint32_t *n_values, uint32_t n_pages, uint32_t dim,
+                                 uint32_t max_def, int f64, uint32_t *bad_page);
+int pqv_parquet_page_headers(const uint8_t *buf, uint64_t len, uint64_t stop_values, uint32_t max_pages, int32_t *out, uint32_t *n_pages);
 /* Adopt an existing device buffer [n, dim] f32 on `device` (borrowed; caller keeps it
  * alive and frees it). */
 int pqv_corpus_from_device(int device, const void *d_rows, uint64_t n, uint32_t dim,

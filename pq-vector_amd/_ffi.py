@@ -75,6 +75,8 @@ SIGNATURES = {
     "pqv_corpus_finish": (C.c_int, [vp, C.c_uint64]),
     "pqv_parquet_levels_check": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_uint64, u64p]),
     "pqv_parquet_dict_decode": (C.c_int, [u8p, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp]),
+    "pqv_corpus_write_plain_pages": (C.c_int, [vp, u8p, u64p, u32p, u64p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p]),
+    "pqv_parquet_page_headers": (C.c_int, [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_int32), u32p]),
     "pqv_corpus_from_device": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "pqv_corpus_rows": (C.c_uint64, [vp]),
     "pqv_corpus_dim": (C.c_uint32, [vp]),

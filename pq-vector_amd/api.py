@@ -90,6 +90,18 @@ class Corpus:
         fn = _ffi.lib().pqv_corpus_write_rows_f64 if f64 else _ffi.lib().pqv_corpus_write_rows
         _check(fn(self._h, row_offset, C.cast(C.c_void_p(address), f64p if f64 else f32p), n_rows))
 
+    def write_plain_pages(self, file_base, body_off, body_len, first_value, n_values, dim, max_def, f64=False):
+        """A run of uncompressed PLAIN data pages from a mapped file (pqv_corpus_write_plain_pages): level runs checked and values
+        uploaded natively.  Returns None, or the index of the first page that is not what the page plan assumed."""
+        bad = C.c_uint32(0)
+        rc = _ffi.lib().pqv_corpus_write_plain_pages(self._h, C.cast(C.c_void_p(file_base), _ffi.u8p), body_off.ctypes.data_as(_ffi.u64p),
+                                                     body_len.ctypes.data_as(_ffi.u32p), first_value.ctypes.data_as(_ffi.u64p),
+                                                     n_values.ctypes.data_as(_ffi.u32p), len(body_off), dim, max_def, 1 if f64 else 0, C.byref(bad))
+        if rc == 1:
+            return int(bad.value)
+        _check(rc)
+        return None
+
     def finish(self, n_rows):
         _check(_ffi.lib().pqv_corpus_finish(self._h, n_rows))
 

@@ -165,14 +165,16 @@ struct UploadStage {
     void *dev64[N] = {};                          // f64 batches: device-side landing area of the same size (made on first use)
     hipEvent_t ev[N] = {};
     int state[N] = {};                            // 0 free, 1 claimed, 2 in flight
-    hipStream_t copy_stream = nullptr;
+    static constexpr int NS = 4;                  // copy streams, slot i uses stream i % NS: several DMA operations in flight (1 MB pages: the
+                                                  // per-operation overhead of ONE engine capped the loader at ~15 GB/s)
+    hipStream_t copy_stream[NS] = {};
     ~UploadStage() {
         for (int i = 0; i < N; ++i) {
             if (ev[i]) (void)hipEventDestroy(ev[i]);
             if (pin[i]) (void)hipHostFree(pin[i]);
             if (dev64[i]) (void)hipFree(dev64[i]);
         }
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (int i = 0; i < NS; ++i) if (copy_stream[i]) (void)hipStreamDestroy(copy_stream[i]);
     }
 };
 
@@ -437,7 +439,7 @@ int upload_stage_of(pqv_corpus *c, UploadStage **out) {
     std::lock_guard<std::mutex> lock(c->upload_mu);
     if (!c->upload) {
         std::unique_ptr<UploadStage> u(new UploadStage());
-        HIP_TRY(hipStreamCreateWithFlags(&u->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < UploadStage::NS; ++i) HIP_TRY(hipStreamCreateWithFlags(&u->copy_stream[i], hipStreamNonBlocking));
         for (int i = 0; i < UploadStage::N; ++i) {
             HIP_TRY(hipHostMalloc(&u->pin[i], UploadStage::BYTES, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&u->ev[i], hipEventDisableTiming));
@@ -486,16 +488,17 @@ int corpus_write_rows(pqv_corpus *c, uint64_t row_offset, const T *rows, uint64_
         int slot = -1;
         if (int rc = upload_claim(u, &slot)) return rc;
         std::memcpy(u->pin[slot], rows + r0 * c->dim, m * row_bytes);
+        hipStream_t cs = u->copy_stream[slot % UploadStage::NS];
         float *dst = c->d_rows + (row_offset + r0) * c->dim;
         hipError_t e = hipSuccess;
         if (std::is_same<T, float>::value) {
-            e = hipMemcpyAsync(dst, u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, u->copy_stream);
+            e = hipMemcpyAsync(dst, u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, cs);
         } else {
             if (!u->dev64[slot]) e = hipMalloc(&u->dev64[slot], UploadStage::BYTES);
-            if (e == hipSuccess) e = hipMemcpyAsync(u->dev64[slot], u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, u->copy_stream);
-            if (e == hipSuccess) e = pqv::launch_narrow_f64(static_cast<const double *>(u->dev64[slot]), m * c->dim, dst, u->copy_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(u->dev64[slot], u->pin[slot], m * row_bytes, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = pqv::launch_narrow_f64(static_cast<const double *>(u->dev64[slot]), m * c->dim, dst, cs);
         }
-        if (e == hipSuccess) e = hipEventRecord(u->ev[slot], u->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(u->ev[slot], cs);
         upload_release(u, slot, e == hipSuccess);
         HIP_TRY(e);
     }
@@ -514,7 +517,7 @@ extern "C" int pqv_corpus_finish(pqv_corpus *c, uint64_t n_rows) {
         if (n_rows > c->capacity) return fail(PQV_ERR_INVALID, "corpus capacity exceeded");
         if (int rc = use_device(c->device)) return rc;
         if (c->upload) {
-            HIP_TRY(hipStreamSynchronize(c->upload->copy_stream));
+            for (int i = 0; i < UploadStage::NS; ++i) HIP_TRY(hipStreamSynchronize(c->upload->copy_stream[i]));
             std::lock_guard<std::mutex> lock(c->upload_mu);
             c->upload.reset();                     // the pinned buffers go back: a resident corpus does not keep 128 MB of them
         }
@@ -608,6 +611,175 @@ extern "C" int pqv_parquet_levels_check(const uint8_t *buf, uint64_t len, uint32
         return ok ? 0 : 1;
     });
 }
+namespace {
+// (levels as above, without the error text: 0 as expected, 1 different, -1 malformed)
+int levels_plain(const uint8_t *buf, uint64_t len, uint32_t bw, uint64_t n_values, int mode, uint64_t expect) {
+    bool ok = true;
+    uint64_t pos = 0;
+    const bool well = hybrid_runs(buf, len, bw, n_values, [&](uint32_t v, uint64_t cnt) {
+        if (mode == 0) { ok = v == expect; return ok; }
+        const uint64_t ph = pos % expect;
+        if (v == 0) ok = ph == 0 && (cnt == 1 || expect == 1);
+        else ok = v == 1 && ph != 0 && ph + cnt <= expect;
+        pos += cnt;
+        return ok;
+    });
+    if (!well) return -1;
+    if (ok && mode == 1 && pos % expect != 0) ok = false;
+    return ok ? 0 : 1;
+}
+}  // namespace
+
+// A run of uncompressed PLAIN v1 data pages of a `List<f32|f64>` leaf, straight from the mapped file: per page the two level
+// runs are checked (repetition level 0 exactly every `dim` values, every definition level == max_def) and the values behind
+// them are uploaded like pqv_corpus_write_rows at row first_value / dim.  One call per dozen pages keeps a Python caller's
+// interpreter lock out of the loop.  Returns 0, or 1 with *bad_page = the first page that is not what the plan assumed
+// (nothing of it is uploaded; the caller re-reads the column through its general reader).
+extern "C" int pqv_corpus_write_plain_pages(pqv_corpus *c, const uint8_t *file_base, const uint64_t *body_off, const uint32_t *body_len,
+                                            const uint64_t *first_value, const uint32_t *n_values, uint32_t n_pages, uint32_t dim,
+                                            uint32_t max_def, int f64, uint32_t *bad_page) {
+    return guard([&]() -> int {
+        if (!c) return fail(PQV_ERR_INVALID, "corpus must not be NULL");
+        if (!file_base || !body_off || !body_len || !first_value || !n_values) return fail(PQV_ERR_INVALID, "page tables must not be NULL");
+        if (dim == 0 || dim != c->dim) return fail(PQV_ERR_INVALID, "list length does not match the corpus");
+        uint32_t def_bw = 0;
+        for (uint32_t v = max_def; v; v >>= 1) ++def_bw;
+        const uint64_t esz = f64 ? 8 : 4;
+        for (uint32_t i = 0; i < n_pages; ++i) {
+            const uint8_t *b = file_base + body_off[i];
+            const uint64_t blen = body_len[i], nv = n_values[i];
+            uint64_t p = 0;
+            bool good = nv > 0 && nv % dim == 0 && first_value[i] % dim == 0;
+            for (int run = 0; run < 2 && good; ++run) {
+                if (p + 4 > blen) { good = false; break; }
+                uint32_t n;
+                std::memcpy(&n, b + p, 4);
+                if (p + 4 + n > blen) { good = false; break; }
+                good = levels_plain(b + p + 4, n, run == 0 ? 1u : def_bw, nv, run == 0 ? 1 : 0, run == 0 ? dim : max_def) == 0;
+                p += 4 + static_cast<uint64_t>(n);
+            }
+            if (good && blen - p != nv * esz) good = false;
+            if (!good) { if (bad_page) *bad_page = i; return 1; }
+            const uint64_t row = first_value[i] / dim, rows = nv / dim;
+            int rc = f64 ? corpus_write_rows<double>(c, row, reinterpret_cast<const double *>(b + p), rows)
+                         : corpus_write_rows<float>(c, row, reinterpret_cast<const float *>(b + p), rows);
+            if (rc != PQV_OK) return rc;
+        }
+        return PQV_OK;
+    });
+}
+
+// ---- Thrift compact protocol, as far as a Parquet PageHeader needs it ----
+namespace {
+struct TcReader {
+    const uint8_t *p, *end;
+    bool ok = true;
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (int sh = 0; sh < 70; sh += 7) {
+            if (p >= end) { ok = false; return 0; }
+            const uint8_t b = *p++;
+            v |= static_cast<uint64_t>(b & 0x7F) << sh;
+            if (!(b & 0x80)) return v;
+        }
+        ok = false;
+        return 0;
+    }
+    int64_t zigzag() { const uint64_t v = varint(); return static_cast<int64_t>(v >> 1) ^ -static_cast<int64_t>(v & 1); }
+    void skip_bytes(uint64_t n) { if (n > static_cast<uint64_t>(end - p)) { ok = false; p = end; } else p += n; }
+    void skip(int type, int depth) {
+        if (!ok || depth > 16) { ok = false; return; }
+        switch (type) {
+            case 1: case 2: return;                       // bool in the field header
+            case 3: skip_bytes(1); return;
+            case 4: case 5: case 6: (void)varint(); return;
+            case 7: skip_bytes(8); return;
+            case 8: skip_bytes(varint()); return;
+            case 9: case 10: {
+                if (p >= end) { ok = false; return; }
+                const uint8_t h = *p++;
+                uint64_t n = h >> 4;
+                const int et = h & 15;
+                if (n == 15) n = varint();
+                for (uint64_t i = 0; i < n && ok; ++i) { if (et == 1 || et == 2) skip_bytes(1); else skip(et, depth + 1); }
+                return;
+            }
+            case 11: {
+                const uint64_t n = varint();
+                if (n == 0) return;
+                if (p >= end) { ok = false; return; }
+                const uint8_t kv = *p++;
+                for (uint64_t i = 0; i < n && ok; ++i) {
+                    const int kt = kv >> 4, vt = kv & 15;
+                    if (kt == 1 || kt == 2) skip_bytes(1); else skip(kt, depth + 1);
+                    if (vt == 1 || vt == 2) skip_bytes(1); else skip(vt, depth + 1);
+                }
+                return;
+            }
+            case 12: skip_struct(depth + 1); return;
+            default: ok = false; return;
+        }
+    }
+    // fields of a struct: f(field id, type) consumes the value and returns true, or returns false to have it skipped
+    template <class F> void fields(int depth, F f) {
+        int16_t last = 0;
+        while (ok) {
+            if (p >= end) { ok = false; return; }
+            const uint8_t h = *p++;
+            if (h == 0) return;
+            const int type = h & 15, delta = h >> 4;
+            int16_t id = delta ? static_cast<int16_t>(last + delta) : static_cast<int16_t>(zigzag());
+            last = id;
+            if (!f(id, type)) skip(type, depth);
+        }
+    }
+    void skip_struct(int depth) { fields(depth, [](int16_t, int) { return false; }); }
+};
+}  // namespace
+
+// Page headers of one column chunk (format/PageHeader of parquet.thrift), one after the other from `buf`: per page 8 ints
+// {type, header bytes, compressed_page_size, uncompressed_page_size, num_values, encoding, definition_level_encoding,
+// repetition_level_encoding} (the last four from data_page_header / dictionary_page_header; -1 where absent; v2 data pages and
+// index pages report their type only).  Stops at `len`, after `max_pages`, or once `stop_values` values have been seen in data
+// pages; *n_pages = pages written.  An error for a header that does not parse or a page that runs past `len`.
+extern "C" int pqv_parquet_page_headers(const uint8_t *buf, uint64_t len, uint64_t stop_values, uint32_t max_pages, int32_t *out, uint32_t *n_pages) {
+    return guard([&]() -> int {
+        if (!buf || !out || !n_pages) return fail(PQV_ERR_INVALID, "buf, out and n_pages must not be NULL");
+        uint64_t pos = 0, seen = 0;
+        uint32_t n = 0;
+        while (pos < len && n < max_pages && (stop_values == 0 || seen < stop_values)) {
+            TcReader r{buf + pos, buf + len};
+            int32_t *o = out + static_cast<size_t>(n) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = -1;
+            r.fields(0, [&](int16_t id, int type) {
+                const bool i32 = type == 4 || type == 5 || type == 6;
+                if (id == 1 && i32) { o[0] = static_cast<int32_t>(r.zigzag()); return true; }
+                if (id == 2 && i32) { o[3] = static_cast<int32_t>(r.zigzag()); return true; }
+                if (id == 3 && i32) { o[2] = static_cast<int32_t>(r.zigzag()); return true; }
+                if ((id == 5 || id == 7) && type == 12) {
+                    r.fields(1, [&](int16_t id2, int type2) {
+                        const bool j32 = type2 == 4 || type2 == 5 || type2 == 6;
+                        if (id2 >= 1 && id2 <= (id == 5 ? 4 : 2) && j32) { o[3 + id2] = static_cast<int32_t>(r.zigzag()); return true; }
+                        return false;
+                    });
+                    return true;
+                }
+                return false;
+            });
+            if (!r.ok) return fail(PQV_ERR_INVALID, "malformed Parquet page header");
+            const uint64_t hlen = static_cast<uint64_t>(r.p - (buf + pos));
+            o[1] = static_cast<int32_t>(hlen);
+            if (o[0] < 0 || o[2] < 0 || o[3] < 0 || hlen + static_cast<uint64_t>(o[2]) > len - pos)
+                return fail(PQV_ERR_INVALID, "Parquet page runs past its column chunk");
+            if (o[0] == 0 && o[4] > 0) seen += static_cast<uint64_t>(o[4]);
+            pos += hlen + static_cast<uint64_t>(o[2]);
+            ++n;
+        }
+        *n_pages = n;
+        return PQV_OK;
+    });
+}
+
 extern "C" int pqv_parquet_dict_decode(const uint8_t *buf, uint64_t len, const void *dict, uint64_t dict_n, uint32_t elem_size,
                                        uint64_t n_values, void *out) {
     return guard([&]() -> int {

@@ -504,6 +504,43 @@ def test_parquet_build_inplace_and_topk(pqv, oracle, tmp_path):
     assert hits2[0].row_idx == 17 and hits2[0].distance == 0.0
 
 
+@pytest.mark.parametrize("value_type", ["f32", "f64"])
+def test_page_runs_from_the_mapped_file_and_what_they_refuse(pqv, tmp_path, value_type):
+    """The page-level loader on an uncompressed PLAIN file with hundreds of small pages: runs of pages go through
+    pqv_corpus_write_plain_pages (levels checked, values uploaded natively) and the resident matrix is the column; one null
+    value, one null row or one ragged list deep inside the file makes its page's check fail, the loader falls back to the Arrow
+    reader and that raises the reference's message (parquet.rs:231-280)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from pq_vector_amd import parquet_io
+    rng = np.random.default_rng(31)
+    n, dim = 60000, 40
+    dt = np.float64 if value_type == "f64" else np.float32
+    vecs = rng.standard_normal((n, dim)).astype(dt)
+
+    def write(path, rows):
+        pq.write_table(pa.table({"emb": pa.array(rows, type=pa.list_(pa.float64() if value_type == "f64" else pa.float32()))}),
+                       path, compression="NONE", use_dictionary=False, data_page_size=32 * 1024, row_group_size=25000)
+
+    good = str(tmp_path / "good.parquet")
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(vecs.reshape(-1)))
+    pq.write_table(pa.table({"emb": col}), good, compression="NONE", use_dictionary=False, data_page_size=32 * 1024, row_group_size=25000)
+    stats = {}
+    corpus = parquet_io.load_embedding_column(good, "emb", stats=stats)
+    assert stats["path"].startswith("data pages") and stats["pages"] > 3 * parquet_io._PAGE_RUN
+    full = corpus.fetch_rows(np.arange(n, dtype=np.uint32))
+    assert np.array_equal(full.view(np.uint32), vecs.astype(np.float32).view(np.uint32))
+    corpus.close()
+    small = vecs[:9000].tolist()
+    for name, row, text in (("null_value", small[5000][:-1] + [None], "null"), ("null_row", None, "null"), ("ragged", small[5000][:-1], "inconsistent")):
+        rows = list(small)
+        rows[5000] = row
+        bad = str(tmp_path / f"{name}.parquet")
+        write(bad, rows)
+        with pytest.raises(pqv.PqvError, match=text):
+            parquet_io.load_embedding_column(bad, "emb")
+
+
 @pytest.mark.parametrize("value_type,list_kind", [("f32", "list"), ("f64", "list"), ("f32", "fixed")])
 def test_streamed_parquet_loader_places_every_row_group(pqv, tmp_path, value_type, list_kind):
     """N1 (src/ivf/parquet.rs:216-305): row groups of unequal sizes decoded by several reader threads, every batch uploaded

@@ -373,3 +373,42 @@ def test_level_run_and_dictionary_helpers(pqv):
     enc_bad = bytes([3, (1 << 1) | 1, 0xFF, 0xFF, 0xFF])                  # index 7 of a 4-entry dictionary
     b = (C.c_uint8 * len(enc_bad)).from_buffer_copy(enc_bad)
     assert L.pqv_parquet_dict_decode(b, len(enc_bad), dict32.ctypes.data_as(_ffi.vp), 4, 4, 8, out.ctypes.data_as(_ffi.vp)) < 0
+
+
+def test_native_page_header_walk_agrees_with_the_file(pqv, tmp_path):
+    """pqv_parquet_page_headers: every page of a column chunk, in file order -- sizes chain up to the chunk's compressed size,
+    the data pages' value counts add up to the chunk's, encodings are what the writer was asked for; garbage is refused."""
+    import ctypes as C
+    from pq_vector_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(8)
+    n, dim = 20000, 16
+    vec = rng.integers(0, 50, (n, dim)).astype(np.float32)
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(vec.reshape(-1)))
+    for use_dict, codec in ((False, "NONE"), (True, "SNAPPY")):
+        path = str(tmp_path / f"h{int(use_dict)}.parquet")
+        pq.write_table(pa.table({"emb": col}), path, compression=codec, use_dictionary=use_dict, data_page_size=16 * 1024,
+                       write_statistics=True)
+        meta = pq.ParquetFile(path).metadata
+        cm = meta.row_group(0).column(0)
+        start = cm.dictionary_page_offset if cm.has_dictionary_page and cm.dictionary_page_offset else cm.data_page_offset
+        raw = open(path, "rb").read()[start:start + cm.total_compressed_size]
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        out = np.full((4096, 8), -7, np.int32)
+        npg = C.c_uint32(0)
+        assert L.pqv_parquet_page_headers(buf, len(raw), 0, 4096, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npg)) == 0
+        h = out[:npg.value]
+        assert npg.value > 3 and int((h[:, 1] + h[:, 2]).sum()) == len(raw)
+        data = h[h[:, 0] == 0]
+        assert int(data[:, 4].sum()) == cm.num_values and (data[:, 6] == 3).all() and (data[:, 7] == 3).all()
+        if use_dict:
+            assert h[0, 0] == 2 and h[0, 5] in (0, 2) and set(data[:, 5].tolist()) <= {2, 8}
+        else:
+            assert (h[:, 0] == 0).all() and (data[:, 5] == 0).all()
+        # stop_values: only as many pages as hold that many values
+        assert L.pqv_parquet_page_headers(buf, len(raw), int(data[0, 4]), 4096, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npg)) == 0
+        assert npg.value == (2 if use_dict else 1)
+        # a truncated chunk and garbage are errors, not crashes
+        assert L.pqv_parquet_page_headers(buf, len(raw) - 5, 0, 4096, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npg)) != 0
+        junk = (C.c_uint8 * 64)(*([0xFF] * 64))
+        assert L.pqv_parquet_page_headers(junk, 64, 0, 16, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npg)) != 0
