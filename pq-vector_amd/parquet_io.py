@@ -601,7 +601,7 @@ def _page_uploader(plan, corpus):
     return do_page
 
 
-_PAGE_RUN = 16          # uncompressed PLAIN pages handed to the library per call (the interpreter lock stays out of the per-page work)
+_PAGE_RUN = 48          # uncompressed PLAIN pages handed to the library per call (the interpreter lock stays out of the per-page work)
 
 
 def _plain_run_uploader(plan, corpus):
@@ -671,7 +671,7 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
     # Whatever the walk cannot take -- or does not like -- goes through pyarrow below, which validates its first batch (before a
     # device is touched, if the walk stopped at the first page) and raises the reference's messages.
     from concurrent.futures import ThreadPoolExecutor
-    corpus, plan, futures, ex, t_first, t_create = None, None, [], None, None, 0.0
+    corpus, plan, futures, ex, t_first, t_create, t_walk = None, None, [], None, None, 0.0, 0.0
     pages = [0, 0]
     fast = False
     if os.environ.get("PQV_PARQUET_PAGES", "1") != "0":
@@ -706,6 +706,7 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
                 plan = _plan_pages(path, column, nthr_pages, on_page)
                 if ex is not None:
                     flush_run()
+                t_walk = time.perf_counter() - t0
             except PqvError:
                 raise
             except Exception:
@@ -753,9 +754,11 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
     errors, lock = [], threading.Lock()
     nbytes = [0]
     if fast:
+        t_up = time.perf_counter() - t0
         corpus.finish(n_rows)
         if stats is not None:
             el = time.perf_counter() - t0
+            stats.update({"walk_done_s": t_walk, "uploads_done_s": t_up})
             stats.update({"rows": int(n_rows), "dim": int(dim), "bytes": int(pages[0]), "seconds": el, "GBps": pages[0] / el / 1e9,
                           "row_groups": int(n_rg), "reader_threads": nthr_pages, "path": "data pages walked in the mapped file", "pages": pages[1],
                           "first_page_s": t_first, "corpus_create_s": t_create})
