@@ -106,6 +106,33 @@ impl Corpus {
         check(unsafe { sys::pqv_corpus_write_rows_f64(self.raw, row_offset as u64, rows.as_ptr(), (rows.len() / dim) as u64) })
     }
 
+    /// A run of uncompressed PLAIN v1 data pages of the embedding leaf, straight from the memory-mapped file `file`: page `i`'s
+    /// body is `file[body_off[i] .. body_off[i] + body_len[i]]`.  Per page the level runs are verified -- a row starts exactly
+    /// every `dim` values, every definition level is `max_def`: the checks of `src/ivf/parquet.rs:231-280`, made on the levels --
+    /// and the values behind them go to rows `first_value[i] / dim ..`.  `Ok(None)`: all uploaded; `Ok(Some(i))`: page `i` is not
+    /// such a page and nothing of the run was uploaded (read the column through the Arrow reader, which owns the error texts).
+    pub fn write_plain_pages(&self, file: &[u8], body_off: &[u64], body_len: &[u32], first_value: &[u64], n_values: &[u32],
+                             max_def: u32, f64_values: bool) -> Result<Option<usize>> {
+        let n = body_off.len();
+        if body_len.len() != n || first_value.len() != n || n_values.len() != n {
+            return Err("page tables must have one entry per page".into());
+        }
+        for i in 0..n {
+            if body_off[i].checked_add(body_len[i] as u64).map_or(true, |e| e > file.len() as u64) {
+                return Err("a page body lies outside the mapped file".into());
+            }
+        }
+        let mut bad = 0u32;
+        let rc = unsafe {
+            sys::pqv_corpus_write_plain_pages(self.raw, file.as_ptr(), body_off.as_ptr(), body_len.as_ptr(), first_value.as_ptr(),
+                                              n_values.as_ptr(), n as u32, self.dim() as u32, max_def, f64_values as c_int, &mut bad)
+        };
+        if rc == 1 {
+            return Ok(Some(bad as usize));
+        }
+        check(rc).map(|_| None)
+    }
+
     /// Waits for every upload and sets the row count.
     pub fn finish(&mut self, n_rows: usize) -> Result<()> {
         check(unsafe { sys::pqv_corpus_finish(self.raw, n_rows as u64) })
