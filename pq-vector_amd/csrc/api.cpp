@@ -2349,6 +2349,10 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 const uint32_t fit4 = two96 ? 96 : s->sdim <= 256 ? 64 : 32;
                 int waves = o.wide_waves == 4 || o.wide_waves == 8 ? o.wide_waves : two96 ? 4 : 8;
                 if (fit8 < 64) waves = 4;
+                // (a call of a few queries has no quad of more: the 4-wave form -- 32-query quads of long rows, 64 KB, two blocks per
+                //  CU -- loses nothing to a second pass and its blocks are not mostly fixed cost; one query at K = 100 on 1 M x 1024:
+                //  330 -> 277 us per call against the 8-wave block of 64; from 8 queries on the 8-wave form is as good or better)
+                if (o.wide_waves != 8 && nq <= 4 && !two96 && fit4 >= 32) waves = 4;
                 p.block_waves = static_cast<uint32_t>(waves);
                 p.quad_width = waves == 8 ? fit8 : fit4;
                 // (a requested width the chosen form has no instantiation for is ignored, never an error at launch: the
@@ -2569,8 +2573,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
 
     // 2. candidate re-rank + per-wave top-k
     bool use_cand = false;     // wide screened path: the final merge also reads the candidate buffers
-    bool use_defer = false;    // ... whose entries carry bounds (deferred evaluation) ...
-    bool resolved = false;     // ... already resolved by launch_resolve
+    bool use_defer = false;    // ... whose entries carried bounds (deferred evaluation), resolved by launch_resolve
     if (p.tile) {
         const uint32_t n_pairs = nq * p.np, kc = s->n_clusters;
         uint32_t *u = pair_u32;
@@ -2728,18 +2731,21 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             HIP_TRY(launch_tile_filter(ta, stream));
             use_cand = true;
             s->counters.kernel_launches += 3;
-            if (use_defer && nq >= 8) {
-                // a batch: the k-th smallest upper bound per query, then every band entry of the batch on the whole chip; the
-                // merge then sees exact keys only.  (Part of the re-rank group: inside its timing events.)
+            if (use_defer) {
+                // the k-th smallest upper bound per query, then every band entry of the call on the whole chip (also for ONE query:
+                // a single block evaluating K = 100 rows of 4 KB took 224 us inside the merge, 490 -> 390 us per call); the merge
+                // then sees exact keys only.  (Part of the re-rank group: inside its timing events.)
                 pqv::MergeArgs rm{};
                 rm.nq = nq; rm.k = k; rm.cand_keys = ta.cand_keys; rm.cand_keys_rw = ta.cand_keys; rm.cand_vals = ta.cand_vals;
                 rm.cand_cnt = ta.cand_cnt; rm.cand_cap = ccap; rm.cand_lb = ta.cand_lb;
                 rm.mat = s->d_mat; rm.queries = d_queries_s; rm.dim = s->sdim; rm.resolve_stats = s->d_stats.as<unsigned long long>();
+                // (one query, K = 100: the block evaluating its 100 defining rows alone is 50 of resolve_select's 81 us; the whole
+                //  chip evaluates the 380-row band of the single cut in 13)
+                rm.resolve_two_cuts = nq >= 32 ? 1 : 0;
                 HIP_TRY(sc.s_work.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t) * 2));
                 HIP_TRY(sc.s_nwork.ensure(sizeof(uint32_t)));
                 HIP_TRY(launch_resolve(rm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), stream));
                 s->counters.kernel_launches += 2;
-                resolved = true;
             }
         } else if (p.filter) {
             TileArgs seed = ta;          // exact on rows [0, seed_rows) of every list: slot chunk 0
@@ -2782,11 +2788,6 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         fm.cand_cnt = sc.s_cand_cnt.as<uint32_t>(); fm.cand_cap = cand_cap_for(s, k);
         fm.spilled = sc.s_spilled.as<uint32_t>();
         fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
-        if (use_defer && !resolved) {          // a handful of queries: the merge's block resolves the buffer itself
-            fm.cand_lb = sc.s_cand_lb.as<float>(); fm.cand_keys_rw = sc.s_cand_keys.as<uint64_t>();
-            fm.mat = s->d_mat; fm.queries = d_queries_s; fm.dim = s->sdim;
-            fm.resolve_stats = s->d_stats.as<unsigned long long>();
-        }
     }
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
@@ -3187,9 +3188,8 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
     }
     if (p.tile && p.filter && p.quad && defer_on(s, std::max<uint32_t>(1, nq), k, p) && cand_cap_for(s, k) <= 8192) {
         const size_t l = std::strlen(t);
-        std::snprintf(t + l, sizeof t - l, "; exact evaluations deferred: survivors appended with their bounds, %s",
-                      nq >= 8 ? "resolve_select_kernel + resolve_exact_kernel evaluate what the k-th smallest upper bound leaves"
-                              : "resolved by the final merge's block");
+        std::snprintf(t + l, sizeof t - l, "; exact evaluations deferred: survivors appended with their bounds, resolve_select_kernel + "
+                                           "resolve_exact_kernel evaluate what the k-th smallest upper bound leaves");
     }
     if (s->sdim != s->dim) {
         const size_t l = std::strlen(t);

@@ -110,6 +110,8 @@ struct MergeArgs {
     uint64_t       *cand_keys_rw;
     const float    *mat;         // row-major f32 rows, `dim` values each; cand_vals are row numbers in it
     unsigned long long *resolve_stats;   // optional: the statistics block (slot q % STATS_SLOTS, word 1 += exact evaluations)
+    int             resolve_two_cuts;    // resolve_select_kernel evaluates the entries that define the first cut itself and cuts again (batches:
+                                         // the chip is full of such blocks; for a few queries one block per query would be the whole latency)
     uint32_t       *tie_flag;    // [nq] or nullptr: 1 iff two of the first k_out+1 merged entries
                                  // (k_out entries + the runner-up) have equal OUTPUT distance --
                                  // then the reference's order/survivors depend on heap history

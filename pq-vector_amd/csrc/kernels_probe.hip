@@ -504,13 +504,15 @@ __device__ __forceinline__ void probe_merge_tail(const MergeArgs &a, uint32_t q,
 // ------------------------------------------------------------------------------------
 // Deferred exact evaluation (TileArgs::cand_lb, wide_filter_kernel): the query's candidate buffer holds survivors of the screen
 // with their distance BOUNDS -- key = (upper bound << 32 | position), cand_lb = lower bound, or cand_lb < 0 and an exact key.
-// The whole block (256 threads) resolves it before wave 0 merges:
+// resolve_select_kernel, a block of 256 threads per query, ahead of the final merge:
 //   1. T = the k-th smallest upper bound (4-pass radix select over the bound bits; +inf with fewer than k entries).  k rows
 //      have a reference distance <= T, so the k-th smallest reference distance is <= T.
-//   2. an entry whose lower bound exceeds T cannot be among the k nearest (not even tied with the k-th): dropped.
-//   3. the others are evaluated in the reference's order -- chunks of 4 values, ((d0^2 + d1^2) + d2^2) + d3^2 added to ONE
-//      running sum in chunk order (index.rs:461-480); L lanes share a row, the sum passes through them in order -- and their
-//      keys become exact.  The merge below then sees what the in-filter evaluation would have left, minus rows that cannot matter.
+//   1b. the entries that define T (upper bound <= T) are evaluated by the block -- in the reference's order: chunks of 4
+//      values, ((d0^2 + d1^2) + d2^2) + d3^2 added to ONE running sum in chunk order (index.rs:461-480); L lanes share a row,
+//      the sum passes through them in order -- and T is taken again over exact distances where they exist.
+//   2. an entry whose lower bound exceeds T cannot be among the k nearest (not even tied with the k-th): dropped; the others go
+//      to the call's work list, resolve_exact_kernel gives them exact keys on the whole chip, and the merge then sees what the
+//      in-filter evaluation would have left, minus rows that cannot matter.
 // ------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void resolve_exact(const MergeArgs &a, uint32_t q, const uint16_t *band, uint32_t m, uint64_t *ck, const uint32_t *cv,
@@ -560,8 +562,8 @@ __device__ __forceinline__ void resolve_exact(const MergeArgs &a, uint32_t q, co
         }
     }
 }
-// work != nullptr: the band goes to a batch-wide work list {query, entry} for resolve_exact_kernel instead of being evaluated here
-__device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t q, uint2 *work = nullptr, uint32_t *n_work = nullptr) {
+// (the band goes to a call-wide work list {query, entry} for resolve_exact_kernel)
+__device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t q, uint2 *work, uint32_t *n_work) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_sel[4];            // {prefix, remaining rank, band count}
     __shared__ uint16_t s_band[8192];
@@ -595,7 +597,7 @@ __device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t 
     //     here, and T is taken again over exact distances where they exist: it drops from "k-th distance + the bound's whole
     //     width" to "+ what the k-th nearest row's own bound leaves", and the band below loses the entries whose lower bound
     //     lies in between.  Skipped when a tie group makes that list long.
-    if (work && n >= a.k) {
+    if (a.resolve_two_cuts && n >= a.k) {
         if (threadIdx.x == 0) s_sel[2] = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256)
@@ -630,19 +632,13 @@ __device__ __forceinline__ void resolve_candidates(const MergeArgs &a, uint32_t 
     }
     __syncthreads();
     const uint32_t m = s_sel[2];
-    if (work) {
-        if (m) {
-            if (threadIdx.x == 0) s_sel[3] = atomicAdd(n_work, m);
-            __syncthreads();
-            const uint32_t base = s_sel[3];
-            for (uint32_t i = threadIdx.x; i < m; i += 256) work[base + i] = make_uint2(q, (uint32_t)s_band[i]);
-            if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
-        }
-        return;
+    if (m) {
+        if (threadIdx.x == 0) s_sel[3] = atomicAdd(n_work, m);
+        __syncthreads();
+        const uint32_t base = s_sel[3];
+        for (uint32_t i = threadIdx.x; i < m; i += 256) work[base + i] = make_uint2(q, (uint32_t)s_band[i]);
+        if (a.resolve_stats && threadIdx.x == 0) atomicAdd(&a.resolve_stats[8 + 16 * (q % STATS_SLOTS) + 1], (unsigned long long)m);
     }
-    // 3. exact keys for the band
-    if (m) exact_list(m, nullptr);
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void resolve_select_kernel(const MergeArgs a, uint2 *work, uint32_t *n_work) {
@@ -762,7 +758,6 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if constexpr (!PROBE) PQV_STAMP_MIN(24);
-    if constexpr (!PROBE && S > 1 && S <= 4) { if (a.cand_lb) resolve_candidates(a, q); }      // (calls of < 8 queries defer for k > 64 only; batches resolve through launch_resolve)
     WaveTopk<S> tk;
     tk.init();
     [[maybe_unused]] bool preselected = false;
@@ -1097,8 +1092,8 @@ static hipError_t launch_merge_t(const MergeArgs &a, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
     // (probe merge with a preset: three helper waves; final merge with deferred evaluation: the block resolves the buffer)
     //  final merge of candidate buffers at k > 64: the block selects, merge_select_large)
-    dim3 grid(a.nq), block(((PROBE && (a.preset_keys || a.preset_flags)) || (!PROBE && (a.cand_lb || (a.cand_keys && a.k > 64 && a.k <= 256)))) ? 256 : 64);
-    if (!PROBE && a.cand_lb && (a.k <= 64 || a.k > 256 || a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 4) != 0)) return hipErrorInvalidValue;
+    dim3 grid(a.nq), block(((PROBE && (a.preset_keys || a.preset_flags)) || (!PROBE && a.cand_keys && a.k > 64 && a.k <= 256)) ? 256 : 64);
+    if (!PROBE && a.cand_lb) return hipErrorInvalidValue;          // (deferred entries are resolved by launch_resolve, before the merge)
     if (a.k <= 64) hipLaunchKernelGGL((merge_kernel<1, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 256) hipLaunchKernelGGL((merge_kernel<4, PROBE>), grid, block, 0, s, a);
     else if (a.k <= 1024) hipLaunchKernelGGL((merge_kernel<16, PROBE>), grid, block, 0, s, a);
