@@ -206,7 +206,8 @@ constexpr int PQV_LANES = 4;
 struct Scratch {
     DevBuf s_probe_keys, s_probe_vals, s_probe, s_cand_base, s_ncand, s_part_keys, s_part_vals, s_queries, s_rows,
         s_dist, s_nfound, s_pair_u32, s_pairs, s_groups, s_quads, s_items, s_ticket, s_ticket2, s_cand_keys, s_cand_vals, s_cand_cnt, s_spilled,
-        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_qresu, s_pair_lb, s_part_flags, s_qpad, s_cand_lb, s_pendv, s_work, s_nwork;
+        s_seed_ub, s_qblk, s_gthr, s_tie, s_replay, s_qnorm, s_qmax, s_thr_hist, s_thr_bins, s_qi8, s_qn2i, s_qres, s_qresu, s_pair_lb, s_part_flags, s_qpad, s_cand_lb, s_pendv, s_work, s_nwork, s_out;
+    PinnedBuf h_io;                 // small host calls: queries in, one block of results out, through pinned memory
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
@@ -3070,14 +3071,47 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     std::vector<uint64_t> h_ncand(batch);
     std::vector<uint32_t> h_tie(batch), h_nf(batch);
     const uint32_t np = std::min<uint32_t>(nprobe, s->n_clusters);
+    // A call of a few queries (TopkBuilder::search is ONE) is six small pageable copies otherwise -- the query in, rows, distances,
+    // counts and tie flags out, each staged and waited for by the runtime: 60-80 us around 180 us of kernels.  Small calls go
+    // through ONE pinned buffer instead: the results are laid out as one device block {candidates u64 | rows | dist | found |
+    // tie} and come back in one copy.
+    const size_t q_bytes = static_cast<size_t>(batch) * s->dim * sizeof(float);
+    const size_t out_bytes = static_cast<size_t>(batch) * (16 + 8 * static_cast<size_t>(k));
+    const bool small_io = q_bytes + out_bytes <= (256u << 10);
+    uint32_t *o_rows = sc.s_rows.as<uint32_t>(), *o_nf = sc.s_nfound.as<uint32_t>(), *o_tie = sc.s_tie.as<uint32_t>();
+    float *o_dist = sc.s_dist.as<float>();
+    if (small_io) {
+        HIP_TRY(sc.s_out.ensure(out_bytes));
+        HIP_TRY(sc.h_io.ensure(q_bytes + out_bytes));
+    }
     for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
         const uint32_t b = std::min<uint32_t>(batch, nq - q0);
-        HIP_TRY(hipMemcpyAsync(sc.s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
-                               static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        if (small_io) {
+            char *ob = static_cast<char *>(sc.s_out.p);           // (laid out for THIS sub-batch's b)
+            o_rows = reinterpret_cast<uint32_t *>(ob + 8ull * b);
+            o_dist = reinterpret_cast<float *>(ob + 8ull * b + 4ull * b * k);
+            o_nf = reinterpret_cast<uint32_t *>(ob + 8ull * b + 8ull * b * k);
+            o_tie = o_nf + b;
+            std::memcpy(sc.h_io.p, queries + static_cast<uint64_t>(q0) * s->dim, static_cast<size_t>(b) * s->dim * sizeof(float));
+            HIP_TRY(hipMemcpyAsync(sc.s_queries.p, sc.h_io.p, static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(sc.s_queries.p, queries + static_cast<uint64_t>(q0) * s->dim,
+                                   static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        }
         if (int rc = enqueue_topk(s, sc.s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
-                                  sqrt_out, sc.s_rows.as<uint32_t>(), sc.s_dist.as<float>(),
-                                  sc.s_nfound.as<uint32_t>(), nullptr, sc.s_tie.as<uint32_t>(), s->stream, sc))
+                                  sqrt_out, o_rows, o_dist, o_nf, small_io ? static_cast<uint64_t *>(sc.s_out.p) : nullptr, o_tie, s->stream, sc))
             return rc;
+        if (small_io) {
+            char *hb = static_cast<char *>(sc.h_io.p) + q_bytes;
+            const size_t ob_bytes = static_cast<size_t>(b) * (16 + 8 * static_cast<size_t>(k));
+            HIP_TRY(hipMemcpyAsync(hb, sc.s_out.p, ob_bytes, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            std::memcpy(h_ncand.data(), hb, static_cast<size_t>(b) * sizeof(uint64_t));
+            std::memcpy(row_idx + static_cast<uint64_t>(q0) * k, hb + 8ull * b, static_cast<size_t>(b) * k * sizeof(uint32_t));
+            std::memcpy(dist + static_cast<uint64_t>(q0) * k, hb + 8ull * b + 4ull * b * k, static_cast<size_t>(b) * k * sizeof(float));
+            std::memcpy(h_nf.data(), hb + 8ull * b + 8ull * b * k, static_cast<size_t>(b) * sizeof(uint32_t));
+            std::memcpy(h_tie.data(), hb + 8ull * b + 8ull * b * k + 4ull * b, static_cast<size_t>(b) * sizeof(uint32_t));
+        } else {
         HIP_TRY(hipMemcpyAsync(row_idx + static_cast<uint64_t>(q0) * k, sc.s_rows.p,
                                static_cast<size_t>(b) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(dist + static_cast<uint64_t>(q0) * k, sc.s_dist.p,
@@ -3089,6 +3123,7 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
         HIP_TRY(hipMemcpyAsync(h_ncand.data(), sc.s_ncand.p, static_cast<size_t>(b) * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
+        }
         for (uint32_t i = 0; i < b; ++i) {      // (candidate_rows / embeddings_fetched are counted on the device)
             if (n_candidates) n_candidates[q0 + i] = h_ncand[i];
             if (h_tie[i]) {
