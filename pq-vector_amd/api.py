@@ -500,6 +500,7 @@ class Searcher:
 
 
 _PATH_SEARCHERS = {}
+_REALPATHS = {}
 
 
 def searcher_for_parquet(path, device=0):
@@ -509,7 +510,10 @@ def searcher_for_parquet(path, device=0):
     import os
     from . import parquet_io
     st = os.stat(path)
-    key = (os.path.realpath(path), st.st_size, st.st_mtime_ns, device)
+    real = _REALPATHS.get(path)              # (realpath is a handful of system calls: once per spelling of the path)
+    if real is None:
+        real = _REALPATHS.setdefault(path, os.path.realpath(path))
+    key = (real, st.st_size, st.st_mtime_ns, device)
     hit = _PATH_SEARCHERS.get(key)
     if hit is None:
         index, column = parquet_io.read_index_from_parquet(path)
@@ -556,7 +560,8 @@ class TopkBuilder:
         if self._searcher is None:
             self._searcher = searcher_for_parquet(self._path, self._device)
         rows, dist, nf, _ = self._searcher.topk(_f32(self._query).reshape(1, -1), self._k, self._nprobe)
-        return [SearchResult(int(rows[0, i]), float(dist[0, i])) for i in range(int(nf[0]))]
+        n = int(nf[0])
+        return [SearchResult(r, d) for r, d in zip(rows[0, :n].tolist(), dist[0, :n].tolist())]
 
 
 # ---------------------------------------------------------------------------------------

@@ -2744,8 +2744,9 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 //  chip evaluates the 380-row band of the single cut in 13)
                 rm.resolve_two_cuts = nq >= 32 ? 1 : 0;
                 HIP_TRY(sc.s_work.ensure(static_cast<size_t>(nq) * ccap * sizeof(uint32_t) * 2));
+                const bool counter_clean = sc.s_nwork.p != nullptr;       // (cleared by the previous call's final merge on this lane)
                 HIP_TRY(sc.s_nwork.ensure(sizeof(uint32_t)));
-                HIP_TRY(launch_resolve(rm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), stream));
+                HIP_TRY(launch_resolve(rm, sc.s_work.p, sc.s_nwork.as<uint32_t>(), counter_clean, stream));
                 s->counters.kernel_launches += 2;
             }
         } else if (p.filter) {
@@ -2790,6 +2791,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         fm.spilled = sc.s_spilled.as<uint32_t>();
         fm.part_flags = sc.s_part_flags.as<uint8_t>();       // row stride: (n_part + 3) / 4 * 4 == n_part (a multiple of 4 waves)
     }
+    if (use_defer) fm.zero_after = sc.s_nwork.as<uint32_t>();
     HIP_TRY(launch_merge_final(fm, stream));
     if (timing) HIP_TRY(hipEventRecord(e3, stream));
     if (int rc = lane_release(sc, stream)) return rc;
@@ -3272,7 +3274,8 @@ static int pqv_searcher_footprint_impl(const pqv_searcher *s, uint64_t *row_orde
         for (const DevBuf *b : {&l.s_probe_keys, &l.s_probe_vals, &l.s_probe, &l.s_cand_base, &l.s_ncand, &l.s_part_keys, &l.s_part_vals,
                                 &l.s_queries, &l.s_rows, &l.s_dist, &l.s_nfound, &l.s_pair_u32, &l.s_pairs, &l.s_groups, &l.s_quads, &l.s_items, &l.s_ticket, &l.s_ticket2,
                                 &l.s_cand_keys, &l.s_cand_vals, &l.s_cand_cnt, &l.s_spilled, &l.s_seed_ub, &l.s_qblk, &l.s_gthr, &l.s_tie,
-                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres, &l.s_part_flags})
+                                &l.s_replay, &l.s_qnorm, &l.s_qmax, &l.s_thr_hist, &l.s_thr_bins, &l.s_qi8, &l.s_qn2i, &l.s_qres, &l.s_part_flags,
+                                &l.s_qresu, &l.s_pair_lb, &l.s_qpad, &l.s_cand_lb, &l.s_pendv, &l.s_work, &l.s_nwork, &l.s_out})
             other += b->p ? b->bytes : 0;
     if (other_bytes) *other_bytes = other;
     return PQV_OK;

@@ -110,6 +110,8 @@ struct MergeArgs {
     uint64_t       *cand_keys_rw;
     const float    *mat;         // row-major f32 rows, `dim` values each; cand_vals are row numbers in it
     unsigned long long *resolve_stats;   // optional: the statistics block (slot q % STATS_SLOTS, word 1 += exact evaluations)
+    uint32_t       *zero_after;          // final merge: this word is cleared (launch_resolve's work counter, ready for the next call:
+                                         // no memset in front of every resolve)
     int             resolve_two_cuts;    // resolve_select_kernel evaluates the entries that define the first cut itself and cuts again (batches:
                                          // the chip is full of such blocks; for a few queries one block per query would be the whole latency)
     uint32_t       *tie_flag;    // [nq] or nullptr: 1 iff two of the first k_out+1 merged entries
@@ -156,7 +158,7 @@ struct MergeArgs {
 };
 hipError_t launch_merge_final(const MergeArgs &a, hipStream_t s);
 // deferred evaluations of a BATCH, ahead of launch_merge_final (which then gets cand_lb = nullptr): work = nq * cand_cap uint2 of scratch
-hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, hipStream_t s);
+hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, bool n_work_is_zero, hipStream_t s);
 hipError_t launch_merge_probe(const MergeArgs &a, hipStream_t s);
 
 // ---- batched re-rank: cluster-major tiles ------------------------------------------------

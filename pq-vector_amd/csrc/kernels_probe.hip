@@ -685,11 +685,13 @@ __global__ __launch_bounds__(256) void resolve_exact_kernel(const MergeArgs a, c
 }
 // Resolve a batch's deferred evaluations in two launches (selection per query, then every band entry of the batch on the
 // whole chip); the final merge then runs without a.cand_lb.  n_work: one u32, zeroed here.
-hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, hipStream_t s) {
+hipError_t launch_resolve(const MergeArgs &a, void *work, uint32_t *n_work, bool n_work_is_zero, hipStream_t s) {
     if (a.nq == 0) return hipSuccess;
     if (!a.cand_lb || a.cand_cap > 8192 || !a.cand_keys_rw || !a.mat || !a.queries || (a.dim % 64) != 0 || !work || !n_work) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(n_work, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
+    if (!n_work_is_zero) {              // (otherwise the previous call's final merge left it cleared: MergeArgs::zero_after)
+        hipError_t e = hipMemsetAsync(n_work, 0, sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(resolve_select_kernel, dim3(a.nq), dim3(256), 0, s, a, static_cast<uint2 *>(work), n_work);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)a.nq * 64 + 31) / 32 + 256);
     if ((a.dim % 256) == 0) hipLaunchKernelGGL(resolve_exact_kernel<8>, dim3(blocks), dim3(256), 0, s, a, static_cast<const uint2 *>(work), n_work);
@@ -758,6 +760,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x;
     if constexpr (!PROBE) PQV_STAMP_MIN(24);
+    if constexpr (!PROBE) { if (a.zero_after && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_after = 0u; }
     WaveTopk<S> tk;
     tk.init();
     [[maybe_unused]] bool preselected = false;
