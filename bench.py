@@ -956,10 +956,21 @@ def main():
             med = np.median(rel, axis=0)
             sys.stderr.write("stamps (us after probe start, median): " + " ".join(
                 f"[{j}]={med[j]:.1f}" for j in range(64) if (st[:, j] != 0).all() and (st[:, j] != -1).all()) + "\n")
+        # the same through the host entry point (pqv_topk: query from host memory, results into host arrays -- what
+        # TopkBuilder::search does per call)
+        hlat = []
+        for i in range(args.single + 5):
+            qh = qs_host[i % nq:i % nq + 1]
+            t1 = time.perf_counter()
+            searcher.topk(qh, K, nprobe)
+            hlat.append(time.perf_counter() - t1)
+        hlat = np.array(hlat[5:]) * 1e6
         result["single_query"] = {"calls": int(lat.size), "p50_us": float(np.percentile(lat, 50)),
                                   "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()),
                                   "qps": float(1e6 / lat.mean()), "dispatch": searcher.describe(1, K, nprobe),
-                                  "note": "one query per call, host-synchronised after each"}
+                                  "host_api_p50_us": float(np.percentile(hlat, 50)), "host_api_p99_us": float(np.percentile(hlat, 99)),
+                                  "note": "one query per call, host-synchronised after each; p50_us: device pointers in and out "
+                                          "(pqv_topk_device + a device synchronise), host_api: pqv_topk with host arrays (copies included)"}
     # ---- recall of the IVF answers against an exact brute force (benches/query.rs prints it too) --------
     if args.recall and rank == 0 and world == 1:
         m = min(args.recall, nq)
