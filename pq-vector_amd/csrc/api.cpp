@@ -2703,7 +2703,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 rf.dim = s->sdim; rf.nprobe = p.np; rf.seed_sw = seed.seed_sw; rf.seed_rows = p.seed_rows; rf.max_pos = max_pos;
             }
             // one query: the seed kernel's last block selects (SeedTail); otherwise a launch of its own
-            const bool seed_tail = nq == 1 && k <= 64 && s->opt.single_bucket > 0;
+            const bool seed_tail = nq == 1 && k <= 256 && s->opt.single_bucket > 0;
             if (seed_tail) {
                 if (!sc.s_ticket2.p) {
                     HIP_TRY(sc.s_ticket2.ensure(sizeof(uint32_t)));
@@ -3244,7 +3244,7 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         std::snprintf(kn, sizeof kn, " | kernels: wide_filter_kernel<%u, %u, %d, %s, %d, %s, %s, 4, %s>; wide_seed_kernel<%d, %s, %d, %d>; seed_select_kernel<%d>@%u",
                       p.quad_width / 16, p.block_waves, S, qlds ? "true" : "false", op, pf ? "true" : "false",
                       ((p.i8 && p.block_waves == 4 && p.quad_width == 64 && std::max<uint32_t>(1, nq) <= 64u) || p.wide_width) ? "true" : "false",
-                      defp ? "true" : "false", seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 64 && s->opt.single_bucket > 0) ? 12 : 1, S,
+                      defp ? "true" : "false", seed_ng, qlds ? "true" : "false", op, (std::max<uint32_t>(1, nq) == 1 && k <= 256 && s->opt.single_bucket > 0) ? 12 : 1, S,
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
         if (p.wide_width) {
             const size_t l = std::strlen(kn);

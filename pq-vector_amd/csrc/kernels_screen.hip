@@ -518,8 +518,12 @@ __device__ __forceinline__ void seed_tail_finish(const TileArgs &a) {
     if (!s_seed_last) return;
     PQV_STAMP_MAX(12);
     extern __shared__ float4 qs_tail[];       // the staged queries are no longer needed: the refinement's term table
-    seed_select_body<1>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
-                        a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf, reinterpret_cast<float *>(qs_tail), a.seed_tail.lds_floats);
+    if (a.seed_tail.k <= 64u)
+        seed_select_body<1>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
+                            a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf, reinterpret_cast<float *>(qs_tail), a.seed_tail.lds_floats);
+    else        // k <= 256: the k-th bound by the block's radix select (one query at K = 100: a launch and its gap less)
+        seed_select_body<4>(0u, a.seed_ub, a.seed_tail.n_vals, a.seed_tail.k, a.seed_tail.gthr, a.seed_tail.cand_cnt, a.seed_tail.spilled,
+                            a.seed_tail.thr_hist, a.seed_tail.thr_bins, a.seed_tail.rf, reinterpret_cast<float *>(qs_tail), a.seed_tail.lds_floats);
 }
 // U: operand stages a wave keeps in flight.  1 for batches (other waves fill the stalls); a one-query call has ONE 64-row
 // tile per wave and nothing else on the CU, so its 48 KB are requested 12 stages at a time.  Only the U > 1 instances

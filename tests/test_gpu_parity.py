@@ -810,9 +810,9 @@ def test_screened_paths_match_oracle(pqv, oracle, monkeypatch, n, dim, kc, k, np
     assert (nc == onc).all()
     _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
     if variant.startswith("deferred"):       # a handful of queries per call (once resolved by the merge's own block)
-        for q0 in (0, 5):
-            r1, d1, n1, _ = s.topk(queries[q0:q0 + 3], k, nprobe)
-            _assert_topk_equal((r1, d1, n1), (orows[q0:q0 + 3], odist[q0:q0 + 3], onf[q0:q0 + 3]), k)
+        for q0, m in ((0, 3), (5, 3), (2, 1), (7, 1)):         # (one query: select + thresholds in the seed kernel's tail)
+            r1, d1, n1, _ = s.topk(queries[q0:q0 + m], k, nprobe)
+            _assert_topk_equal((r1, d1, n1), (orows[q0:q0 + m], odist[q0:q0 + m], onf[q0:q0 + m]), k)
     c = s.counters()
     # (K = 100 of the ~10 k candidates a query has here is 1 % of them before any margin: the screen cannot drop as much)
     assert c["screened_pairs"] > 0 and 0 < c["screen_survivors"] < (0.2 if k <= 32 else 0.6) * c["screened_pairs"]
