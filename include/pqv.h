@@ -61,6 +61,9 @@ typedef enum pqv_metric {
 #define PQV_LAYOUT_IVF_ORDERED   0x0u /* copy rows into cluster-contiguous order in HBM (default) */
 #define PQV_LAYOUT_ROW_ORDER     0x1u /* keep file row order; re-rank gathers rows by id          */
 #define PQV_RELEASE_ROW_ORDER    0x2u /* with IVF_ORDERED: let the corpus drop its row-order copy */
+#define PQV_RELEASE_IF_COPIED    0x4u /* with IVF_ORDERED: drop the row-order copy only where the searcher made a list-ordered
+                                         f32 copy of its own (the images-only layout keeps reading the caller's rows): one f32
+                                         copy of the column resident either way                                              */
 
 typedef struct pqv_index    pqv_index;    /* IvfIndex: dim, n_clusters, centroids, inverted lists */
 typedef struct pqv_corpus   pqv_corpus;   /* the embedding column, resident in one GPU's HBM     */

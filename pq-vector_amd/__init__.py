@@ -18,10 +18,10 @@ from .api import (CandidateCursor, Corpus, Index, IndexBuilder, PqvError, Search
                   device_count, merge_topk, rerank_batch, rerank_finish, searcher_for_parquet)
 from .parquet_io import has_pq_vector_index, read_index_from_parquet
 from ._ffi import (PQV_L2SQ_REF4, PQV_L2SQ_SEQ, PQV_COSINE, PQV_L2SQ_MFMA, PQV_LAYOUT_IVF_ORDERED, PQV_LAYOUT_ROW_ORDER,
-                   PQV_RELEASE_ROW_ORDER, LIB_PATH)
+                   PQV_RELEASE_ROW_ORDER, PQV_RELEASE_IF_COPIED, LIB_PATH)
 
 __all__ = ["CandidateCursor", "Corpus", "Index", "IndexBuilder", "PqvError", "Searcher", "SearchResult",
            "TopkBuilder", "device_count", "merge_topk", "rerank_batch", "rerank_finish", "searcher_for_parquet", "PQV_COSINE", "PQV_L2SQ_MFMA",
            "has_pq_vector_index", "read_index_from_parquet", "PQV_L2SQ_REF4",
            "PQV_L2SQ_SEQ", "PQV_LAYOUT_IVF_ORDERED", "PQV_LAYOUT_ROW_ORDER",
-           "PQV_RELEASE_ROW_ORDER", "LIB_PATH"]
+           "PQV_RELEASE_ROW_ORDER", "PQV_RELEASE_IF_COPIED", "LIB_PATH"]

@@ -33,6 +33,7 @@ PQV_L2SQ_MFMA = 3
 PQV_LAYOUT_IVF_ORDERED = 0x0
 PQV_LAYOUT_ROW_ORDER = 0x1
 PQV_RELEASE_ROW_ORDER = 0x2
+PQV_RELEASE_IF_COPIED = 0x4
 
 
 class Counters(C.Structure):

@@ -518,8 +518,10 @@ def searcher_for_parquet(path, device=0):
     if hit is None:
         index, column = parquet_io.read_index_from_parquet(path)
         corpus = parquet_io.load_embedding_column(path, column, device)
-        # (the images-only IVF layout keeps ONE f32 copy -- the column as loaded -- next to the list-ordered screen images)
-        hit = Searcher(index, corpus, _ffi.PQV_LAYOUT_IVF_ORDERED)
+        # ONE f32 copy of the column stays resident either way: the images-only IVF layout keeps reading the column as loaded;
+        # where the searcher falls back to a list-ordered f32 copy of its own (dim % 64 != 0, short lists, PQV_IVF_COPY=1) the
+        # loaded row-order rows are released once that copy exists
+        hit = Searcher(index, corpus, _ffi.PQV_LAYOUT_IVF_ORDERED | _ffi.PQV_RELEASE_IF_COPIED)
         _PATH_SEARCHERS.clear()          # one resident file at a time by default
         _PATH_SEARCHERS[key] = hit
     return hit

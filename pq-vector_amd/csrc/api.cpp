@@ -547,8 +547,10 @@ bool hybrid_runs(const uint8_t *p, uint64_t len, uint32_t bw, uint64_t want, F &
             if (!(b & 0x80)) break;
         }
         if (h & 1) {                                     // bit-packed: (h >> 1) groups of 8 values
-            const uint64_t nvals = (h >> 1) * 8, nbytes = (h >> 1) * bw;
-            if (nvals == 0 || static_cast<uint64_t>(end - p) < nbytes) return false;
+            // (group count checked BEFORE the multiplications: a crafted 9-byte varint would wrap nbytes to 0 and pass)
+            const uint64_t groups = h >> 1;
+            if (groups == 0 || groups > (1ull << 56) || (bw != 0 && groups > static_cast<uint64_t>(end - p) / bw)) return false;
+            const uint64_t nvals = groups * 8, nbytes = groups * bw;
             const uint64_t use = std::min<uint64_t>(nvals, want - got);
             uint64_t acc = 0; uint32_t nb = 0; const uint8_t *q = p;
             for (uint64_t i = 0; i < use; ++i) {
@@ -2189,7 +2191,8 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     }
     S_TRY(hipStreamSynchronize(s->stream));
     mark("blocked operand copy");
-    if (!(flags & PQV_LAYOUT_ROW_ORDER) && (flags & PQV_RELEASE_ROW_ORDER) && corpus->owned) {
+    if (!(flags & PQV_LAYOUT_ROW_ORDER) && corpus->owned &&
+        ((flags & PQV_RELEASE_ROW_ORDER) || ((flags & PQV_RELEASE_IF_COPIED) && !s->images_only))) {
         (void)hipFree(corpus->d_rows);
         corpus->d_rows = nullptr;
     }

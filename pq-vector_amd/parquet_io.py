@@ -410,7 +410,9 @@ def _column_chunks(path, column, batch_rows=1 << 16, row_groups=None):
 # ---------------------------------------------------------------------------------------
 # N1 fast path: the data pages of the embedding leaf, walked directly
 # ---------------------------------------------------------------------------------------
-_CODECS = {"UNCOMPRESSED": None, "SNAPPY": "snappy", "ZSTD": "zstd", "LZ4": "lz4", "GZIP": "gzip", "BROTLI": "brotli"}
+# (Parquet's deprecated 'LZ4' is Hadoop-framed blocks -- pyarrow's 'lz4' codec is the FRAME format and cannot read them: such a
+#  chunk is "not mine" up front and goes through the Arrow reader; LZ4_RAW is the plain block format)
+_CODECS = {"UNCOMPRESSED": None, "SNAPPY": "snappy", "ZSTD": "zstd", "LZ4_RAW": "lz4_raw", "GZIP": "gzip", "BROTLI": "brotli"}
 
 
 def _i32_fields(raw):
@@ -445,14 +447,26 @@ def _page_levels(L, addr, blen, nv, dim, max_def, def_bw):
     return p
 
 
-def _plan_pages(path, column, n_threads, on_page=None):
+def _rg_range(meta, row_groups):
+    """(lo, hi, rows before lo, rows in [lo, hi)) of a half-open row-group range (None = the whole file)."""
+    n_rg = meta.num_row_groups
+    lo, hi = (0, n_rg) if row_groups is None else (int(row_groups[0]), int(row_groups[1]))
+    if not (0 <= lo <= hi <= n_rg):
+        raise _err(f"row-group range [{lo}, {hi}) outside the file's {n_rg} row groups")
+    rows = [meta.row_group(i).num_rows for i in range(hi)]
+    return lo, hi, int(sum(rows[:lo])), int(sum(rows[lo:hi]))
+
+
+def _plan_pages(path, column, n_threads, on_page=None, row_groups=None):
     """Walk the data pages of the embedding leaf in the memory-mapped file WITHOUT touching a device: a no-null `List<f32|f64>`
     leaf stores its values contiguously behind the page's two level runs.  The level runs are CHECKED, not trusted
     (pqv_parquet_levels_check: every definition level at its maximum -- no null row, no null value, no empty list -- and a
     repetition level 0 exactly every `dim` values, `dim` discovered from the first page); uncompressed pages are all checked
     here, of a compressed chunk the first page (the others when they are decompressed for the upload).  Returns None -- the
     caller takes the Arrow path, which owns the reference's error messages -- for anything it does not handle: v2 pages, other
-    encodings, pages that end inside a row, levels that differ."""
+    encodings, pages that end inside a row, levels that differ.  `row_groups` = (lo, hi): only the column chunks of that
+    half-open row-group range (a shard of the file; value positions count from the range's first row -- pages never cross a
+    column chunk and rows never cross a row group, src/df_vector/access.rs:128-144)."""
     import ctypes
     from concurrent.futures import ThreadPoolExecutor
     import pyarrow as pa
@@ -471,13 +485,15 @@ def _plan_pages(path, column, n_threads, on_page=None):
     plan.esz = 8 if plan.f64 else 4
     plan.max_def, plan.def_bw = cs.max_definition_level, int(cs.max_definition_level).bit_length()
     plan.mm = mm = np.memmap(path, dtype=np.uint8, mode="r")
-    plan.n_rows = meta.num_rows
+    rg_lo, rg_hi, _, plan.n_rows = _rg_range(meta, row_groups)
+    if plan.n_rows == 0:
+        return None
     base = mm.ctypes.data
     L = _ffi.lib()
     plan.dim = None
     tasks = []            # [first value position in values, file offset of the page body, body bytes, uncompressed bytes, n_values, encoding, dictionary, codec, value offset | None]
     values_before = 0
-    for rg in range(meta.num_row_groups):
+    for rg in range(rg_lo, rg_hi):
         cm = meta.row_group(rg).column(leaf)
         codec = _CODECS.get(cm.compression, "?")
         if codec == "?":
@@ -636,21 +652,30 @@ def _upload_pages(plan, corpus, n_threads, counters):
     return True
 
 
-def _load_pages(path, column, corpus, dim, rg_off, n_threads, counters):
+def _load_pages(path, column, corpus, dim, rg_off, n_threads, counters, row_groups=None):
     """plan + upload (tests drive the walker through this with a stand-in corpus)."""
-    plan = _plan_pages(path, column, n_threads)
-    if plan is None or plan.dim != dim:
+    try:
+        plan = _plan_pages(path, column, n_threads, None, row_groups)
+        if plan is None or plan.dim != dim:
+            return False
+        return _upload_pages(plan, corpus, n_threads, counters)
+    except PqvError:
+        raise
+    except Exception:                      # a codec / mapping problem: "not mine", as load_embedding_column treats it
         return False
-    return _upload_pages(plan, corpus, n_threads, counters)
 
 
-def load_embedding_column(path, column, device=0, readers=None, stats=None):
+def load_embedding_column(path, column, device=0, readers=None, stats=None, row_groups=None):
     """The column -> one resident [n, dim] f32 matrix (src/ivf/parquet.rs:216-305; Float64 values are narrowed on the device,
     :246-256).  Row groups are decoded by `readers` threads (pyarrow releases the GIL while it decodes), each with its own file
     handle; every decoded batch goes through the corpus' pinned staging buffers as an asynchronous DMA (pqv_corpus_write_rows)
     at its row offset, so decoding batch i + 1 overlaps the upload of batch i and nothing larger than a batch is ever
     materialised on the host -- unlike the reference's Vec<f32> of the whole column (:226).  `stats` (a dict) receives rows,
-    bytes, seconds and GB/s."""
+    bytes, seconds and GB/s.
+
+    `row_groups` = (lo, hi): only that half-open range of the file's row groups -- ONE shard of a file that several GPUs share
+    (sharding.shard_row_groups cuts at row-group boundaries; the shard's row 0 is the range's first row, its file-global row
+    base the prefix sum of the row groups before it, src/df_vector/access.rs:128-144)."""
     import os
     import threading
     import time
@@ -659,10 +684,11 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
     pf = pq.ParquetFile(path)
     typ = _check_column_type(pf, column)
     meta = pf.metadata
-    n_rows, n_rg = meta.num_rows, meta.num_row_groups
-    rg_off = np.zeros(n_rg + 1, dtype=np.int64)
+    rg_lo, rg_hi, _, n_rows = _rg_range(meta, row_groups)
+    n_rg = rg_hi - rg_lo
+    rg_off = np.zeros(n_rg + 1, dtype=np.int64)           # shard-local row offset of every row group of the range
     for i in range(n_rg):
-        rg_off[i + 1] = rg_off[i] + meta.row_group(i).num_rows
+        rg_off[i + 1] = rg_off[i] + meta.row_group(rg_lo + i).num_rows
     if n_rows == 0:
         raise _err("Embedding column has no rows")
     nthr_pages = max(1, readers or int(os.environ.get("PQV_LOADER_THREADS", "0")) or min(8, os.cpu_count() or 1))
@@ -703,7 +729,7 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
 
         try:
             try:
-                plan = _plan_pages(path, column, nthr_pages, on_page)
+                plan = _plan_pages(path, column, nthr_pages, on_page, row_groups)
                 if ex is not None:
                     flush_run()
                 t_walk = time.perf_counter() - t0
@@ -734,7 +760,7 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
             ex.shutdown(wait=True)
     if not fast:
         try:
-            first = next(_column_chunks(path, column, batch_rows=4096), None)      # the first batch fixes the dimension
+            first = next(_column_chunks(path, column, batch_rows=4096, row_groups=list(range(rg_lo, rg_hi))), None)      # the first batch fixes the dimension
             if first is None:
                 raise _err("Embedding column has no rows")
         except Exception:
@@ -765,23 +791,26 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
         return corpus
 
     def work(t):
+        rg = t
         try:
             for rg in range(t, n_rg, nthr):
                 at = int(rg_off[rg])
-                for vals in _column_chunks(path, column, row_groups=[rg]):
+                for vals in _column_chunks(path, column, row_groups=[rg_lo + rg]):
                     if vals.shape[1] != dim:
                         raise _err("Embedding vectors have inconsistent dimensions")
                     corpus.write_rows(at, vals)
                     at += vals.shape[0]
                     with lock:
                         nbytes[0] += vals.nbytes
-                    if errors:
+                    if errors and min(e[0] for e in errors) < rg:     # an EARLIER row group already failed: its error is the answer
                         return
                 if at != int(rg_off[rg + 1]):
                     raise _err("Embedding column row count does not match the file metadata")
-        except Exception as e:          # the first error wins; the other readers stop at their next batch
+        except Exception as e:
+            # the reference walks the batches in file order and returns the FIRST error in that order (parquet.rs:231-280): keep
+            # (row group, error) and raise the lowest row group's after the join -- not whichever thread failed first in time
             with lock:
-                errors.append(e)
+                errors.append((rg, e))
 
     threads = [threading.Thread(target=work, args=(t,), daemon=True) for t in range(nthr)]
     for th in threads:
@@ -790,7 +819,7 @@ def load_embedding_column(path, column, device=0, readers=None, stats=None):
         th.join()
     if errors:
         corpus.close()
-        raise errors[0]
+        raise min(errors, key=lambda e: e[0])[1]
     corpus.finish(n_rows)
     if stats is not None:
         el = time.perf_counter() - t0

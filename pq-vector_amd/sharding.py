@@ -19,6 +19,55 @@ def shard_range(rank, world, n_rows):
     return rank * n_rows // world, (rank + 1) * n_rows // world
 
 
+def shard_row_groups(rank, world, rg_rows):
+    """Shard `rank` of ONE Parquet file that `world` GPUs share: a contiguous range of ROW GROUPS.
+
+    `rg_rows`: the rows of every row group in file order (or a pyarrow FileMetaData / a path).  Returns
+    (rg_lo, rg_hi, row_base, n_rows): the half-open row-group range, the file-global row id of the shard's row 0 -- the prefix
+    sum of the row groups before it, exactly how the reference maps file-global row ids to row groups
+    (src/df_vector/access.rs:128-144) -- and the shard's row count.  Cut r (between ranks r - 1 and r) is the row-group
+    boundary whose prefix sum is nearest to r * n / world (the lower one on a tie): a row group is never split (a data page never
+    crosses a column chunk, so a shard is a set of whole column chunks), every rank computes every cut from the footer alone, the
+    ranges tile the file, and with fewer row groups than ranks the surplus ranks get an EMPTY range (n_rows == 0: they answer
+    with empty lists).  parquet_io.load_embedding_column(path, column, device, row_groups=(rg_lo, rg_hi)) loads the range."""
+    rows = _rg_rows(rg_rows)
+    pre = [0]
+    for r in rows:
+        pre.append(pre[-1] + int(r))
+    n = pre[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = r * n / world
+        # nearest boundary at or after the previous cut (monotone)
+        best = min(range(cuts[-1], len(pre)), key=lambda b: (abs(pre[b] - target), b))
+        cuts.append(best)
+    cuts.append(len(rows))
+    lo, hi = cuts[rank], cuts[rank + 1]
+    return lo, hi, pre[lo], pre[hi] - pre[lo]
+
+
+def _rg_rows(src):
+    if isinstance(src, (list, tuple)):
+        return [int(x) for x in src]
+    if hasattr(src, "num_row_groups"):
+        meta = src
+    else:
+        import pyarrow.parquet as pq
+        meta = pq.ParquetFile(src).metadata
+    return [meta.row_group(i).num_rows for i in range(meta.num_row_groups)]
+
+
+def load_parquet_shard(path, column, rank, world, device=0, readers=None, stats=None):
+    """This rank's row-group range of `path` -> a resident corpus.  Returns (corpus or None for an empty range, row_base,
+    n_rows, (rg_lo, rg_hi))."""
+    from . import parquet_io
+    lo, hi, base, n = shard_row_groups(rank, world, path)
+    if n == 0:
+        return None, base, 0, (lo, hi)
+    corpus = parquet_io.load_embedding_column(path, column, device, readers=readers, stats=stats, row_groups=(lo, hi))
+    return corpus, base, n, (lo, hi)
+
+
 def merge_gathered(gath_dist, gath_rows, k):
     """gath_dist/gath_rows: [world, nq, k] (unused slots: +inf / -1).  Returns ([nq,k],[nq,k]).
 
@@ -117,8 +166,10 @@ class RcclShardComm:
         INSIDE ncclCommInitRank itself (a rank dying mid-rendezvous) is RCCL's to time out."""
         import ctypes as C
         from . import _ffi
-        dev = torch.device("cuda", device_index)
         on_gpu = world > 1 and dist.get_backend() == "nccl"
+        # the torch collectives of this hand-shake run on the device the PROCESS GROUP already uses (the current device), never on
+        # `device_index`: a rank whose index is out of range must still be able to join them and report 0
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         pre_ok, pre_why = 1, ""
         try:
             if not _ffi.lib().pqv_shard_rccl_path():
@@ -128,7 +179,7 @@ class RcclShardComm:
         except Exception as e:
             pre_ok, pre_why = 0, str(e)
         if world > 1:
-            okt = torch.tensor([pre_ok], dtype=torch.int32, device=dev if on_gpu else "cpu")
+            okt = torch.tensor([pre_ok], dtype=torch.int32, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             if int(okt.item()) != 1:
                 return None, pre_why or "the RCCL pre-flight failed on another rank"
@@ -154,7 +205,7 @@ class RcclShardComm:
             comm = cls(rank, world, device_index, id_bytes=bytes(msg[1:].tolist()))
         except Exception as e:
             reason = str(e)
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) != 1:

@@ -306,6 +306,48 @@ def test_page_walker_uploads_exactly_the_column(pqv, tmp_path, value_type, codec
     assert np.array_equal(c.a.view(np.uint32), vec.astype(np.float32).view(np.uint32))
 
 
+@pytest.mark.parametrize("codec,dictionary", [("NONE", False), ("SNAPPY", True)])
+def test_page_walker_loads_a_row_group_range_as_a_shard(pqv, tmp_path, codec, dictionary):
+    """One file shared by several GPUs (BASELINE config 4: 8 Parquet row-group ranges): shard_row_groups cuts at row-group
+    boundaries, row_base = the prefix sum of the row groups before the range (src/df_vector/access.rs:128-144), and the walker
+    uploads exactly the range's rows, numbered from the range's first row.  The ranges tile the file."""
+    from pq_vector_amd import parquet_io
+    from pq_vector_amd.sharding import shard_row_groups
+    rng = np.random.default_rng(15)
+    n, dim = 25000, 16
+    vec = rng.integers(0, 40, (n, dim)).astype(np.float32) if dictionary else rng.standard_normal((n, dim)).astype(np.float32)
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(vec.reshape(-1)))
+    path = str(tmp_path / "s.parquet")
+    pq.write_table(pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "emb": col}), path, row_group_size=3000,
+                   compression=codec, use_dictionary=dictionary, data_page_size=16 * 1024)
+    meta = pq.ParquetFile(path).metadata
+    assert meta.num_row_groups == 9
+    for world in (1, 2, 3, 8, 12):
+        covered = 0
+        for rank in range(world):
+            lo, hi, base, rows = shard_row_groups(rank, world, meta)
+            assert base == covered and rows == sum(meta.row_group(i).num_rows for i in range(lo, hi))
+            assert shard_row_groups(rank, world, path) == (lo, hi, base, rows)
+            covered += rows
+            if rows == 0:
+                assert world > meta.num_row_groups
+                assert parquet_io._plan_pages(path, "emb", 2, None, (lo, hi)) is None
+                continue
+            c, counters = _CollectingCorpus(rows, dim), [0, 0]
+            assert parquet_io._load_pages(path, "emb", c, dim, None, 3, counters, row_groups=(lo, hi)) is True
+            assert counters[0] == rows * dim * 4
+            assert np.array_equal(c.a.view(np.uint32), vec[base:base + rows].view(np.uint32))
+            # the Arrow fallback reads the same range
+            got = np.concatenate(list(parquet_io._column_chunks(path, "emb", row_groups=list(range(lo, hi)))))
+            assert np.array_equal(got, vec[base:base + rows])
+        assert covered == n
+        if world <= meta.num_row_groups:          # balanced to within one row group
+            sizes = [shard_row_groups(r, world, meta)[3] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 3000
+    with pytest.raises(pqv.PqvError, match="row-group range"):
+        parquet_io._plan_pages(path, "emb", 2, None, (3, 99))
+
+
 @pytest.mark.parametrize("lists", [[[1.0, 2.0], [3.0], [4.0, 5.0]], [[1.0, None], [3.0, 4.0]], [[1.0, 2.0], None, [3.0, 4.0]],
                                    [[1.0, 2.0], [], [3.0, 4.0]]])
 def test_page_walker_refuses_what_the_reference_rejects(pqv, tmp_path, lists):
@@ -373,6 +415,23 @@ def test_level_run_and_dictionary_helpers(pqv):
     enc_bad = bytes([3, (1 << 1) | 1, 0xFF, 0xFF, 0xFF])                  # index 7 of a 4-entry dictionary
     b = (C.c_uint8 * len(enc_bad)).from_buffer_copy(enc_bad)
     assert L.pqv_parquet_dict_decode(b, len(enc_bad), dict32.ctypes.data_as(_ffi.vp), 4, 4, 8, out.ctypes.data_as(_ffi.vp)) < 0
+    # a crafted bit-packed header whose byte count wraps to 0 in 64 bits ((1 << 59) groups x 32 bits): refused, nothing past the
+    # declared length is read (the guard page of a mapped file would be next)
+    def varint(h):
+        o = []
+        while True:
+            o.append((h & 0x7F) | (0x80 if h >> 7 else 0))
+            h >>= 7
+            if not h:
+                return o
+    crafted = bytes([32] + varint(((1 << 59) << 1) | 1) + [0])
+    assert len(crafted) == 11
+    big = np.full(64, -1.0, np.float32)
+    b = (C.c_uint8 * len(crafted)).from_buffer_copy(crafted)
+    assert L.pqv_parquet_dict_decode(b, len(crafted), dict32.ctypes.data_as(_ffi.vp), 4, 4, 16, big.ctypes.data_as(_ffi.vp)) < 0
+    assert (big == -1.0).all()
+    assert check(varint(((1 << 61) << 1) | 1) + [0xEE], 8, 16, 0, 2) < 0     # the same through the level checker (bit width 8)
+    assert check(varint(((1 << 60) << 1) | 1) + [0xEE], 1, 16, 0, 2) < 0     # a count no buffer can hold
 
 
 def test_native_page_header_walk_agrees_with_the_file(pqv, tmp_path):

@@ -102,3 +102,79 @@ def test_shard_ranges_tile_exactly():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- ONE Parquet file, one row-group range per rank (BASELINE config 4's partition unit) ----------------------------------
+def _write_shared_file(path):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    data, _ = _inputs()
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (N + 1) * DIM, DIM, dtype=np.int32)), pa.array(data.reshape(-1)))
+    pq.write_table(pa.table({"id": pa.array(np.arange(N, dtype=np.int32)), "emb": col}), path, row_group_size=431,
+                   compression="NONE", use_dictionary=False, data_page_size=8 * 1024)
+
+
+class _HostRows:
+    """Stand-in for the device corpus on a CPU-only box: collects what the page walker would upload."""
+
+    def __init__(self, n, dim):
+        self.a = np.full((n, dim), np.nan, np.float32)
+
+    def write_rows_ptr(self, row, addr, m, f64=False):
+        import ctypes
+        dim = self.a.shape[1]
+        self.a[row:row + m] = np.frombuffer(ctypes.string_at(addr, m * dim * 4), dtype=np.float32).reshape(m, dim)
+
+
+def _file_worker(rank, world, port, path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle_binding import Oracle
+    from pq_vector_amd import parquet_io
+    from pq_vector_amd.sharding import ShardExchange, shard_row_groups
+    _, queries = _inputs()
+    lo, hi, base, rows = shard_row_groups(rank, world, path)          # from the footer alone, the same cuts on every rank
+    shard = _HostRows(rows, DIM)
+    assert parquet_io._load_pages(path, "emb", shard, DIM, None, 2, [0, 0], row_groups=(lo, hi)) is True
+    idx = Oracle().build_index(shard.a, n_clusters=KC, workers=2)      # the shard's own index, shard-local row ids
+    r, d, nf, _ = idx.topk_batch(shard.a, queries, K, KC)              # every list probed
+    r = r.astype(np.int64)
+    for q in range(NQ):
+        r[q, nf[q]:] = -1
+        d[q, nf[q]:] = np.inf
+    x = ShardExchange(world, NQ, K, torch.device("cpu"))
+    md, mr = x.exchange(torch.from_numpy(d), torch.from_numpy(r), base)
+    meta = torch.tensor([lo, hi, base, rows], dtype=torch.int64)
+    allmeta = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(allmeta, meta)
+    if rank == 0:
+        np.savez(out_path, dist=md.numpy(), rows=mr.numpy(), meta=torch.stack(allmeta).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_one_parquet_file_by_row_group_ranges(oracle, tmp_path):
+    """Two shards built from ONE file: the ranges are cut at row-group boundaries, tile the file, and the merged answer carries
+    the same FILE-GLOBAL row ids as a single-shard search with every list probed (= the exact top-k of the whole column)."""
+    import pyarrow.parquet as pq
+    path, out = str(tmp_path / "shared.parquet"), str(tmp_path / "merged_file.npz")
+    _write_shared_file(path)
+    n_rg = pq.ParquetFile(path).metadata.num_row_groups
+    assert n_rg == 7
+    world = 2
+    mp.spawn(_file_worker, args=(world, _free_port(), path, out), nprocs=world, join=True)
+    got = np.load(out)
+    meta = got["meta"]
+    assert meta[0][0] == 0 and meta[-1][1] == n_rg and meta[0][1] == meta[1][0]          # row-group ranges tile the file
+    assert meta[0][2] == 0 and meta[1][2] == meta[0][3] and meta[:, 3].sum() == N          # row bases = prefix sums
+    assert meta[0][3] % 431 == 0                                                           # cut AT a row-group boundary
+    data, queries = _inputs()
+    whole = oracle.build_index(data, n_clusters=KC, workers=2)
+    r1, d1, nf1, _ = whole.topk_batch(data, queries, K, KC)
+    assert (nf1 == K).all()
+    assert (got["rows"] == r1.astype(np.int64)).all()
+    assert (got["dist"].view(np.uint32) == d1.view(np.uint32)).all()
