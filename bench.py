@@ -37,6 +37,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the stream lanes of a step must land on different hardware queues to overlap (new_streams); the ROCm runtime reads this once
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -203,6 +205,31 @@ class OracleParity:
                 "ok": self.ok()}
 
 
+_HIP = None
+
+
+def new_streams(torch, dev, n):
+    """n HIP streams of their own (hipStreamCreateWithFlags, non-blocking -- what the library creates for itself), wrapped for
+    torch.  Explicit handles: torch's DEFAULT stream has handle 0, which the ABI reads as "the searcher's own stream", so the
+    torch ops that follow a call on the default stream (the exchange's pack above all) would not be ordered behind it.
+    Whether two streams overlap at all depends on the hardware queues the runtime maps them to: with its default of 4 queues
+    (GPU_MAX_HW_QUEUES) the same two lanes measured 465 k or 515 k q/s on C3 depending on how many other streams the process
+    had created before them; bench.py therefore asks for 8 queues (set below, before the runtime starts; recorded in the line)."""
+    global _HIP
+    import ctypes
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    out = []
+    with torch.cuda.device(dev):
+        for _ in range(n):
+            h = ctypes.c_void_p()
+            if _HIP.hipStreamCreateWithFlags(ctypes.byref(h), 1) != 0 or not h.value:     # hipStreamNonBlocking
+                out.append(torch.cuda.Stream(device=dev))
+            else:
+                out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    return out
+
+
 def spread(nq, m):
     """m query indices spread over a batch of nq (first, last and evenly between)."""
     m = min(m, nq)
@@ -212,7 +239,9 @@ def spread(nq, m):
 def ivf_measure(pqv, torch, dev, searcher, index, queries_t, nq, k, nprobe, dim, min_time=0.4, steps=20, exchange=None):
     """Timed blocks of `steps` steps over two stream lanes (median block), then a serial pass with HIP events around the
     re-rank kernels; min_bytes of the step (see roofline.min_bytes_definition).  Returns (record, lane-0 outputs)."""
-    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=dev)]
+    # (explicit streams only: new_streams)
+    torch.cuda.synchronize()
+    streams = new_streams(torch, dev, 2)
     rows = [torch.empty((nq, k), dtype=torch.int32, device=dev) for _ in range(2)]
     dd = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
     nc = [torch.empty((nq,), dtype=torch.int64, device=dev) for _ in range(2)]
@@ -431,6 +460,170 @@ def from_parquet_config(args, pqv, torch, dev, local_rank, name="refbench", k=10
     return rec
 
 
+def from_parquet_sharded(args, pqv, torch, dist, dev, local_rank, rank, world, real_stdout):
+    """BASELINE configs[3]'s partition unit end to end (`--gpus N --from-parquet`): ONE Parquet file on the node, one row-group
+    RANGE per rank.  Rank 0 writes the synthetic file (uneven row groups, so the cuts are not trivially equal); every rank
+    computes every cut from the footer alone (sharding.shard_row_groups: row-group boundaries, row_base = prefix sum of the row
+    groups before the range -- src/df_vector/access.rs:128-144), loads ITS range through the page walker
+    (parquet_io.load_embedding_column(row_groups=...)), builds its own index (the reference's per-file index,
+    src/df_vector/index_exec.rs:85-164) and searches the whole batch; one all-gather + the deterministic merge per step.
+    Parity leg: with every list probed the merged answer must carry the same FILE-GLOBAL row ids and distance bits as a
+    single-shard search of the whole file on rank 0 (files up to 48 GB of f32; skipped and said so beyond)."""
+    import shutil
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from pq_vector_amd.sharding import ShardExchange, load_parquet_shard, shard_row_groups
+    _, dim, kc, nprobe, nq_default = WORKLOADS["c4"]
+    rpr = args.rows_per_rank or 1_000_000
+    n_total = rpr * world
+    nq = args.nq or nq_default
+    k = K
+    rg_rows = max(1, int(n_total / (4 * world + 0.5)))     # 4 full row groups per rank + a short last one: the cuts are not at n / world
+    t_all = time.perf_counter()
+    path_box = [None]
+    tmp = None
+    if rank == 0:
+        tmp = tempfile.mkdtemp(prefix="pqv_bench_shards_")
+        path_box[0] = os.path.join(tmp, "shared.parquet")
+        t0 = time.perf_counter()
+        schema = pa.schema([("id", pa.int32()), ("embedding", pa.list_(pa.field("item", pa.float32())))])
+        w = pq.ParquetWriter(path_box[0], schema, compression="NONE", use_dictionary=False)
+        at, g = 0, 0
+        while at < n_total:
+            m = min(rg_rows, n_total - at)
+            host = synth(torch, dev, 1234 + g, m, dim).cpu().numpy()
+            col = pa.ListArray.from_arrays(pa.array(np.arange(0, (m + 1) * dim, dim, dtype=np.int64 if (m + 1) * dim > 2**31 - 1 else np.int32)),
+                                           pa.array(host.reshape(-1)))
+            if pa.types.is_large_list(col.type):
+                col = col.cast(schema.field("embedding").type)
+            w.write_table(pa.table({"id": pa.array(np.arange(at, at + m, dtype=np.int32)), "embedding": col}, schema=schema), row_group_size=m)
+            at += m
+            g += 1
+        w.close()
+        write_s = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+    if world > 1:
+        dist.broadcast_object_list(path_box, src=0)
+    path = path_box[0]
+    try:
+        meta = pq.ParquetFile(path).metadata
+        cuts = [shard_row_groups(r, world, meta) for r in range(world)]
+        lo, hi, base, n_shard = cuts[rank]
+        stats = {}
+        t0 = time.perf_counter()
+        corpus, base2, n2, _ = load_parquet_shard(path, "embedding", rank, world, device=local_rank, stats=stats)
+        load_s = time.perf_counter() - t0
+        assert (base2, n2) == (base, n_shard)
+        if corpus is None:
+            raise SystemExit(f"rank {rank}: empty row-group range (the file has {meta.num_row_groups} row groups for {world} ranks)")
+        t0 = time.perf_counter()
+        index = pqv.IndexBuilder(corpus).max_iters(20).seed(42).workers(os.cpu_count() or 1).n_clusters(kc).build()
+        build_s = time.perf_counter() - t0
+        searcher = pqv.Searcher(index, corpus, pqv.PQV_LAYOUT_IVF_ORDERED)
+        queries_t = synth(torch, dev, 7, nq, dim)
+        rows_t = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        dist_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        bases = [c[2] for c in cuts]
+        fast = args.backend == "nccl"
+        xchg = ShardExchange(world, nq, k, dev, always_collective=args.force_dist, row_bases=bases if fast else None)
+
+        torch.cuda.synchronize()
+        st = new_streams(torch, dev, 1)[0]         # (explicit: handle 0 would be the searcher's own stream, see new_streams)
+
+        def step(npr=nprobe):
+            with torch.cuda.stream(st):
+                searcher.topk_device(queries_t.data_ptr(), nq, k, npr, rows_t.data_ptr(), dist_t.data_ptr(), 0, 0, stream=st.cuda_stream)
+                if world == 1 and not args.force_dist:
+                    return dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF
+                if xchg.fast:
+                    return xchg.exchange_u32(dist_t, rows_t)
+                return xchg.exchange(dist_t, rows_t.to(torch.int64) & 0xFFFFFFFF, base)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        steps = args.steps if args.steps > 0 else 20
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        loads = torch.tensor([load_s, build_s, float(stats.get("GBps", 0.0))], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(loads) for _ in range(world)]
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_gather(every, loads)
+        else:
+            every = [loads]
+        elapsed = float(el.item())
+        # ---- parity: every list probed -> the exact top-k of the whole file, whichever way it was cut --------------------------
+        parity = {"checker": "single-shard search of the whole file on rank 0, every list probed", "ok": True}
+        npq = min(nq, max(0, args.parity_queries))
+        if npq and n_total * dim * 4 <= 48e9:
+            md, mr = step(kc)
+            torch.cuda.synchronize()
+            if os.environ.get("PQV_DBG"):
+                import pq_vector_amd.parquet_io as _pio
+                hostrows = np.concatenate(list(_pio._column_chunks(path, "embedding", row_groups=list(range(lo, hi)))))
+                sh = torch.from_numpy(hostrows).to(dev)
+                bd, br = torch.topk(torch.cdist(queries_t[:npq], sh), k, dim=1, largest=False)
+                lr = (rows_t[:npq].to(torch.int64) & 0xFFFFFFFF)
+                log(f"[dbg rank {rank}] local device rows == brute on shard: {bool((lr == br).all())}; base {base}; merged rows[0] {mr[0].tolist()} local[0] {lr[0].tolist()} dist[0] {dist_t[0].tolist()[:3]} md[0] {md[0].tolist()[:3]}")
+            md, mr = md[:npq].cpu().numpy().copy(), mr[:npq].cpu().numpy().astype(np.int64)
+            barrier()
+            if rank == 0:
+                from pq_vector_amd import parquet_io
+                whole = parquet_io.load_embedding_column(path, "embedding", local_rank)
+                widx = pqv.IndexBuilder(whole).max_iters(20).seed(42).workers(os.cpu_count() or 1).n_clusters(kc).build()
+                ws = pqv.Searcher(widx, whole, pqv.PQV_LAYOUT_IVF_ORDERED)
+                wr, wd, wnf, _ = ws.topk(queries_t[:npq].cpu().numpy(), k, kc)
+                if os.environ.get("PQV_DBG"):
+                    log(f"[dbg whole] rows {whole.rows} wr[0] {wr[0].tolist()} wd[0] {wd[0].tolist()[:3]} nf {wnf[:4].tolist()} mr.shape {mr.shape} wr.shape {wr.shape} nrows_equal {(wr.astype(np.int64) == mr).mean()}")
+                    bad = np.nonzero((wr.astype(np.int64) != mr).any(axis=1))[0]
+                    log(f"[dbg whole] bad queries {bad.tolist()}")
+                    for q in bad[:2]:
+                        log(f"[dbg whole] q{q} merged {mr[q].tolist()} {md[q].tolist()}\n              whole {wr[q].tolist()} {wd[q].tolist()}")
+                same_rows = bool((wr.astype(np.int64) == mr).all())
+                same_dist = bool((wd.view(np.uint32) == md.view(np.uint32)).all())
+                parity.update({"queries_checked": int(npq), "global_row_ids_identical": same_rows, "dist_bit_identical": same_dist,
+                               "ok": same_rows and same_dist})
+                ws.close(); whole.close()
+            barrier()
+        else:
+            parity.update({"skipped": "no parity queries asked for" if not npq else "the whole file does not fit beside a shard on one GPU"})
+        if rank == 0:
+            line = {"metric": "topk_queries_per_s_k10" if k == 10 else f"topk_queries_per_s_k{k}", "value": nq * steps / elapsed, "unit": "queries/s",
+                    "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": f"c4 from ONE Parquet file: {n_total}x{dim} uniform f32 as List<f32> in {meta.num_row_groups} row groups "
+                                           f"(uncompressed), one row-group range per rank, n_clusters {kc} per shard, k {k}, nprobe {nprobe}, {nq} queries/step",
+                               "shards": world, "rows_per_gpu": rpr, "row_groups": int(meta.num_row_groups),
+                               "row_group_ranges": [[c[0], c[1]] for c in cuts], "row_bases": bases, "shard_rows": [c[3] for c in cuts]},
+                    "file": {"bytes": os.path.getsize(path), "synthetic_file_write_s": write_s},
+                    "per_rank": {"load_s": [float(x[0]) for x in every], "build_s": [float(x[1]) for x in every],
+                                 "loader_GBps": [float(x[2]) for x in every], "loader_path": stats.get("path")},
+                    "exchange": {"ranks": world, "backend": args.backend, "form": "packed u32 all-gather + device merge" if xchg.fast else "generic (i64 rows)"},
+                    "parity": parity, "seconds": time.perf_counter() - t_all}
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        barrier()
+        searcher.close(); corpus.close()
+        ok = torch.tensor([1 if parity.get("ok", True) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.broadcast(ok, src=0)
+        return 0 if int(ok.item()) == 1 else 3
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0 and tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 def build_record(n, dim, kc, build_s):
     """Phases of the last index build (pqv_index_build_stats) and the roofline of its dominant step, the final
     assignment of every row (src/ivf/index.rs:189-206): a dense n x n_clusters x dim contraction, SURVEY 8(d):
@@ -521,7 +714,8 @@ def main():
                     help="c4 only: rows of every rank's shard (default 12 500 000; a smaller shard makes a quick multi-rank path check)")
     ap.add_argument("--from-parquet", action="store_true",
                     help="only the reference's end-to-end benches (IndexBuilder(path).build_inplace(), TopkBuilder(path).search()) on a synthetic "
-                         "Parquet file of its own bench shape; prints that record as the line")
+                         "Parquet file of its own bench shape; prints that record as the line.  With --gpus N > 1 (or --force-dist): ONE file, "
+                         "one row-group range per rank (--rows-per-rank, default 1 M), loaded, indexed and searched per shard, lists exchanged")
     ap.add_argument("--no-configs", action="store_true", help="skip the c2 / refbench / c4-shard / c5 passes that follow the default C3 run")
     ap.add_argument("--parity-queries", type=int, default=64, help="queries of the step checked bit for bit against the CPU oracle")
     ap.add_argument("--recall", type=int, default=32, help="queries checked against an exact brute force (0 disables)")
@@ -563,6 +757,11 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.from_parquet and use_dist:
+        rc = from_parquet_sharded(args, pqv, torch, dist, dev, local_rank, rank, world, real_stdout)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        sys.exit(rc)
     if args.from_parquet:
         rec = from_parquet_config(args, pqv, torch, dev, local_rank)
         bi = rec.get("build_inplace", {})
@@ -626,7 +825,9 @@ def main():
     # per stream, so step i + 1's probe / bucketing / seed kernels and the head of its screen kernel run
     # in the tail of step i's screen kernel.  Each step is still one complete pass over one batch.
     n_lanes = max(1, args.streams)
-    lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
+    # (explicit streams only: new_streams)
+    torch.cuda.synchronize()
+    lane_streams = new_streams(torch, dev, n_lanes)
     rows_l = [torch.empty((nq, K), dtype=torch.int32, device=dev) for _ in range(n_lanes)]
     dist_l = [torch.empty((nq, K), dtype=torch.float32, device=dev) for _ in range(n_lanes)]
     nf_l = [torch.empty((nq,), dtype=torch.int32, device=dev) for _ in range(n_lanes)]
@@ -799,7 +1000,7 @@ def main():
         "repeats": len(block_s),
         "repeats_note": "blocks of exactly `steps` steps (barrier + synchronize on both sides, max over ranks); ms_per_step and value "
                         "are the MEDIAN block; min / max block ms_per_step: %.4f / %.4f" % (min(block_s) / steps * 1e3, max(block_s) / steps * 1e3),
-        "pipelining": {"streams": n_lanes,
+        "pipelining": {"streams": n_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "note": "steps alternate between %d HIP streams, so consecutive steps overlap on the GPU and ms_per_step "
                                "(throughput) is below one step's own latency; ms_per_step_serial is the same step issued "
                                "alone and host-synchronised" % n_lanes if n_lanes > 1 else "steps are serial on one stream"},

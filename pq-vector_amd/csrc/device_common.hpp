@@ -69,6 +69,10 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
     const f32x4_raw v = __builtin_bit_cast(f32x4_raw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, AUX));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// one dword per lane through a (wave-uniform) buffer descriptor: no 64-bit per-lane address arithmetic, no pointer registers
+__device__ __forceinline__ uint32_t buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_bytes, (int)uniform_bytes, 0);
+}
 #ifndef PQV_ROW_AUX
 #define PQV_ROW_AUX 0
 #endif
@@ -97,6 +101,9 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
 #ifndef PQV_XTA
 #define PQV_XTA 0              // ... in the 64-row-tile instances (measured 3 % slower: 8 more spills)
 #endif
+#ifndef PQV_XTC
+#define PQV_XTC 0              // 64-row-tile int8 instances: the next tile's operand stages go out FIRST after a K loop, the fresh thresholds
+#endif                         // and the next tile's row terms behind them -- nothing is waited for between two K loops (thresholds one tile old)
 #ifndef PQV_EVAL_NB_TS2
 #define PQV_EVAL_NB_TS2 16     // row chunks in flight per lane in the wide-quad instance's exact evaluations
 #endif

@@ -1860,8 +1860,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     constexpr bool XTA = XT && I8 && (TS == 2 ? PQV_XTA_TS2 : PQV_XTA);
     [[maybe_unused]] int xn2i_nn[XTA ? TS : 1] = {};
     [[maybe_unused]] float xres_nn[XTA ? TS : 1] = {};
-    [[maybe_unused]] uint64_t gthr_pf[XTA ? QS : 1];
-    if constexpr (XTA) {
+    // XTC (the 64-row-tile int8 instances): the same without the extra row-term registers -- after a K loop the next tile's
+    // operand stages are issued FIRST, the thresholds (for the next tile's screen) and the next tile's row terms behind them in
+    // the in-order queue; they are consumed at the next tile's top / after its K loop, when everything issued here has long
+    // landed.  The plain form waited out a fabric round trip (thresholds + row terms, vmcnt(0)) between every two K loops
+    // with nothing of the wave in flight: 13 % of a wave's life on C3 (tools/phases_now.sh).
+    constexpr bool XTC = XT && I8 && !XTA && PQV_XTC;
+    [[maybe_unused]] uint64_t gthr_pf[(XTA || XTC) ? QS : 1];
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rt_n2i = operand_rsrc(a.mat_blk), rt_res = rt_n2i;      // (XTC: the wave's row terms, from r0)
+    if constexpr (XTC) { rt_n2i = operand_rsrc(a.row_n2i + lbeg + r0); rt_res = operand_rsrc(a.row_res + lbeg + r0); }
+    if constexpr (XTA || XTC) {
 #pragma unroll
         for (int s = 0; s < QS; ++s) gthr_pf[s] = cur_gthr[s];
     }
@@ -2104,11 +2112,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                         xres_nn[t] = a.row_res[lbeg + t2 + rr];
                     }
                 }
+            } else if constexpr (XTC) {
+#pragma unroll
+                for (int s = 0; s < QS; ++s) cur_gthr[s] = gthr_pf[s];
             } else {
 #pragma unroll
                 for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if constexpr (I8 && !XTA) {
+            if constexpr (I8 && !XTA && !XTC) {
                 if (tn < r1) {
                     const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
 #pragma unroll
@@ -2122,7 +2133,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             }
 #pragma unroll
             for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
-            if constexpr (!XTA) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
+            if constexpr (!XTA && !XTC) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
             __builtin_amdgcn_sched_barrier(0);
             if (XPF && tn < r1) {
                 uint32_t nso[TS];
@@ -2133,6 +2144,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                     for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(nxr, lane_b, nso[t] + j * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (XTC) {
+#pragma unroll
+                for (int s = 0; s < QS; ++s) gthr_pf[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tn < r1) {
+                    // (through wave-uniform descriptors: a per-lane 64-bit pointer here is a register pair the allocator spills, and
+                    //  its reload -- a VMEM load behind the operand stages just issued -- would wait for all of them)
+                    const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
+                    const uint32_t ub = (uint32_t)(tn - r0) * 4u;
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {
+                        uint32_t rr = (uint32_t)(16 * t + l15);
+                        if (rr >= nv) rr = nv - 1;
+                        xn2i_next[t] = (int)buf_ld4(rt_n2i, rr * 4u, ub);
+                        xres_next[t] = __uint_as_float(buf_ld4(rt_res, rr * 4u, ub));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
 #ifdef PQV_PROFILE_PHASES
@@ -2477,6 +2506,9 @@ static size_t wide_lds_bytes(uint32_t width, uint32_t dim, bool f16, bool *q32) 
 
 template <int S>
 static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
+#ifdef PQV_DEV_C3_ONLY      // tools/regs_c3.sh: only C3's two instances are instantiated (register / ISA checks in seconds, never shipped)
+    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<10, 8, 1, true, OP_I8, false, true, 2>(a, 0, s); }
+#else
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || (a.row_of && !a.norm_by_pos) || !a.cand_keys) return hipErrorInvalidValue;
         const uint32_t nw = a.block_waves ? a.block_waves : 4;
@@ -2570,20 +2602,25 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
     } else {
         hipLaunchKernelGGL((tile_filter_kernel<S, false, false>), grid, block, 0, s, a);
     }
+#endif
     return hipGetLastError();
 }
 
 hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s) {
     if ((a.filter_variant == 0 ? a.max_quads : a.max_groups) == 0 || a.grid_x == 0) return hipSuccess;
     if (a.k <= 64) return launch_filter_s<1>(a, s);
+#ifndef PQV_DEV_C3_ONLY
     if (a.k <= 256) return launch_filter_s<4>(a, s);
+#endif
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
     if (a.max_groups == 0 || a.grid_x == 0) return hipSuccess;
+#ifndef PQV_DEV_C3_ONLY
     if (a.k <= 64) return launch_tile_s<1>(a, s);
     if (a.k <= 256) return launch_tile_s<4>(a, s);
+#endif
     return hipErrorInvalidValue;   // larger k uses stream_kernel
 }
 

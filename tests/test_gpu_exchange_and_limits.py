@@ -146,6 +146,29 @@ def test_bench_c4_two_ranks_with_a_small_shard():
     assert rec["exchange"]["ranks"] == 2 and 0.0 < rec["exchange"]["share_of_step"]
 
 
+def test_bench_two_ranks_share_one_parquet_file_by_row_group_ranges():
+    """BASELINE configs[3]'s partition unit: ONE Parquet file, one row-group range per rank (sharding.shard_row_groups +
+    parquet_io.load_embedding_column(row_groups=...)), a shard index per rank, the lists exchanged -- two ranks on this box's one
+    GPU (gloo).  The line's parity leg: with every list probed the merged answer carries the same file-global row ids and
+    distance bits as a single-shard search of the whole file."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--from-parquet",
+                        "--rows-per-rank", "150000", "--nq", "64", "--steps", "3", "--warmup", "1", "--parity-queries", "32"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["shards"] == 2 and cfg["row_groups"] == 9 and rec["value"] > 0
+    (a0, a1), (b0, b1) = cfg["row_group_ranges"]
+    assert a0 == 0 and a1 == b0 and b1 == 9 and cfg["row_bases"][0] == 0 and cfg["row_bases"][1] == cfg["shard_rows"][0]
+    assert sum(cfg["shard_rows"]) == 300000 and cfg["shard_rows"][0] != cfg["shard_rows"][1]      # cut at a row-group boundary, not at n / 2
+    assert rec["parity"]["ok"] and rec["parity"]["queries_checked"] == 32
+    assert rec["parity"]["global_row_ids_identical"] and rec["parity"]["dist_bit_identical"]
+    assert "data pages" in rec["per_rank"]["loader_path"]
+
+
 @pytest.mark.parametrize("k,nprobe", [(1024, 4), (1500, 6), (3000, 3), (10, 1500)])
 def test_topk_beyond_the_kernel_list_capacity(pqv, oracle, k, nprobe):
     """search.rs:56-81 accepts any NonZeroUsize for k and nprobe.  k >= 1024 (no runner-up slot in the kernels' lists) and

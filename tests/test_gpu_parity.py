@@ -504,6 +504,40 @@ def test_parquet_build_inplace_and_topk(pqv, oracle, tmp_path):
     assert hits2[0].row_idx == 17 and hits2[0].distance == 0.0
 
 
+@pytest.mark.parametrize("dim,kc,images_only", [(64, 8, True), (48, 8, False), (64, 64, False)])
+def test_path_searcher_keeps_one_f32_copy_of_the_column_resident(pqv, oracle, tmp_path, dim, kc, images_only):
+    """searcher_for_parquet (TopkBuilder(path)): the images-only IVF layout keeps reading the column as loaded; where the searcher
+    falls back to its own list-ordered f32 copy (dim % 64 != 0, lists under 192 rows) the loaded row-order rows are released
+    (PQV_RELEASE_IF_COPIED) -- one f32 copy of the column in HBM either way, and the answers are the oracle's."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from pq_vector_amd import api as _api
+    rng = np.random.default_rng(31)
+    n = 4000
+    data = rng.random((n, dim), dtype=np.float32)
+    col = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32)), pa.array(data.reshape(-1)))
+    path = str(tmp_path / "c.parquet")
+    pq.write_table(pa.table({"embedding": col}), path, row_group_size=1500)
+    pqv.IndexBuilder(path, "embedding").n_clusters(kc).workers(4).build_inplace()
+    oidx = oracle.build_index(data, n_clusters=kc, workers=4)
+    _api._PATH_SEARCHERS.clear()
+    try:
+        s = pqv.searcher_for_parquet(path)
+        fp = s.footprint()
+        column_bytes = n * dim * 4
+        if images_only:
+            assert fp["row_order_bytes"] == column_bytes and fp["ivf_rows_bytes"] == 0
+        else:
+            assert fp["row_order_bytes"] == 0 and fp["ivf_rows_bytes"] >= column_bytes
+        for q in (data[5], rng.random(dim, dtype=np.float32)):
+            hits = pqv.TopkBuilder(path, q).k(7).nprobe(3).search()
+            orows, odist, _ = oidx.topk(data, q, 7, 3)
+            assert [h.row_idx for h in hits] == orows.tolist()
+            assert [np.float32(h.distance) for h in hits] == odist.tolist()
+    finally:
+        _api._PATH_SEARCHERS.clear()
+
+
 @pytest.mark.parametrize("value_type", ["f32", "f64"])
 def test_page_runs_from_the_mapped_file_and_what_they_refuse(pqv, tmp_path, value_type):
     """The page-level loader on an uncompressed PLAIN file with hundreds of small pages: runs of pages go through

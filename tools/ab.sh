@@ -5,7 +5,7 @@ out=$1; shift
 mkdir -p gpurun_out
 for lib in "$@"; do
   for rep in $(seq 1 ${AB_REPS:-2}); do
-    PQV_LIB_PATH=$PWD/pq-vector_amd/libpqv_$lib.so python bench.py --no-cpu --no-secondary --recall 0 --parity-queries 0 ${AB_ARGS} 2>/dev/null |
+    PQV_LIB_PATH=$PWD/pq-vector_amd/libpqv_$lib.so python bench.py --no-cpu --no-secondary --no-configs --recall 0 --parity-queries 0 ${AB_ARGS} 2>/dev/null |
       python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
