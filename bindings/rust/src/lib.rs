@@ -17,6 +17,10 @@
 //! checked by that test to exist with the right number of arguments.  Error texts are the library's, which are the
 //! reference's own (`"k must be > 0"`, `"Query dimension mismatch: expected {}, got {}"`, ...).
 pub mod sys;
+/// The reference's path-taking call shapes -- `IndexBuilder::new(source, column).build_inplace()`, `TopkBuilder::new(path, &query)`
+/// -- over an indexed Parquet file (cargo feature `parquet-files`).
+#[cfg(feature = "parquet-files")]
+pub mod file;
 
 use std::ffi::CStr;
 use std::num::NonZeroUsize;
@@ -26,7 +30,7 @@ use std::ptr;
 pub type Error = Box<dyn std::error::Error + Send + Sync>;
 pub type Result<T> = std::result::Result<T, Error>;
 
-fn check(rc: c_int) -> Result<()> {
+pub(crate) fn check(rc: c_int) -> Result<()> {
     if rc == sys::PQV_OK {
         return Ok(());
     }
@@ -136,6 +140,12 @@ impl Corpus {
     /// Waits for every upload and sets the row count.
     pub fn finish(&mut self, n_rows: usize) -> Result<()> {
         check(unsafe { sys::pqv_corpus_finish(self.raw, n_rows as u64) })
+    }
+
+    /// (crate-internal: the handle, for entry points that take `pqv_corpus *`)
+    #[allow(dead_code)]
+    pub(crate) fn raw_mut(&mut self) -> *mut sys::PqvCorpus {
+        self.raw
     }
 
     pub fn rows(&self) -> usize {
