@@ -70,8 +70,10 @@ __device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t la
     return make_float4(v.x, v.y, v.z, v.w);
 }
 // one dword per lane through a (wave-uniform) buffer descriptor: no 64-bit per-lane address arithmetic, no pointer registers
+// (AUX: cache policy bits of the load -- 16 = sc1: agent scope, what a relaxed agent-scope atomic load compiles to on gfx942 / gfx950)
+template <int AUX = 0>
 __device__ __forceinline__ uint32_t buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes) {
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_bytes, (int)uniform_bytes, 0);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_bytes, (int)uniform_bytes, AUX);
 }
 #ifndef PQV_ROW_AUX
 #define PQV_ROW_AUX 0
@@ -100,6 +102,12 @@ __device__ __forceinline__ uint32_t buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t l
 #endif
 #ifndef PQV_XTA
 #define PQV_XTA 0              // ... in the 64-row-tile instances (measured 3 % slower: 8 more spills)
+#endif
+#ifndef PQV_RELANE
+#define PQV_RELANE 1           // wide_filter_kernel: the lane index is re-defined opaquely after every K loop (no hoisted lane-derived invariants)
+#endif
+#ifndef PQV_REPF
+#define PQV_REPF 1             // wide_filter_kernel: the operand prefetch is issued again behind exact evaluations in mid-wave (stages dead across them)
 #endif
 #ifndef PQV_XTC
 #define PQV_XTC 0              // 64-row-tile int8 instances: the next tile's operand stages go out FIRST after a K loop, the fresh thresholds

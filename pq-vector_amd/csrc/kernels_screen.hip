@@ -1248,17 +1248,20 @@ __device__ __forceinline__ uint64_t qsel_u64(const uint64_t (&v)[QS], uint32_t q
 }
 template <int QS>
 __device__ __forceinline__ uint32_t qread_u32(const uint32_t (&v)[QS], uint32_t qq) {      // qq wave-uniform
-    uint32_t x = v[0];
+    // (the lane is read from EVERY slot and the scalars are selected: a select between the array's elements on a uniform
+    //  condition is turned into ONE load through a selected address -- the array then lives in scratch memory and every
+    //  access to it, the screen's static ones included, is a VMEM load: seen with QS = 3, the wide-quad instance)
+    uint32_t x = readlane_u32(v[0], (int)(qq & 63u));
 #pragma unroll
-    for (int s = 1; s < QS; ++s) x = (qq >> 6) == (uint32_t)s ? v[s] : x;
-    return readlane_u32(x, (int)(qq & 63u));
+    for (int s = 1; s < QS; ++s) { const uint32_t xs = readlane_u32(v[s], (int)(qq & 63u)); x = (qq >> 6) == (uint32_t)s ? xs : x; }
+    return x;
 }
 template <int QS>
 __device__ __forceinline__ uint64_t qread_u64(const uint64_t (&v)[QS], uint32_t qq) {
-    uint64_t x = v[0];
+    uint64_t x = readlane_u64(v[0], (int)(qq & 63u));
 #pragma unroll
-    for (int s = 1; s < QS; ++s) x = (qq >> 6) == (uint32_t)s ? v[s] : x;
-    return readlane_u64(x, (int)(qq & 63u));
+    for (int s = 1; s < QS; ++s) { const uint64_t xs = readlane_u64(v[s], (int)(qq & 63u)); x = (qq >> 6) == (uint32_t)s ? xs : x; }
+    return x;
 }
 
 // ONCE: every row of the launch is read by exactly one block (a batch that fits one quad, a one-query call above all): the
@@ -1314,7 +1317,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     }
     const uint32_t c = quad.x, p0 = quad.y;
     uint32_t cnt = quad.z;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;                 // (re-defined opaquely after every K loop: PQV_RELANE below)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t k = a.k;
     // Pairs that cannot contribute: pair_lb[p] is a lower bound of the reference distance between the pair's query and
@@ -1408,10 +1411,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     __shared__ uint64_t qst_cbase[LST ? NQ : 1];
     __shared__ uint32_t qst_pair[LST ? NQ : 1];
     __shared__ float qst_qn[LST && !I8 ? NQ : 1];     // |q|^2; NaN = never skip this query (float operand forms)
-    __shared__ float qst_res[LST ? NQ : 1];           // int8: residual bound (+inf = never skip)
-    __shared__ int qst_n2i[LST ? NQ : 1];             // int8: |qi|^2
+    // (the two the screen reads by LANE index are padded to 64 QS entries: slot s of lane l reads entry 64 s + l without a clamp --
+    //  a clamped index is a computed address in a register of its own, which the allocator spilled and reloaded right behind
+    //  the next tile's operand prefetch: a wait for the whole queue; entries past NQ are never used)
+    __shared__ float qst_res[LST ? 64 * QS : 1];      // int8: residual bound (+inf = never skip)
+    __shared__ int qst_n2i[LST ? 64 * QS : 1];        // int8: |qi|^2
     uint32_t my_qrow[QS];
-    uint64_t my_lkth[QS];
     [[maybe_unused]] uint32_t my_pairi[I8 ? QS : 1];         // int8: the pair (its image is per (query, list))
     [[maybe_unused]] uint32_t my_pair[LST ? 1 : QS];
     [[maybe_unused]] uint64_t my_cbase[LST ? 1 : QS], my_base[LST ? 1 : QS];
@@ -1425,7 +1430,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const uint32_t pair = a.pairs[p0 + (prune ? s_perm[qic] : qic)];
         my_qrow[s] = pair / a.nprobe;
         if constexpr (I8) my_pairi[s] = a.i8_pair_images ? pair : my_qrow[s];      // the image: per pair or per query
-        my_lkth[s] = KEY_EMPTY;
         const float qn = a.query_norm2[my_qrow[s]];
         // F16: a query whose scaled image overflows f16 or whose scaled norm is below 1 is never skipped
         const bool noskip = F16 && (!(a.query_maxabs[my_qrow[s]] * a.scale <= 32768.0f) || !(qn * a.scale2 >= 1.0f) || !(qn <= 3.0e38f));
@@ -1489,7 +1493,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     const float4 *qblk = a.q_blk + (uint64_t)by * NG * G * 16;   // + (g G + ch) 16 + query-in-group
     const __amdgpu_buffer_rsrc_t qr = operand_rsrc(QLDS ? (const void *)a.queries : (const void *)qblk);
 
-    const int l15 = lane & 15, kk = lane >> 4;
+    int l15 = lane & 15, kk = lane >> 4;
     const uint64_t blk0 = a.blk_off[c], blk_last = a.blk_off[c + 1] - 1;   // the list's 16-row tiles
     uint32_t npend = 0;
     uint32_t n_exact = 0;
@@ -1497,9 +1501,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     uint64_t ph_k = 0, ph_s = 0, ph_e = 0, ph_em = 0, ph_top_sum = 0, ph_xt = 0; const uint64_t ph_pro = __builtin_amdgcn_s_memtime() - ph_t0;
 #endif
 
-    uint64_t cur_gthr[QS];
+    // The queries' running thresholds as the wave sees them: the DISTANCE half of the 64-bit threshold key only (one register per
+    // slot).  A pair is kept / appended whenever its distance does not exceed it -- the position half of the key only decides
+    // between equal distances, and a lenient test merely appends a pair the merge drops again.  Read through a wave-uniform
+    // buffer descriptor (no per-lane 64-bit pointer registers), agent scope (sc1): thresholds tighten while the kernel runs.
+    // (the k-th key of a wave's own overflow list is not kept: tile_fold publishes it to the query's global threshold)
+    const __amdgpu_buffer_rsrc_t rt_thr = operand_rsrc(a.gthr);
+    auto load_thr = [&](int s) -> uint32_t { return buf_ld4<16>(rt_thr, my_qrow[s] * 8u + 4u, 0u); };
+    auto widen = [](uint32_t h) -> uint64_t { return ((uint64_t)h << 32) | 0xFFFFFFFFull; };
+    uint32_t cur_gthr[QS];
 #pragma unroll
-    for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int s = 0; s < QS; ++s) cur_gthr[s] = load_thr(s);
     // Running threshold + append of one lane's pair (deferred: the UPPER bound stands for the distance -- a pair counted in a
     // bin is truly at or below the bin's edge -- and lbv >= 0 is its lower bound; exact: lbv = -1).  Returns false when the
     // query's buffer is full.
@@ -1580,11 +1592,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         const uint64_t lpos = lbeg + roff;
         const uint32_t srow = a.row_of ? a.row_of[lpos] : (uint32_t)lpos;
         const uint32_t qrow = qsel_u32<QS>(my_qrow, qsl);
-        uint64_t my_thr[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
-        const uint64_t pair_thr = qsel_u64<QS>(my_thr, qsl);
-        const float thr_d = __uint_as_float((uint32_t)(pair_thr >> 32));
+        const float thr_d = __uint_as_float(qsel_u32<QS>(cur_gthr, qsl));
         uint64_t pos;
         if constexpr (LST) pos = qst_cbase[qsl] + roff; else pos = qsel_u64<QS>(my_cbase, qsl) + roff;
         float lb = 0.0f, ub = INFINITY;
@@ -1722,9 +1730,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         ph_em += (__builtin_amdgcn_s_memtime() - ph_e0) | (1ull << 48);
 #endif
         // the wave's view of the thresholds (refreshed every tile)
-        uint64_t my_thr[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
         uint64_t pos;
         if constexpr (LST) pos = qst_cbase[qsl] + roff; else pos = qsel_u64<QS>(my_cbase, qsl) + roff;
         const uint64_t mykey_all =
@@ -1732,7 +1737,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // A pair that beats its query's threshold is APPENDED to the query's candidate buffer: one
         // atomic per lane, all lanes in parallel (a sorted per-wave list would cost one global
         // read-modify-write round trip per query, serially -- measured: half of the kernel).
-        const uint64_t pair_thr = qsel_u64<QS>(my_thr, qsl);
+        const uint64_t pair_thr = widen(qsel_u32<QS>(cur_gthr, qsl));
         const bool pass = mykey_all < pair_thr;
         const bool counted = (pe & QCNT) != 0u;               // (deferred pass: in the bins already)
         const bool spill = !append_pair(pass, qrow, sum, mykey_all, srow, -1.0f, !counted);
@@ -1742,7 +1747,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             const bool mine = spill && qsl == qq;
             todo &= ~__ballot(mine);
             const uint64_t mykey = mine ? mykey_all : KEY_EMPTY;
-            const uint64_t thr = qread_u64<QS>(my_thr, qq);
+            const uint64_t thr = widen(qread_u32<QS>(cur_gthr, qq));
             if (__ballot(mykey < thr) != 0ull) {
                 uint32_t pr;
                 if constexpr (LST) pr = qst_pair[qq]; else pr = qread_u32<QS>(my_pair, qq);
@@ -1756,22 +1761,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 }
                 const uint64_t nk = tile_fold<S>(a.part_keys + base, a.part_vals + base,
                                                  a.gthr + qread_u32<QS>(my_qrow, qq),
-                                                 qread_u64<QS>(cur_gthr, qq), qread_u64<QS>(my_lkth, qq),
-                                                 mykey, srow, k, lane, fresh);
-#pragma unroll
-                for (int s = 0; s < QS; ++s)
-                    if ((uint32_t)(64 * s + lane) == qq) my_lkth[s] = nk;
+                                                 thr, KEY_EMPTY, mykey, srow, k, lane, fresh);
+                (void)nk;
             }
         }
         return count;
     };
-    auto drain = [&](uint32_t keep_below) {
+    auto drain = [&](uint32_t keep_below) -> bool {        // true: exact evaluations ran (the caller re-issues the operand prefetch)
+        bool ran = false;
         while (npend >= keep_below && npend > 0) {
             const uint32_t take = npend < 64 ? npend : 64;
             n_exact += eval(npend - take, take);
             npend -= take;
+            ran = true;
         }
         wave_lds_fence();
+        return ran;
     };
 
     const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;   // this lane's float4 inside a 1 KiB operand block
@@ -1809,7 +1814,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     if (pf && r0 < r1) issue_tile(r0);
     // the query thresholds are read one tile ahead (they tighten while the kernel runs, and a freshly
     // modified line costs a fabric round trip that must not sit in front of the operand waits)
-    uint64_t gthr_next[QS];
+    uint32_t gthr_next[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) gthr_next[s] = cur_gthr[s];
     // B-operand registers of the K loop (two ping-pong stages).  They persist across tiles: the loads of a tile's
@@ -1840,15 +1845,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // (f32 operands keep the per-tile form: their kernels are built for three waves per SIMD and have no registers
     //  to carry two operand stages through the exact evaluations)
     constexpr bool XT = PQV_XT && QLDS && !PF && OP != OP_F32;
+    auto prefetch_tile = [&](uint64_t tn) {          // the first NS operand stages of the tile at row tn
+        uint32_t so[TS];
+        const __amdgpu_buffer_rsrc_t r = tile_desc(tn, so);
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+            for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(r, lane_b, so[t] + j * 1024);
+    };
+    // After exact evaluations in the middle of a wave's rows (rare: nearly all run behind the last tile) the prefetch is issued
+    // AGAIN: the operand registers are then dead across the evaluation code -- its 8 + 8 row / query chunks per lane were the
+    // kernel's register peak with the stages live through it, and what did not fit was spilled, with the reloads in the screen.
+    constexpr bool REPF = XT && XPF && PQV_REPF;
     if constexpr (XT && XPF) {
-        if (r0 < r1) {
-            uint32_t so[TS];
-            const __amdgpu_buffer_rsrc_t r = tile_desc(r0, so);
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-#pragma unroll
-                for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(r, lane_b, so[t] + j * 1024);
-        }
+        if (r0 < r1) prefetch_tile(r0);
     }
     [[maybe_unused]] int xn2i_next[TS] = {};
     [[maybe_unused]] float xres_next[TS] = {};
@@ -1866,35 +1876,32 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
     // landed.  The plain form waited out a fabric round trip (thresholds + row terms, vmcnt(0)) between every two K loops
     // with nothing of the wave in flight: 13 % of a wave's life on C3 (tools/phases_now.sh).
     constexpr bool XTC = XT && I8 && !XTA && PQV_XTC;
-    [[maybe_unused]] uint64_t gthr_pf[(XTA || XTC) ? QS : 1];
-    [[maybe_unused]] __amdgpu_buffer_rsrc_t rt_n2i = operand_rsrc(a.mat_blk), rt_res = rt_n2i;      // (XTC: the wave's row terms, from r0)
-    if constexpr (XTC) { rt_n2i = operand_rsrc(a.row_n2i + lbeg + r0); rt_res = operand_rsrc(a.row_res + lbeg + r0); }
+    [[maybe_unused]] uint32_t gthr_pf[(XTA || XTC) ? QS : 1];
+    // the wave's row terms (int8: |xi|^2 and the residual bound, from its first row r0) through wave-uniform descriptors: a
+    // per-lane 64-bit pointer is a register pair the allocator spills, and its reload -- a VMEM load -- waits for every operand
+    // stage issued before it
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rt_n2i = operand_rsrc(a.mat_blk), rt_res = rt_n2i;
+    if constexpr (I8) { rt_n2i = operand_rsrc(a.row_n2i + lbeg + r0); rt_res = operand_rsrc(a.row_res + lbeg + r0); }
+    auto row_terms = [&](uint64_t tn, int (&n2)[TS], float (&rs)[TS]) {       // tile starting at row tn < r1 of the list
+        const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
+        const uint32_t ub = (uint32_t)(tn - r0) * 4u;
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            uint32_t rr = (uint32_t)(16 * t + l15);
+            if (rr >= nv) rr = nv - 1;
+            n2[t] = (int)buf_ld4(rt_n2i, rr * 4u, ub);
+            rs[t] = __uint_as_float(buf_ld4(rt_res, rr * 4u, ub));
+        }
+    };
     if constexpr (XTA || XTC) {
 #pragma unroll
         for (int s = 0; s < QS; ++s) gthr_pf[s] = cur_gthr[s];
     }
     if constexpr (I8) {
         if (r0 < r1) {
-            const uint32_t nv = (r1 - r0 < TROWS) ? (uint32_t)(r1 - r0) : TROWS;
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                uint32_t rr = (uint32_t)(16 * t + l15);
-                if (rr >= nv) rr = nv - 1;
-                xn2i_next[t] = a.row_n2i[lbeg + r0 + rr];
-                xres_next[t] = a.row_res[lbeg + r0 + rr];
-            }
+            row_terms(r0, xn2i_next, xres_next);
             if constexpr (XTA) {
-                const uint64_t t2 = r0 + TROWS;
-                if (t2 < r1) {
-                    const uint32_t nv2 = (r1 - t2 < TROWS) ? (uint32_t)(r1 - t2) : TROWS;
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) {
-                        uint32_t rr = (uint32_t)(16 * t + l15);
-                        if (rr >= nv2) rr = nv2 - 1;
-                        xn2i_nn[t] = a.row_n2i[lbeg + t2 + rr];
-                        xres_nn[t] = a.row_res[lbeg + t2 + rr];
-                    }
-                }
+                if (r0 + TROWS < r1) row_terms(r0 + TROWS, xn2i_nn, xres_nn);
             }
         }
     }
@@ -1932,13 +1939,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         uint32_t xso[TS];
 #pragma unroll
         for (int t = 0; t < TS; ++t) xso[t] = (uint32_t)((xbase[t] - xbase[0]) * 16);
-        uint64_t my_thr[QS];
         if constexpr (!XT) {
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
                 cur_gthr[s] = gthr_next[s];
-                gthr_next[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
+                gthr_next[s] = load_thr(s);
             }
         }
 
@@ -2085,6 +2090,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_x0 = __builtin_amdgcn_s_memtime();
 #endif
+#if PQV_RELANE
+        // The lane index is handed back through an opaque (empty) asm after every K loop: everything the screen, the expansion
+        // and the exact evaluations derive from it -- validity masks, LDS addresses, prefix masks: loop invariants the compiler
+        // otherwise hoists out of the tile loop and keeps in ~80 registers ACROSS the K loop, spilling what does not fit -- is
+        // recomputed per tile (a few dozen VALU operations against ~35 k cycles) and the K loop keeps its registers.
+        asm volatile("" : "+v"(lane));
+        l15 = lane & 15; kk = lane >> 4;
+#endif
         if constexpr (XT) {
             // Between the K loops NOTHING this wave loads may be consumed while operand prefetches are in flight: loads
             // return in order, so waiting for a fresh one drains the whole queue (and a register the allocator spills
@@ -2097,69 +2110,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int s = 0; s < QS; ++s) {
                     cur_gthr[s] = gthr_pf[s];
-                    gthr_pf[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gthr_pf[s] = load_thr(s);
                 }
 #pragma unroll
                 for (int t = 0; t < TS; ++t) { xn2i_next[t] = xn2i_nn[t]; xres_next[t] = xres_nn[t]; }
-                const uint64_t t2 = tn + TROWS;
-                if (t2 < r1) {
-                    const uint32_t nv2 = (r1 - t2 < TROWS) ? (uint32_t)(r1 - t2) : TROWS;
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) {
-                        uint32_t rr = (uint32_t)(16 * t + l15);
-                        if (rr >= nv2) rr = nv2 - 1;
-                        xn2i_nn[t] = a.row_n2i[lbeg + t2 + rr];
-                        xres_nn[t] = a.row_res[lbeg + t2 + rr];
-                    }
-                }
+                if (tn + TROWS < r1) row_terms(tn + TROWS, xn2i_nn, xres_nn);
             } else if constexpr (XTC) {
 #pragma unroll
                 for (int s = 0; s < QS; ++s) cur_gthr[s] = gthr_pf[s];
             } else {
 #pragma unroll
-                for (int s = 0; s < QS; ++s) cur_gthr[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int s = 0; s < QS; ++s) cur_gthr[s] = load_thr(s);
             }
             if constexpr (I8 && !XTA && !XTC) {
-                if (tn < r1) {
-                    const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) {
-                        uint32_t rr = (uint32_t)(16 * t + l15);
-                        if (rr >= nv) rr = nv - 1;
-                        xn2i_next[t] = a.row_n2i[lbeg + tn + rr];
-                        xres_next[t] = a.row_res[lbeg + tn + rr];
-                    }
-                }
+                if (tn < r1) row_terms(tn, xn2i_next, xres_next);
             }
-#pragma unroll
-            for (int s = 0; s < QS; ++s) my_thr[s] = my_lkth[s] < cur_gthr[s] ? my_lkth[s] : cur_gthr[s];
             if constexpr (!XTA && !XTC) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): (1) has landed before (2) is issued
             __builtin_amdgcn_sched_barrier(0);
-            if (XPF && tn < r1) {
-                uint32_t nso[TS];
-                const __amdgpu_buffer_rsrc_t nxr = tile_desc(tn, nso);
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) xs[j][t] = buf_ld16<ROW_AUX>(nxr, lane_b, nso[t] + j * 1024);
-            }
+            if (XPF && tn < r1) prefetch_tile(tn);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (XTC) {
 #pragma unroll
-                for (int s = 0; s < QS; ++s) gthr_pf[s] = __hip_atomic_load(a.gthr + my_qrow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tn < r1) {
-                    // (through wave-uniform descriptors: a per-lane 64-bit pointer here is a register pair the allocator spills, and
-                    //  its reload -- a VMEM load behind the operand stages just issued -- would wait for all of them)
-                    const uint32_t nv = (r1 - tn < TROWS) ? (uint32_t)(r1 - tn) : TROWS;
-                    const uint32_t ub = (uint32_t)(tn - r0) * 4u;
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) {
-                        uint32_t rr = (uint32_t)(16 * t + l15);
-                        if (rr >= nv) rr = nv - 1;
-                        xn2i_next[t] = (int)buf_ld4(rt_n2i, rr * 4u, ub);
-                        xres_next[t] = __uint_as_float(buf_ld4(rt_res, rr * 4u, ub));
-                    }
-                }
+                for (int s = 0; s < QS; ++s) gthr_pf[s] = load_thr(s);
+                if (tn < r1) row_terms(tn, xn2i_next, xres_next);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -2193,15 +2166,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
                 const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
-                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
-                const float qres = qst_res[qi < NQ ? qi : 0];
-                const bool open = !(qres <= 3.0e38f) || my_thr[s] == KEY_EMPTY || !(thr_d <= 3.0e38f);
+                const float thr_d = __uint_as_float(cur_gthr[s]);
+                const float qres = qst_res[qi];
+                const bool open = !(qres <= 3.0e38f) || cur_gthr[s] == 0xFFFFFFFFu || !(thr_d <= 3.0e38f);
                 int a2 = 1 << 29;                              // never skip
                 if (qi >= cnt) a2 = -(1 << 30);                // not a query of this quad: always "skipped"
                 else if (!open) {
                     const float v = lscale * (sqrtf(thr_d * (1.0f + 4.0f * cmargin)) * 1.000002f + qres + R);
                     const float v2 = fminf(v * v * 1.000002f, 1.0e9f);
-                    a2 = ((int)ceilf(v2) + 1 - qst_n2i[qi < NQ ? qi : 0] + 1) >> 1;
+                    a2 = ((int)ceilf(v2) + 1 - qst_n2i[qi] + 1) >> 1;
                 }
                 if (qi < NQ) reinterpret_cast<int *>(aq)[qi] = a2;
             }
@@ -2212,12 +2185,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
             for (int s = 0; s < QS; ++s) {
                 const uint32_t qi = 64u * (uint32_t)s + (uint32_t)lane;
                 // threshold DISTANCE of this lane's query; KEY_EMPTY: "cannot skip"
-                const float thr_d = __uint_as_float((uint32_t)(my_thr[s] >> 32));
+                const float thr_d = __uint_as_float(cur_gthr[s]);
                 float qn;
                 bool noskip;
                 if constexpr (LST) { qn = qst_qn[qi < NQ ? qi : 0]; noskip = !(qn == qn); }
                 else { qn = my_qn[s]; noskip = my_noskip[s]; }
-                if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (noskip || my_thr[s] == KEY_EMPTY) ? -3.0e38f : alpha * qn - beta * thr_d;
+                if (qi < NQ) aq[qi] = qi >= cnt ? INFINITY : (noskip || cur_gthr[s] == 0xFFFFFFFFu) ? -3.0e38f : alpha * qn - beta * thr_d;
             }
             wave_lds_fence();
         }
@@ -2362,7 +2335,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
 #endif
-            drain(last_tile ? 1u : 64u);
+            const bool ran = drain(last_tile ? 1u : 64u);
+            if constexpr (REPF) { if (ran && !last_tile) prefetch_tile(t0 + TROWS); }
 #ifdef PQV_PROFILE_PHASES
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
@@ -2371,6 +2345,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         constexpr uint32_t BP = (uint32_t)PASS / 64u < FW ? (uint32_t)PASS / 64u : FW;
         constexpr uint32_t PPG = FW / BP;                    // passes per group
         const uint32_t hend = one_pass ? 0u : PPG * ng + (last_tile ? 1u : 0u);
+        [[maybe_unused]] bool ran_slow = false;
 #pragma unroll 1
         for (uint32_t hg = 0; hg < hend; ++hg) {
             const uint32_t g = hg / PPG, ps = hg % PPG;
@@ -2397,11 +2372,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
 #endif
-            drain(g == ng ? 1u : 64u);   // g == ng only in the flush pass
+            ran_slow = drain(g == ng ? 1u : 64u) || ran_slow;   // g == ng only in the flush pass
 #ifdef PQV_PROFILE_PHASES
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
 #endif
         }
+        if constexpr (REPF) { if (ran_slow && !last_tile) prefetch_tile(t0 + TROWS); }
 #ifdef PQV_PROFILE_PHASES
         ph_s += __builtin_amdgcn_s_memtime() - ph_b;
 #endif
