@@ -211,7 +211,15 @@ struct Scratch {
     hipEvent_t done = nullptr;      // recorded after the last kernel of the call that used this lane
     hipStream_t stream = nullptr;   // the stream of that call
     bool used = false;
-    ~Scratch() { if (done) (void)hipEventDestroy(done); }
+    // the lane's side stream for the wide-quad launch of a batch (TileArgs::side_stream), created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~Scratch() {
+        if (done) (void)hipEventDestroy(done);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 struct pqv_searcher {
@@ -293,6 +301,9 @@ struct pqv_searcher {
         uint32_t min_blocks = 0;           // wide kernel: blocks a launch should at least have before rows per block shrink (0 = by rule)
         int pair_prune = 1;                // int8 path: drop (query, list) pairs whose centre-distance bound exceeds the query's threshold
         int i8_form = 0;                   // int8 images: 0 by rule (per-list residual where the lists are tight), 1 one centre, 2 residual
+        int xcd_items = 1;                 // PairSortArgs::xcd_items (PQV_XCD_ITEMS)
+        int drain_min = 0;                 // TileArgs::drain_min (PQV_DRAIN_MIN)
+        int fork_wide = 0;                 // the wide-quad launch on the lane's side stream, beside the regular instance (PQV_FORK_WIDE)
         int wide_quads = 1;                // int8, 96-query quads: lists probed by 97..160 queries of the batch take ONE 160-query quad
                                            // (8-wave blocks on 32-row tiles) instead of two passes; 0 = off
         uint32_t wide_quad_rows = 0;       // rows per block of that instance (0 = by rule: 6144)
@@ -1931,6 +1942,9 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.quad_width = static_cast<uint32_t>(num("PQV_QUAD_WIDTH", o.quad_width));
     o.min_blocks = static_cast<uint32_t>(num("PQV_MIN_BLOCKS", o.min_blocks));
     o.wide_quads = static_cast<int>(num("PQV_WIDE_QUADS", o.wide_quads));
+    o.fork_wide = static_cast<int>(num("PQV_FORK_WIDE", o.fork_wide));
+    o.drain_min = static_cast<int>(num("PQV_DRAIN_MIN", o.drain_min));
+    o.xcd_items = static_cast<int>(num("PQV_XCD_ITEMS", o.xcd_items));
     o.wide_quad_rows = static_cast<uint32_t>(num("PQV_WIDE_QUAD_ROWS", o.wide_quad_rows));
     o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
     o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
@@ -2394,7 +2408,7 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && o.item_grid >= 1 && 160ull * s->sdim <= 122880 &&
                     pairs >= 16ull * s->n_clusters) {
                     p.wide_width = 160;
-                    const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 6144ull;
+                    const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 8192ull;
                     p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
                     p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
                     p.slots_per_pair = std::max(p.slots_per_pair, 8 * p.wide_bpl);
@@ -2606,7 +2620,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ps.wide_stats = s->h_wide_stats.as<uint32_t>();
             }
             if (wide) {
-                ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
+                ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block; ps.xcd_items = s->opt.xcd_items ? 1u : 0u;
                 ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
                 ps.wide_item_quad = sc.s_items.as<uint32_t>() + max_items; ps.wide_max_items = wide_max_items;
             }
@@ -2726,10 +2740,19 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
             if (items) { ta.item_quad = ps.item_quad; ta.item_chunk = ps.item_chunk; ta.wide_item_chunk = ps.wide_item_chunk; ta.n_items = ps.n_items; ta.max_items = max_items; }
+            ta.drain_min = static_cast<uint32_t>(std::max(0, s->opt.drain_min));
             if (wide) {
                 ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
                 ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
                 ta.wide_nt = wide_rows_nt(s) ? 1u : 0u;
+                if (s->opt.fork_wide) {
+                    if (!sc.side) {
+                        HIP_TRY(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming));
+                    }
+                    ta.side_stream = sc.side; ta.ev_fork = sc.ev_fork; ta.ev_join = sc.ev_join;
+                }
                 s->counters.kernel_launches += 1;
             }
             HIP_TRY(launch_tile_filter(ta, stream));
@@ -3180,6 +3203,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "pair_prune") o.pair_prune = value != 0;
     else if (n == "wide_quads") o.wide_quads = value != 0;
+    else if (n == "fork_wide") o.fork_wide = value != 0;
     else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "i8_form") {        // takes effect when the int8 copy is (re)built
         o.i8_form = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));

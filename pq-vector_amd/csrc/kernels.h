@@ -207,6 +207,7 @@ struct PairSortArgs {
     uint32_t       *item_chunk;      // [max_items] row chunk of each item
     uint32_t       *wide_item_chunk; // [wide_max_items]
     uint32_t       *wide_stats;      // optional [2]: items of the wide table, and how many of them belong to lists with no other quad
+    uint32_t        xcd_items;       // wide table: a level's slots filled column by column of an 8-column layout (same list -> same XCD)
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
     // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
     // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the
@@ -311,6 +312,12 @@ struct TileArgs {
     const uint32_t *wide_item_quad;
     const uint32_t *item_chunk, *wide_item_chunk;   // chunk-major tables (PairSortArgs::item_chunk); nullptr = chunk = item - quads[q].w
     uint32_t        wide_nt;         // the wide-quad instance streams its rows with the nt policy (most of its lists have one quad)
+    // host side only (launch_tile_filter): run the wide-quad instance on `side_stream`, forked from and joined to the call's stream
+    // by the two events, so that the two instances' tails fill each other (they cannot share a CU -- 2 x 81 KB against 142 KB
+    // of LDS -- but they can share the chip); NULL: one after the other on the call's stream
+    uint32_t        drain_min;       // wide_filter_kernel: queue entries that start a batch of exact evaluations before the wave's last tile (0 = 64)
+    hipStream_t     side_stream;
+    hipEvent_t      ev_fork, ev_join;
     const uint32_t *wide_n_items;
     uint32_t        wide_max_items, wide_rows_per_block;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates

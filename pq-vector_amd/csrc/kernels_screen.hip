@@ -1779,6 +1779,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         return ran;
     };
 
+    // A wave evaluates its queue when this many survivors wait (and behind its last tile).  64 fills the wave; fewer -- several
+    // lanes per pair -- makes the results (and with them the queries' running thresholds) arrive during the scan instead of at its end
+    const uint32_t drain_min = a.drain_min ? (a.drain_min < 64u ? a.drain_min : 64u) : 64u;
     const uint32_t lane_off = (uint32_t)kk * 16 + (uint32_t)l15;   // this lane's float4 inside a 1 KiB operand block
     const uint32_t lane_b = lane_off * 16u;                       // ... in bytes
     // Short f16 rows (<= 4 K steps = 128 dims): with the MFMA time gone the tile is latency-bound, so ALL of
@@ -1987,12 +1990,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // group g + APD is issued before the MFMAs of group g (rotating register quads; group indices past the quad's last
         // group are clamped to it, the staged part of the LDS).
         constexpr int APD = TS == 2 ? PQV_APD_TS2 : PQV_APD;
+        // `full`: std::integral_constant<int, NA> -- NA > 0: exactly the first NA groups, branch-free (NA = NG: a full quad);
+        // NA = 0: the quad's ng groups behind per-group branches
         auto mma = [&](const float4 (&x)[TS], uint32_t ks, auto full) {
+            constexpr int NA = decltype(full)::value, NGL = NA ? NA : NG;
             const uint32_t chq = ks * 4 + (uint32_t)kk;
             if constexpr (APD == 0) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (decltype(full)::value || (uint32_t)g < ng) {
+                for (int g = 0; g < NGL; ++g) {
+                    if (NA || (uint32_t)g < ng) {
                         const float4 qc = qs[(16 * g + l15) * G + (chq ^ (uint32_t)l15)];
 #pragma unroll
                         for (int t = 0; t < TS; ++t) mfma_step<OP>(acc[g][t], qc, x[t]);
@@ -2003,15 +2009,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
                 const uint32_t gstride = 16u * G;
                 float4 qb[APD + 1];
 #pragma unroll
-                for (int g = 0; g < APD && g < NG; ++g) {
-                    const uint32_t gi = decltype(full)::value || (uint32_t)g < ng ? (uint32_t)g : ng - 1u;
+                for (int g = 0; g < APD && g < NGL; ++g) {
+                    const uint32_t gi = NA || (uint32_t)g < ng ? (uint32_t)g : ng - 1u;
                     qb[g] = qb0[gi * gstride];
                 }
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (decltype(full)::value || (uint32_t)g < ng) {
-                        if (g + APD < NG) {
-                            const uint32_t gi = decltype(full)::value || (uint32_t)(g + APD) < ng ? (uint32_t)(g + APD) : ng - 1u;
+                for (int g = 0; g < NGL; ++g) {
+                    if (NA || (uint32_t)g < ng) {
+                        if (g + APD < NGL) {
+                            const uint32_t gi = NA || (uint32_t)(g + APD) < ng ? (uint32_t)(g + APD) : ng - 1u;
                             qb[(g + APD) % (APD + 1)] = qb0[gi * gstride];
                         }
 #pragma unroll
@@ -2080,13 +2086,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         else if constexpr (PF) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                if ((uint32_t)ks < nks) mma(xt[ks], (uint32_t)ks, std::false_type{});
+                if ((uint32_t)ks < nks) mma(xt[ks], (uint32_t)ks, std::integral_constant<int, 0>{});
         }
-        // (32-row tiles: always the branch-free body -- a wide quad has 7..10 of its 10 groups, the matrix pipe has room for
-        //  the idle ones, whose garbage scores are masked with the queries past cnt, and the per-group branches would cost
-        //  the exact wait counts of the A-operand pipeline)
-        else if (ng == (uint32_t)NG || TS == 2) kloop(std::true_type{});
-        else kloop(std::false_type{});
+        // (32-row tiles: a branch-free body per group count -- a wide quad has 7..10 of its 10 groups; per-group branches would
+        //  cost the exact wait counts of the A-operand pipeline, and running all ten always (round 3 / 4) costs up to 30 % of the
+        //  K loop's MFMAs where two waves share a SIMD's matrix pipe and full quads keep it ~75 % busy inside the loops)
+        else if constexpr (TS == 2 && NG == 10) {
+            if (ng >= 10u) kloop(std::integral_constant<int, 10>{});
+            else if (ng == 9u) kloop(std::integral_constant<int, 9>{});
+            else if (ng == 8u) kloop(std::integral_constant<int, 8>{});
+            else kloop(std::integral_constant<int, 7>{});
+        }
+        else if constexpr (PQV_NA_REG && TS == 4 && NG == 6 && I8 && NW == 4) {
+            // (the regular int8 instance: most quads of a batch have 3..5 of their 6 groups -- C3: 51 queries on average)
+            if (ng >= 6u) kloop(std::integral_constant<int, 6>{});
+            else if (ng == 5u) kloop(std::integral_constant<int, 5>{});
+            else if (ng == 4u) kloop(std::integral_constant<int, 4>{});
+            else if (ng == 3u) kloop(std::integral_constant<int, 3>{});
+            else kloop(std::integral_constant<int, 0>{});
+        }
+        else if (ng == (uint32_t)NG || TS == 2) kloop(std::integral_constant<int, NG>{});
+        else kloop(std::integral_constant<int, 0>{});
 #ifdef PQV_PROFILE_PHASES
         const uint64_t ph_x0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2335,7 +2355,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #ifdef PQV_PROFILE_PHASES
             const uint64_t ph_c = __builtin_amdgcn_s_memtime();
 #endif
-            const bool ran = drain(last_tile ? 1u : 64u);
+            const bool ran = drain(last_tile ? 1u : drain_min);
             if constexpr (REPF) { if (ran && !last_tile) prefetch_tile(t0 + TROWS); }
 #ifdef PQV_PROFILE_PHASES
             ph_e += __builtin_amdgcn_s_memtime() - ph_c;
@@ -2483,7 +2503,13 @@ static size_t wide_lds_bytes(uint32_t width, uint32_t dim, bool f16, bool *q32) 
 template <int S>
 static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
 #ifdef PQV_DEV_C3_ONLY      // tools/regs_c3.sh: only C3's two instances are instantiated (register / ISA checks in seconds, never shipped)
-    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<10, 8, 1, true, OP_I8, false, true, 2>(a, 0, s); }
+#ifndef PQV_DEV_WIDE_TS
+#define PQV_DEV_WIDE_TS 2
+#endif
+#ifndef PQV_DEV_WIDE_NG
+#define PQV_DEV_WIDE_NG 10
+#endif
+    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<PQV_DEV_WIDE_NG, 8, 1, true, OP_I8, false, true, PQV_DEV_WIDE_TS>(a, 0, s); }
 #else
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || (a.row_of && !a.norm_by_pos) || !a.cand_keys) return hipErrorInvalidValue;
@@ -2523,6 +2549,18 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                             if (e != hipSuccess) return e;
                             return a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2, true>(w, (size_t)a.wide_width * a.dim, s)
                                              : launch_wide<10, 8, S, true, OP_I8, false, false, 2, true>(w, (size_t)a.wide_width * a.dim, s);
+                        }
+                        if (a.side_stream) {
+                            // fork: the wide-quad launch on the side stream, behind everything the call has enqueued so far
+                            hipError_t e = hipEventRecord(a.ev_fork, s);
+                            if (e == hipSuccess) e = hipStreamWaitEvent(a.side_stream, a.ev_fork, 0);
+                            if (e == hipSuccess) e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
+                            if (e == hipSuccess)
+                                e = a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, a.side_stream)
+                                              : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, a.side_stream);
+                            if (e == hipSuccess) e = hipEventRecord(a.ev_join, a.side_stream);
+                            if (e == hipSuccess) e = hipStreamWaitEvent(s, a.ev_join, 0);
+                            return e;
                         }
                         hipError_t e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
                         if (e != hipSuccess) return e;
