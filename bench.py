@@ -63,7 +63,7 @@ WORKLOADS = {
 }
 K = 10
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def log(*a):

@@ -1960,6 +1960,19 @@ bool wide_rows_nt(const pqv_searcher *s) {
     return total == 0 || static_cast<uint64_t>(lone) * 4 >= static_cast<uint64_t>(total) * 3;
 }
 
+// Wide-quad instance or regular quads only?  A list probed by 97..160 queries is read ONCE by a wide quad (32-row tiles, one
+// 8-wave block per CU, 4.7 TB/s) instead of twice by two regular quads -- uniform C3: 585 against 549 k q/s.  A list probed by
+// HUNDREDS of queries (clustered queries) is read by several quads either way; the regular ones then share its rows through one
+// XCD's L2 (PairSortArgs::xcd_items) at the regular instance's rate -- mixture: kernels 2.13 against 2.34 ms.  The previous
+// batch's shape decides (pair_scan_kernel -> pinned memory; an unsynchronised hint that never changes a result): regular only
+// when more than half of the rows in lists of > 96 pairs sit in lists of > 160.
+bool prefer_regular(const pqv_searcher *s) {
+    if (!s->h_wide_stats.p) return false;
+    const volatile uint32_t *h = s->h_wide_stats.as<uint32_t>();
+    const uint32_t multi = h[2], pop = h[3];
+    return pop > 0 && static_cast<uint64_t>(multi) * 2 > pop;
+}
+
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
 bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && (!s->d_row_of || s->images_only) && s->n > 0; }
 
@@ -2405,8 +2418,8 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // Lists that more than 96 queries of the batch probe (the long, popular ones: 36 % of C3's distinct probed
                 // rows) would be streamed twice; a quad of up to 160 queries on 32-row tiles (same accumulator registers) in
                 // one 8-wave block per CU reads them once.  Batches only (pairs >= 16 per list on average), work-item grid.
-                if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && o.item_grid >= 1 && 160ull * s->sdim <= 122880 &&
-                    pairs >= 16ull * s->n_clusters) {
+                if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && !(o.wide_quads == 1 && prefer_regular(s)) && o.item_grid >= 1 &&
+                    160ull * s->sdim <= 122880 && pairs >= 16ull * s->n_clusters) {
                     p.wide_width = 160;
                     const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 8192ull;
                     p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
@@ -2614,13 +2627,24 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             }
             if (wide && ps.item_chunk) {         // pair_scan_kernel writes the two counts straight into pinned host memory
                 if (!s->h_wide_stats.p) {
-                    HIP_TRY(s->h_wide_stats.ensure(2 * sizeof(uint32_t)));
-                    std::memset(s->h_wide_stats.p, 0, 2 * sizeof(uint32_t));
+                    HIP_TRY(s->h_wide_stats.ensure(4 * sizeof(uint32_t)));
+                    std::memset(s->h_wide_stats.p, 0, 4 * sizeof(uint32_t));
                 }
                 ps.wide_stats = s->h_wide_stats.as<uint32_t>();
             }
+            if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && ps.item_chunk && s->opt.wide_quads == 1) {
+                // the batch's shape for the NEXT batch's choice between the wide-quad instance and regular quads only (prefer_regular)
+                if (!s->h_wide_stats.p) {
+                    HIP_TRY(s->h_wide_stats.ensure(4 * sizeof(uint32_t)));
+                    std::memset(s->h_wide_stats.p, 0, 4 * sizeof(uint32_t));
+                }
+                ps.shape_stats = s->h_wide_stats.as<uint32_t>() + 2; ps.shape_wide = 160;
+            }
+            // XCD-aware slots: in the wide table always (lists of several wide quads); in the regular table where it has lists of
+            // several quads too -- no wide-quad instance, or option 3 (every table)
+            ps.xcd_items = !s->opt.xcd_items ? 0u : s->opt.xcd_items >= 3 ? 3u : wide ? 2u : 1u;
             if (wide) {
-                ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block; ps.xcd_items = s->opt.xcd_items ? 1u : 0u;
+                ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
                 ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
                 ps.wide_item_quad = sc.s_items.as<uint32_t>() + max_items; ps.wide_max_items = wide_max_items;
             }

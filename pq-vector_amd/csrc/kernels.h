@@ -207,7 +207,10 @@ struct PairSortArgs {
     uint32_t       *item_chunk;      // [max_items] row chunk of each item
     uint32_t       *wide_item_chunk; // [wide_max_items]
     uint32_t       *wide_stats;      // optional [2]: items of the wide table, and how many of them belong to lists with no other quad
-    uint32_t        xcd_items;       // wide table: a level's slots filled column by column of an 8-column layout (same list -> same XCD)
+    uint32_t       *shape_stats;     // optional [2] (pinned host memory): rows of the lists that more than shape_wide pairs of the batch
+    uint32_t        shape_wide;      // probe, and of those that more than quad_width do -- how the next batch cuts its quads
+    uint32_t        xcd_items;       // bit 0: the regular table, bit 1: the wide table -- a level's slots filled column by column of an
+                                     // 8-column layout (the quads of one list -> the same XCD, back to back)
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
     // quad_width (160) pairs wide, and a quad of >= wide_min (97) pairs is WIDE -- its items (chunks of wide_item_rows rows)
     // go to a table of their own, quads[q].w = its first item THERE; the others (<= 96 pairs: one per list at most, the

@@ -1124,9 +1124,10 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
     const uint32_t tid = threadIdx.x;
     const bool levels = a.item_rows && a.item_chunk;
     __shared__ uint32_t s_ext[2];                      // ... items beyond the last level
-    __shared__ uint32_t s_lbase[ITEM_LEVELS], s_lcnt[ITEM_LEVELS];     // wide table: first slot / slots of every level (xcd_items)
+    __shared__ uint32_t s_lbase[2 * ITEM_LEVELS], s_lcnt[2 * ITEM_LEVELS];     // first slot / slots of every level of the two tables (xcd_items)
     __shared__ uint32_t s_lone;                        // wide items of lists whose only quad is that wide one
-    if (tid == 0) s_lone = 0;
+    __shared__ uint32_t s_shape[2];                    // shape_stats
+    if (tid == 0) { s_lone = 0; s_shape[0] = 0; s_shape[1] = 0; }
     if (levels && tid < 2 * ITEM_LEVELS) s_lvl[tid] = 0;
     if (levels && tid < 2) s_ext[tid] = 0;
     if (tid == 0) { carry_pair = 0; carry_grp = 0; carry_quad = 0; carry_item = 0; carry_witem = 0; }
@@ -1145,6 +1146,12 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                 h += hv[r];
             }
             a.hist[c] = h;
+        }
+        if (a.shape_stats && c < a.n_clusters && h > a.quad_width) {
+            const uint64_t len = a.list_off[c + 1] - a.list_off[c];
+            const uint32_t l32 = len < 0x00FFFFFFull ? (uint32_t)len : 0x00FFFFFFu;
+            atomicAdd(&s_shape[1], l32);
+            if (h > a.shape_wide) atomicAdd(&s_shape[0], l32);
         }
         const uint32_t g = (h + TILE_QB - 1) / TILE_QB;
         const uint32_t qd = (h + a.quad_width - 1) / a.quad_width;
@@ -1182,6 +1189,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
         __syncthreads();
     }
     if (tid == 0) {
+        if (a.shape_stats) { a.shape_stats[0] = s_shape[0]; a.shape_stats[1] = s_shape[1]; }
         a.pair_off[a.n_clusters] = carry_pair;
         a.group_off[a.n_clusters] = carry_grp;
         a.quad_off[a.n_clusters] = carry_quad;
@@ -1248,13 +1256,13 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                         first = readlane_u32(first, 0) + incl - mine;
                         uint32_t *iq = tb ? a.wide_item_quad : a.item_quad, *ic = tb ? a.wide_item_chunk : a.item_chunk;
                         const uint32_t lim = tb ? a.wide_max_items : a.max_items;
-                        if (tb == 1 && a.xcd_items) {
+                        if (a.xcd_items & (1u << tb)) {
                             // XCD-aware slots: the quads of ONE list at the same chunk level stream the same rows, so they go to
                             // the same XCD back to back (workgroup i of a 1-D grid runs on XCD i % 8): the level's slots are
                             // filled column by column of an 8-column layout -- logical neighbours are 8 slots apart -- and the
                             // second reader of a row finds it in that XCD's L2 instead of fetching it through the fabric again
                             // (clustered queries: hundreds of pairs per popular list, 3.3 x the distinct rows fetched before)
-                            const uint32_t lb = s_lbase[lv], n_l = s_lcnt[lv];
+                            const uint32_t lb = s_lbase[tb * ITEM_LEVELS + lv], n_l = s_lcnt[tb * ITEM_LEVELS + lv];
                             const uint32_t rf = n_l >> 3, rem = n_l & 7u;
                             for (uint32_t k = 0; k < mine; ++k) {
                                 const uint32_t j = first + k - lb;
@@ -1280,7 +1288,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
                     cnt += s_lvl[tid * ITEM_LEVELS + t];
                     s_lvl[tid * ITEM_LEVELS + t] = b;
                     const uint32_t n_l = cnt + (t == LL ? s_ext[tid] : 0u);
-                    if (tid == 1) { s_lbase[t] = b; s_lcnt[t] = n_l; }
+                    s_lbase[tid * ITEM_LEVELS + t] = b; s_lcnt[tid * ITEM_LEVELS + t] = n_l;
                     b += n_l;
                 }
                 if (tid == 1 && a.wide_stats) { a.wide_stats[0] = b; a.wide_stats[1] = s_lone; }

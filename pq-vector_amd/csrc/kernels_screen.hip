@@ -2506,10 +2506,13 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
 #ifndef PQV_DEV_WIDE_TS
 #define PQV_DEV_WIDE_TS 2
 #endif
+#ifndef PQV_DEV_WIDE_NW
+#define PQV_DEV_WIDE_NW 8
+#endif
 #ifndef PQV_DEV_WIDE_NG
 #define PQV_DEV_WIDE_NG 10
 #endif
-    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<PQV_DEV_WIDE_NG, 8, 1, true, OP_I8, false, true, PQV_DEV_WIDE_TS>(a, 0, s); }
+    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<PQV_DEV_WIDE_NG, PQV_DEV_WIDE_NW, 1, true, OP_I8, false, true, PQV_DEV_WIDE_TS>(a, 0, s); }
 #else
     if (a.filter_variant == 0) {
         if ((a.dim % 64) != 0 || a.max_quads == 0 || !a.mat_blk || (a.row_of && !a.norm_by_pos) || !a.cand_keys) return hipErrorInvalidValue;
