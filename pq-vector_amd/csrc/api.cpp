@@ -3226,8 +3226,10 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "quad_width") o.quad_width = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "pair_prune") o.pair_prune = value != 0;
-    else if (n == "wide_quads") o.wide_quads = value != 0;
+    else if (n == "wide_quads") o.wide_quads = value <= 0 ? 0 : value >= 2 ? 2 : 1;       // 1: by the previous batch's shape; 2: always
     else if (n == "fork_wide") o.fork_wide = value != 0;
+    else if (n == "drain_min") o.drain_min = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(64, value)));
+    else if (n == "xcd_items") o.xcd_items = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(3, value)));
     else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "i8_form") {        // takes effect when the int8 copy is (re)built
         o.i8_form = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));

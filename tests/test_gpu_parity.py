@@ -1500,6 +1500,75 @@ def test_wide_quads_stream_popular_lists_once(pqv, oracle, dim, k, wide_rows):
     assert abs(screened[1] - screened[0]) <= 0.02 * screened[0], screened
 
 
+@pytest.mark.parametrize("opts", [{"wide_quads": 2}, {"wide_quads": 0, "xcd_items": 1}, {"wide_quads": 0, "xcd_items": 0}, {"xcd_items": 3},
+                                  {"xcd_items": 0}, {"fork_wide": 1}, {"drain_min": 8}, {"fork_wide": 1, "drain_min": 16, "xcd_items": 3}])
+def test_round5_quad_scheduling_options_never_change_a_result(pqv, oracle, opts):
+    """Round 5: how a batch's quads are cut and placed -- wide-quad instance or regular quads only, a level's work items filled
+    column by column so that the quads of one list run back to back on one XCD, the wide-quad launch forked onto a side stream,
+    exact evaluations started before a wave's queue is full -- is scheduling: ids, distance bits and counters must equal the
+    oracle's under every combination, on a batch with lists of 0..96, 97..160, 161..320 and > 320 pairs."""
+    rng = np.random.default_rng(1234)
+    dim, k, kc, nprobe, nq = 256, 10, 9, 3, 700
+    sizes = [4001, 2977, 1500, 833, 700, 650, 517, 300, 45]
+    cen = (rng.standard_normal((kc, dim)) * 2.0).astype(np.float32)
+    data = np.concatenate([cen[c] + 0.3 * rng.standard_normal((m, dim)).astype(np.float32) for c, m in enumerate(sizes)])
+    data = np.ascontiguousarray(data[rng.permutation(len(data))].astype(np.float32))
+    pop = np.array([0.45, 0.2, 0.12, 0.08, 0.06, 0.04, 0.03, 0.015, 0.005])
+    queries = (cen[rng.choice(kc, size=nq, p=pop)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=10)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    corpus = pqv.Corpus.upload(data)
+    orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+    s = pqv.Searcher(index, corpus)
+    s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2); s.set_option("wide_rows", 512); s.set_option("wide_quad_rows", 512)
+    for name, value in opts.items():
+        s.set_option(name, value)
+    d = s.describe(nq, k, nprobe)
+    assert "int8 screen operands" in d and ("lists probed by 97..160 queries" in d) == (opts.get("wide_quads", 1) != 0), d
+    for _ in range(2):
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        assert (_bits(dist) == _bits(odist)).all(), opts
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+
+
+def test_quads_follow_the_previous_batch_shape(pqv, oracle):
+    """Round 5: with the default `wide_quads` = 1 the NEXT batch takes regular quads only once a batch has shown that most rows of
+    its popular lists (> 96 pairs) sit in lists of > 160 pairs (several quads either way: they share the rows through one XCD's
+    L2), and goes back when a batch shows the opposite.  The hint is read without synchronisation and never changes a result."""
+    import torch
+    rng = np.random.default_rng(4321)
+    dim, k, kc, nprobe = 256, 10, 8, 2
+    sizes = [3000, 2500, 2000, 1500, 900, 700, 500, 300]
+    cen = (rng.standard_normal((kc, dim)) * 2.0).astype(np.float32)
+    data = np.concatenate([cen[c] + 0.3 * rng.standard_normal((m, dim)).astype(np.float32) for c, m in enumerate(sizes)])
+    data = np.ascontiguousarray(data[rng.permutation(len(data))].astype(np.float32))
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=10)
+    index = pqv.Index.from_bytes(oidx.to_bytes())
+    corpus = pqv.Corpus.upload(data)
+    s = pqv.Searcher(index, corpus)
+    s.set_option("rerank_mode", 2); s.set_option("tile_filter", 2)
+    # batch A: 1200 queries piled on two centres -> lists of several hundred pairs each; batch B: 8 x 130 queries -> 97..160 pairs per list
+    qa = (cen[rng.choice(2, size=1200)] + 0.4 * rng.standard_normal((1200, dim))).astype(np.float32)
+    qb = (cen[np.repeat(np.arange(kc), 40)] + 0.05 * rng.standard_normal((kc * 40, dim))).astype(np.float32)
+    lens = np.diff(index.list_offsets.astype(np.int64))
+
+    def regular_next(queries):          # the rule of prefer_regular (api.cpp) on this batch's pairs per list
+        per = np.bincount(np.concatenate([np.asarray(oidx.find_closest_centroids(q, nprobe)) for q in queries]), minlength=kc)
+        multi, pop = int(lens[per > 160].sum()), int(lens[per > 96].sum())
+        return pop > 0 and 2 * multi > pop
+    assert regular_next(qa) and not regular_next(qb)
+    for queries in (qa, qb, qa):
+        nq = len(queries)
+        want_wide_next = not regular_next(queries)
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all() and (_bits(dist) == _bits(odist)).all()
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+        torch.cuda.synchronize()
+        assert ("lists probed by 97..160 queries" in s.describe(nq, k, nprobe)) == want_wide_next, (nq, s.describe(nq, k, nprobe))
+
+
 @pytest.mark.parametrize("case", ["levels", "clusters"])
 def test_chunk_major_work_items(pqv, oracle, case):
     """Round 3: the filter kernel's work items are numbered chunk-major (row chunk 0 of every quad first) by pair_scan_kernel.
