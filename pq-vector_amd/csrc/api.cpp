@@ -1965,12 +1965,14 @@ bool wide_rows_nt(const pqv_searcher *s) {
 // HUNDREDS of queries (clustered queries) is read by several quads either way; the regular ones then share its rows through one
 // XCD's L2 (PairSortArgs::xcd_items) at the regular instance's rate -- mixture: kernels 2.13 against 2.34 ms.  The previous
 // batch's shape decides (pair_scan_kernel -> pinned memory; an unsynchronised hint that never changes a result): regular only
-// when more than half of the rows in lists of > 96 pairs sit in lists of > 160.
+// when more than half of the rows in lists of > 96 pairs sit in lists of > 160 (and such lists hold >= 1 / 32 of the corpus).
 bool prefer_regular(const pqv_searcher *s) {
     if (!s->h_wide_stats.p) return false;
     const volatile uint32_t *h = s->h_wide_stats.as<uint32_t>();
     const uint32_t multi = h[2], pop = h[3];
-    return pop > 0 && static_cast<uint64_t>(multi) * 2 > pop;
+    // (... and those popular lists are a real part of the corpus -- 1 / 32 of its rows: a uniform batch on short lists has a
+    //  handful of them, and their split says nothing about the query load)
+    return static_cast<uint64_t>(pop) * 32 >= s->n && static_cast<uint64_t>(multi) * 2 > pop;
 }
 
 // the wide screened kernels need IVF-ordered rows of a multiple of 64 dims
@@ -2285,6 +2287,11 @@ static bool defer_on(const pqv_searcher *s, uint32_t nq, uint32_t k, const TopkP
     if (k > 64) return true;                    // (the kernels carry the deferred form in their k > 64 instances ...)
     const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
     // (... and in the DEFP instances of the int8 two-blocks-per-CU form: launch_filter_s)
+    // (round 5, 768-dim rows, q/s deferred against in-filter on the final kernels -- uniform: 488-row lists 2.14 / 1.68 M, 976: 2.03 /
+    //  1.72 M, 2441: 1.45 / 1.27 M; Gaussian mixture: 488: 2.25 / 2.30 M, 976: 1.87 / 1.78 M, 2441: 1.14 / 1.22 M -- on clustered
+    //  query loads the upper-bound counting loosens the running thresholds and the gain is gone from ~1500-row lists on: there the
+    //  previous batch's shape (prefer_regular: most popular lists probed by hundreds of queries) switches the form off)
+    if (s->opt.defer != 2 && mean_len > 1536 && prefer_regular(s)) return false;
     return nq >= 8 && p.i8 && p.block_waves == 4 && p.quad_width == 96 && s->sdim >= 512 && (s->opt.defer == 2 || mean_len <= 3072);
 }
 static bool seed_refine_on(const pqv_searcher *s, uint32_t nq, uint32_t k) {
@@ -2775,7 +2782,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                         HIP_TRY(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming));
                         HIP_TRY(hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming));
                     }
-                    ta.side_stream = sc.side; ta.ev_fork = sc.ev_fork; ta.ev_join = sc.ev_join;
+                    ta.side_stream = sc.side; ta.ev_fork = sc.ev_fork; ta.ev_join = sc.ev_join; ta.fork_wide_first = s->opt.fork_wide >= 2 ? 1u : 0u;
                 }
                 s->counters.kernel_launches += 1;
             }
@@ -3227,7 +3234,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "min_blocks") o.min_blocks = static_cast<uint32_t>(std::max<int64_t>(0, value));
     else if (n == "pair_prune") o.pair_prune = value != 0;
     else if (n == "wide_quads") o.wide_quads = value <= 0 ? 0 : value >= 2 ? 2 : 1;       // 1: by the previous batch's shape; 2: always
-    else if (n == "fork_wide") o.fork_wide = value != 0;
+    else if (n == "fork_wide") o.fork_wide = value <= 0 ? 0 : value >= 2 ? 2 : 1;
     else if (n == "drain_min") o.drain_min = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(64, value)));
     else if (n == "xcd_items") o.xcd_items = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(3, value)));
     else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));

@@ -321,6 +321,7 @@ struct TileArgs {
     uint32_t        drain_min;       // wide_filter_kernel: queue entries that start a batch of exact evaluations before the wave's last tile (0 = 64)
     hipStream_t     side_stream;
     hipEvent_t      ev_fork, ev_join;
+    uint32_t        fork_wide_first; // the wide-quad launch is enqueued first, on the call's stream; the regular one on the side stream
     const uint32_t *wide_n_items;
     uint32_t        wide_max_items, wide_rows_per_block;
     // wide_filter_kernel: per-query append buffers of exact-verified candidates

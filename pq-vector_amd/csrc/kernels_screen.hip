@@ -2557,10 +2557,14 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                             // fork: the wide-quad launch on the side stream, behind everything the call has enqueued so far
                             hipError_t e = hipEventRecord(a.ev_fork, s);
                             if (e == hipSuccess) e = hipStreamWaitEvent(a.side_stream, a.ev_fork, 0);
-                            if (e == hipSuccess) e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
-                            if (e == hipSuccess)
-                                e = a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, a.side_stream)
-                                              : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, a.side_stream);
+                            hipStream_t s_reg = a.fork_wide_first ? a.side_stream : s, s_wide = a.fork_wide_first ? s : a.side_stream;
+                            if (e == hipSuccess && a.fork_wide_first)
+                                e = a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, s_wide)
+                                              : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s_wide);
+                            if (e == hipSuccess) e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s_reg);
+                            if (e == hipSuccess && !a.fork_wide_first)
+                                e = a.wide_nt ? launch_wide<10, 8, S, true, OP_I8, false, true, 2>(w, (size_t)a.wide_width * a.dim, s_wide)
+                                              : launch_wide<10, 8, S, true, OP_I8, false, false, 2>(w, (size_t)a.wide_width * a.dim, s_wide);
                             if (e == hipSuccess) e = hipEventRecord(a.ev_join, a.side_stream);
                             if (e == hipSuccess) e = hipStreamWaitEvent(s, a.ev_join, 0);
                             return e;
