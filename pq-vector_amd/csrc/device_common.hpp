@@ -115,6 +115,9 @@ __device__ __forceinline__ uint32_t buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t l
 #ifndef PQV_XTC
 #define PQV_XTC 0              // 64-row-tile int8 instances: the next tile's operand stages go out FIRST after a K loop, the fresh thresholds
 #endif                         // and the next tile's row terms behind them -- nothing is waited for between two K loops (thresholds one tile old)
+#ifndef PQV_EVAL_NB
+#define PQV_EVAL_NB 16         // ... in the regular int8 instance (8: C3 kernels + 0.8 %, mixture + 2.4 %; its accumulators are dead there too)
+#endif
 #ifndef PQV_EVAL_NB_TS2
 #define PQV_EVAL_NB_TS2 16     // row chunks in flight per lane in the wide-quad instance's exact evaluations
 #endif

@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
         // sum is bit-identical.  The pair's first lane carries on with the result.
         // (32-row tiles: 16 row chunks in flight per lane -- its batches are larger (a lane per pair: 12 round trips per
         //  768-dim row instead of 24), and the accumulators, dead here, leave the registers)
-        constexpr int NB = TS == 2 ? PQV_EVAL_NB_TS2 : 8;
+        constexpr int NB = TS == 2 ? PQV_EVAL_NB_TS2 : (I8 && NW == 4 && NG == 6) ? PQV_EVAL_NB : 8;
         uint32_t lg = 0;
         while (lg < 3 && (count << (lg + 1)) <= 64u && (Gx % ((2u * NB) << lg)) == 0u) ++lg;      // wave-uniform
         const uint32_t L = 1u << lg;
