@@ -224,6 +224,17 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *                   thresholds have seen a piece of each of its lists before the bulk is screened; 0 = list by list
  *   "probe_rows"    batched centroid probe (a lane per centroid): 1 for batches of >= 8 queries (default), 2 always,
  *                   0 = the per-query stream over the centroid table
+ *   "wide_quads"    int8 path, batches: lists probed by 97..160 queries in ONE quad of the wide-quad instance (32-row tiles, one
+ *                   8-wave block per CU) instead of two regular quads.  1 (default): by the PREVIOUS batch's shape -- regular quads
+ *                   only while most rows of the popular lists sit in lists of > 160 pairs (clustered query loads); 2 always; 0 never
+ *   "wide_quad_rows" rows per block of that instance (0 by rule: 8192)
+ *   "xcd_items"     a level's work items are filled column by column of an 8-column layout, so that the quads of one list run
+ *                   back to back on one XCD and share its rows through that L2: 1 (default) = in the table that has several
+ *                   quads per list, 3 = in both tables, 0 = off
+ *   "fork_wide"     the wide-quad launch on a side stream of the call's lane: 0 off (default), 1 regular instance first, 2 wide first
+ *   "pf96"          f16 96-query form on rows of <= 128 dims: all of the next tile's operands are requested behind the current tile's
+ *                   MFMAs (1 = for lists of <= 2048 rows on average (default), 2 always, 0 never)
+ *   "drain_min"     queued survivors that start a batch of exact evaluations before a wave's last tile (0 = 64)
  * The same names, upper-cased with a PQV_ prefix, are read from the environment ONCE when a searcher is created
  * (profiling scripts). */
 int pqv_searcher_set_option(pqv_searcher *searcher, const char *name, int64_t value);

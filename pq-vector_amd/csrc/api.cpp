@@ -302,6 +302,7 @@ struct pqv_searcher {
         int pair_prune = 1;                // int8 path: drop (query, list) pairs whose centre-distance bound exceeds the query's threshold
         int i8_form = 0;                   // int8 images: 0 by rule (per-list residual where the lists are tight), 1 one centre, 2 residual
         int xcd_items = 1;                 // PairSortArgs::xcd_items (PQV_XCD_ITEMS)
+        int pf96 = 1;                      // TileArgs::opt_pf96 (PQV_PF96)
         int drain_min = 0;                 // TileArgs::drain_min (PQV_DRAIN_MIN)
         int fork_wide = 0;                 // the wide-quad launch on the lane's side stream, beside the regular instance (PQV_FORK_WIDE)
         int wide_quads = 1;                // int8, 96-query quads: lists probed by 97..160 queries of the batch take ONE 160-query quad
@@ -1944,6 +1945,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.wide_quads = static_cast<int>(num("PQV_WIDE_QUADS", o.wide_quads));
     o.fork_wide = static_cast<int>(num("PQV_FORK_WIDE", o.fork_wide));
     o.drain_min = static_cast<int>(num("PQV_DRAIN_MIN", o.drain_min));
+    o.pf96 = static_cast<int>(num("PQV_PF96", o.pf96));
     o.xcd_items = static_cast<int>(num("PQV_XCD_ITEMS", o.xcd_items));
     o.wide_quad_rows = static_cast<uint32_t>(num("PQV_WIDE_QUAD_ROWS", o.wide_quad_rows));
     o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
@@ -2771,7 +2773,8 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             ta.rows_per_block = p.filter_rows_per_block; ta.filter_variant = 0;
             ta.part_flags = sc.s_part_flags.as<uint8_t>();
             if (items) { ta.item_quad = ps.item_quad; ta.item_chunk = ps.item_chunk; ta.wide_item_chunk = ps.wide_item_chunk; ta.n_items = ps.n_items; ta.max_items = max_items; }
-            ta.drain_min = static_cast<uint32_t>(std::max(0, s->opt.drain_min));
+            ta.drain_min = static_cast<uint32_t>(std::max(0, s->opt.drain_min)); // (whole-tile prefetch in the 96-query f16 form: 1000-row lists of 128 dims 5.96 -> 6.14 M q/s, C2's 10 k-row lists 7.68 -> 7.14 M)
+            ta.opt_pf96 = (s->opt.pf96 >= 2 || (s->opt.pf96 == 1 && s->n / std::max<uint32_t>(1, s->n_clusters) <= 2048)) ? 1u : 0u;
             if (wide) {
                 ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
                 ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
@@ -3235,6 +3238,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "pair_prune") o.pair_prune = value != 0;
     else if (n == "wide_quads") o.wide_quads = value <= 0 ? 0 : value >= 2 ? 2 : 1;       // 1: by the previous batch's shape; 2: always
     else if (n == "fork_wide") o.fork_wide = value <= 0 ? 0 : value >= 2 ? 2 : 1;
+    else if (n == "pf96") o.pf96 = value <= 0 ? 0 : value >= 2 ? 2 : 1;
     else if (n == "drain_min") o.drain_min = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(64, value)));
     else if (n == "xcd_items") o.xcd_items = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(3, value)));
     else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));

@@ -318,6 +318,7 @@ struct TileArgs {
     // host side only (launch_tile_filter): run the wide-quad instance on `side_stream`, forked from and joined to the call's stream
     // by the two events, so that the two instances' tails fill each other (they cannot share a CU -- 2 x 81 KB against 142 KB
     // of LDS -- but they can share the chip); NULL: one after the other on the call's stream
+    uint32_t        opt_pf96;        // f16 96-query form on rows of <= 128 dims: whole-tile operand prefetch (PQV_PF96)
     uint32_t        drain_min;       // wide_filter_kernel: queue entries that start a batch of exact evaluations before the wave's last tile (0 = 64)
     hipStream_t     side_stream;
     hipEvent_t      ev_fork, ev_join;

@@ -2512,6 +2512,9 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
 #ifndef PQV_DEV_WIDE_NG
 #define PQV_DEV_WIDE_NG 10
 #endif
+#ifdef PQV_DEV_C2
+    if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_F16, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<6, 4, 1, true, OP_F16, false>(a, 0, s); }
+#endif
     if (a.dim) { hipError_t e = launch_wide<6, 4, 1, true, OP_I8, false, true>(a, 0, s); return e != hipSuccess ? e : launch_wide<PQV_DEV_WIDE_NG, PQV_DEV_WIDE_NW, 1, true, OP_I8, false, true, PQV_DEV_WIDE_TS>(a, 0, s); }
 #else
     if (a.filter_variant == 0) {
@@ -2600,6 +2603,8 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                 if (a.quad_width == 64) return launch_wide<4, 8, S, true, OP_F16>(b, lds, s);
                 return hipErrorInvalidValue;
             }
+            // (rows of <= 128 dims, k <= 64: the whole-tile operand prefetch in the 96-query form too -- 233 registers, no scratch since round 5)
+            if constexpr (S == 1) { if (a.quad_width == 96 && lds <= 73728 && pf && a.opt_pf96) return launch_wide<6, 4, S, true, OP_F16, true>(b, lds, s); }
             if (a.quad_width == 96 && lds <= 73728) return launch_wide<6, 4, S, true, OP_F16>(b, lds, s);     // 80 KB per block: two per CU
             if (lds > 65536) return hipErrorInvalidValue;           // + 10 KB of static LDS: two blocks per CU
             if (a.quad_width == 64 && pf) return launch_wide<4, 4, S, true, OP_F16, true>(b, lds, s);
