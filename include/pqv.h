@@ -284,7 +284,8 @@ int pqv_topk(const pqv_searcher *searcher, const float *queries, uint32_t nq,
  * work is enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = the searcher's
  * own NON-BLOCKING stream -- NOT HIP's legacy default stream, whose handle is also 0: a caller
  * whose next operation runs on the default stream (torch.cuda.current_stream() outside a stream
- * context) must pass an explicit stream or synchronise) and the call returns without
+ * context) must pass an explicit stream -- hipStreamLegacy, ((hipStream_t)1), names the default stream itself -- or
+ * synchronise) and the call returns without
  * synchronising.  d_n_found / d_n_candidates may be NULL.  This is what bench.py times. */
 int pqv_topk_device(const pqv_searcher *searcher, const void *d_queries, uint32_t nq,
                     uint32_t k, uint32_t nprobe, uint64_t max_candidates, int metric,

@@ -444,7 +444,8 @@ class Searcher:
                     max_candidates=0, metric=_ffi.PQV_L2SQ_REF4, sqrt_out=True, stream=0, d_tie_flags=0):
         """Device-pointer form (ints from tensor.data_ptr()); asynchronous on `stream` -- a hipStream_t handle; 0 means the
         searcher's OWN non-blocking stream, not HIP's / torch's default stream (whose handle is 0 too): work that must follow
-        the call on the default stream is NOT ordered behind it, so pass an explicit stream.  d_tie_flags (u32 [nq]):
+        the call on the default stream is NOT ordered behind it, so pass an explicit stream (1 = hipStreamLegacy names the default
+        stream itself).  d_tie_flags (u32 [nq]):
         also flag the queries whose answer depends on the reference's heap history (re-submit those to topk())."""
         if d_tie_flags:
             _check(_ffi.lib().pqv_topk_device_flags(self._h, vp(d_queries), nq, k, nprobe, max_candidates, metric,

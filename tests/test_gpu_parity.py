@@ -1303,6 +1303,36 @@ def test_dims_without_an_mfma_tiling_are_screened_on_zero_padded_rows(pqv, oracl
     assert np.array_equal(got, data[[5, 17]])
 
 
+def test_topk_device_is_ordered_on_the_stream_it_is_given(pqv, oracle):
+    """include/pqv.h: `hip_stream` NULL is the searcher's OWN non-blocking stream -- not the default stream, whose handle is 0 too.
+    A consumer that must follow the call WITHOUT a synchronise passes the stream it runs on: an explicit one, or hipStreamLegacy
+    (handle 1) for the default stream.  Each of the two: the search, then a dependent copy on that stream into buffers preset with
+    garbage, with only a final device synchronise -- the copies must hold the oracle's answer (round 5: bench.py's lane 0 passed
+    handle 0 and its exchange ran unordered behind the search)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    n, dim, kc, nprobe, nq, k = 200_000, 128, 64, 16, 512, 10
+    data = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    oidx = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=4)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    orows, odist, onf, _ = oidx.topk_batch(data, queries, k, nprobe)
+    q_t = torch.from_numpy(queries).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    for stream_obj, handle in ((side, side.cuda_stream), (torch.cuda.default_stream(dev), 1)):
+        r_t = torch.full((nq, k), -7, dtype=torch.int32, device=dev)
+        d_t = torch.full((nq, k), -7.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream_obj):
+            for _ in range(3):                      # (a few calls back to back: the copy must wait for the LAST one's kernels)
+                s.topk_device(q_t.data_ptr(), nq, k, nprobe, r_t.data_ptr(), d_t.data_ptr(), stream=handle)
+            r_c, d_c = r_t.clone(), d_t.clone()
+        torch.cuda.synchronize()
+        assert (r_c.cpu().numpy().view(np.uint32) == orows).all(), handle
+        assert (_bits(d_c.cpu().numpy()) == _bits(odist)).all(), handle
+
+
 def test_topk_device_flags_mark_every_query_that_needs_the_heap_replay(pqv, oracle):
     """pqv_topk_device_flags: the asynchronous device path + a per-query tie flag.  On tie-heavy data (a coarse grid,
     hundreds of equal distances) and on float data: every UNFLAGGED query must equal the reference position by
