@@ -665,12 +665,15 @@ def build_record(n, dim, kc, build_s):
     2 n k_c dim flops in GEMM form against the f32 MFMA peak (the screen runs on v_mfma_f32_16x16x4_f32)."""
     import ctypes as C
     from pq_vector_amd import _ffi
-    st = (C.c_double * 8)()
-    _ffi.lib().pqv_index_build_stats(st, 8)
-    kpp, lloyd, iters, fa, host, fa_screen, lloyd_screen, sample = list(st)
+    st = (C.c_double * 10)()
+    _ffi.lib().pqv_index_build_stats(st, 10)
+    kpp, lloyd, iters, fa, host, fa_screen, lloyd_screen, sample, aw_s, aw_n = list(st)
     flops = 2.0 * n * kc * dim
-    tf = flops / fa / 1e12 if fa > 0 else 0.0
+    tf_phase = flops / fa / 1e12 if fa > 0 else 0.0
     gemm = fa_screen >= 2
+    # the contraction kernel's own time (HIP events around every assign_wide_kernel launch of the final assignment) where the
+    # f16 form ran; else the phase's wall time
+    tf = flops / aw_s / 1e12 if (gemm and aw_s > 0) else tf_phase
     peak = 2500.0 if gemm else 157.3
     return {"seconds": build_s, "vectors_per_s": n / build_s,
             "phases_s": {"kmeans_pp": kpp, "lloyd": lloyd, "lloyd_iterations": int(iters), "final_assignment": fa,
@@ -681,11 +684,13 @@ def build_record(n, dim, kc, build_s):
                                    "final assignment: wide_seed_kernel + seed_select_kernel + wide_filter_kernel<f32 operands> + merge_kernel"
                                    if fa_screen else "final assignment: assign_kernel (exact-order VALU)",
                          "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                         "frac_of_f32_mfma_peak": tf / 157.3,
+                         "kernel_s": aw_s if gemm else None, "kernel_launches": int(aw_n) if gemm else None,
+                         "whole_phase": {"achieved": tf_phase, "frac": tf_phase / peak, "seconds": fa},
                          "algo_flops": flops,
-                         "note": "2 n k_c dim flops / the wall time of the whole final-assignment phase (images, contraction, exact "
-                                 "re-scoring of the candidates, download of the assignment): a lower bound for the contraction kernel; "
-                                 "peak = dense f16 MFMA for the f16 contraction, f32 MFMA for the f32 screen"}}
+                         "note": "2 n k_c dim flops / the summed HIP-event time of the assign_wide_kernel launches of the final assignment "
+                                 "(`kernel_s`); `whole_phase` divides by the phase's wall time instead (images, contraction, exact "
+                                 "re-scoring of the candidates, download of the assignment); peak = dense f16 MFMA for the f16 contraction, "
+                                 "f32 MFMA for the f32 screen"}}
 
 
 def self_launch(n):
@@ -1166,6 +1171,7 @@ def main():
         nc1 = torch.empty((1,), dtype=torch.int64, device=dev)
         st0 = lane_streams[0].cuda_stream
         lat = []
+        cand1 = []           # candidate rows of every timed one-query call (its min_bytes)
         # diagnostic build only (make -C pq-vector_amd/csrc stamps; PQV_LIB_PATH): device wall-clock stamps inside the kernels
         import ctypes
         from pq_vector_amd import _ffi
@@ -1181,6 +1187,7 @@ def main():
                                  nf1.data_ptr(), nc1.data_ptr(), stream=st0)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
+            cand1.append(int(nc1.item()))
             if stamps_fn is not None:
                 buf = (ctypes.c_ulonglong * 64)()
                 stamps_fn(buf, 0)
@@ -1207,6 +1214,15 @@ def main():
                                   "host_api_p50_us": float(np.percentile(hlat, 50)), "host_api_p99_us": float(np.percentile(hlat, 99)),
                                   "note": "one query per call, host-synchronised after each; p50_us: device pointers in and out "
                                           "(pqv_topk_device + a device synchronise), host_api: pqv_topk with host arrays (copies included)"}
+        # roofline of the CALL (not of a kernel): the operand image + 8 bytes of every candidate row of the query, once, over the
+        # whole call's p50 -- probe, seed, screen, merge and the launch boundaries between them included
+        sq_plan = result["single_query"]["dispatch"]
+        sq_opb = 1 if "int8 screen operands" in sq_plan else 2 if "f16 screen operands" in sq_plan else 4
+        sq_bytes = float(np.mean(cand1[5:])) * (sq_opb * dim + 8) if "wide_filter_kernel" in sq_plan else float(np.mean(cand1[5:])) * (4 * dim + 4)
+        sq_p50 = result["single_query"]["p50_us"] * 1e-6
+        result["single_query"]["roofline"] = {"bound": "hbm", "min_bytes": sq_bytes, "achieved": sq_bytes / sq_p50 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": sq_bytes / sq_p50 / 1e9 / HBM_PEAK_GBS,
+                                              "basis": "candidate rows of the query x (operand image bytes per row + 8) / p50 of the whole call"}
     # ---- recall of the IVF answers against an exact brute force (benches/query.rs prints it too) --------
     if args.recall and rank == 0 and world == 1:
         m = min(args.recall, nq)

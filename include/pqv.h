@@ -153,7 +153,8 @@ int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_
 /* Phase wall times of the calling thread's last pqv_index_build / pqv_index_build_host / pqv_kmeans (bench records):
  * out[0] k-means++ seconds, [1] Lloyd seconds, [2] Lloyd iterations run, [3] final assignment seconds (device work +
  * download), [4] host inverted-list build seconds, [5] 1 if the final assignment ran through the MFMA screen, [6] same for
- * the Lloyd assignments, [7] sample rows; entries beyond n are not written. */
+ * the Lloyd assignments, [7] sample rows, [8] summed HIP-event seconds of the assign_wide_kernel launches of the final
+ * assignment (0 where another form ran), [9] their count; entries beyond n are not written. */
 int pqv_index_build_stats(double *out, uint32_t n);
 /* Host-pointer form with the reference's exact argument shape: uploads, builds, frees. */
 int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,

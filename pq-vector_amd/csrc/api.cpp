@@ -118,7 +118,7 @@ struct PinnedBuf {
 };
 
 // phase wall times of this thread's last index build (pqv_index_build_stats)
-thread_local double g_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_build_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // [8]: assign_wide_kernel seconds of the final assignment (HIP events), [9]: its launches
 
 // PQV_VERBOSE=1: phase timings of the build on stderr
 bool verbose() {
@@ -1372,7 +1372,16 @@ struct GemmAssign {
                 // running sum one per group (index.rs:461-480; all terms non-negative) -- (dim / 4 + 6) 2^-24, taken twice over
                 w.cm = static_cast<float>(dim / 4 + 16) * 1.1920928955078125e-07f;
                 w.cand = cand.as<uint32_t>(); w.cand_t = cand_t.as<float>(); w.cand_cnt = cnt.as<uint32_t>(); w.best_t = best_t.as<float>(); w.cap = cap;
+                // (the final assignment brackets the contraction kernel with HIP events -- time_kernels: the roofline of bench.py's
+                //  index_build record divides by KERNEL time, not by the phase's wall time)
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (time_kernels) {
+                    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+                    kernel_ev.push_back(e0); kernel_ev.push_back(e1);
+                    HIP_TRY(hipEventRecord(e0, stream));
+                }
                 HIP_TRY(launch_assign_wide(w, stream));
+                if (time_kernels) HIP_TRY(hipEventRecord(e1, stream));
                 // (the two counters are same-address atomics from every wave: diagnostic runs only)
                 HIP_TRY(launch_assign_resolve(w, rows, d_centroids, dim, d_cluster + r0, verbose() ? rstats.as<unsigned long long>() : nullptr, stream));
             } else {
@@ -1415,9 +1424,21 @@ struct GemmAssign {
                                          hs[0] ? static_cast<double>(hs[1]) / static_cast<double>(hs[0]) : 0.0);
         }
         HIP_TRY(hipStreamSynchronize(stream));
+        if (!kernel_ev.empty()) {
+            double ms_sum = 0.0;
+            for (size_t i = 0; i + 1 < kernel_ev.size(); i += 2) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, kernel_ev[i], kernel_ev[i + 1]) == hipSuccess) ms_sum += ms;
+            }
+            g_build_stats[8] = ms_sum * 1e-3; g_build_stats[9] = static_cast<double>(kernel_ev.size() / 2);
+            for (hipEvent_t e : kernel_ev) (void)hipEventDestroy(e);
+            kernel_ev.clear();
+        }
         *fallback = h != 0;
         return PQV_OK;
     }
+    std::vector<hipEvent_t> kernel_ev;
+    bool time_kernels = false;
 };
 
 // acc[c] = ((0 + m[0][c]) + m[1][c]) + ... + m[rows - 1][c] for c in [0, width), width a multiple of 16: `width` independent f32
@@ -1661,7 +1682,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     d_min.release(); d_init_own.release(); d_idx.release(); d_kimg.release(); d_kn2i.release(); d_kres.release(); d_kaux.release(); d_kmm.release();
     HIP_TRY(hipStreamSynchronize(stream));
     const double t_pp1 = now_s();
-    g_build_stats[0] = t_pp1 - t_pp0;
+    g_build_stats[0] = t_pp1 - t_pp0; g_build_stats[8] = 0.0; g_build_stats[9] = 0.0;
     if (verbose()) std::fprintf(stderr, "[pqv] k-means++: %u rounds over %llu rows in %.3f s\n", k,
                                 (unsigned long long)init_n, t_pp1 - t_pp0);
 
@@ -1797,6 +1818,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         if (!bad_c) {
             // (chunk-wise downloads behind the next chunk's kernels were measured and dropped: a device-to-pageable copy on a
             //  second stream stalls the compute stream's queue -- 53 ms for the loop against 34 ms of kernels on C3)
+            gemm.time_kernels = true;
             if (int rc = gemm.run(corpus->d_rows, n, d_cluster.as<uint32_t>(), stream, &bad_r, nullptr)) return rc;
             exact_assign = bad_r;
             downloaded = false;
@@ -1863,7 +1885,7 @@ extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, ui
 
 extern "C" int pqv_index_build_stats(double *out, uint32_t n) {
     if (!out) return fail(PQV_ERR_INVALID, "out must not be NULL");
-    for (uint32_t i = 0; i < n; ++i) out[i] = i < 8 ? g_build_stats[i] : 0.0;
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 10 ? g_build_stats[i] : 0.0;
     return PQV_OK;
 }
 
