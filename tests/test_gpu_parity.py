@@ -575,6 +575,40 @@ def test_page_runs_from_the_mapped_file_and_what_they_refuse(pqv, tmp_path, valu
             parquet_io.load_embedding_column(bad, "emb")
 
 
+def test_loader_reports_the_first_error_in_file_order(pqv, tmp_path):
+    """The reference walks the batches in file order and returns the FIRST error in that order (parquet.rs:231-280).  The threaded
+    Arrow fallback (one reader per row group) must too: a null row in row group 1 and ragged lists in row groups 3 and 5 -- whichever
+    thread fails first in TIME, the message is row group 1's, every time; with the defects swapped, the other one.  A shard that
+    starts behind the first defect (row_groups=(2, 6)) reports ITS first one."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from pq_vector_amd import parquet_io
+    rng = np.random.default_rng(9)
+    dim, per = 24, 3000
+    base = rng.standard_normal((6 * per, dim)).astype(np.float32).tolist()
+
+    def write(name, defects):
+        rows = list(base)
+        for rg, kind in defects.items():
+            rows[rg * per + 17] = None if kind == "null" else rows[rg * per + 17][:-1]
+        path = str(tmp_path / name)
+        pq.write_table(pa.table({"emb": pa.array(rows, type=pa.list_(pa.float32()))}), path, compression="NONE", use_dictionary=False,
+                       row_group_size=per)
+        return path
+    a = write("a.parquet", {1: "null", 3: "ragged", 5: "ragged"})
+    b = write("b.parquet", {1: "ragged", 3: "null", 5: "null"})
+    for _ in range(4):
+        with pytest.raises(pqv.PqvError, match="contains null rows"):
+            parquet_io.load_embedding_column(a, "emb", readers=6)
+        with pytest.raises(pqv.PqvError, match="inconsistent dimensions"):
+            parquet_io.load_embedding_column(b, "emb", readers=6)
+    with pytest.raises(pqv.PqvError, match="inconsistent dimensions"):
+        parquet_io.load_embedding_column(a, "emb", readers=4, row_groups=(2, 6))
+    ok = parquet_io.load_embedding_column(a, "emb", row_groups=(2, 3))          # a clean row group of the same file loads
+    assert ok.rows == per and np.array_equal(ok.fetch_rows(np.array([0, per - 1], np.uint32)), np.array([base[2 * per], base[3 * per - 1]], np.float32))
+    ok.close()
+
+
 @pytest.mark.parametrize("value_type,list_kind", [("f32", "list"), ("f64", "list"), ("f32", "fixed")])
 def test_streamed_parquet_loader_places_every_row_group(pqv, tmp_path, value_type, list_kind):
     """N1 (src/ivf/parquet.rs:216-305): row groups of unequal sizes decoded by several reader threads, every batch uploaded
