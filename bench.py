@@ -62,6 +62,11 @@ WORKLOADS = {
     "tiny": (20_000, 64, 16, 4, 64),       # plumbing check
 }
 K = 10
+# Stream lanes the steps alternate between (--streams): the library keeps one scratch set per stream (four of them), so step i + 1's
+# probe / bucketing / seed kernels and the head of its screen run in the tails of the steps before it.  Round 5, 8 hardware queues:
+# 2 / 3 / 4 lanes = C3 583 / 601 / 610 k q/s, C2 7.8 / - / 9.6 M, refbench 848 / - / 962 k, mixture 502 / - / 531 k; 5, 6, 8 are
+# slower again (a fifth stream evicts a scratch set, which orders it behind that set's last call).
+N_LANES = 4
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 PROFILE_ROUND = "r05"
 
@@ -272,24 +277,25 @@ def spread(nq, m):
 
 
 def ivf_measure(pqv, torch, dev, searcher, index, queries_t, nq, k, nprobe, dim, min_time=0.4, steps=20, exchange=None):
-    """Timed blocks of `steps` steps over two stream lanes (median block), then a serial pass with HIP events around the
+    """Timed blocks of `steps` steps over N_LANES stream lanes (median block), then a serial pass with HIP events around the
     re-rank kernels; min_bytes of the step (see roofline.min_bytes_definition).  Returns (record, lane-0 outputs)."""
     # (explicit streams only: new_streams)
     torch.cuda.synchronize()
-    streams = new_streams(torch, dev, 2)
-    rows = [torch.empty((nq, k), dtype=torch.int32, device=dev) for _ in range(2)]
-    dd = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
-    nc = [torch.empty((nq,), dtype=torch.int64, device=dev) for _ in range(2)]
+    NL = N_LANES
+    streams = new_streams(torch, dev, NL)
+    rows = [torch.empty((nq, k), dtype=torch.int32, device=dev) for _ in range(NL)]
+    dd = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(NL)]
+    nc = [torch.empty((nq,), dtype=torch.int64, device=dev) for _ in range(NL)]
 
     def st(i):
-        s_ = streams[i % 2]
+        s_ = streams[i % NL]
         with torch.cuda.stream(s_):
-            searcher.topk_device(queries_t.data_ptr(), nq, k, nprobe, rows[i % 2].data_ptr(), dd[i % 2].data_ptr(), 0, nc[i % 2].data_ptr(),
+            searcher.topk_device(queries_t.data_ptr(), nq, k, nprobe, rows[i % NL].data_ptr(), dd[i % NL].data_ptr(), 0, nc[i % NL].data_ptr(),
                                  stream=s_.cuda_stream)
             if exchange is not None:
-                exchange[i % 2].exchange_u32(dd[i % 2], rows[i % 2])
+                exchange[i % NL].exchange_u32(dd[i % NL], rows[i % NL])
 
-    for i in range(4):
+    for i in range(2 * NL):
         st(i)
     torch.cuda.synchronize()
     c0 = searcher.counters()
@@ -376,7 +382,7 @@ def ivf_config(args, pqv, torch, dev, local_rank, name, k, data="uniform", parit
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        xchg = [ShardExchange(1, nq, k, dev, always_collective=True, row_bases=[0]) for _ in range(2)]
+        xchg = [ShardExchange(1, nq, k, dev, always_collective=True, row_bases=[0]) for _ in range(N_LANES)]
     rec, (rows_t, dist_t, nc_t, qs_host) = ivf_measure(pqv, torch, dev, srch, index, q_t, nq, k, nprobe, dim, exchange=xchg)
     rec.update({"config": f"{name}: {n}x{dim} {data} f32, n_clusters {index.n_clusters}, k {k}, nprobe {nprobe}, {nq} queries/step"
                           + (", one shard on one rank: RCCL all-gather (1 rank) + device merge inside every step" if rccl else ""),
@@ -735,7 +741,7 @@ def main():
                     help="initialise RCCL and run the shard exchange even with one rank (path check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU (path check only; the real run uses RCCL)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=N_LANES,
                     help="HIP streams the steps alternate between (1 = strictly serial steps)")
     ap.add_argument("--no-timing", action="store_true",
                     help="do not record HIP events around the kernels (roofline.kernel_ms is then 0)")
