@@ -731,6 +731,7 @@ def main():
                     help="default: c3 on one GPU, c4 (one 12.5 M-row shard per rank) on several")
     ap.add_argument("--nq", type=int, default=0, help="queries per step (default per workload)")
     ap.add_argument("--k", type=int, default=10, help="neighbours per query (BASELINE metric: 10)")
+    ap.add_argument("--nprobe", type=int, default=0, help="probed lists per query (default per workload; a diagnostic sweep changes the workload's meaning)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget per column")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--layout", default="ivf", choices=["ivf", "row"])
@@ -820,6 +821,8 @@ def main():
     if args.workload is None:
         args.workload = "c3" if world == 1 else "c4"
     n_total, dim, n_clusters, nprobe, nq_default = WORKLOADS[args.workload]
+    if args.nprobe > 0:
+        nprobe = args.nprobe
     if args.workload == "c4" and args.rows_per_rank > 0:
         n_total = args.rows_per_rank
     nq = args.nq or nq_default
