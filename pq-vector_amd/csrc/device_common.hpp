@@ -112,6 +112,9 @@ __device__ __forceinline__ uint32_t buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t l
 #ifndef PQV_NA_REG
 #define PQV_NA_REG 0           // regular int8 instance: branch-free K loop bodies for quads of 3 / 4 / 5 groups too (124 bytes of spills: off)
 #endif
+#ifndef PQV_THR_EVERY
+#define PQV_THR_EVERY 1        // 64-row-tile instances: thresholds re-read behind every n-th tile
+#endif
 #ifndef PQV_XTC
 #define PQV_XTC 0              // 64-row-tile int8 instances: the next tile's operand stages go out FIRST after a K loop, the fresh thresholds
 #endif                         // and the next tile's row terms behind them -- nothing is waited for between two K loops (thresholds one tile old)

@@ -2139,8 +2139,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (NG == 4 && !QLDS) || (QLDS &&
 #pragma unroll
                 for (int s = 0; s < QS; ++s) cur_gthr[s] = gthr_pf[s];
             } else {
+                // (PQV_THR_EVERY = n: the thresholds are re-read behind every n-th tile only -- a scattered agent-scope load
+                //  fetches a 32-byte sector per 4-byte threshold: 3 KB per tile and wave against its 48 KB of rows)
+                if (PQV_THR_EVERY <= 1 || (((uint32_t)((t0 - r0) / TROWS)) % (uint32_t)PQV_THR_EVERY) == 0u || tn >= r1) {
 #pragma unroll
-                for (int s = 0; s < QS; ++s) cur_gthr[s] = load_thr(s);
+                    for (int s = 0; s < QS; ++s) cur_gthr[s] = load_thr(s);
+                }
             }
             if constexpr (I8 && !XTA && !XTC) {
                 if (tn < r1) row_terms(tn, xn2i_next, xres_next);
