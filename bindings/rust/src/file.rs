@@ -50,26 +50,15 @@ pub type RowGroupRange = Option<(usize, usize)>;
 
 /// Shard `rank` of `world` of ONE file: a contiguous row-group range cut at the row-group boundary nearest to
 /// `rank * n / world`, and the file-global row id of its first row = the prefix sum of the row groups before it
-/// (`src/df_vector/access.rs:128-144`).  Returns `(rg_lo, rg_hi, row_base, n_rows)`; the same rule as
-/// `pq_vector_amd.sharding.shard_row_groups`.
-pub fn shard_row_groups(rank: usize, world: usize, rg_rows: &[u64]) -> (usize, usize, u64, u64) {
-    let mut pre = vec![0u64; rg_rows.len() + 1];
-    for (i, r) in rg_rows.iter().enumerate() {
-        pre[i + 1] = pre[i] + r;
-    }
-    let n = pre[rg_rows.len()] as f64;
-    let mut cuts = vec![0usize];
-    for r in 1..world {
-        let target = r as f64 * n / world as f64;
-        let from = *cuts.last().unwrap();
-        let best = (from..pre.len())
-            .min_by(|&a, &b| (pre[a] as f64 - target).abs().partial_cmp(&(pre[b] as f64 - target).abs()).unwrap().then(a.cmp(&b)))
-            .unwrap();
-        cuts.push(best);
-    }
-    cuts.push(rg_rows.len());
-    let (lo, hi) = (cuts[rank], cuts[rank + 1]);
-    (lo, hi, pre[lo], pre[hi] - pre[lo])
+/// (`src/df_vector/access.rs:128-144`).  Returns `(rg_lo, rg_hi, row_base, n_rows)`: `pqv_shard_row_groups`, which
+/// `pq_vector_amd.sharding.shard_row_groups` calls too.
+pub fn shard_row_groups(rank: usize, world: usize, rg_rows: &[u64]) -> Result<(usize, usize, u64, u64)> {
+    let (mut lo, mut hi, mut base, mut n) = (0u32, 0u32, 0u64, 0u64);
+    // ONE implementation of the rule, in the library (host only; no device is touched)
+    crate::check(unsafe {
+        sys::pqv_shard_row_groups(rg_rows.as_ptr(), rg_rows.len() as u32, rank as u32, world as u32, &mut lo, &mut hi, &mut base, &mut n)
+    })?;
+    Ok((lo as usize, hi as usize, base, n))
 }
 
 /// The embedding column of `path` (or of one row-group range of it) as a resident `[n, dim]` f32 matrix.  Batches are

@@ -389,6 +389,14 @@ const char *pqv_shard_rccl_path(void);
 int  pqv_shard_unique_id(uint8_t *id /* [PQV_SHARD_ID_BYTES] */);
 int  pqv_shard_comm_create(int device, uint32_t rank, uint32_t world, const uint8_t *id, pqv_shard_comm **out);
 int  pqv_shard_comm_adopt(int device, void *nccl_comm, pqv_shard_comm **out);
+/* ONE Parquet file shared by `world` GPUs (host only; no device is touched): the half-open row-group range [*rg_lo, *rg_hi) of
+ * shard `rank`, the file-global row id of its first row (*row_base = rows of the row groups before it: how the reference maps
+ * file-global row ids to row groups, src/df_vector/access.rs:128-144) and its row count.  rg_rows[i] = rows of row group i in
+ * file order.  Cut r (between shards r - 1 and r) is the row-group boundary whose prefix sum is nearest to r n / world -- the lower
+ * one on a tie, never before the previous cut; every rank computes every cut from the footer alone, the ranges tile the file, a row
+ * group is never split, and with fewer row groups than shards the surplus shards are empty (*n_rows = 0). */
+int  pqv_shard_row_groups(const uint64_t *rg_rows, uint32_t n_row_groups, uint32_t rank, uint32_t world,
+                          uint32_t *rg_lo, uint32_t *rg_hi, uint64_t *row_base, uint64_t *n_rows);
 uint32_t pqv_shard_comm_rank(const pqv_shard_comm *comm);
 uint32_t pqv_shard_comm_world(const pqv_shard_comm *comm);
 int  pqv_shard_exchange(pqv_shard_comm *comm, const void *d_dist, const void *d_rows, const void *d_row_base,

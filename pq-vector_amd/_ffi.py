@@ -53,6 +53,7 @@ SIGNATURES = {
     "pqv_shard_unique_id": (C.c_int, [u8p]),
     "pqv_shard_comm_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, u8p, C.POINTER(vp)]),
     "pqv_shard_comm_adopt": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "pqv_shard_row_groups": (C.c_int, [u64p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u64p, u64p]),
     "pqv_shard_comm_rank": (C.c_uint32, [vp]),
     "pqv_shard_comm_world": (C.c_uint32, [vp]),
     "pqv_shard_exchange": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]),

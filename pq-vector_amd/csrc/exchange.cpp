@@ -214,3 +214,37 @@ extern "C" int pqv_shard_exchange(pqv_shard_comm *c, const void *d_dist, const v
         return static_cast<int>(PQV_OK);
     });
 }
+
+// One Parquet file shared by `world` GPUs: the row-group range of shard `rank` (host only; sharding.shard_row_groups and
+// bindings/rust/src/file.rs call this).  Cut r is the row-group boundary whose prefix sum of rows is nearest to r n / world
+// (the lower one on a tie, never before the previous cut), compared exactly in integers: |pre[b] world - r n|.
+extern "C" int pqv_shard_row_groups(const uint64_t *rg_rows, uint32_t n_row_groups, uint32_t rank, uint32_t world,
+                                    uint32_t *rg_lo, uint32_t *rg_hi, uint64_t *row_base, uint64_t *n_rows) {
+    return guard([&]() -> int {
+        if (world == 0 || rank >= world) return fail(PQV_ERR_INVALID, "rank must be < world, world > 0");
+        if (n_row_groups && !rg_rows) return fail(PQV_ERR_INVALID, "rg_rows must not be NULL");
+        if (!rg_lo || !rg_hi || !row_base || !n_rows) return fail(PQV_ERR_INVALID, "output pointers must not be NULL");
+        std::vector<unsigned __int128> pre(static_cast<size_t>(n_row_groups) + 1, 0);
+        for (uint32_t i = 0; i < n_row_groups; ++i) pre[i + 1] = pre[i] + rg_rows[i];
+        const unsigned __int128 n = pre[n_row_groups];
+        if (n > static_cast<unsigned __int128>(0xFFFFFFFFFFFFFFFFull)) return fail(PQV_ERR_INVALID, "row count exceeds 64 bits");
+        uint32_t cut_prev = 0, lo = 0, hi = n_row_groups;
+        for (uint32_t r = 1; r <= rank + 1 && r < world; ++r) {
+            const unsigned __int128 target = static_cast<unsigned __int128>(r) * n;          // x world
+            uint32_t best = cut_prev;
+            unsigned __int128 best_d = ~static_cast<unsigned __int128>(0);
+            for (uint32_t b = cut_prev; b <= n_row_groups; ++b) {
+                const unsigned __int128 v = pre[b] * world, d = v > target ? v - target : target - v;
+                if (d < best_d) { best_d = d; best = b; }
+            }
+            if (r == rank) lo = best;
+            if (r == rank + 1) hi = best;
+            cut_prev = best;
+        }
+        if (rank == 0) lo = 0;
+        if (rank + 1 == world) hi = n_row_groups;
+        *rg_lo = lo; *rg_hi = hi;
+        *row_base = static_cast<uint64_t>(pre[lo]); *n_rows = static_cast<uint64_t>(pre[hi] - pre[lo]);
+        return static_cast<int>(PQV_OK);
+    });
+}

@@ -30,6 +30,18 @@ def shard_row_groups(rank, world, rg_rows):
     crosses a column chunk, so a shard is a set of whole column chunks), every rank computes every cut from the footer alone, the
     ranges tile the file, and with fewer row groups than ranks the surplus ranks get an EMPTY range (n_rows == 0: they answer
     with empty lists).  parquet_io.load_embedding_column(path, column, device, row_groups=(rg_lo, rg_hi)) loads the range."""
+    import ctypes as C
+    import numpy as np
+    from . import _ffi
+    rows = np.ascontiguousarray(_rg_rows(rg_rows), dtype=np.uint64)
+    lo, hi, base, n = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    # ONE implementation of the rule, behind the C ABI (pqv_shard_row_groups, host only): a Rust host cuts the same way
+    _rc(_ffi.lib().pqv_shard_row_groups(rows.ctypes.data_as(_ffi.u64p), len(rows), rank, world, C.byref(lo), C.byref(hi), C.byref(base), C.byref(n)))
+    return lo.value, hi.value, base.value, n.value
+
+
+def _shard_row_groups_py(rank, world, rg_rows):
+    """The same rule in plain Python (tests cross-check the library against it): exact integer comparison |pre[b] world - r n|."""
     rows = _rg_rows(rg_rows)
     pre = [0]
     for r in rows:
@@ -37,9 +49,7 @@ def shard_row_groups(rank, world, rg_rows):
     n = pre[-1]
     cuts = [0]
     for r in range(1, world):
-        target = r * n / world
-        # nearest boundary at or after the previous cut (monotone)
-        best = min(range(cuts[-1], len(pre)), key=lambda b: (abs(pre[b] - target), b))
+        best = min(range(cuts[-1], len(pre)), key=lambda b: (abs(pre[b] * world - r * n), b))
         cuts.append(best)
     cuts.append(len(rows))
     lo, hi = cuts[rank], cuts[rank + 1]

@@ -151,4 +151,16 @@ def test_rust_row_group_shard_rule_matches_python():
     assert [shard_row_groups(r, 3, [5, 1, 1, 1, 100]) for r in range(3)] == [(0, 4, 0, 8), (4, 5, 8, 100), (5, 5, 108, 0)]
     assert shard_row_groups(0, 1, []) == (0, 0, 0, 0)
     src = open(FILE_RS).read()
-    assert "min_by" in src and ".then(a.cmp(&b))" in src and "let from = *cuts.last().unwrap();" in src
+    assert "sys::pqv_shard_row_groups(" in src                      # the Rust shim asks the library: one implementation
+    # ... which must agree with the rule restated in plain Python on random layouts (ties, empty ranges, huge row groups)
+    import random
+    from pq_vector_amd.sharding import _shard_row_groups_py
+    rnd = random.Random(7)
+    for _ in range(300):
+        n_rg = rnd.randint(0, 40)
+        rows = [rnd.choice([0, 1, 5, 1000, 1000, 4096, rnd.randint(1, 10**7), 2**40]) for _ in range(n_rg)]
+        world = rnd.randint(1, 12)
+        ranges = [shard_row_groups(r, world, rows) for r in range(world)]
+        assert ranges == [_shard_row_groups_py(r, world, rows) for r in range(world)], (rows, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == n_rg and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        assert sum(x[3] for x in ranges) == sum(rows)
