@@ -3170,8 +3170,11 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     }
     for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
         const uint32_t b = std::min<uint32_t>(batch, nq - q0);
+        // (round 5: the result block of a small call is WRITTEN by the kernels straight into the pinned buffer -- host memory the
+        //  device can address -- so there is no device-to-host copy behind them, only the synchronise: PQV_SMALL_IO_DIRECT=0 keeps the copy)
+        static const bool direct_out = [] { const char *e = std::getenv("PQV_SMALL_IO_DIRECT"); return !(e && *e == '0'); }();
         if (small_io) {
-            char *ob = static_cast<char *>(sc.s_out.p);           // (laid out for THIS sub-batch's b)
+            char *ob = direct_out ? static_cast<char *>(sc.h_io.p) + q_bytes : static_cast<char *>(sc.s_out.p);           // (laid out for THIS sub-batch's b)
             o_rows = reinterpret_cast<uint32_t *>(ob + 8ull * b);
             o_dist = reinterpret_cast<float *>(ob + 8ull * b + 4ull * b * k);
             o_nf = reinterpret_cast<uint32_t *>(ob + 8ull * b + 8ull * b * k);
@@ -3183,12 +3186,14 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
                                    static_cast<size_t>(b) * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
         }
         if (int rc = enqueue_topk(s, sc.s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
-                                  sqrt_out, o_rows, o_dist, o_nf, small_io ? static_cast<uint64_t *>(sc.s_out.p) : nullptr, o_tie, s->stream, sc))
+                                  sqrt_out, o_rows, o_dist, o_nf,
+                                  small_io ? reinterpret_cast<uint64_t *>(direct_out ? static_cast<char *>(sc.h_io.p) + q_bytes : static_cast<char *>(sc.s_out.p)) : nullptr,
+                                  o_tie, s->stream, sc))
             return rc;
         if (small_io) {
             char *hb = static_cast<char *>(sc.h_io.p) + q_bytes;
             const size_t ob_bytes = static_cast<size_t>(b) * (16 + 8 * static_cast<size_t>(k));
-            HIP_TRY(hipMemcpyAsync(hb, sc.s_out.p, ob_bytes, hipMemcpyDeviceToHost, s->stream));
+            if (!direct_out) HIP_TRY(hipMemcpyAsync(hb, sc.s_out.p, ob_bytes, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
             std::memcpy(h_ncand.data(), hb, static_cast<size_t>(b) * sizeof(uint64_t));
             std::memcpy(row_idx + static_cast<uint64_t>(q0) * k, hb + 8ull * b, static_cast<size_t>(b) * k * sizeof(uint32_t));
