@@ -1077,6 +1077,14 @@ def main():
         "min_bytes_frac": (min_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms and k_ms > 0 else None,
         "traffic_over_min": (traffic / min_bytes) if traffic and min_bytes else None,
         "kernel_ms": k_ms, "kernel_ms_in_timed_region": rr_ms,
+        # the WHOLE step of the pipelined (timed) run -- not a kernel's roofline: consecutive steps overlap on the stream lanes, so a
+        # step's bytes pass in ms_per_step although its own kernels, issued alone, take kernel_ms
+        "pipelined_step_view": {"min_bytes_GBps": min_bytes / (elapsed / steps) / 1e9,
+                                "min_bytes_frac_of_peak": min_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS,
+                                "traffic_GBps": (traffic / (elapsed / steps) / 1e9) if traffic else None,
+                                "traffic_frac_of_copy_ceiling": (traffic / (elapsed / steps) / 1e9 / 6290.0) if traffic else None,
+                                "note": "bytes of ONE step over ms_per_step of the timed, pipelined run (probe, bucketing, seed, screen and merge of "
+                                        "neighbouring steps overlap); copy ceiling = 6.29 TB/s (MI355X_MICROARCH.md)"},
         "achieved_basis": "min_bytes of this run / kernel_ms of this run (frac == min_bytes_frac)",
         "min_bytes_definition": ("screened path: (operand bytes per value x dim + 8) per DISTINCT probed row of the step + 4 dim per "
                                  "survivor of the screen" if wide else "SURVEY 8d bytes"),
