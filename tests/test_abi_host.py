@@ -176,3 +176,26 @@ def test_candidate_cursor_matches_reference_semantics_and_oracle(oracle):
         g1, _ = c2.next_batch(a)
         g2, _ = c2.next_batch(cap - a)
         assert len(g1) + len(g2) == len(want) and sorted(g1 + g2) == sorted(want)
+
+
+def test_shard_row_groups_abi_contract():
+    """pqv_shard_row_groups (host only): ranges tile the file, row bases are prefix sums, invalid arguments are refused with a text."""
+    import ctypes as C
+    import numpy as np
+    from pq_vector_amd import _ffi
+    L = _ffi.lib()
+    rows = np.array([1000] * 10 + [37], dtype=np.uint64)
+    out = [C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)]
+
+    def call(rank, world, arr=rows):
+        rc = L.pqv_shard_row_groups(arr.ctypes.data_as(_ffi.u64p) if len(arr) else None, len(arr), rank, world, *[C.byref(o) for o in out])
+        return rc, tuple(o.value for o in out)
+    assert call(0, 1) == (0, (0, 11, 0, 10037))
+    assert [call(r, 2)[1] for r in range(2)] == [(0, 5, 0, 5000), (5, 11, 5000, 5037)]
+    got = [call(r, 16)[1] for r in range(16)]
+    assert got[0][0] == 0 and got[-1][1] == 11 and all(got[i][1] == got[i + 1][0] for i in range(15)) and sum(g[3] for g in got) == 10037
+    assert any(g[3] == 0 for g in got)                       # more shards than row groups: empty ranges
+    assert call(0, 3, np.zeros(0, np.uint64)) == (0, (0, 0, 0, 0))
+    assert call(2, 2)[0] < 0 and b"rank" in L.pqv_last_error()
+    assert call(0, 0)[0] < 0
+    assert L.pqv_shard_row_groups(rows.ctypes.data_as(_ffi.u64p), len(rows), 0, 1, None, None, None, None) < 0
