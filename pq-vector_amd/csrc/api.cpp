@@ -340,6 +340,13 @@ static int lane_release(Scratch &sc, hipStream_t stream) {
     HIP_TRY(hipEventRecord(sc.done, stream));
     return PQV_OK;
 }
+// Records the lane's `done` event on EVERY way out of an entry point (an error return half-way through a call has enqueued
+// work on `stream` that the lane's next owner must still be ordered behind); recording again after a successful
+// lane_release() is harmless.
+struct LaneGuard {
+    Scratch &sc; hipStream_t stream;
+    ~LaneGuard() { if (sc.done) (void)hipEventRecord(sc.done, stream); }
+};
 
 // ---------------------------------------------------------------------------------------
 // misc
@@ -1439,6 +1446,8 @@ struct GemmAssign {
     }
     std::vector<hipEvent_t> kernel_ev;
     bool time_kernels = false;
+    // (an early error return of run() leaves its events here)
+    ~GemmAssign() { for (hipEvent_t e : kernel_ev) (void)hipEventDestroy(e); }
 };
 
 // acc[c] = ((0 + m[0][c]) + m[1][c]) + ... + m[rows - 1][c] for c in [0, width), width a multiple of 16: `width` independent f32
@@ -1765,6 +1774,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     if (!corpus->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
     if (int rc = use_device(corpus->device)) return rc;
     hipStream_t stream = corpus->stream;
+    g_build_stats[8] = 0.0; g_build_stats[9] = 0.0;      // (kernel seconds / launches of THIS build's final assignment, whichever path it takes)
 
     uint64_t sample_size = std::max<uint64_t>(n / 20, 1);                              // :172
     sample_size = std::min<uint64_t>(sample_size, 100000);                             // :173
@@ -2669,7 +2679,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                     HIP_TRY(s->h_wide_stats.ensure(4 * sizeof(uint32_t)));
                     std::memset(s->h_wide_stats.p, 0, 4 * sizeof(uint32_t));
                 }
-                ps.shape_stats = s->h_wide_stats.as<uint32_t>() + 2; ps.shape_wide = 160;
+                ps.shape_stats = s->h_wide_stats.as<uint32_t>() + 2; ps.shape_wide = 160; ps.shape_narrow = p.quad_width;
             }
             // XCD-aware slots: in the wide table always (lists of several wide quads); in the regular table where it has lists of
             // several quads too -- no wide-quad instance, or option 3 (every table)
@@ -3094,6 +3104,7 @@ static int pqv_topk_device_impl(const pqv_searcher *s, const void *d_queries, ui
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, stream, &lane)) return rc;
+    LaneGuard lane_guard{*lane, stream};
     // with flags the kernels carry one extra merged entry (the runner-up), exactly as pqv_topk does
     const int rc = enqueue_topk(s, static_cast<const float *>(d_queries), nq, d_tie_flags ? k + 1 : k, k, nprobe, max_candidates,
                                 metric, sqrt_out, static_cast<uint32_t *>(d_row_idx),
@@ -3134,6 +3145,7 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
     Scratch &sc = *lane;
+    LaneGuard lane_guard{sc, s->stream};
     if (k >= 1024u || beyond_kernel_lists(s, k_int, nprobe)) {
         const int rc = topk_unbounded(s, sc, queries, nq, k, nprobe, max_candidates, metric, sqrt_out, row_idx, dist, n_found, n_candidates);
         const int rc2 = lane_release(sc, s->stream);
@@ -3161,12 +3173,15 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
     // tie} and come back in one copy.
     const size_t q_bytes = static_cast<size_t>(batch) * s->dim * sizeof(float);
     const size_t out_bytes = static_cast<size_t>(batch) * (16 + 8 * static_cast<size_t>(k));
-    const bool small_io = q_bytes + out_bytes <= (256u << 10);
+    // (the result block starts with the u64 candidate counts: its offset behind the queries is rounded up to 64 bytes -- batch * dim
+    //  may be odd, and the kernels store 64-bit values there)
+    const size_t out_off = (q_bytes + 63) & ~static_cast<size_t>(63);
+    const bool small_io = out_off + out_bytes <= (256u << 10);
     uint32_t *o_rows = sc.s_rows.as<uint32_t>(), *o_nf = sc.s_nfound.as<uint32_t>(), *o_tie = sc.s_tie.as<uint32_t>();
     float *o_dist = sc.s_dist.as<float>();
     if (small_io) {
         HIP_TRY(sc.s_out.ensure(out_bytes));
-        HIP_TRY(sc.h_io.ensure(q_bytes + out_bytes));
+        HIP_TRY(sc.h_io.ensure(out_off + out_bytes));
     }
     for (uint32_t q0 = 0; q0 < nq; q0 += batch) {
         const uint32_t b = std::min<uint32_t>(batch, nq - q0);
@@ -3174,7 +3189,7 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
         //  device can address -- so there is no device-to-host copy behind them, only the synchronise: PQV_SMALL_IO_DIRECT=0 keeps the copy)
         static const bool direct_out = [] { const char *e = std::getenv("PQV_SMALL_IO_DIRECT"); return !(e && *e == '0'); }();
         if (small_io) {
-            char *ob = direct_out ? static_cast<char *>(sc.h_io.p) + q_bytes : static_cast<char *>(sc.s_out.p);           // (laid out for THIS sub-batch's b)
+            char *ob = direct_out ? static_cast<char *>(sc.h_io.p) + out_off : static_cast<char *>(sc.s_out.p);           // (laid out for THIS sub-batch's b)
             o_rows = reinterpret_cast<uint32_t *>(ob + 8ull * b);
             o_dist = reinterpret_cast<float *>(ob + 8ull * b + 4ull * b * k);
             o_nf = reinterpret_cast<uint32_t *>(ob + 8ull * b + 8ull * b * k);
@@ -3187,11 +3202,11 @@ static int pqv_topk_impl(const pqv_searcher *s, const float *queries, uint32_t n
         }
         if (int rc = enqueue_topk(s, sc.s_queries.as<float>(), b, k_int, k, nprobe, max_candidates, metric,
                                   sqrt_out, o_rows, o_dist, o_nf,
-                                  small_io ? reinterpret_cast<uint64_t *>(direct_out ? static_cast<char *>(sc.h_io.p) + q_bytes : static_cast<char *>(sc.s_out.p)) : nullptr,
+                                  small_io ? reinterpret_cast<uint64_t *>(direct_out ? static_cast<char *>(sc.h_io.p) + out_off : static_cast<char *>(sc.s_out.p)) : nullptr,
                                   o_tie, s->stream, sc))
             return rc;
         if (small_io) {
-            char *hb = static_cast<char *>(sc.h_io.p) + q_bytes;
+            char *hb = static_cast<char *>(sc.h_io.p) + out_off;
             const size_t ob_bytes = static_cast<size_t>(b) * (16 + 8 * static_cast<size_t>(k));
             if (!direct_out) HIP_TRY(hipMemcpyAsync(hb, sc.s_out.p, ob_bytes, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -3391,6 +3406,7 @@ static int pqv_probe_impl(const pqv_searcher *s, const float *query, uint32_t qu
     Scratch *lane = nullptr;
     if (int rc = lane_acquire(s, s->stream, &lane)) return rc;
     Scratch &sc = *lane;
+    LaneGuard lane_guard{sc, s->stream};
     if (np > 1024) {            // beyond the kernels' sorted lists: distances on the GPU, the stable sort on the host
         HIP_TRY(sc.s_queries.ensure(static_cast<size_t>(s->dim) * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(sc.s_queries.p, query, static_cast<size_t>(s->dim) * sizeof(float), hipMemcpyHostToDevice, s->stream));

@@ -208,7 +208,8 @@ struct PairSortArgs {
     uint32_t       *wide_item_chunk; // [wide_max_items]
     uint32_t       *wide_stats;      // optional [2]: items of the wide table, and how many of them belong to lists with no other quad
     uint32_t       *shape_stats;     // optional [2] (pinned host memory): rows of the lists that more than shape_wide pairs of the batch
-    uint32_t        shape_wide;      // probe, and of those that more than quad_width do -- how the next batch cuts its quads
+    uint32_t        shape_wide;      // probe, and of those that more than shape_narrow do -- how the next batch cuts its quads
+    uint32_t        shape_narrow;    // (its own width: quad_width is the 160-wide cut while the wide-quad instance is active)
     uint32_t        xcd_items;       // bit 0: the regular table, bit 1: the wide table -- a level's slots filled column by column of an
                                      // 8-column layout (the quads of one list -> the same XCD, back to back)
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut

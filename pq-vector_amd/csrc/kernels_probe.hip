@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
             }
             a.hist[c] = h;
         }
-        if (a.shape_stats && c < a.n_clusters && h > a.quad_width) {
+        if (a.shape_stats && c < a.n_clusters && h > a.shape_narrow) {
             const uint64_t len = a.list_off[c + 1] - a.list_off[c];
             const uint32_t l32 = len < 0x00FFFFFFull ? (uint32_t)len : 0x00FFFFFFu;
             atomicAdd(&s_shape[1], l32);

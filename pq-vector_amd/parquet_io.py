@@ -654,6 +654,7 @@ def _upload_pages(plan, corpus, n_threads, counters):
 
 def _load_pages(path, column, corpus, dim, rg_off, n_threads, counters, row_groups=None):
     """plan + upload (tests drive the walker through this with a stand-in corpus)."""
+    import pyarrow as pa
     try:
         plan = _plan_pages(path, column, n_threads, None, row_groups)
         if plan is None or plan.dim != dim:
@@ -661,7 +662,9 @@ def _load_pages(path, column, corpus, dim, rg_off, n_threads, counters, row_grou
         return _upload_pages(plan, corpus, n_threads, counters)
     except PqvError:
         raise
-    except Exception:                      # a codec / mapping problem: "not mine", as load_embedding_column treats it
+    except (pa.ArrowException, OSError, ValueError, IndexError, EOFError, struct.error):
+        # a codec / mapping / page-framing problem: "not mine", as load_embedding_column treats it.  Anything else (a TypeError or
+        # AttributeError out of the walker itself) is a bug and must surface, not turn into a silent fall-back to the Arrow path.
         return False
 
 

@@ -78,6 +78,23 @@ def load_parquet_shard(path, column, rank, world, device=0, readers=None, stats=
     return corpus, base, n, (lo, hi)
 
 
+def check_shard_dims(dim, group=None):
+    """Every shard discovers the list length from ITS row-group range; the reference reads the whole column and rejects a file
+    whose vectors differ in length ("Embedding vectors have inconsistent dimensions", src/ivf/parquet.rs:231-280).  All ranks
+    compare (`dim` = this rank's, 0 / None for an empty range): raises the reference's message on every rank on a mismatch."""
+    from .api import PqvError
+    from . import _ffi
+    mine = int(dim or 0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mine
+    dims = [None] * dist.get_world_size(group)
+    dist.all_gather_object(dims, mine, group=group)
+    seen = sorted({int(d) for d in dims if d})
+    if len(seen) > 1:
+        raise PqvError(_ffi.PQV_ERR_INVALID, "Embedding vectors have inconsistent dimensions")
+    return seen[0] if seen else 0
+
+
 def merge_gathered(gath_dist, gath_rows, k):
     """gath_dist/gath_rows: [world, nq, k] (unused slots: +inf / -1).  Returns ([nq,k],[nq,k]).
 

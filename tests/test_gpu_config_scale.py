@@ -232,3 +232,28 @@ def test_c3_shape_screened_final_assignment_matches_oracle_on_a_slice(pqv, oracl
         want = np.array([c for part in ex.map(nearest, range(0, len(sel), 500)) for c in part], dtype=np.uint32)
     bad = np.nonzero(cluster_of[sel] != want)[0]
     assert len(bad) == 0, (len(bad), sel[bad[:5]], cluster_of[sel][bad[:5]], want[bad[:5]])
+
+
+def test_c1_vldb_standin_through_the_path_builders(pqv, tmp_path):
+    """BASELINE configs[0] as BASELINE.md defines its stand-in: 1 024 x 4096 `embedding` List<f32> + Utf8 `title` in a Parquet
+    file; IndexBuilder(path, "embedding").build_inplace() with the default n_clusters (ceil(sqrt(n)) = 32, index.rs:161-167);
+    TopkBuilder(path, q).k(10).nprobe(5).search() per query (search.rs:49-81; queries = rows of the file as in
+    src/df_vector/tests.rs:106-149, and fresh vectors).  bench.c1_config is the very leg the default bench line runs as
+    configs.c1: blob and answers (row ids + distance bits) == oracle, the file still reads as Parquet and carries the blob."""
+    import argparse
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    rec = bench.c1_config(argparse.Namespace(no_cpu=False), pqv, torch, dev, 0, n_queries=64, keep_dir=str(tmp_path))
+    assert rec["n_clusters"] == 32
+    par = rec["parity"]
+    assert par["index_blob_identical"] and par["topk_rows_and_distance_bits_identical"] and par["file_round_trip"] and par["ok"]
+    assert par["queries_checked"] == 64 and rec["value"] > 0
+    # a query that IS a row of the file finds itself first, at distance 0 (the reference's vldb query is row 0 of the file)
+    import pyarrow.parquet as pq
+    path = str(tmp_path / "vldb_standin.parquet")
+    row0 = np.asarray(pq.read_table(path, columns=["embedding"]).column("embedding")[0].as_py(), dtype=np.float32)
+    hits = pqv.TopkBuilder(path, row0).k(10).nprobe(5).search()
+    assert len(hits) == 10 and hits[0].row_idx == 0 and hits[0].distance == 0.0
+    summary = bench.summarize_config(rec)
+    assert summary["parity_ok"] is True and summary["n_clusters"] == 32 and "config" not in summary

@@ -91,6 +91,21 @@ def test_torch_rccl_exchange_one_rank_matches_merge_gathered(pqv, tmp_path):
         dist.destroy_process_group()
 
 
+
+def _reject_constant(x):
+    raise ValueError("non-finite number in the bench line: " + x)
+
+
+def _one_compact_line(p):
+    """ONE stdout line, strict JSON (no NaN / Infinity), under bench.py's 8 KB cap (round 5's 19.8 KB line was not parsed by the driver)."""
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 8192, len(lines[0])
+    rec = json.loads(lines[0], parse_constant=_reject_constant)
+    assert rec["full_record"] == "bench_full.json" and os.path.exists(os.path.join(ROOT, "bench_full.json"))
+    return rec
+
+
 @pytest.mark.timeout(600)
 def test_bench_self_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` exactly as the driver calls it (no launcher environment): it must start its own two
@@ -99,9 +114,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tiny",
                         "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    rec = _one_compact_line(p)
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["shards"] == 2 and rec["value"] > 0
 
 
@@ -137,9 +150,7 @@ def test_bench_c4_two_ranks_with_a_small_shard():
                         "--rows-per-rank", "1000000", "--steps", "5", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    rec = _one_compact_line(p)
     assert rec["n_gpus"] == 2 and rec["config"]["shards"] == 2 and rec["config"]["rows_per_gpu"] == 1000000 and rec["value"] > 0
     assert rec["scaling"] == "weak" and len(rec["per_rank_ms_per_step"]["ranks"]) == 2
     assert rec["per_rank_ms_per_step"]["max"] <= rec["ms_per_step"] * 1.5 + 1.0
@@ -156,9 +167,7 @@ def test_bench_two_ranks_share_one_parquet_file_by_row_group_ranges():
                         "--rows-per-rank", "150000", "--nq", "64", "--steps", "3", "--warmup", "1", "--parity-queries", "32"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=570)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    rec = _one_compact_line(p)
     cfg = rec["config"]
     assert rec["n_gpus"] == 2 and cfg["shards"] == 2 and cfg["row_groups"] == 9 and rec["value"] > 0
     (a0, a1), (b0, b1) = cfg["row_group_ranges"]
@@ -167,6 +176,46 @@ def test_bench_two_ranks_share_one_parquet_file_by_row_group_ranges():
     assert rec["parity"]["ok"] and rec["parity"]["queries_checked"] == 32
     assert rec["parity"]["global_row_ids_identical"] and rec["parity"]["dist_bit_identical"]
     assert "data pages" in rec["per_rank"]["loader_path"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_share_one_parquet_file():
+    """The --gpus 8 job shape on this box's one GPU (gloo): EIGHT row-group cuts from one footer, eight shard indexes, the 8-way
+    merge.  With every list probed the merged answer equals a single-shard search of the whole file; the line obeys the
+    compact-line rule with eight ranks' figures on it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--from-parquet",
+                        "--rows-per-rank", "100000", "--nq", "64", "--steps", "3", "--warmup", "1", "--parity-queries", "32"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=870)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _one_compact_line(p)
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 8 and cfg["shards"] == 8 and cfg["row_groups"] == 33 and rec["value"] > 0
+    rng = cfg["row_group_ranges"]
+    assert len(rng) == 8 and rng[0][0] == 0 and rng[-1][1] == 33 and all(rng[i][1] == rng[i + 1][0] for i in range(7))
+    assert all(hi > lo for lo, hi in rng) and sum(cfg["shard_rows"]) == 800000
+    assert cfg["row_bases"] == [sum(cfg["shard_rows"][:i]) for i in range(8)]
+    assert len(set(cfg["shard_rows"])) > 1                    # cuts at row-group boundaries, not at n / 8
+    assert rec["parity"]["ok"] and rec["parity"]["queries_checked"] == 32
+    assert rec["parity"]["global_row_ids_identical"] and rec["parity"]["dist_bit_identical"]
+    assert len(rec["per_rank"]["load_s"]) == 8 and rec["exchange"]["ranks"] == 8
+
+
+@pytest.mark.timeout(900)
+def test_bench_c4_eight_ranks_with_small_shards():
+    """BASELINE configs[3] as the driver launches it (--gpus 8), eight 250 k-row shards on this box's one GPU (gloo): one shard
+    and one index per rank, the whole batch on every shard, one exchange per step; only rank 0 may run the CPU baseline, and it
+    does not at N > 1 (the brief: rank 0 at N = 1 only)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--workload", "c4",
+                        "--rows-per-rank", "250000", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=870)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _one_compact_line(p)
+    assert rec["n_gpus"] == 8 and rec["config"]["shards"] == 8 and rec["config"]["rows_per_gpu"] == 250000 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and len(rec["per_rank_ms_per_step"]["ranks"]) == 8
+    assert rec["exchange"]["ranks"] == 8 and 0.0 < rec["exchange"]["share_of_step"]
+    assert "cpu_baseline" not in rec and p.stderr.count("oracle -O3") == 0
 
 
 @pytest.mark.parametrize("k,nprobe", [(1024, 4), (1500, 6), (3000, 3), (10, 1500)])

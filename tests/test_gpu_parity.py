@@ -1626,7 +1626,14 @@ def test_quads_follow_the_previous_batch_shape(pqv, oracle):
         multi, pop = int(lens[per > 160].sum()), int(lens[per > 96].sum())
         return pop > 0 and 2 * multi > pop
     assert regular_next(qa) and not regular_next(qb)
-    for queries in (qa, qb, qa):
+    # batch C (round 6, the advisor's middle regime): the lists of 97..160 pairs hold most of the popular rows while one list of > 160
+    # pairs holds >= n / 32 rows.  While the wide-quad instance is active the scan's quad width is the 160-wide cut; counted against
+    # THAT width the statistic read "every popular row sits in a list of > 160 pairs" and the plan flipped on every call.
+    cnts = [60, 60, 60, 60, 0, 0, 100, 0]
+    qc = (cen[np.repeat(np.arange(kc), cnts)] + 0.05 * rng.standard_normal((sum(cnts), dim))).astype(np.float32)
+    per_c = np.bincount(np.concatenate([np.asarray(oidx.find_closest_centroids(q, nprobe)) for q in qc]), minlength=kc)
+    assert not regular_next(qc) and int(lens[per_c > 160].sum()) * 32 >= len(data) and ((per_c > 96) & (per_c <= 160)).any()
+    for queries in (qa, qb, qc, qc, qa):
         nq = len(queries)
         want_wide_next = not regular_next(queries)
         orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)

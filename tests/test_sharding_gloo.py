@@ -136,15 +136,27 @@ def _file_worker(rank, world, port, path, out_path):
     from pq_vector_amd import parquet_io
     from pq_vector_amd.sharding import ShardExchange, shard_row_groups
     _, queries = _inputs()
+    from pq_vector_amd.sharding import check_shard_dims
     lo, hi, base, rows = shard_row_groups(rank, world, path)          # from the footer alone, the same cuts on every rank
-    shard = _HostRows(rows, DIM)
-    assert parquet_io._load_pages(path, "emb", shard, DIM, None, 2, [0, 0], row_groups=(lo, hi)) is True
-    idx = Oracle().build_index(shard.a, n_clusters=KC, workers=2)      # the shard's own index, shard-local row ids
-    r, d, nf, _ = idx.topk_batch(shard.a, queries, K, KC)              # every list probed
-    r = r.astype(np.int64)
-    for q in range(NQ):
-        r[q, nf[q]:] = -1
-        d[q, nf[q]:] = np.inf
+    if rows:
+        shard = _HostRows(rows, DIM)
+        assert parquet_io._load_pages(path, "emb", shard, DIM, None, 2, [0, 0], row_groups=(lo, hi)) is True
+        idx = Oracle().build_index(shard.a, n_clusters=min(KC, rows), workers=2)      # the shard's own index, shard-local row ids
+        r, d, nf, _ = idx.topk_batch(shard.a, queries, K, KC)          # every list probed
+        r = r.astype(np.int64)
+        for q in range(NQ):
+            r[q, nf[q]:] = -1
+            d[q, nf[q]:] = np.inf
+    else:       # fewer row groups than ranks: a surplus rank holds an empty range and answers with empty lists
+        r, d = np.full((NQ, K), -1, np.int64), np.full((NQ, K), np.inf, np.float32)
+    assert check_shard_dims(DIM if rows else 0) == DIM                 # every shard found the same list length
+    if world > 2:                                                      # ... and a shard that found another one stops every rank
+        from pq_vector_amd import PqvError
+        try:
+            check_shard_dims(DIM + 1 if rank == 1 else (DIM if rows else 0))
+            raise AssertionError("inconsistent shard dimensions went unnoticed")
+        except PqvError as e:
+            assert "Embedding vectors have inconsistent dimensions" in str(e)
     x = ShardExchange(world, NQ, K, torch.device("cpu"))
     md, mr = x.exchange(torch.from_numpy(d), torch.from_numpy(r), base)
     meta = torch.tensor([lo, hi, base, rows], dtype=torch.int64)
@@ -176,5 +188,31 @@ def test_two_ranks_share_one_parquet_file_by_row_group_ranges(oracle, tmp_path):
     whole = oracle.build_index(data, n_clusters=KC, workers=2)
     r1, d1, nf1, _ = whole.topk_batch(data, queries, K, KC)
     assert (nf1 == K).all()
+    assert (got["rows"] == r1.astype(np.int64)).all()
+    assert (got["dist"].view(np.uint32) == d1.view(np.uint32)).all()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_share_one_parquet_file_with_fewer_row_groups_than_ranks(oracle, tmp_path):
+    """The --gpus 8 job shape on CPU (world-8 gloo): EIGHT cuts from one footer of SEVEN row groups -- one rank holds an empty
+    range and answers with empty lists --, eight shard indexes, the 8-way deterministic merge; with every list probed the merged
+    answer is the exact top-k of the whole column with file-global row ids.  Also: check_shard_dims agrees across the ranks and
+    raises the reference's message everywhere when one shard found another list length (src/ivf/parquet.rs:231-280)."""
+    import pyarrow.parquet as pq
+    path, out = str(tmp_path / "shared8.parquet"), str(tmp_path / "merged_file8.npz")
+    _write_shared_file(path)
+    n_rg = pq.ParquetFile(path).metadata.num_row_groups
+    assert n_rg == 7
+    world = 8
+    mp.spawn(_file_worker, args=(world, _free_port(), path, out), nprocs=world, join=True)
+    got = np.load(out)
+    meta = got["meta"]
+    assert meta.shape == (8, 4) and meta[0][0] == 0 and meta[-1][1] == n_rg
+    assert all(meta[i][1] == meta[i + 1][0] for i in range(7))                             # the ranges tile the file in rank order
+    assert (meta[:, 3] == 0).sum() == 1 and meta[:, 3].sum() == N                          # exactly one empty range
+    assert all(meta[i][2] == meta[:i, 3].sum() for i in range(8))                          # row bases = prefix sums
+    data, queries = _inputs()
+    whole = oracle.build_index(data, n_clusters=KC, workers=2)
+    r1, d1, nf1, _ = whole.topk_batch(data, queries, K, KC)
     assert (got["rows"] == r1.astype(np.int64)).all()
     assert (got["dist"].view(np.uint32) == d1.view(np.uint32)).all()
