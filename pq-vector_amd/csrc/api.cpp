@@ -308,6 +308,10 @@ struct pqv_searcher {
         int wide_quads = 1;                // int8, 96-query quads: lists probed by 97..160 queries of the batch take ONE 160-query quad
                                            // (8-wave blocks on 32-row tiles) instead of two passes; 0 = off
         uint32_t wide_quad_rows = 0;       // rows per block of that instance (0 = by rule: 6144)
+        int list_once = 0;                 // round 6: 1 = lists probed by more than 96 queries of the batch go to list_filter_kernel (rows stationary in
+                                           // registers, ALL the list's pairs streamed past them: every such list is read once -- and measured SLOWER than
+                                           // the wide-quad instance / regular quads sharing an L2: C3 2.18 against 1.87 ms of kernels, the mixture 3.7
+                                           // against 2.1; DESIGN 5.4d has the counters); 0 (default) = the wide-quad instance
     };
     mutable Opts opt;
     mutable pqv_counters_t counters{};
@@ -1980,6 +1984,7 @@ void opts_from_env(pqv_searcher::Opts &o) {
     o.pf96 = static_cast<int>(num("PQV_PF96", o.pf96));
     o.xcd_items = static_cast<int>(num("PQV_XCD_ITEMS", o.xcd_items));
     o.wide_quad_rows = static_cast<uint32_t>(num("PQV_WIDE_QUAD_ROWS", o.wide_quad_rows));
+    o.list_once = static_cast<int>(num("PQV_LIST_ONCE", o.list_once));
     o.pair_prune = static_cast<int>(num("PQV_PAIR_PRUNE", o.pair_prune));
     o.i8_form = static_cast<int>(num("PQV_I8_FORM", o.i8_form));
 }
@@ -2296,6 +2301,7 @@ struct TopkPlan {
     uint32_t slots_per_pair;   // partial lists per (query, probe rank)
     uint32_t wide_width;    // > 0: quads of 97..wide_width pairs go to the wide-quad instance (its own item table)
     uint32_t wide_rows_per_block, wide_bpl;
+    bool list_once;         // the wide table's quads hold up to wide_width (<= 1024) pairs of ONE list and run in list_filter_kernel
 };
 
 // Exact refinement of the seed threshold (SeedRefine): where survivors are expensive (rows of >= 256 dims; C2, 128 dims:
@@ -2459,13 +2465,25 @@ TopkPlan plan_topk(const pqv_searcher *s, uint32_t nq, uint32_t nprobe, uint32_t
                 // Lists that more than 96 queries of the batch probe (the long, popular ones: 36 % of C3's distinct probed
                 // rows) would be streamed twice; a quad of up to 160 queries on 32-row tiles (same accumulator registers) in
                 // one 8-wave block per CU reads them once.  Batches only (pairs >= 16 per list on average), work-item grid.
-                if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && !(o.wide_quads == 1 && prefer_regular(s)) && o.item_grid >= 1 &&
-                    160ull * s->sdim <= 122880 && pairs >= 16ull * s->n_clusters) {
-                    p.wide_width = 160;
-                    const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 8192ull;
-                    p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
-                    p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
-                    p.slots_per_pair = std::max(p.slots_per_pair, 8 * p.wide_bpl);
+                // Round 6: list_filter_kernel instead -- the list's rows stationary in registers and ALL its pairs (one quad of up to 1024)
+                // streamed past them, so a list is read ONCE however many queries probe it (clustered query loads: hundreds).  Not with
+                // the deferred form (its survivors carry the wide_filter_kernel queue's raw scores).
+                if (p.i8 && p.block_waves == 4 && p.quad_width == 96 && o.wide_quads && o.item_grid >= 1 && pairs >= 16ull * s->n_clusters) {
+                    const bool deferred = defer_on(s, nq, k, p) && cand_cap_for(s, k) <= 8192;
+                    if (o.list_once && o.wide_quads != 2 && !deferred && (s->sdim % 256) == 0 && s->sdim <= 768 && k <= 256) {
+                        p.list_once = true;
+                        p.wide_width = std::min<uint32_t>(1024u, std::max<uint32_t>(192u, (nq + 63u) / 64u * 64u));
+                        const uint64_t wr = o.wide_quad_rows >= 256 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 2048ull;
+                        p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
+                        p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
+                        p.slots_per_pair = std::max(p.slots_per_pair, 4 * p.wide_bpl);
+                    } else if (!(o.wide_quads == 1 && prefer_regular(s)) && 160ull * s->sdim <= 122880) {
+                        p.wide_width = 160;
+                        const uint64_t wr = o.wide_quad_rows >= 512 ? std::min<uint64_t>(o.wide_quad_rows, 1u << 22) / 256 * 256 : 8192ull;
+                        p.wide_rows_per_block = static_cast<uint32_t>(std::min<uint64_t>(wr, (max_len + 255) / 256 * 256));
+                        p.wide_bpl = static_cast<uint32_t>((max_len + p.wide_rows_per_block - 1) / p.wide_rows_per_block);
+                        p.slots_per_pair = std::max(p.slots_per_pair, 8 * p.wide_bpl);
+                    }
                 }
             } else {                // narrow kernel: exact seed window (slot chunk 0), screened remainder
                 p.filter_bpl = static_cast<uint32_t>((max_len - p.seed_rows + r - 1) / r);
@@ -2685,6 +2703,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
             // several quads too -- no wide-quad instance, or option 3 (every table)
             ps.xcd_items = !s->opt.xcd_items ? 0u : s->opt.xcd_items >= 3 ? 3u : wide ? 2u : 1u;
             if (wide) {
+                ps.wide_list_major = p.list_once ? 1u : 0u;
                 ps.wide_min = p.quad_width + 1; ps.wide_item_rows = p.wide_rows_per_block;
                 ps.wide_item_off = v + 6ull * kc + 7; ps.wide_n_items = v + 7ull * kc + 8;
                 ps.wide_item_quad = sc.s_items.as<uint32_t>() + max_items; ps.wide_max_items = wide_max_items;
@@ -2811,6 +2830,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
                 ta.wide_width = p.wide_width; ta.wide_item_quad = ps.wide_item_quad; ta.wide_n_items = ps.wide_n_items;
                 ta.wide_max_items = wide_max_items; ta.wide_rows_per_block = p.wide_rows_per_block;
                 ta.wide_nt = wide_rows_nt(s) ? 1u : 0u;
+                ta.list_once = p.list_once ? 1u : 0u;
                 if (s->opt.fork_wide) {
                     if (!sc.side) {
                         HIP_TRY(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking));
@@ -3284,6 +3304,7 @@ static int pqv_searcher_set_option_impl(pqv_searcher *s, const char *name, int64
     else if (n == "drain_min") o.drain_min = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(64, value)));
     else if (n == "xcd_items") o.xcd_items = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(3, value)));
     else if (n == "wide_quad_rows") o.wide_quad_rows = static_cast<uint32_t>(std::max<int64_t>(0, value));
+    else if (n == "list_once") o.list_once = static_cast<int>(value);
     else if (n == "i8_form") {        // takes effect when the int8 copy is (re)built
         o.i8_form = static_cast<int>(std::min<int64_t>(2, std::max<int64_t>(0, value)));
         (void)hipSetDevice(s->device);
@@ -3326,6 +3347,10 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
         std::snprintf(t, sizeof t, "stream_kernel: one candidate stream per (query, probed list), %u rows per block", p.rr_rows_per_block);
     if (p.tile && p.filter && p.quad && p.wide_width) {
         const size_t l = std::strlen(t);
+        if (p.list_once)
+            std::snprintf(t + l, sizeof t - l, "; lists probed by more than %u queries: list_filter_kernel -- 32 rows per wave stationary in registers, all the list's pairs "
+                          "(quads of up to %u) streamed past them in chunks of 32: every such list read once, %u rows per block", p.quad_width, p.wide_width, p.wide_rows_per_block);
+        else
         std::snprintf(t + l, sizeof t - l, "; lists probed by %u..%u queries: one quad, 8 waves per block on 32-row tiles, %u rows per block",
                       p.quad_width + 1, p.wide_width, p.wide_rows_per_block);
     }
@@ -3354,6 +3379,8 @@ static int pqv_searcher_describe_impl(const pqv_searcher *s, uint32_t nq, uint32
                       std::max<uint32_t>(1, nq) * (seed_refine_on(s, std::max<uint32_t>(1, nq), k) ? 256u : 64u));
         if (p.wide_width) {
             const size_t l = std::strlen(kn);
+            if (p.list_once) std::snprintf(kn + l, sizeof kn - l, "; list_filter_kernel<%u, %d>", s->sdim / 64, S);
+            else
             std::snprintf(kn + l, sizeof kn - l, "; wide_filter_kernel<%u, 8, %d, true, 2, false, %s, 2, %s>", p.wide_width / 16, S, wide_rows_nt(s) ? "true" : "false",
                           defp ? "true" : "false");
         }

@@ -210,6 +210,9 @@ struct PairSortArgs {
     uint32_t       *shape_stats;     // optional [2] (pinned host memory): rows of the lists that more than shape_wide pairs of the batch
     uint32_t        shape_wide;      // probe, and of those that more than shape_narrow do -- how the next batch cuts its quads
     uint32_t        shape_narrow;    // (its own width: quad_width is the 160-wide cut while the wide-quad instance is active)
+    uint32_t        wide_list_major; // the WIDE table keeps list-major order (a list's chunks are consecutive items: pair_scatter_kernel writes
+                                     // them, wide_item_chunk stays unused) while the regular one is chunk-major -- list_filter_kernel maps
+                                     // consecutive items to ONE XCD, whose L2 then holds the list's pair images for all of its chunks
     uint32_t        xcd_items;       // bit 0: the regular table, bit 1: the wide table -- a level's slots filled column by column of an
                                      // 8-column layout (the quads of one list -> the same XCD, back to back)
     // optional second class of quads (the wide-quad instance of the filter kernel): with wide_min > 0 the quads are cut
@@ -316,6 +319,7 @@ struct TileArgs {
     const uint32_t *wide_item_quad;
     const uint32_t *item_chunk, *wide_item_chunk;   // chunk-major tables (PairSortArgs::item_chunk); nullptr = chunk = item - quads[q].w
     uint32_t        wide_nt;         // the wide-quad instance streams its rows with the nt policy (most of its lists have one quad)
+    uint32_t        list_once;       // the wide table's quads (up to wide_width <= 1024 pairs of one list) run in list_filter_kernel (kernels_list.hip)
     // host side only (launch_tile_filter): run the wide-quad instance on `side_stream`, forked from and joined to the call's stream
     // by the two events, so that the two instances' tails fill each other (they cannot share a CU -- 2 x 81 KB against 142 KB
     // of LDS -- but they can share the chip); NULL: one after the other on the call's stream
@@ -366,6 +370,9 @@ constexpr uint32_t wide_filter_pend(uint32_t quad_width, uint32_t waves, bool f1
 // distance; only pairs that could still beat the query's admission threshold are evaluated in
 // the reference's exact order.  Needs thresholds seeded by a prior launch_tile_rerank window.
 hipError_t launch_tile_filter(const TileArgs &a, hipStream_t s);
+// The row-stationary int8 screen for the lists that many queries of the batch probe (kernels_list.hip): `a` is the wide table's
+// view of the step -- item_quad / item_chunk / n_items / max_items / rows_per_block of THAT table, quads of up to 1024 pairs.
+hipError_t launch_list_filter(const TileArgs &a, hipStream_t s);
 // After the exact seed window: gthr[q] = min(gthr[q], k-th smallest key over ALL of q's seed lists)
 // (slots 0..3 of every (query, probe rank) pair) -- the k-th of the union, far tighter than the min
 // of the per-wave k-th keys the fold publishes.

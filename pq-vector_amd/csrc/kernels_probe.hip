@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const PairSortArgs a) {
             if (!one_round) cluster_shape(base + tid);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {          // table 0: the quads of <= quad_width pairs; table 1: the wide quads (the cluster's first mw quads)
+                if (tb == 1 && a.wide_list_major) continue;      // (list-major wide table: pair_scatter_kernel writes it)
                 const uint32_t m = tb ? mw : mn, n = tb ? wnch : nch, qf = tb ? q0 : q0 + mw;
                 if (pass == 0) {
                     // counts per level as a difference array: + m at level 0, - m behind the cluster's last level; what lies
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const PairSortArgs a)
         if (a.item_rows) {
             const uint64_t len = a.list_off[c + 1] - a.list_off[c];
             const bool wq = a.wide_min && qcnt >= a.wide_min;      // a wide quad: the list's quads before it are wide too
-            if (a.item_chunk) {                // chunk-major: pair_scan_kernel wrote both tables
+            if (a.item_chunk && !(wq && a.wide_list_major)) {                // chunk-major: pair_scan_kernel wrote the table(s)
             } else if (wq) {
                 const uint32_t nch = (uint32_t)((len + a.wide_item_rows - 1) / a.wide_item_rows);
                 first = a.wide_item_off[c] + (i / a.quad_width) * nch;

@@ -2539,12 +2539,20 @@ static hipError_t launch_filter_s(const TileArgs &a, hipStream_t s) {
                     if (a.wide_width) {
                         // lists that 97..160 queries of the batch probe: ONE quad on 32-row tiles, one 8-wave block per CU --
                         // every row of such a list is read once instead of twice.
-                        if (a.wide_width != 160 || !a.item_quad || !a.wide_item_quad || !a.wide_max_items || !a.wide_rows_per_block)
+                        if ((a.wide_width != 160 && !a.list_once) || !a.item_quad || !a.wide_item_quad || !a.wide_max_items || !a.wide_rows_per_block)
                             return hipErrorInvalidValue;
                         TileArgs w = a;
                         w.quad_width = a.wide_width; w.block_waves = 8; w.wide_width = 0; w.pendv = a.pendv_wide;
                         w.item_quad = a.wide_item_quad; w.item_chunk = a.wide_item_chunk; w.n_items = a.wide_n_items; w.max_items = a.wide_max_items;
                         w.rows_per_block = a.wide_rows_per_block;
+                        if (a.list_once) {
+                            // round 6: the popular lists' rows stationary, their pairs streamed (kernels_list.hip) -- the regular instance
+                            // first, as below: every query's thresholds have met most of its lists before the popular ones are read
+                            if (a.cand_lb) return hipErrorInvalidValue;
+                            w.block_waves = 4; w.item_chunk = nullptr;       // (its table is list-major: PairSortArgs::wide_list_major)
+                            hipError_t e = launch_wide<6, 4, S, true, OP_I8, false, true>(a, lds, s);
+                            return e != hipSuccess ? e : launch_list_filter(w, s);
+                        }
                         // the regular instance first: most lists are its, so every query's thresholds have met most of its lists'
                         // first chunks before the popular lists are read (C3: 257 -> 225 exact evaluations per query, the serial
                         // step's kernels 2.09 -> 2.065 ms against the wide instance first)
