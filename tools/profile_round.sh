@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $O/kt -- $B --steps 20 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find $O/kt -name "*.db" | head -1) --match pqv > $O/${tag}_${wl}_kernel_trace.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -- $B --steps 3 --warmup 1 --streams 1 > /dev/null 2>&1
-  python $R/tools/rocpd_summary.py $(find $O/pmc_$c -name "*.db" | head -1) --match pqv | grep -E "^#|wide_|tile_|merge_kernel|stream_kernel|probe_rows|quantize_|pair_|seed_" > $O/${tag}_${wl}_pmc_$c.txt
+  python $R/tools/rocpd_summary.py $(find $O/pmc_$c -name "*.db" | head -1) --match pqv | grep -E "^#|wide_|list_|tile_|merge_kernel|stream_kernel|probe_rows|quantize_|pair_|seed_" > $O/${tag}_${wl}_pmc_$c.txt
 done
 : > $O/${tag}_${wl}_pmc_sq.txt
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
