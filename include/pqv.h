@@ -228,7 +228,10 @@ void pqv_searcher_free(pqv_searcher *searcher);
  *   "wide_quads"    int8 path, batches: lists probed by 97..160 queries in ONE quad of the wide-quad instance (32-row tiles, one
  *                   8-wave block per CU) instead of two regular quads.  1 (default): by the PREVIOUS batch's shape -- regular quads
  *                   only while most rows of the popular lists sit in lists of > 160 pairs (clustered query loads); 2 always; 0 never
- *   "wide_quad_rows" rows per block of that instance (0 by rule: 8192)
+ *   "wide_quad_rows" rows per block of that instance (0 by rule: 8192; 2048 for the list form below)
+ *   "list_once"     int8 path, batches, dims 256 / 512 / 768, no deferred evaluation: 1 = lists probed by more than 96 queries run in
+ *                   list_filter_kernel -- 32 rows per wave stationary in registers, ALL the list's pairs (quads of up to 1024) streamed
+ *                   past them: every such list is read once.  0 (default): measured slower than the wide-quad instance
  *   "xcd_items"     a level's work items are filled column by column of an 8-column layout, so that the quads of one list run
  *                   back to back on one XCD and share its rows through that L2: 1 (default) = in the table that has several
  *                   quads per list, 3 = in both tables, 0 = off

@@ -558,8 +558,12 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     if ((uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull) return hipErrorInvalidValue;
     // 256 x 256 tiles from 256 queries on (PQV_BRUTE_TILE=128 keeps the 128 x 256 form for comparison)
     static const int tile_env = [] { const char *e = std::getenv("PQV_BRUTE_TILE"); return e ? std::atoi(e) : 0; }();
-    const bool big = tile_env == 256 || (tile_env != 128 && a.nq > 128);
-    const uint64_t bm = big ? 256 : 128, bn = 256;
+    // round 6 (PQV_BRUTE_TILE=384): 256 queries x 128 rows, four waves of 128 x 64 -- the big tile's wave shape (128 accumulators) in
+    // TWO 48 KB blocks per CU: one block's epilogue (a quarter of the 8-wave block's time, nothing else on its CU) overlaps the
+    // other's K loop; the price is 85 instead of 128 operations per staged byte
+    const bool half = tile_env == 384 && a.nq > 128;
+    const bool big = !half && (tile_env == 256 || (tile_env != 128 && a.nq > 128));
+    const uint64_t bm = (big || half) ? 256 : 128, bn = half ? 128 : 256;
     const uint64_t nb = (a.row_end - a.row_begin + bn - 1) / bn, ny = (a.nq + bm - 1) / bm;
     const uint64_t blocks = (nb + 7) / 8 * 8 * ny;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -584,6 +588,10 @@ hipError_t launch_brute_f16(const BruteF16Args &a, hipStream_t s) {
     }
     // (measured and dropped: four waves of 128 x 128 -- 16 accumulator tiles per wave in AGPRs, one wave per SIMD, half the LDS
     //  reads per MFMA: hipcc keeps 1 KB of scratch per lane for it and the launch takes 136 ms against 18.5)
+    if (half) {
+        if (i8) return launch(brute_f16_kernel<2, 2, 4, 2, true, 4>, 256, 2 * 384 * 4 * 16);
+        return launch(brute_f16_kernel<2, 2, 4, 2, false, 4>, 256, 2 * 384 * 4 * 16);
+    }
     if (i8) {
         if (st8) return launch(brute_f16_kernel<2, 4, 4, 2, true, 8>, 512, 2 * 512 * 8 * 16);
         if (big) return launch(brute_f16_kernel<2, 4, 4, 2, true, 4>, 512, 2 * 512 * 4 * 16);
