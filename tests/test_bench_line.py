@@ -119,3 +119,15 @@ def test_eight_rank_line_fits(bench):
     assert len(text) < bench.LINE_CAP
     line = json.loads(text)
     assert len(line["per_rank_ms_per_step"]["ranks"]) == 8 and line["exchange"]["ranks"] == 8 and len(line["config"]["row_bases"]) == 8
+
+
+def test_a_line_always_comes_out(bench, monkeypatch):
+    """Whatever goes wrong while the summary is built -- an exception, a summary beyond the cap -- the run still prints the contract
+    keys with `roofline` and `cpu_baseline`."""
+    full = _canned()
+    monkeypatch.setattr(bench, "compact_line", lambda r: (_ for _ in ()).throw(KeyError("boom")))
+    line = json.loads(bench.line_text(full))
+    assert line["metric"] == full["metric"] and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    monkeypatch.setattr(bench, "compact_line", lambda r: {"x": "y" * 20000})
+    text = bench.line_text(full)
+    assert len(text) < bench.LINE_CAP and json.loads(text)["config"]["workload"].startswith("c3")
