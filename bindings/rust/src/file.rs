@@ -31,7 +31,8 @@ use arrow::datatypes::DataType;
 use parquet::arrow::arrow_reader::ParquetRecordBatchReaderBuilder;
 use parquet::arrow::{ArrowWriter, ProjectionMask};
 use parquet::file::metadata::{FileMetaData, KeyValue, ParquetMetaData, ParquetMetaDataBuilder, ParquetMetaDataReader, ParquetMetaDataWriter};
-use parquet::file::properties::WriterProperties;
+use parquet::basic::Encoding;
+use parquet::file::properties::{EnabledStatistics, WriterProperties};
 use parquet::schema::types::ColumnPath;
 
 use crate::{sys, Corpus, Index, Result, SearchResult};
@@ -55,9 +56,9 @@ pub type RowGroupRange = Option<(usize, usize)>;
 pub fn shard_row_groups(rank: usize, world: usize, rg_rows: &[u64]) -> Result<(usize, usize, u64, u64)> {
     let (mut lo, mut hi, mut base, mut n) = (0u32, 0u32, 0u64, 0u64);
     // ONE implementation of the rule, in the library (host only; no device is touched)
-    crate::check(unsafe {
-        sys::pqv_shard_row_groups(rg_rows.as_ptr(), rg_rows.len() as u32, rank as u32, world as u32, &mut lo, &mut hi, &mut base, &mut n)
-    })?;
+    // (the ABI takes u32 counts: a value that does not fit is an error, not a silent truncation)
+    let (n_rg, rank32, world32) = (u32::try_from(rg_rows.len())?, u32::try_from(rank)?, u32::try_from(world)?);
+    crate::check(unsafe { sys::pqv_shard_row_groups(rg_rows.as_ptr(), n_rg, rank32, world32, &mut lo, &mut hi, &mut base, &mut n) })?;
     Ok((lo as usize, hi as usize, base, n))
 }
 
@@ -256,33 +257,63 @@ impl IndexBuilder {
         Ok(())
     }
 
-    /// The same into a copy of the file (`src/ivf/parquet.rs:70-87`, writer properties `:307-377`: the embedding leaf without
-    /// a dictionary and one vector per data page, every other column with the codec and dictionary flag it had).
+    /// The same into a copy of the file (`src/ivf/parquet.rs:70-87`).  Layout as the reference writes it (`:315-377`): data pages, then
+    /// `PQ_VECTOR1 | u64 length | blob` through the SAME writer behind its last flushed row group -- `bytes_written()` at that
+    /// point is the index offset --, then ONE footer that carries the two keys.  Writer properties as there: one vector per data
+    /// page of the embedding leaf (page size limit = one vector, row count limit 1), every column with the codec, dictionary flag,
+    /// data encoding and statistics level of its first source chunk; the embedding leaf without a dictionary, with chunk-level
+    /// statistics and none in the page headers.
     pub fn build_new(self, output: impl AsRef<Path>) -> Result<()> {
         let index = self.build_index()?;
         let src = ParquetRecordBatchReaderBuilder::try_new(File::open(&self.source)?)?;
         let meta = src.metadata().clone();
-        let mut props = WriterProperties::builder()
-            .set_data_page_row_count_limit(1)
-            .set_data_page_size_limit(index.dim().max(1) * 4)
-            .set_write_batch_size(index.dim().max(1));
+        let mut props = WriterProperties::builder().set_data_page_size_limit(index.dim().max(1) * 4).set_data_page_row_count_limit(1);
+        let mut embedding_leaf: Option<ColumnPath> = None;
         if meta.num_row_groups() > 0 {
             for col in meta.row_group(0).columns() {
                 let cp = ColumnPath::from(col.column_path().parts().to_vec());
-                let is_embedding = col.column_path().parts().first().map(String::as_str) == Some(self.embedding_column.as_str());
-                let uses_dict = col.encodings().any(|e| matches!(e, parquet::basic::Encoding::RLE_DICTIONARY | parquet::basic::Encoding::PLAIN_DICTIONARY));
-                props = props.set_column_compression(cp.clone(), col.compression()).set_column_dictionary_enabled(cp, uses_dict && !is_embedding);
+                let mut uses_dict = false;
+                let mut data_encoding = None;
+                for e in col.encodings() {
+                    match e {
+                        Encoding::RLE_DICTIONARY | Encoding::PLAIN_DICTIONARY => uses_dict = true,
+                        Encoding::RLE | Encoding::BIT_PACKED => {} // level encodings, not the values'
+                        other => data_encoding = Some(other),
+                    }
+                }
+                let stats = if col.statistics().is_some() { EnabledStatistics::Chunk } else { EnabledStatistics::None };
+                props = props.set_column_compression(cp.clone(), col.compression()).set_column_dictionary_enabled(cp.clone(), uses_dict);
+                if let Some(enc) = data_encoding {
+                    if !uses_dict {
+                        props = props.set_column_encoding(cp.clone(), enc);
+                    }
+                }
+                props = props.set_column_statistics_enabled(cp.clone(), stats);
+                if col.column_path().parts().first().map(String::as_str) == Some(self.embedding_column.as_str()) {
+                    embedding_leaf = Some(cp);
+                }
             }
         }
-        let rg_rows = (0..meta.num_row_groups()).map(|i| meta.row_group(i).num_rows() as usize).max().unwrap_or(1 << 20);
-        let props = props.set_max_row_group_size(rg_rows.max(1)).build();
+        let leaf = embedding_leaf.ok_or_else(|| format!("Column '{}' not found", self.embedding_column))?;
+        let props = props
+            .set_column_dictionary_enabled(leaf.clone(), false)
+            .set_column_statistics_enabled(leaf.clone(), EnabledStatistics::Chunk)
+            .set_column_write_page_header_statistics(leaf, false)
+            .build();
         let schema = src.schema().clone();
         let mut w = ArrowWriter::try_new(File::create(output.as_ref())?, schema, Some(props))?;
-        for batch in src.with_batch_size(1 << 14).build()? {
+        for batch in src.build()? {
             w.write(&batch?)?;
         }
+        w.flush()?;
+        let offset = w.bytes_written();
+        let blob = index.to_bytes()?;
+        w.write_all(INDEX_MAGIC)?;
+        w.write_all(&(blob.len() as u64).to_le_bytes())?;
+        w.write_all(&blob)?;
+        w.append_key_value_metadata(KeyValue::new(KEY_OFFSET.to_string(), offset.to_string()));
+        w.append_key_value_metadata(KeyValue::new(KEY_COLUMN.to_string(), self.embedding_column.clone()));
         w.close()?;
-        append_index_inplace(output.as_ref(), &index, &self.embedding_column)?;
         Ok(())
     }
 }
