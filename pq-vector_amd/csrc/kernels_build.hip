@@ -819,23 +819,34 @@ hipError_t launch_center_normalize_f16(const float *rows, const float *mu, uint6
                        static_cast<uint16_t *>(out), fixed_scale, idx);
     return hipGetLastError();
 }
-// mu[d] = mean over the k rows of m[., d]: one block per 64 columns, four row slices per column reduced through LDS
-__global__ __launch_bounds__(256) void col_mean_kernel(const float *__restrict__ m, uint32_t k, uint32_t dim, float *__restrict__ mu) {
-    __shared__ float part[4][64];
-    const uint32_t d = blockIdx.x * 64u + (threadIdx.x & 63u), sl = threadIdx.x >> 6;
+// mu[d] = mean over the k rows of m[., d]: one block per 64 columns, SIXTEEN row slices per column (four loads in flight each)
+// reduced through LDS.  (mu only centres the f16 images of the assignment -- the bounds hold for any mu --, so the order of this
+// sum is free; with four slices of 256 dependent loads it was 80 us of every Lloyd iteration.)
+__global__ __launch_bounds__(1024) void col_mean_kernel(const float *__restrict__ m, uint32_t k, uint32_t dim, float *__restrict__ mu) {
+    __shared__ float part[16][64];
+    const uint32_t lane = threadIdx.x & 63u, d = blockIdx.x * 64u + lane, sl = threadIdx.x >> 6;
     float acc = 0.0f;
-    if (d < dim)
-        for (uint32_t r = sl; r < k; r += 4) acc += m[(uint64_t)r * dim + d];
-    part[sl][threadIdx.x & 63u] = acc;
+    if (d < dim) {
+        uint32_t r = sl;
+        for (; r + 48 < k; r += 64) {
+            const float v0 = m[(uint64_t)r * dim + d], v1 = m[(uint64_t)(r + 16) * dim + d];
+            const float v2 = m[(uint64_t)(r + 32) * dim + d], v3 = m[(uint64_t)(r + 48) * dim + d];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; r < k; r += 16) acc += m[(uint64_t)r * dim + d];
+    }
+    part[sl][lane] = acc;
     __syncthreads();
     if (sl == 0 && d < dim) {
-        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][lane];
         mu[d] = k ? t / (float)k : 0.0f;
     }
 }
 hipError_t launch_col_mean(const float *m, uint32_t k, uint32_t dim, float *mu, hipStream_t s) {
     if (dim == 0) return hipSuccess;
-    hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, m, k, dim, mu);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dim + 63) / 64), dim3(1024), 0, s, m, k, dim, mu);
     return hipGetLastError();
 }
 
