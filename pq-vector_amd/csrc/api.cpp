@@ -1459,6 +1459,80 @@ struct GemmAssign {
 // run time; both bodies add the same operands in the same order, so the sums are identical bit for bit.
 typedef float v4f_t __attribute__((vector_size(16), aligned(4)));
 typedef float v8f_t __attribute__((vector_size(32), aligned(4)));
+// k-means++ pick (index.rs:372-383): the first slot whose SEQUENTIAL f32 cumulative sum reaches `gen_range(0.0..1.0) * total`.  The
+// cumulative sum does not depend on the threshold, and `total` (the chunk sums of :356-370, ~6 us per round) does not depend on the
+// cumulative sum: a second host thread starts the walk the moment a round's minima are final, keeping the prefix it has passed; when
+// the main thread publishes the threshold it looks back through that prefix (linearly: the reference's "first slot", whatever the
+// values -- a NaN makes the prefix non-monotone) or walks on with the reference's own compare.  The same adds in the same order on
+// the same values: the pick is the reference's.
+struct PrefixScout {
+    const float *md = nullptr;
+    uint64_t n = 0;
+    std::vector<float> prefix;
+    alignas(64) std::atomic<uint32_t> req{0};          // main -> scout: walk round r (0: none yet; ~0u: exit)
+    alignas(64) std::atomic<uint32_t> thr_round{0};    // main -> scout: round whose threshold (or cancellation) is published
+    float thr_value = 0.0f;
+    bool cancel = false;
+    alignas(64) std::atomic<uint32_t> res_round{0};    // scout -> main: round whose result is published
+    uint64_t res_slot = ~0ull;
+    std::thread th;
+    static void relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void run() {
+        uint32_t seen = 0;
+        for (;;) {
+            uint32_t r;
+            while ((r = req.load(std::memory_order_acquire)) == seen) relax();
+            if (r == ~0u) return;
+            seen = r;
+            float cumsum = 0.0f;
+            uint64_t pos = 0, found = ~0ull;
+            bool have_thr = false, stop = false;
+            float thr = 0.0f;
+            while (!have_thr && pos < n) {                     // the threshold is not known yet: walk and remember
+                const uint64_t e = pos + 64 < n ? pos + 64 : n;
+                for (; pos < e; ++pos) { cumsum = cumsum + md[pos]; prefix[pos] = cumsum; }
+                if (thr_round.load(std::memory_order_acquire) == r) have_thr = true;
+                else if (req.load(std::memory_order_acquire) == ~0u) return;          // (the build failed half-way through a round)
+            }
+            while (!have_thr) {                                // (walked to the end before the total was there)
+                if (thr_round.load(std::memory_order_acquire) == r) have_thr = true;
+                else if (req.load(std::memory_order_acquire) == ~0u) return;
+                else relax();
+            }
+            thr = thr_value; stop = cancel;
+            if (!stop) {
+                for (uint64_t i = 0; i < pos; ++i)             // what has been passed already: the FIRST slot at or above the threshold
+                    if (prefix[i] >= thr) { found = i; break; }
+                if (found == ~0ull)
+                    for (; pos < n; ++pos) {                   // index.rs:375-383 from here on
+                        cumsum = cumsum + md[pos];
+                        if (cumsum >= thr) { found = pos; break; }
+                    }
+            }
+            res_slot = found;
+            res_round.store(r, std::memory_order_release);
+        }
+    }
+    void start(const float *minima, uint64_t count) {
+        md = minima; n = count; prefix.assign(count, 0.0f);
+        th = std::thread([this] { run(); });
+    }
+    void begin(uint32_t r) { req.store(r, std::memory_order_release); }
+    uint64_t finish(uint32_t r, float threshold, bool cancelled) {
+        thr_value = threshold; cancel = cancelled;
+        thr_round.store(r, std::memory_order_release);
+        while (res_round.load(std::memory_order_acquire) != r) relax();
+        return res_slot;
+    }
+    ~PrefixScout() {
+        if (th.joinable()) { req.store(~0u, std::memory_order_release); th.join(); }
+    }
+};
+
 __attribute__((target("avx2"))) static void chain_sums_avx2(const float *m, uint64_t rows, uint64_t width, float *acc) {
     for (uint64_t c0 = 0; c0 < width; c0 += 32) {          // four 8-lane accumulators: 32 chains per pass over the rows
         const uint64_t nb = std::min<uint64_t>(4, (width - c0) / 8);
@@ -1609,6 +1683,15 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
     double tt_gpu = 0.0, tt_sum = 0.0, tt_pick = 0.0;       // PQV_VERBOSE: where a round's time goes
     const bool vb = verbose();
+    // round 6: the pick's walk starts on a second host thread while this one adds the chunk sums (PrefixScout; PQV_KPP_SCOUT=0: one thread)
+    std::unique_ptr<PrefixScout> scout;
+    {
+        const char *e = std::getenv("PQV_KPP_SCOUT");
+        if (!(e && *e == '0') && std::thread::hardware_concurrency() >= 2 && k > 2 && init_n >= 4096) {
+            scout.reset(new (std::nothrow) PrefixScout());
+            if (scout) scout->start(h_min.as<float>(), init_n);
+        }
+    }
     for (uint32_t i = 1; i < k; ++i) {
         const double tr0 = vb ? now_s() : 0.0;
         if (i > 1) {  // round 1 would re-measure centroid 0: min-update is the identity
@@ -1628,6 +1711,7 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
             if (qe != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamSynchronize(stream)); }
         }
         const double tr1 = vb ? now_s() : 0.0;
+        if (scout) scout->begin(i);
         const float *md = h_min.as<float>();
         // total = sum over worker chunks of the chunk's sequential f32 sum (:356-370)
         // Each chunk's sum is its own sequential f32 chain and the chains are independent of each other, so eight
@@ -1662,12 +1746,17 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
         const double tr2 = vb ? now_s() : 0.0;
         if (total > 0.0f) {
             const float threshold = rng.unit_f32() * total;                            // :373
-            float cumsum = 0.0f;
-            for (uint64_t slot = 0; slot < init_n; ++slot) {                           // :375-383
-                cumsum = cumsum + md[slot];
-                if (cumsum >= threshold) { picks[i] = slot; break; }
+            if (scout) {
+                picks[i] = scout->finish(i, threshold, false);                         // (~0: no slot reached it, as below)
+            } else {
+                float cumsum = 0.0f;
+                for (uint64_t slot = 0; slot < init_n; ++slot) {                       // :375-383
+                    cumsum = cumsum + md[slot];
+                    if (cumsum >= threshold) { picks[i] = slot; break; }
+                }
             }
         } else {
+            if (scout) (void)scout->finish(i, 0.0f, true);
             picks[i] = rng.range_usize(0, init_n);                                     // :385
         }
         if (vb) { const double tr3 = now_s(); tt_gpu += tr1 - tr0; tt_sum += tr2 - tr1; tt_pick += tr3 - tr2; }
