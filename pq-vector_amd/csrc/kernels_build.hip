@@ -340,12 +340,16 @@ __device__ __forceinline__ float assign_cut(float xn, float ub_best, float cm) {
 
 constexpr int AW_TM = 4, AW_TN = 2, AW_NWM = 2, AW_NWN = 4, AW_ST = 8;
 constexpr int AW_BM = 32 * AW_TM * AW_NWM, AW_BN = 32 * AW_TN * AW_NWN, AW_NT = 64 * AW_NWM * AW_NWN;     // 256 centroids x 256 rows, 512 threads
-__global__ __launch_bounds__(AW_NT, 1) void assign_wide_kernel(const AssignWideArgs a) {
-    constexpr int TM = AW_TM, TN = AW_TN, NWN = AW_NWN, ST = AW_ST, BM = AW_BM, BN = AW_BN, NT = AW_NT;
+// <NWN, ST>: <4, 8> = the 256 x 256 tile, eight waves, 128-byte K stages, ONE block per CU (the default);
+// <2, 4> (round 6, PQV_ASSIGN_SHAPE=128): 256 centroids x 128 rows, four waves of the same 128 x 64 shape, 64-byte stages -- 48 KB of LDS,
+// TWO blocks per CU, so that one block's epilogue (its CU otherwise idle: 20 % of a centroid tile) runs under the other's K loop
+template <int NWN, int ST>
+__global__ __launch_bounds__(64 * AW_NWM * NWN, NWN == 4 ? 1 : 2) void assign_wide_kernel(const AssignWideArgs a) {
+    constexpr int TM = AW_TM, TN = AW_TN, BM = AW_BM, BN = 32 * AW_TN * NWN, NT = 64 * AW_NWM * NWN;
     constexpr int CA = BM * ST / NT, CB = BN * ST / NT;        // 16-byte chunks a thread stages per K stage and side
     extern __shared__ float4 aw_lds[];                         // [2][BM * ST] centroid stages, [2][BN * ST] row stages
     float4 *const As4 = aw_lds, *const Bs4 = aw_lds + 2 * BM * ST;
-    auto sw = [](int r) { return ((r >> 1) & 1) | (((r >> 2) & 3) << 1); };      // 128-byte rows: brute_f16_kernel's swizzle
+    auto sw = [](int r) { return ST == 4 ? (r >> 2) & 3 : ((r >> 1) & 1) | (((r >> 2) & 3) << 1); };      // 64- / 128-byte rows: brute_f16_kernel's swizzles
     __shared__ float cn_s[BM];               // cn2 of the current centroid tile (+inf beyond kc)
     __shared__ float gcs_s[BM / 32], gcn_s[BM / 32];      // per 32-centroid group of the tile: >= max |c - mu|, >= max cn2
     __shared__ uint32_t best_s[BN];          // sortable bits of the rows' smallest upper-bound score so far
@@ -498,12 +502,21 @@ __global__ __launch_bounds__(AW_NT, 1) void assign_wide_kernel(const AssignWideA
 hipError_t launch_assign_wide(const AssignWideArgs &a, hipStream_t s) {
     if (a.m == 0 || a.kc == 0) return hipSuccess;
     if ((a.dim_p % 64) != 0 || (uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull || (a.kc_pad % AW_BM) != 0 || a.kc_pad < a.kc) return hipErrorInvalidValue;
+    static const bool half = [] { const char *e = getenv("PQV_ASSIGN_SHAPE"); return e && atoi(e) == 128; }();
+    if (half) {
+        constexpr int BN = 32 * AW_TN * 2;
+        const uint64_t blocks = (a.m + BN - 1) / BN;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        constexpr size_t lds = 2 * (size_t)(AW_BM + BN) * 4 * 16;
+        hipLaunchKernelGGL((assign_wide_kernel<2, 4>), dim3((uint32_t)blocks), dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
     const uint64_t blocks = (a.m + AW_BN - 1) / AW_BN;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t lds = 2 * (size_t)(AW_BM + AW_BN) * AW_ST * 16;
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assign_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assign_wide_kernel<AW_NWN, AW_ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-    hipLaunchKernelGGL(assign_wide_kernel, dim3((uint32_t)blocks), dim3(AW_NT), lds, s, a);
+    hipLaunchKernelGGL((assign_wide_kernel<AW_NWN, AW_ST>), dim3((uint32_t)blocks), dim3(AW_NT), lds, s, a);
     return hipGetLastError();
 }
 
