@@ -1557,6 +1557,33 @@ static void chain_sums(const float *m, uint64_t rows, uint64_t width, float *acc
     }
 }
 
+// The inverted lists built on the device (kernels_build.hip: launch_list_sort) -- the same ascending-row-id lists as
+// lists_from_assignment above, without the assignment's trip to the host.  PQV_DEVICE_LISTS=0 keeps the host sort (A/B).
+struct DeviceLists {
+    DevBuf cnt, tot, bad;
+    uint32_t rpb = 4096;
+    static bool applicable(uint64_t n, uint32_t k) {
+        static const bool on = [] { const char *e = std::getenv("PQV_DEVICE_LISTS"); return !(e && e[0] == '0'); }();
+        return on && n > 0 && n <= 0xFFFFFFFFull && k > 0 && k <= 4096;
+    }
+    int prepare(uint64_t n, uint32_t k) {
+        // blocks of 4096 rows; below 2^20 rows smaller blocks keep a few hundred of them in flight
+        rpb = n >= (1u << 20) ? 4096 : n >= (1u << 17) ? 1024 : 256;
+        const uint64_t nblk = (n + rpb - 1) / rpb;
+        HIP_TRY(cnt.alloc(static_cast<size_t>(k) * nblk * sizeof(uint32_t)));
+        HIP_TRY(tot.alloc(static_cast<size_t>(k) * sizeof(unsigned long long)));
+        HIP_TRY(bad.alloc(sizeof(uint32_t)));
+        return PQV_OK;
+    }
+    // enqueues the sort; *bad stays 0 unless an assignment is out of range (check() after the stream drained)
+    int run(const uint32_t *d_assign, uint64_t n, uint32_t k, uint64_t *d_list_off, uint32_t *d_list_rows, hipStream_t stream) {
+        HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(uint32_t), stream));
+        HIP_TRY(pqv::launch_list_sort(d_assign, n, k, cnt.as<uint32_t>(), rpb, tot.as<unsigned long long>(), d_list_off, d_list_rows,
+                                 bad.as<uint32_t>(), stream));
+        return PQV_OK;
+    }
+};
+
 // d_data [n, dim] resident; writes d_centroids [k, dim] (device) and optionally the final
 // assignment (host).
 int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uint32_t max_iters,
@@ -1806,6 +1833,13 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     GemmAssign gemm;
     const bool use_gemm = GemmAssign::applicable(dim, k);
     const bool use_screen = !use_gemm && ScreenedAssign::applicable(dim, k);
+    const bool dev_lists = DeviceLists::applicable(n, k);
+    DeviceLists dlists;
+    uint32_t h_bad = 0;
+    if (dev_lists) {
+        if (int rc = dlists.prepare(n, k)) return rc;
+        HIP_TRY(hipMemsetAsync(dlists.bad.p, 0, sizeof(uint32_t), stream));
+    }
     for (uint32_t iter = 0; iter < max_iters; ++iter) {
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, (static_cast<size_t>(k) + 1) * sizeof(unsigned long long), stream));
         unsigned long long *d_changed = d_counts.as<unsigned long long>() + k;
@@ -1832,19 +1866,31 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
             HIP_TRY(launch_assign(d_data, n, dim, d_centroids, k, d_cur, d_prev, d_changed, nullptr, stream));
         HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts.p, h_counts.size() * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_assign.data(), d_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (!dev_lists) HIP_TRY(hipMemcpyAsync(h_assign.data(), d_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (dev_lists && iter > 0)                 // (the previous iteration's range check rides on this synchronisation)
+            HIP_TRY(hipMemcpyAsync(&h_bad, dlists.bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (h_bad) return fail(PQV_ERR_HIP, "internal error: Lloyd assignment out of range");
         iters++;
         std::swap(d_prev, d_cur);
         if (h_counts[k] == 0) break;                                                   // :432
-        if (!lists_from_assignment(h_assign.data(), n, k, off, rows))
-            return fail(PQV_ERR_HIP, "internal error: Lloyd assignment out of range");
-        HIP_TRY(hipMemcpyAsync(d_list_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_list_rows.p, rows.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (dev_lists) {
+            if (int rc = dlists.run(d_prev, n, k, d_list_off.as<uint64_t>(), d_list_rows.as<uint32_t>(), stream)) return rc;
+        } else {
+            if (!lists_from_assignment(h_assign.data(), n, k, off, rows))
+                return fail(PQV_ERR_HIP, "internal error: Lloyd assignment out of range");
+            HIP_TRY(hipMemcpyAsync(d_list_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_list_rows.p, rows.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
         HIP_TRY(launch_lloyd_update(d_data, dim, d_list_rows.as<uint32_t>(), d_list_off.as<uint64_t>(),
                                     k, d_centroids, stream));                          // :436-453
     }
+    if (dev_lists && iters > 0) {
+        HIP_TRY(hipMemcpyAsync(&h_bad, dlists.bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (assign_out) HIP_TRY(hipMemcpyAsync(h_assign.data(), d_prev, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (h_bad) return fail(PQV_ERR_HIP, "internal error: Lloyd assignment out of range");
     g_build_stats[1] = now_s() - t_pp1; g_build_stats[2] = iters; g_build_stats[6] = use_gemm ? 2.0 : use_screen ? 1.0 : 0.0;
     if (verbose()) std::fprintf(stderr, "[pqv] Lloyd: %u iterations over %llu rows in %.3f s\n", iters,
                                 (unsigned long long)n, now_s() - t_pp1);
@@ -1904,11 +1950,12 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     // The two host arrays of n row ids (the downloaded assignment and the lists) are allocated and first-touched by a
     // helper thread while the device assigns: 2 x 40 MB of page faults on C3 that used to follow the kernels.
     std::vector<uint32_t> cluster_of, rows_buf;
+    const bool dev_lists = DeviceLists::applicable(n, static_cast<uint32_t>(k));      // (the lists sorted on the device: no assignment download)
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } warm;
     if (n >= (1u << 20)) {
         try {
-            warm.t = std::thread([&cluster_of, &rows_buf, n] {
-                try { cluster_of.resize(n); rows_buf.resize(n); } catch (...) { }
+            warm.t = std::thread([&cluster_of, &rows_buf, n, dev_lists] {
+                try { if (!dev_lists) cluster_of.resize(n); rows_buf.resize(n); } catch (...) { }
             });
         } catch (const std::system_error &) { }
     }
@@ -1918,6 +1965,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         GemmAssign gemm;
         bool bad_c = false, bad_r = false;
         if (int rc = gemm.set_centroids(d_centroids.as<float>(), static_cast<uint32_t>(k), dim, stream, &bad_c)) return rc;
+        if (verbose()) std::fprintf(stderr, "[pqv] final assignment: centroids set at %.1f ms\n", (now_s() - t_fa0) * 1e3);
         if (!bad_c) {
             // (chunk-wise downloads behind the next chunk's kernels were measured and dropped: a device-to-pageable copy on a
             //  second stream stalls the compute stream's queue -- 53 ms for the loop against 34 ms of kernels on C3)
@@ -1943,14 +1991,37 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     if (exact_assign)
         HIP_TRY(launch_assign(corpus->d_rows, n, dim, d_centroids.as<float>(), static_cast<uint32_t>(k),
                               d_cluster.as<uint32_t>(), nullptr, nullptr, nullptr, stream));
+    // the lists: sorted on the device (the rows of a list ascending, index.rs:193-206), then ONE download of the sorted row ids
+    // in place of the assignment's download + the host threads' counting sort
+    DeviceLists dlists;
+    DevBuf d_rows_sorted, d_off;
+    if (dev_lists) {
+        if (int rc = dlists.prepare(n, static_cast<uint32_t>(k))) return rc;
+        HIP_TRY(d_rows_sorted.alloc(n * sizeof(uint32_t)));
+        HIP_TRY(d_off.alloc((k + 1) * sizeof(uint64_t)));
+        if (int rc = dlists.run(d_cluster.as<uint32_t>(), n, static_cast<uint32_t>(k), d_off.as<uint64_t>(), d_rows_sorted.as<uint32_t>(), stream))
+            return rc;
+    }
+    if (verbose()) { HIP_TRY(hipStreamSynchronize(stream)); std::fprintf(stderr, "[pqv] final assignment: lists sorted at %.1f ms\n", (now_s() - t_fa0) * 1e3); }
     if (warm.t.joinable()) warm.t.join();
-    cluster_of.resize(n);
+    if (verbose()) std::fprintf(stderr, "[pqv] final assignment: host arrays ready at %.1f ms\n", (now_s() - t_fa0) * 1e3);
+    if (!dev_lists) cluster_of.resize(n);
     pqv_index *idx = new (std::nothrow) pqv_index();
     if (!idx) return fail(PQV_ERR_OOM, "host allocation failed");
     idx->list_rows = std::move(rows_buf);
     idx->dim = dim; idx->n_clusters = static_cast<uint32_t>(k);
     idx->centroids.resize(k * dim);
-    hipError_t e = downloaded ? hipSuccess : hipMemcpyAsync(cluster_of.data(), d_cluster.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    uint32_t h_bad = 0;
+    hipError_t e = hipSuccess;
+    if (dev_lists) {
+        idx->list_rows.resize(n);
+        idx->list_off.resize(k + 1);
+        e = hipMemcpyAsync(idx->list_rows.data(), d_rows_sorted.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(idx->list_off.data(), d_off.p, (k + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, dlists.bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    } else if (!downloaded) {
+        e = hipMemcpyAsync(cluster_of.data(), d_cluster.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    }
     if (e == hipSuccess)
         e = hipMemcpyAsync(idx->centroids.data(), d_centroids.p, k * dim * sizeof(float), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -1959,7 +2030,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         return fail(PQV_ERR_HIP, std::string("final assignment: ") + hipGetErrorString(e));
     }
     const double t_fa1 = now_s();
-    if (!lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows)) {
+    if (dev_lists ? h_bad != 0 : !lists_from_assignment(cluster_of.data(), n, idx->n_clusters, idx->list_off, idx->list_rows)) {
         delete idx;
         return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
     }

@@ -537,6 +537,12 @@ hipError_t launch_pack_queries(const float *queries, const uint32_t *pairs, cons
 hipError_t launch_assign_setup(uint32_t *pairs, uint4 *quads, uint32_t *n_quads, uint64_t *cand_base, unsigned long long *gthr,
                                uint32_t nq, uint32_t width, hipStream_t s);
 hipError_t launch_nonfinite_flag(const float *v, uint64_t n, uint32_t *flag, hipStream_t s);
+// The inverted lists on the device (kernels_build.hip: list_*_kernel): a stable counting sort of the rows by cluster -- list c holds
+// the row ids assigned to c in ascending order (index.rs:193-206).  cnt: scratch [k][ceil(n / rows_per_block)] u32, tot: scratch [k] u64,
+// list_off: [k + 1] u64, list_rows: [n] u32, *bad: set to 1 if an assignment is >= k (preset 0).  k <= 4096, n < 2^32,
+// rows_per_block a multiple of 256.
+hipError_t launch_list_sort(const uint32_t *assign, uint64_t n, uint32_t k, uint32_t *cnt, uint32_t rows_per_block,
+                            unsigned long long *tot, uint64_t *list_off, uint32_t *list_rows, uint32_t *bad, hipStream_t s);
 hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint64_t n, unsigned long long *changed, hipStream_t s);
 
 // pqv_rerank's running state <-> merge lists (see kernels_layout.hip)

@@ -913,6 +913,121 @@ hipError_t launch_count_changed(const uint32_t *cur, const uint32_t *prev, uint6
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------
+// Round 6: the inverted lists on the device -- a stable counting sort of the rows by cluster (index.rs:193-206: list c = the row ids
+// assigned to c in ASCENDING order, as the sequential scan pushes them).  Three launches:
+//   list_hist_kernel     block b counts the clusters of its rows_per_block consecutive rows (LDS), cnt[c][b] = count
+//   list_scan_kernel     block c turns cnt[c][.] into exclusive prefixes over the blocks and leaves the cluster's total in tot[c];
+//   list_offsets_kernel  one block: list_off = exclusive scan of tot (u64), list_off[k] = n
+//   list_scatter_kernel  block b again: wave w takes the w-th quarter of the block's rows, 64 at a time in row order; a row's slot is
+//                        list_off[c] + (rows of c in earlier blocks) + (in earlier waves of this block) + (earlier in this wave):
+//                        blocks, waves, steps and lanes are all walked in row order, so every list comes out ascending.
+// An assignment >= k sets *bad (the host then reports it like lists_from_assignment's failure).  k <= 4096 (LDS: 4 k counters).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void list_hist_kernel(const uint32_t *__restrict__ assign, uint64_t n, uint32_t k, uint32_t rpb,
+                                                        uint32_t nblk, uint32_t *__restrict__ cnt, uint32_t *__restrict__ bad) {
+    extern __shared__ uint32_t lh_hist[];
+    for (uint32_t c = threadIdx.x; c < k; c += 256) lh_hist[c] = 0u;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r1 = r0 + rpb < n ? r0 + rpb : n;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const uint32_t c = assign[r];
+        if (c < k) atomicAdd(&lh_hist[c], 1u); else *bad = 1u;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < k; c += 256) cnt[(uint64_t)c * nblk + blockIdx.x] = lh_hist[c];
+}
+__global__ __launch_bounds__(256) void list_scan_kernel(uint32_t *__restrict__ cnt, uint32_t nblk, unsigned long long *__restrict__ tot) {
+    __shared__ uint32_t part[256];
+    uint32_t *row = cnt + (uint64_t)blockIdx.x * nblk;
+    const uint32_t per = (nblk + 255u) / 256u, b0 = threadIdx.x * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += row[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t b = b0; b < b1; ++b) { const uint32_t x = row[b]; row[b] = run; run += x; }
+    if (threadIdx.x == 255) tot[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(1024) void list_offsets_kernel(const unsigned long long *__restrict__ tot, uint32_t k, uint64_t n,
+                                                            uint64_t *__restrict__ list_off) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t per = (k + 1023u) / 1024u, c0 = threadIdx.x * per, c1 = c0 + per < k ? c0 + per : k;
+    unsigned long long sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) sum += tot[c];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[threadIdx.x] - sum;
+    for (uint32_t c = c0; c < c1; ++c) { list_off[c] = run; run += tot[c]; }
+    if (threadIdx.x == 0) list_off[k] = n;
+}
+__global__ __launch_bounds__(256) void list_scatter_kernel(const uint32_t *__restrict__ assign, uint64_t n, uint32_t k, uint32_t rpb,
+                                                           uint32_t nblk, const uint32_t *__restrict__ cnt,
+                                                           const uint64_t *__restrict__ list_off, uint32_t *__restrict__ list_rows) {
+    extern __shared__ uint32_t ls_base[];            // [4][k]: first the waves' counts, then their first slots inside the cluster
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += 256) ls_base[i] = 0u;
+    __syncthreads();
+    const uint32_t wrows = rpb / 4u;                 // rows per wave: a multiple of 64
+    const uint64_t r0 = (uint64_t)blockIdx.x * rpb + (uint64_t)wave * wrows;
+    uint64_t r1 = r0 + wrows; if (r1 > n) r1 = n;
+    uint32_t *mine = ls_base + (uint32_t)wave * k;
+    for (uint64_t r = r0 + (uint32_t)lane; r < r1; r += 64) {
+        const uint32_t c = assign[r];
+        if (c < k) atomicAdd(&mine[c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < k; c += 256) {
+        uint32_t run = cnt[(uint64_t)c * nblk + blockIdx.x];       // rows of c in the blocks before this one
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t x = ls_base[(uint32_t)w * k + c]; ls_base[(uint32_t)w * k + c] = run; run += x; }
+    }
+    __syncthreads();
+    for (uint64_t rs = r0; rs < r1; rs += 64) {      // 64 rows per step, in row order
+        const uint64_t r = rs + (uint32_t)lane;
+        const bool valid = r < r1;
+        const uint32_t c = valid ? assign[r] : 0xFFFFFFFFu;
+        unsigned long long todo = __ballot(valid && c < k);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t c0 = readlane_u32(c, l);
+            const unsigned long long m = __ballot(c == c0) & todo;
+            const uint32_t first = mine[c0];                                   // (wave-uniform address: a broadcast read)
+            if (c == c0 && ((todo >> lane) & 1ull))
+                list_rows[list_off[c0] + first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            wave_lds_fence();
+            if (lane == l) mine[c0] = first + (uint32_t)__popcll(m);
+            wave_lds_fence();
+            todo &= ~m;
+        }
+    }
+}
+hipError_t launch_list_sort(const uint32_t *assign, uint64_t n, uint32_t k, uint32_t *cnt, uint32_t rows_per_block,
+                            unsigned long long *tot, uint64_t *list_off, uint32_t *list_rows, uint32_t *bad, hipStream_t s) {
+    if (n == 0 || k == 0 || k > 4096 || rows_per_block < 256 || (rows_per_block % 256) != 0 || n > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t nblk = (n + rows_per_block - 1) / rows_per_block;
+    if (nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(list_hist_kernel, dim3((uint32_t)nblk), dim3(256), (size_t)k * 4, s, assign, n, k, rows_per_block, (uint32_t)nblk, cnt, bad);
+    hipLaunchKernelGGL(list_scan_kernel, dim3(k), dim3(256), 0, s, cnt, (uint32_t)nblk, tot);
+    hipLaunchKernelGGL(list_offsets_kernel, dim3(1), dim3(1024), 0, s, tot, k, n, list_off);
+    hipLaunchKernelGGL(list_scatter_kernel, dim3((uint32_t)nblk), dim3(256), (size_t)k * 16, s, assign, n, k, rows_per_block, (uint32_t)nblk, cnt,
+                       list_off, list_rows);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // assign_kernel: Lloyd assign + final assignment (index.rs:395-424, :189-201, :244-257).
 // Same skeleton as the tile re-rank: lane-per-row, 128 B of the lane's own row per step, a

@@ -257,3 +257,39 @@ def test_c1_vldb_standin_through_the_path_builders(pqv, tmp_path):
     assert len(hits) == 10 and hits[0].row_idx == 0 and hits[0].distance == 0.0
     summary = bench.summarize_config(rec)
     assert summary["parity_ok"] is True and summary["n_clusters"] == 32 and "config" not in summary
+
+
+_LISTS_SCRIPT = r"""
+import sys, os, hashlib
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import pq_vector_amd as pqv
+n, dim, kc = (int(x) for x in sys.argv[1:4])
+rng = np.random.default_rng(n + dim)
+data = rng.integers(0, 1 << 24, size=(n, dim), dtype=np.int32).astype(np.float32) * np.float32(1.0 / (1 << 24))
+idx = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).max_iters(3).seed(5).workers(8).build()
+off = np.asarray(idx.list_offsets); rows = np.asarray(idx.list_rows)
+assert off[0] == 0 and off[-1] == n and np.all(np.diff(off.astype(np.int64)) >= 0)
+assert np.array_equal(np.sort(rows), np.arange(n, dtype=rows.dtype))             # every row in exactly one list
+asc = np.diff(rows.astype(np.int64)) > 0
+asc[off[1:-1][(off[1:-1] > 0) & (off[1:-1] < n)].astype(np.int64) - 1] = True    # (list boundaries may step down)
+assert asc.all()                                                                 # ascending row ids inside every list
+print("BLOB", hashlib.sha256(idx.to_bytes()).hexdigest())
+"""
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,dim,kc", [(5_000, 64, 37), (200_000, 64, 700), (1_300_000, 32, 4096), (1_100_003, 48, 1)])
+def test_device_sorted_lists_equal_the_host_counting_sort(n, dim, kc):
+    """index.rs:193-206: list c = the rows assigned to c, ascending.  The device's stable counting sort (list_*_kernel; block sizes
+    256 / 1024 / 4096 rows by corpus size) against the host threads' sort (PQV_DEVICE_LISTS=0) on the same build: same blob."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, PQV_DEVICE_LISTS=mode)
+        p = subprocess.run([sys.executable, "-c", _LISTS_SCRIPT, str(n), str(dim), str(kc)], cwd=root, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[mode] = [l for l in p.stdout.splitlines() if l.startswith("BLOB")][0]
+    assert got["1"] == got["0"]
