@@ -156,6 +156,13 @@ int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_
  * the Lloyd assignments, [7] sample rows, [8] summed HIP-event seconds of the assign_wide_kernel launches of the final
  * assignment (0 where another form ran), [9] their count; entries beyond n are not written. */
 int pqv_index_build_stats(double *out, uint32_t n);
+/* ONE k-means++ pick (src/ivf/index.rs:354-390) over given minima, taken the way the build's device rounds take it (kernels_kpp.hip):
+ * *total = the `workers` chunks' sequential f32 sums joined in ascending order (:356-370), *pick = the first slot whose sequential f32
+ * cumulative sum reaches draw * total (:373-383).  A test entry point: *status 0 = decided; otherwise the reason the build hands the
+ * round to its host walk (1 total not positive or not finite, 2 a value that is not a finite non-negative number, 3 no slot reaches the
+ * threshold) and *pick is not written.  n in [1, 57344]; workers 0 => this host's online CPU count. */
+int pqv_kpp_pick(int device, const float *minima, uint32_t n, uint32_t workers, float draw, uint64_t *pick, float *total,
+                 uint32_t *status);
 /* Host-pointer form with the reference's exact argument shape: uploads, builds, frees. */
 int pqv_index_build_host(int device, const float *data, uint64_t data_len, uint32_t dim,
                          uint32_t n_clusters, uint32_t max_iters, uint64_t seed,

@@ -87,6 +87,8 @@ SIGNATURES = {
     "pqv_corpus_free": (None, [vp]),
     "pqv_index_build": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "pqv_index_build_stats": (C.c_int, [C.POINTER(C.c_double), C.c_uint32]),
+    "pqv_kpp_pick": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "pqv_index_build_host": (C.c_int, [C.c_int, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "pqv_kmeans": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, f32p, u32p, u32p]),

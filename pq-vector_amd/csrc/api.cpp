@@ -1706,22 +1706,93 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     //  system-scope loads, minima mirrored with system-scope stores, a ticket per block -- 45 us a round against 24 for a launch per
     //  round: the PCIe round trips of the hand-shake cost more than a kernel launch and its completion.  Likewise a completion flag
     //  written by the last block of a per-round launch: the per-block system-scope release costs the kernel 20 us.)
+    // Round 6: the rounds enqueued ahead with the pick on the device (kernels_kpp.hip: the reference's sequential f32 sums evaluated
+    // exactly by composing the additions' integer images) -- no host round trip per centroid.  The draws of :373 are taken from a copy
+    // of the generator (one per round while every total is positive); a round the device cannot decide the reference's way stops the
+    // chain and the host walk below takes over from that round.  PQV_KPP_DEVICE=0 keeps the host walk for every round (A/B, tests).
+    uint32_t i_start = 1;
+    bool resume_after_update = false;
     sa.queries = centroid_row(0);  // distances to centroid 0
-    HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+    bool kpp_dev = false;
+    {
+        const char *e = std::getenv("PQV_KPP_DEVICE");
+        kpp_dev = !(e && *e == '0') && kpp_screen && k >= 3 && init_n <= 57344 && n_chunks <= 1024 && chunk <= 0xFFFFFFFFull;
+    }
+    if (kpp_dev) {
+        const double t_d0 = now_s();
+        // picks [k] | chunk sums [n_chunks] | block sums [64] | quarter-run pairs [4096] | block flags [64] | head [72] (u64 each), draws [k] f32, state [4] u32
+        const size_t n64 = static_cast<size_t>(k) + n_chunks + 64 + 4096 + 64 + 72;
+        const size_t bytes = n64 * 8 + (static_cast<size_t>(k) + 4) * 4;
+        DevBuf d_kpp;
+        HIP_TRY(d_kpp.alloc(bytes));
+        HIP_TRY(hipMemsetAsync(d_kpp.p, 0, bytes, stream));
+        unsigned long long *d_picks = d_kpp.as<unsigned long long>();
+        float *d_u = reinterpret_cast<float *>(d_picks + n64);
+        uint32_t *d_state = reinterpret_cast<uint32_t *>(d_u + k);
+        StdRng ahead = rng;
+        std::vector<float> draws(k, 0.0f);
+        for (uint32_t i = 1; i < k; ++i) draws[i] = ahead.unit_f32();
+        const unsigned long long pick0 = picks[0];
+        HIP_TRY(hipMemcpyAsync(d_picks, &pick0, sizeof pick0, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_u, draws.data(), static_cast<size_t>(k) * sizeof(float), hipMemcpyHostToDevice, stream));
+        StreamArgs sd = sa;
+        sd.mirror_f32 = nullptr; sd.mirror_t = nullptr;
+        HIP_TRY(launch_stream(sd, STREAM_MINUPD, stream));
+        MinUpdScreenArgs md_args = ms;
+        md_args.mirror = nullptr; md_args.mirror_t = nullptr; md_args.stop = d_state;
+        KppPickArgs pa{};
+        pa.md = d_min.as<float>(); pa.n = static_cast<uint32_t>(init_n);
+        pa.chunk = static_cast<uint32_t>(chunk); pa.n_chunks = static_cast<uint32_t>(n_chunks);
+        pa.chunk_sum = d_picks + k; pa.blk_sum = pa.chunk_sum + n_chunks; pa.run_sum = pa.blk_sum + 64; pa.blk_done = pa.run_sum + 4096; pa.head = pa.blk_done + 64;
+        pa.u = d_u; pa.picks = d_picks; pa.state = d_state;
+        for (uint32_t i = 1; i < k; ++i) {
+            if (i > 1) {                                   // (round 1 would re-measure centroid 0)
+                md_args.pick_dev = d_picks + (i - 1);
+                HIP_TRY(launch_minupd_screen(md_args, stream));
+            }
+            pa.round = i;
+            HIP_TRY(launch_kpp_pick(pa, stream));
+        }
+        uint32_t h_state[4] = {0, 0, 0, 0};
+        std::vector<unsigned long long> h_picks(k, ~0ull);
+        HIP_TRY(hipMemcpyAsync(h_picks.data(), d_picks, static_cast<size_t>(k) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const uint32_t decided = h_state[0] ? std::min<uint32_t>(std::max<uint32_t>(h_state[1], 1), k) : k;   // rounds 1 .. decided - 1
+        for (uint32_t i = 1; i < decided; ++i) picks[i] = h_picks[i];
+        for (uint32_t i = 1; i < decided; ++i) (void)rng.unit_f32();     // the generator follows the rounds that were decided
+        if (verbose()) std::fprintf(stderr, "[pqv] k-means++ on the device: rounds 1..%u of %u in %.1f ms%s\n", decided - 1, k - 1,
+                                    (now_s() - t_d0) * 1e3, h_state[0] ? " (the host walk takes over)" : "");
+        if (decided < k) {
+            if (verbose()) std::fprintf(stderr, "[pqv] k-means++: round %u back to the host (reason %u)\n", decided, h_state[2]);
+            // the host walk needs its mirrors of the minima as the device left them (round `decided`'s update has run)
+            HIP_TRY(hipMemcpyAsync(h_min.as<float>(), d_min.p, init_n * sizeof(float), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (use_t) {
+                float *mt = h_min_t.as<float>();
+                const float *hm = h_min.as<float>();
+                for (uint64_t pos = 0; pos < init_n; ++pos) mt[(pos % chunk) * wpad + pos / chunk] = hm[pos];
+            }
+            resume_after_update = decided > 1;
+        }
+        i_start = decided;
+    } else {
+        HIP_TRY(launch_stream(sa, STREAM_MINUPD, stream));
+    }
     double tt_gpu = 0.0, tt_sum = 0.0, tt_pick = 0.0;       // PQV_VERBOSE: where a round's time goes
     const bool vb = verbose();
     // round 6: the pick's walk starts on a second host thread while this one adds the chunk sums (PrefixScout; PQV_KPP_SCOUT=0: one thread)
     std::unique_ptr<PrefixScout> scout;
     {
         const char *e = std::getenv("PQV_KPP_SCOUT");
-        if (!(e && *e == '0') && std::thread::hardware_concurrency() >= 2 && k > 2 && init_n >= 4096) {
+        if (!(e && *e == '0') && std::thread::hardware_concurrency() >= 2 && k > 2 && init_n >= 4096 && i_start < k) {
             scout.reset(new (std::nothrow) PrefixScout());
             if (scout) scout->start(h_min.as<float>(), init_n);
         }
     }
-    for (uint32_t i = 1; i < k; ++i) {
+    for (uint32_t i = i_start; i < k; ++i) {
         const double tr0 = vb ? now_s() : 0.0;
-        if (i > 1) {  // round 1 would re-measure centroid 0: min-update is the identity
+        if (i > 1 && !(resume_after_update && i == i_start)) {  // round 1 would re-measure centroid 0: min-update is the identity
             if (kpp_screen && picks[i - 1] != ~0ull) {
                 ms.pick = picks[i - 1];
                 HIP_TRY(launch_minupd_screen(ms, stream));
@@ -2055,6 +2126,65 @@ static int pqv_index_build_impl(const pqv_corpus *corpus, uint32_t n_clusters, u
 extern "C" int pqv_index_build(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max_iters,
                                uint64_t seed, uint32_t workers, pqv_index **out) {
     return guard([&] { return pqv_index_build_impl(corpus, n_clusters, max_iters, seed, workers, out); });
+}
+
+static int pqv_kpp_pick_impl(int device, const float *minima, uint32_t n, uint32_t workers, float draw, uint64_t *pick, float *total,
+                             uint32_t *status) {
+    using namespace pqv;
+    if (!minima || !pick || !total || !status) return fail(PQV_ERR_INVALID, "minima, pick, total and status must not be NULL");
+    if (n == 0 || n > 57344) return fail(PQV_ERR_INVALID, "n must be in [1, 57344]");
+    if (int rc = use_device(device)) return rc;
+    if (workers == 0) workers = host_workers();
+    const uint64_t w = std::max<uint64_t>(1, std::min<uint64_t>(workers, n));          // index.rs:259-265
+    const uint64_t chunk = (n + w - 1) / w, n_chunks = (n + chunk - 1) / chunk;
+    if (n_chunks > 1024) return fail(PQV_ERR_INVALID, "more than 1024 worker chunks");
+    const size_t n64 = 2 + n_chunks + 64 + 4096 + 64 + 72;
+    const size_t bytes = n64 * 8 + 4 * 4 + 4 * 4 + 16 + static_cast<size_t>(n) * 4;
+    DevBuf buf;
+    HIP_TRY(buf.alloc(bytes));
+    HIP_TRY(hipMemset(buf.p, 0, bytes));
+    unsigned long long *d_picks = buf.as<unsigned long long>();
+    float *d_u = reinterpret_cast<float *>(d_picks + n64);
+    uint32_t *d_state = reinterpret_cast<uint32_t *>(d_u + 4);
+    float *d_md = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(d_state + 4) + 15) & ~static_cast<uintptr_t>(15));   // 16-byte aligned, as the build's minima are
+    const float u2[2] = {0.0f, draw};
+    HIP_TRY(hipMemcpy(d_u, u2, sizeof u2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_md, minima, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+    KppPickArgs pa{};
+    pa.md = d_md; pa.n = n; pa.chunk = static_cast<uint32_t>(chunk); pa.n_chunks = static_cast<uint32_t>(n_chunks);
+    pa.chunk_sum = d_picks + 2; pa.blk_sum = pa.chunk_sum + n_chunks; pa.run_sum = pa.blk_sum + 64; pa.blk_done = pa.run_sum + 4096; pa.head = pa.blk_done + 64;
+    pa.u = d_u; pa.round = 1; pa.picks = d_picks; pa.state = d_state;
+    DevBuf d_stamps;
+    const char *want_stamps = std::getenv("PQV_KPP_STAMPS");
+    if (want_stamps && *want_stamps == '1') {
+        HIP_TRY(d_stamps.alloc(40 * 8));
+        HIP_TRY(hipMemset(d_stamps.p, 0, 40 * 8));
+        pa.stamps = d_stamps.as<unsigned long long>();
+    }
+    HIP_TRY(launch_kpp_pick(pa, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (pa.stamps) {
+        unsigned long long h[40];
+        HIP_TRY(hipMemcpy(h, d_stamps.p, sizeof h, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < 40; ++i) if (h[i] && h[i] < t0) t0 = h[i];
+        std::fprintf(stderr, "[pqv] kpp stamps (us after the first; chain block 0-7: start, loaded, summaries there, pairs read, chain done, total, found, picked;"
+                             " last summary block 8-12: start, sum out, prefix in, pairs, flag out; chunk block 0 16-17; end of wave w's turn 20+w):");
+        for (int i = 0; i < 40; ++i) if (h[i]) std::fprintf(stderr, " %d:%.2f", i, (h[i] - t0) * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+    uint32_t h_state[4];
+    unsigned long long h_pick[2];
+    HIP_TRY(hipMemcpy(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_pick, d_picks, sizeof h_pick, hipMemcpyDeviceToHost));
+    *status = h_state[0] ? h_state[2] : 0;
+    std::memcpy(total, &h_state[3], 4);
+    if (!h_state[0]) *pick = h_pick[1];
+    return PQV_OK;
+}
+extern "C" int pqv_kpp_pick(int device, const float *minima, uint32_t n, uint32_t workers, float draw, uint64_t *pick, float *total,
+                            uint32_t *status) {
+    return guard([&] { return pqv_kpp_pick_impl(device, minima, n, workers, draw, pick, total, status); });
 }
 
 extern "C" int pqv_index_build_stats(double *out, uint32_t n) {

@@ -600,8 +600,30 @@ struct MinUpdScreenArgs {
     float        *mirror;    // optional pinned mirror of min_d (see StreamArgs::mirror_f32)
     float        *mirror_t;  // optional chunk-transposed mirror (StreamArgs::mirror_t)
     uint32_t      mirror_chunk, mirror_stride;
+    const unsigned long long *pick_dev;   // optional: the pick is read from device memory (the rounds enqueued ahead, kernels_kpp.hip)
+    const uint32_t *stop;                 // optional: a non-zero word makes the launch return at once (KppPickArgs::state)
 };
 hipError_t launch_minupd_screen(const MinUpdScreenArgs &a, hipStream_t s);
+
+// The k-means++ pick of one round on the device (kernels_kpp.hip; index.rs:354-390): total = the worker chunks' sequential f32 sums joined in
+// order, threshold = u[round] * total, picks[round] = the first slot whose sequential f32 cumulative sum reaches it -- bit for bit the
+// host walk's result.  n <= 57 344, n_chunks <= 1024.  All scratch words start zeroed and carry the round number as a tag.
+struct KppPickArgs {
+    const float *md;                 // [n] the current minima
+    uint32_t n;
+    uint32_t chunk, n_chunks;        // worker chunks: chunk c = [c chunk, min(n, (c + 1) chunk))
+    unsigned long long *chunk_sum;   // [n_chunks]
+    unsigned long long *blk_sum;     // [64]
+    unsigned long long *run_sum;     // [4096] pairs of the quarter runs
+    unsigned long long *blk_done;    // [64]
+    unsigned long long *head;        // [72] the head block's run starts [64] and its last value
+    const float *u;                  // [k] gen_range(0.0..1.0) draws by round
+    uint32_t round;                  // 1 .. k - 1
+    unsigned long long *picks;       // [k] picks[round] is written
+    unsigned long long *stamps;      // optional [32]: diagnostics (pqv_kpp_pick with PQV_KPP_STAMPS=1)
+    uint32_t *state;                 // [0] != 0: stopped; [1] the round the host has to decide; [2] why (1 total, 2 value, 3 no slot, 4 wait, 5 slot); [3] bits of the last total
+};
+hipError_t launch_kpp_pick(const KppPickArgs &a, hipStream_t s);
 
 // out[i, :] = src[idx[i], :]  (sampling gather and the IVF-order re-layout)
 hipError_t launch_gather_rows(const float *src, const uint32_t *idx32, const uint64_t *idx64,

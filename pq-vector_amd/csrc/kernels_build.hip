@@ -735,18 +735,21 @@ __global__ __launch_bounds__(256) void minupd_screen_kernel(const MinUpdScreenAr
     const uint32_t G16 = a.dim >> 4;
     float4 *cimg = mus_lds;
     float *terms = reinterpret_cast<float *>(mus_lds + G16) + wave * (64 * 17);
+    if (a.stop && *a.stop) return;                   // (the rounds enqueued ahead: an earlier one went back to the host)
+    const uint64_t pick = a.pick_dev ? (uint64_t)*a.pick_dev : a.pick;
+    if (pick >= a.n) return;
     {
-        const uint64_t Tp = a.pick >> 4, jp = a.pick & 15;
+        const uint64_t Tp = pick >> 4, jp = pick & 15;
         for (uint32_t cc = threadIdx.x; cc < G16; cc += 256) cimg[cc] = a.img[(Tp * G16 + cc) * 16 + jp];
     }
     __syncthreads();
     const uint64_t n_tiles = (a.n + 15) >> 4;
     const uint64_t T = (uint64_t)blockIdx.x * 4 + (uint32_t)wave;
-    if (T < n_tiles) minupd_screen_tile(a, a.pick, T, cimg, terms, lane);
+    if (T < n_tiles) minupd_screen_tile(a, pick, T, cimg, terms, lane);
 }
 hipError_t launch_minupd_screen(const MinUpdScreenArgs &a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    if ((a.dim % 64) != 0 || a.pick >= a.n) return hipErrorInvalidValue;
+    if ((a.dim % 64) != 0 || (!a.pick_dev && a.pick >= a.n)) return hipErrorInvalidValue;
     const uint64_t n_tiles = (a.n + 15) / 16, blocks = (n_tiles + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = (size_t)(a.dim / 16) * 16 + 4 * 64 * 17 * sizeof(float);

@@ -293,3 +293,42 @@ def test_device_sorted_lists_equal_the_host_counting_sort(n, dim, kc):
         assert p.returncode == 0, p.stderr[-2000:]
         got[mode] = [l for l in p.stdout.splitlines() if l.startswith("BLOB")][0]
     assert got["1"] == got["0"]
+
+
+_KPP_SCRIPT = r"""
+import sys, os, hashlib
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import pq_vector_amd as pqv
+n, dim, kc, style, workers = (int(x) for x in sys.argv[1:6])
+rng = np.random.default_rng(n + dim + style)
+if style == 0:      # the bench recipe: 24-bit uniform [0, 1)
+    data = rng.integers(0, 1 << 24, size=(n, dim), dtype=np.int32).astype(np.float32) * np.float32(1.0 / (1 << 24))
+elif style == 1:    # integer-valued features (SIFT-like): integer squared distances, a tie of round-to-nearest-even in almost every add
+    data = rng.integers(0, 256, size=(n, dim)).astype(np.float32)
+else:               # clustered, with a few rows far outside
+    cen = rng.standard_normal((32, dim)).astype(np.float32) * 4
+    data = (cen[rng.integers(0, 32, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.2).astype(np.float32)
+    data[rng.integers(0, n, 5)] *= np.float32(1000.0)
+idx = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).max_iters(2).seed(11).workers(workers).build()
+print("BLOB", hashlib.sha256(idx.to_bytes()).hexdigest())
+"""
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,dim,kc,style,workers", [(200_000, 128, 300, 0, 8), (200_000, 128, 300, 1, 8), (120_000, 128, 1000, 2, 256),
+                                                    (1_050_000, 128, 1024, 0, 3), (60_000, 192, 64, 1, 1), (3_000, 256, 50, 0, 8)])
+def test_device_kmeanspp_rounds_equal_the_host_walk(n, dim, kc, style, workers):
+    """index.rs:354-390: the k-means++ rounds enqueued ahead with the pick taken on the device (kernels_kpp.hip) against the host's
+    sequential walk (PQV_KPP_DEVICE=0) on the same build -- worker chunkings 1 / 3 / 8 / 256, uniform, integer-valued and clustered data:
+    the same blob, i.e. the same 'first slot whose sequential f32 cumulative sum reaches the threshold' in every round."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, PQV_KPP_DEVICE=mode)
+        p = subprocess.run([sys.executable, "-c", _KPP_SCRIPT, str(n), str(dim), str(kc), str(style), str(workers)], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[mode] = [l for l in p.stdout.splitlines() if l.startswith("BLOB")][0]
+    assert got["1"] == got["0"]

@@ -23,9 +23,10 @@ for seed in range(int(os.environ.get("FZ_LO", 100)), int(os.environ.get("FZ_HI",
     else:
         base = rng.random((n // 4 + 1, dim), dtype=np.float32); data = base[rng.integers(0, len(base), n)]
         data[rng.integers(0, n, 3)] *= np.float32(rng.choice([1.0, 50.0, 1e6]))       # rows far outside the centroid range
-    want = oracle.build_index(data, n_clusters=kc, workers=2, max_iters=3, seed=seed).to_bytes()
-    got = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).max_iters(3).seed(seed).workers(2).build().to_bytes()
+    workers = int(os.environ.get("FZ_WORKERS", 2)) or int(rng.choice([1, 2, 3, 8, 64, 256]))     # FZ_WORKERS=0: a different chunking per case
+    want = oracle.build_index(data, n_clusters=kc, workers=workers, max_iters=3, seed=seed).to_bytes()
+    got = pqv.IndexBuilder(pqv.Corpus.upload(data)).n_clusters(kc).max_iters(3).seed(seed).workers(workers).build().to_bytes()
     if got != want:
-        bad += 1; print("FAIL seed", seed, dim, kc, n, style)
+        bad += 1; print("FAIL seed", seed, dim, kc, n, style, workers)
 print("build fuzz done:", bad, "failures", round(time.time() - t, 1), "s")
 PY
