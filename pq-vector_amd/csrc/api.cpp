@@ -2157,14 +2157,14 @@ static int pqv_kpp_pick_impl(int device, const float *minima, uint32_t n, uint32
     DevBuf d_stamps;
     const char *want_stamps = std::getenv("PQV_KPP_STAMPS");
     if (want_stamps && *want_stamps == '1') {
-        HIP_TRY(d_stamps.alloc(40 * 8));
-        HIP_TRY(hipMemset(d_stamps.p, 0, 40 * 8));
+        HIP_TRY(d_stamps.alloc(48 * 8));
+        HIP_TRY(hipMemset(d_stamps.p, 0, 48 * 8));
         pa.stamps = d_stamps.as<unsigned long long>();
     }
     HIP_TRY(launch_kpp_pick(pa, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (pa.stamps) {
-        unsigned long long h[40];
+        unsigned long long h[48];
         HIP_TRY(hipMemcpy(h, d_stamps.p, sizeof h, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
         for (int i = 0; i < 40; ++i) if (h[i] && h[i] < t0) t0 = h[i];

@@ -138,14 +138,10 @@ __device__ __forceinline__ void run_summary(const float (&xv)[E], uint32_t e, ui
 }
 
 // c + run f's elements, one f32 add after the other.  Every lane walks its OWN run from the same c (56 dependent vector adds, no
-// cross-lane traffic inside the chain); lane f's result is the one that counts.
+// cross-lane traffic inside the chain); lane f's result is the one that counts.  (Measured and dropped: walking by quarters with the
+// quarters' own pairs -- one integer addition for a quarter that agrees -- 20.1 against 17.8 us for the launch.)
 template <int E>
 __device__ __forceinline__ float run_adds(float c, const float (&xv)[E], int f) {
-#ifdef KPP_READLANE_ADDS
-#pragma unroll
-    for (int j = 0; j < E; ++j) c = c + kpp_float(readlane_u32(kpp_bits(xv[j]), f));
-    return c;
-#endif
     float cl = c;
 #pragma unroll
     for (int j = 0; j < E; ++j) cl = cl + xv[j];
@@ -159,7 +155,7 @@ template <int E>
 __device__ __forceinline__ float wave_chain(float c, int cur, const float (&xv)[E], uint32_t e, bool usable, uint32_t D0, uint32_t D1, int nl,
                                             float *table, int lane) {
     while (cur < nl) {
-        const uint32_t cb = kpp_bits(c), ec = cb >> 23;
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kpp_bits(c)), ec = cb >> 23;   // (c is the same in every lane: scalar code from here)
         const bool okl = usable && e == ec && lane >= cur && lane < nl;
         const unsigned long long okm = __ballot(okl);
         const unsigned long long from = ~0ull << cur;
@@ -195,33 +191,71 @@ __device__ __forceinline__ float wave_chain(float c, int cur, const float (&xv)[
     return c;
 }
 
-// A wave's turn.  Before the turns start every wave has composed its runs under the hypothesis "all my runs are usable and lie in the
-// binade of my first one" (pre: ok, e, the inclusive pairs I0 / I1); if the arriving c agrees and nothing crosses, the turn is a dozen
-// instructions, otherwise the general walk above.
-struct WavePre { bool ok; uint32_t e0; uint32_t I0, I1; };
+// A wave's turn.  Before the turns start every wave has composed its runs in SEGMENTS -- maximal stretches of usable runs predicted
+// into the same binade (a segmented scan: a head flag stops the composition) -- so that a turn needs no scan: for the segment at `cur`
+// the arriving c either agrees with the prediction (then the first crossing, if any, is one ballot away) or the run is walked.  A wave
+// that is one segment and is not crossed can even be passed over by the wave before it (WavePre::ok, e0 and the last lane's pair).
+struct WavePre { bool ok; uint32_t e0; uint32_t I0, I1; unsigned long long H, U; };
 __device__ __forceinline__ WavePre wave_pre(uint32_t e, bool usable, uint32_t D0, uint32_t D1, int nl, int lane) {
     WavePre p;
+    const uint32_t e_below = lane_below(e), us_below = lane_below(usable ? 1u : 0u);
+    bool h = lane == 0 || !usable || !us_below || e != e_below;
+    p.H = __ballot(h); p.U = __ballot(usable);
+    uint32_t a0 = usable ? D0 : 0u, a1 = usable ? D1 : 0u;
+#define KPP_SEG_STEP(CTRL, ROWS)                                                                               \
+    {                                                                                                          \
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a0, CTRL, ROWS, 0xF, false);         \
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, CTRL, ROWS, 0xF, false);         \
+        const uint32_t ph = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(h ? 1u : 0u), CTRL, ROWS, 0xF, false); \
+        if (!h) { pair_then(p0, p1, a0, a1); h = ph != 0; }                                                    \
+    }
+    // (a lane without a source composes with the identity and keeps looking: the row broadcasts bring the rows before it)
+    KPP_SEG_STEP(0x111, 0xF) KPP_SEG_STEP(0x112, 0xF) KPP_SEG_STEP(0x114, 0xF) KPP_SEG_STEP(0x118, 0xF)
+    KPP_SEG_STEP(0x142, 0xA) KPP_SEG_STEP(0x143, 0xC)
+#undef KPP_SEG_STEP
+    p.I0 = a0; p.I1 = a1;
+    const unsigned long long lanes = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
     p.e0 = readlane_u32(e, 0);
-    p.ok = nl > 0 && __ballot(lane < nl && !(usable && e == p.e0)) == 0;
-    p.I0 = lane < nl ? D0 : 0u; p.I1 = lane < nl ? D1 : 0u;
-    if (p.ok) pair_scan(p.I0, p.I1);
+    p.ok = nl > 0 && (p.H & lanes) == 1ull && (p.U & lanes) == lanes;
     return p;
 }
 template <int E>
 __device__ __forceinline__ float wave_turn(float c, const WavePre &pre, const float (&xv)[E], uint32_t e, bool usable, uint32_t D0, uint32_t D1,
                                            int nl, float *table, int lane) {
-    const uint32_t cb = kpp_bits(c), ec = cb >> 23;
-    if (pre.ok && ec == pre.e0) {
+    const unsigned long long lanes = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+    int cur = 0;
+    while (cur < nl) {
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kpp_bits(c)), ec = cb >> 23;
+        const bool us_cur = (pre.U >> cur) & 1ull, head_cur = (pre.H >> cur) & 1ull;
+        const bool agree = us_cur && readlane_u32(e, cur) == ec;
+        if (agree && !head_cur) return wave_chain<E>(c, cur, xv, e, usable, D0, D1, nl, table, lane);   // inside a segment: the scanning walk
+        if (!agree) {                                         // not covered by its summary: the additions themselves
+            if (table && lane == cur) table[cur] = c;
+            c = run_adds<E>(c, xv, cur);
+            ++cur;
+            continue;
+        }
+        const unsigned long long later = pre.H & lanes & ((~0ull << cur) << 1);
+        const int se = later ? __builtin_ctzll(later) : nl;   // the segment is [cur, se)
         const uint32_t C = (cb & 0x7FFFFFu) | 0x800000u;
         const uint32_t Iv = (C & 1u) ? pre.I1 : pre.I0;
-        const uint32_t Cend = C + readlane_u32(Iv, nl - 1);
+        const bool in = lane >= cur && lane < se;
+        const unsigned long long cm = __ballot(in && C + Iv >= (1u << 24));
+        const int f = cm ? __builtin_ctzll(cm) : se;          // the first run that crosses into the next binade, or the segment's end
         const uint32_t below = lane_below(Iv);
-        if (Cend < (1u << 24)) {
-            if (table && lane < nl) table[lane] = kpp_float((ec << 23) | ((lane == 0 ? C : C + below) & 0x7FFFFFu));
-            return kpp_float((ec << 23) | (Cend & 0x7FFFFFu));
+        const uint32_t Cst = lane == cur ? C : C + below;     // exact integer at the start of run `lane`, for lanes in [cur, f]
+        if (table && lane >= cur && lane <= f && lane < se) table[lane] = kpp_float((ec << 23) | (Cst & 0x7FFFFFu));
+        if (f == se) {
+            const uint32_t Cend = C + readlane_u32(Iv, se - 1);
+            c = kpp_float((ec << 23) | (Cend & 0x7FFFFFu));
+            cur = se;
+            continue;
         }
+        c = kpp_float((ec << 23) | (readlane_u32(Cst, f) & 0x7FFFFFu));
+        c = run_adds<E>(c, xv, f);
+        cur = f + 1;
     }
-    return wave_chain<E>(c, 0, xv, e, usable, D0, D1, nl, table, lane);
+    return c;
 }
 
 // E elements x[off .. off + E) (zero beyond len: c + 0 == c), V floats per load where the address allows
@@ -301,6 +335,18 @@ __device__ __forceinline__ float wave_chain_alone(const float *x, uint32_t len, 
     return wave_turn<E>(0.0f, pre, xv, e, usable, D0, D1, nl, nullptr, lane);
 }
 
+// total (:356-370): the chunk sums (LDS) joined in ascending chunk order from 0, by one wave -- 64 at a time in registers, each added
+// from a scalar register (the adds are the chain; the lane reads run ahead of it)
+__device__ __forceinline__ float join_chunk_sums(const float *cs, uint32_t jobs, int lane) {
+    float c = 0.0f;
+    for (uint32_t base = 0; base < jobs; base += 64) {
+        const uint32_t sv = base + (uint32_t)lane < jobs ? kpp_bits(cs[base + lane]) : 0u;   // (+0.0 beyond the last chunk: c + 0 == c)
+#pragma unroll
+        for (int l = 0; l < 64; ++l) c = c + kpp_float(readlane_u32(sv, l));
+    }
+    return c;
+}
+
 }  // namespace
 
 template <int EC>
@@ -311,7 +357,8 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
     __shared__ float sh_cs[1024];
     __shared__ uint32_t sh_first, sh_fail, sh_next[2];
     __shared__ uint32_t sh_wok[16], sh_we0[16], sh_wT0[16], sh_wT1[16], sh_wskip[16];
-    __shared__ float sh_wstart[16];
+    __shared__ float sh_wstart[16], sh_total;
+    __shared__ uint32_t sh_cs_done, sh_total_done;
     if (a.state[0] != 0) return;                              // an earlier round went back to the host
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t round = a.round;
@@ -332,7 +379,8 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
         const bool usable = e >= 23u && e < 254u;
         uint32_t D0 = 0, D1 = 0;
         if (usable) run_summary<KPP_E>(xv, e, D0, D1);
-        const float c = wave_chain<KPP_E>(0.0f, 0, xv, e, usable, D0, D1, nl, sh_table, lane);
+        const WavePre pre = wave_pre(e, usable, D0, D1, nl, lane);
+        const float c = wave_turn<KPP_E>(0.0f, pre, xv, e, usable, D0, D1, nl, sh_table, lane);
         wave_lds_fence();
         if (lane < nl) kpp_store(a.head + lane, tag | kpp_bits(sh_table[lane]));
         if (lane == 0) kpp_store(a.head + 64, tag | kpp_bits(c));
@@ -398,11 +446,12 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
     if (tid == 0) kpp_stamp(a.stamps, 0);
     float xv[KPP_E];
     const uint32_t t = (uint32_t)tid;
+    // (measured and dropped: the wave's 3584 floats read as coalesced rows and handed to the lanes through LDS -- 22.1 against 20.5 us)
     load_run<KPP_E>(a.md, t * KPP_E, t < n_runs ? a.n : 0u, xv);
     bool badv = false;
 #pragma unroll
     for (int j = 0; j < KPP_E; ++j) badv = badv || !(xv[j] >= 0.0f && xv[j] < INFINITY);
-    if (tid == 0) { sh_c = 0.0f; sh_first = 0xFFFFFFFFu; sh_fail = 0; }
+    if (tid == 0) { sh_c = 0.0f; sh_first = 0xFFFFFFFFu; sh_fail = 0; sh_cs_done = 0; sh_total_done = 0; }
     __syncthreads();
     if (badv) sh_fail = 2;
     if (tid == 0) kpp_stamp(a.stamps, 1);
@@ -440,6 +489,7 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
     // lane v of every wave: what is needed to pass over wave v
     const uint32_t r_ok = lane < n_waves ? sh_wok[lane] : 0u, r_e0 = lane < n_waves ? sh_we0[lane] : 0u;
     const uint32_t r_T0 = lane < n_waves ? sh_wT0[lane] : 0u, r_T1 = lane < n_waves ? sh_wT1[lane] : 0u;
+    const int fetch_it = EC == 0 ? 1 : 2;                     // (a block per chunk -- 6250-element chunks on an 8-core host -- takes ~10 us)
     for (int it = 0;; ++it) {                                 // (sh_next is double-buffered: a turn writes the word the NEXT iteration reads)
         const int nx = (int)sh_next[it & 1];
         if (nx >= n_waves) break;
@@ -455,17 +505,32 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
             } else {
                 c = wave_turn<KPP_E>(sh_c, pre, xv, e, usable, D0, D1, nl, sh_table + 64 * wave, lane);
             }
-            int v = wave + 1;
+            uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)kpp_bits(c));    // scalar from here on
+            int v = __builtin_amdgcn_readfirstlane(wave) + 1;
             for (; v < n_waves; ++v) {                        // the waves after this one that the arriving value agrees with
-                const uint32_t cb = kpp_bits(c), ec = cb >> 23;
+                const uint32_t ec = cb >> 23;
                 if (!(readlane_u32(r_ok, v) && readlane_u32(r_e0, v) == ec)) break;
                 const uint32_t C = (cb & 0x7FFFFFu) | 0x800000u;
-                const uint32_t Cend = C + ((C & 1u) ? readlane_u32(r_T1, v) : readlane_u32(r_T0, v));
+                const uint32_t T0 = readlane_u32(r_T0, v), T1 = readlane_u32(r_T1, v);
+                const uint32_t Cend = C + ((C & 1u) ? T1 : T0);
                 if (Cend >= (1u << 24)) break;
-                if (lane == 0) { sh_wstart[v] = c; sh_wskip[v] = 1u; }
-                c = kpp_float((ec << 23) | (Cend & 0x7FFFFFu));
+                if (lane == 0) { sh_wstart[v] = kpp_float(cb); sh_wskip[v] = 1u; }
+                cb = (ec << 23) | (Cend & 0x7FFFFFu);
             }
-            if (lane == 0) { sh_c = c; sh_next[(it + 1) & 1] = (uint32_t)v; kpp_stamp(a.stamps, 20 + wave); }
+            if (lane == 0) { sh_c = kpp_float(cb); sh_next[(it + 1) & 1] = (uint32_t)v; kpp_stamp(a.stamps, 20 + wave); }
+        } else if (it == fetch_it) {
+            // The waves that wait for this turn fetch the worker chunks' sums meanwhile (their blocks have finished by now; the turn
+            // takes about as long as the fetch): the 960 waiting threads share the chunks
+            const uint32_t rank = (int)wave < nx ? t : t - 64u;                 // 0 .. 959 over the waiting threads
+            for (uint32_t j = rank; j < jobs; j += 960) {
+                unsigned long long v = 0;
+                if (!kpp_wait(a.chunk_sum + j, round, v)) sh_fail = 4;
+                sh_cs[j] = kpp_float((uint32_t)v);
+            }
+            if (rank == 0) sh_cs_done = 1u;
+        } else if (it == fetch_it + 1 && sh_cs_done && jobs && wave == (nx == 15 ? 14 : 15)) {
+            const float c = join_chunk_sums(sh_cs, jobs, lane);     // ... and the last wave joins them
+            if (lane == 0) { sh_total = c; sh_total_done = 1u; }
         }
         __syncthreads();
     }
@@ -480,22 +545,18 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const KppPickArgs a) {
     if (tid == 0) sh_table[n_runs] = sh_c;
     if (tid == 0) kpp_stamp(a.stamps, 4);
     // total (:356-370): the chunk sums joined in ascending chunk order (one chunk: its sum is the chain's last value)
-    if (t < jobs) {
+    if (!sh_cs_done && t < jobs) {                            // (a chain of fewer than two turns)
         unsigned long long v = 0;
         if (!kpp_wait(a.chunk_sum + t, round, v)) sh_fail = 4;
         sh_cs[t] = kpp_float((uint32_t)v);
     }
     __syncthreads();
     float total = sh_table[n_runs];
-    if (jobs) {
+    if (jobs && sh_total_done) {
+        total = sh_total;
+    } else if (jobs) {
         if (wave == 0) {
-            float c = 0.0f;
-            if (jobs <= 512) {
-                c = wave_chain_alone(sh_cs, jobs, lane);      // the chain over the chunk sums, from 0
-            } else {
-#pragma unroll 8
-                for (uint32_t j = 0; j < jobs; ++j) c = c + sh_cs[j];
-            }
+            const float c = join_chunk_sums(sh_cs, jobs, lane);
             if (lane == 0) sh_c = c;
         }
         __syncthreads();
