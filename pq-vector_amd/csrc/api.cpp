@@ -77,10 +77,34 @@ int use_device(int device) {
         return fail(PQV_ERR_NO_DEVICE, "device index " + std::to_string(device) +
                                            " out of range (" + std::to_string(count) + " devices)");
     HIP_TRY(hipSetDevice(device));
+    // The first call for a device loads the kernels' code objects (the runtime would otherwise do it inside whatever launches a unit's
+    // first kernel: 7-8 ms of the first index build).  PQV_LAZY_INIT=1 leaves it to the runtime.
+    static std::once_flag warmed[64];
+    static const bool lazy = [] { const char *e = std::getenv("PQV_LAZY_INIT"); return e && *e == '1'; }();
+    if (!lazy && device < 64)
+        std::call_once(warmed[device], [] {
+            (void)pqv::touch_probe(nullptr); (void)pqv::touch_screen(nullptr); (void)pqv::touch_brute(nullptr); (void)pqv::touch_build(nullptr);
+            (void)pqv::touch_layout(nullptr); (void)pqv::touch_list(nullptr); (void)pqv::touch_kpp(nullptr);
+            (void)hipStreamSynchronize(nullptr);
+            // ... and the runtime's staging buffers for copies from / to pageable host memory are made by the first such copies
+            void *d = nullptr;
+            if (hipMalloc(&d, 1 << 20) == hipSuccess) {
+                std::vector<char> h(1 << 20, 0);
+                (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
+                (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
+                (void)hipFree(d);
+            }
+            (void)hipGetLastError();
+        });
     return PQV_OK;
 }
 
 // RAII device buffer
+bool verbose();
+double now_s();
+// PQV_VERBOSE: seconds and calls spent in hipMalloc / hipFree since the last report (the build prints them)
+static thread_local double g_alloc_s = 0.0, g_free_s = 0.0;
+static thread_local unsigned g_alloc_n = 0, g_free_n = 0;
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -89,12 +113,19 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (!p) return;
+        const bool vb = verbose();
+        const double t0 = vb ? now_s() : 0.0;
+        (void)hipFree(p); p = nullptr; bytes = 0;
+        if (vb) { g_free_s += now_s() - t0; ++g_free_n; }
     }
     hipError_t alloc(size_t n) {
         release();
         if (n == 0) n = 16;
+        const bool vb = verbose();
+        const double t0 = vb ? now_s() : 0.0;
         hipError_t e = hipMalloc(&p, n);
+        if (vb) { g_alloc_s += now_s() - t0; ++g_alloc_n; }
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
@@ -413,6 +444,8 @@ static int pqv_corpus_create_impl(int device, uint64_t capacity_rows, uint32_t d
         delete c;
         return fail(PQV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    (void)pqv::touch_build(c->stream);            // (the stream's hardware queue is set up by its first launch: here, not in the build)
+    (void)hipStreamSynchronize(c->stream);
     *out = c;
     return PQV_OK;
 }
@@ -862,6 +895,8 @@ static int pqv_corpus_from_device_impl(int device, const void *d_rows, uint64_t 
         delete c;
         return fail(PQV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    (void)pqv::touch_build(c->stream);            // (the stream's hardware queue is set up by its first launch: here, not in the build)
+    (void)hipStreamSynchronize(c->stream);
     *out = c;
     return PQV_OK;
 }
@@ -1997,6 +2032,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     if (sample_size != n) {                                                            // :182-187
         StdRng rng = StdRng::seed_from_u64(seed);                                      // :231
         std::vector<uint64_t> idx = index_sample(rng, n, sample_size);                 // :232
+        if (verbose()) std::fprintf(stderr, "[pqv] build: sample indices drawn at %.1f ms\n", (now_s() - t_b0) * 1e3);
         HIP_TRY(d_idx.alloc(sample_size * sizeof(uint64_t)));
         HIP_TRY(d_sample.alloc(sample_size * dim * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(d_idx.p, idx.data(), sample_size * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -2109,7 +2145,11 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     g_build_stats[7] = static_cast<double>(sample_size);
     if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
                                 (unsigned long long)n, t_fa1 - t_fa0, now_s() - t_fa1);
-    if (verbose()) std::fprintf(stderr, "[pqv] build: %.3f s in all\n", now_s() - t_b0);
+    if (verbose()) {
+        std::fprintf(stderr, "[pqv] build: %.3f s in all; hipMalloc %u calls %.1f ms, hipFree %u calls %.1f ms (this thread, since the last report)\n",
+                     now_s() - t_b0, g_alloc_n, g_alloc_s * 1e3, g_free_n, g_free_s * 1e3);
+        g_alloc_s = g_free_s = 0.0; g_alloc_n = g_free_n = 0;
+    }
     *out = idx;
     return PQV_OK;
 }

@@ -653,4 +653,14 @@ inline uint32_t waves_per_block() { return 4; }
 #ifdef PQV_STAMPS
 hipError_t stamps_io(unsigned long long *out, int reset);
 #endif
+// one per kernel unit: an empty launch -- the runtime loads the unit's code object (api.cpp: use_device, once per device) and sets up
+// the stream's hardware queue (a corpus' own stream, when it is made)
+hipError_t touch_probe(hipStream_t s);
+hipError_t touch_screen(hipStream_t s);
+hipError_t touch_brute(hipStream_t s);
+hipError_t touch_build(hipStream_t s);
+hipError_t touch_layout(hipStream_t s);
+hipError_t touch_list(hipStream_t s);
+hipError_t touch_kpp(hipStream_t s);
+
 }  // namespace pqv

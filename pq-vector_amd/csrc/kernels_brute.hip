@@ -816,4 +816,13 @@ hipError_t launch_brute_finish(const unsigned long long *cand, const uint32_t *c
 }
 
 
+
+// an empty kernel the library launches at the first call for a device (and on a new stream): the runtime loads this unit's code
+// object and sets up the stream's hardware queue then, not inside the first build or the first query
+__global__ void touch_brute_kernel() {}
+hipError_t touch_brute(hipStream_t s) {
+    hipLaunchKernelGGL(touch_brute_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace pqv

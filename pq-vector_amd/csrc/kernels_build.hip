@@ -1234,4 +1234,13 @@ hipError_t launch_lloyd_update(const float *rows, uint32_t dim, const uint32_t *
 }
 
 
+
+// an empty kernel the library launches at the first call for a device (and on a new stream): the runtime loads this unit's code
+// object and sets up the stream's hardware queue then, not inside the first build or the first query
+__global__ void touch_build_kernel() {}
+hipError_t touch_build(hipStream_t s) {
+    hipLaunchKernelGGL(touch_build_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace pqv

@@ -676,4 +676,13 @@ hipError_t launch_narrow_f64(const double *src, uint64_t count, float *out, hipS
 }
 
 
+
+// an empty kernel the library launches at the first call for a device (and on a new stream): the runtime loads this unit's code
+// object and sets up the stream's hardware queue then, not inside the first build or the first query
+__global__ void touch_layout_kernel() {}
+hipError_t touch_layout(hipStream_t s) {
+    hipLaunchKernelGGL(touch_layout_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace pqv

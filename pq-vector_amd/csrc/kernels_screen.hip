@@ -2663,4 +2663,13 @@ hipError_t launch_tile_rerank(const TileArgs &a, hipStream_t s) {
 }
 
 
+
+// an empty kernel the library launches at the first call for a device (and on a new stream): the runtime loads this unit's code
+// object and sets up the stream's hardware queue then, not inside the first build or the first query
+__global__ void touch_screen_kernel() {}
+hipError_t touch_screen(hipStream_t s) {
+    hipLaunchKernelGGL(touch_screen_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace pqv
