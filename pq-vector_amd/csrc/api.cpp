@@ -68,6 +68,33 @@ int guard(F &&body) noexcept {
     }
 }
 
+// A few streams per device made (and their hardware queues set up by an empty launch) at the library's first call for the device;
+// a searcher takes its stream from here and gives it back -- made right after a build, a stream costs 10+ ms (the driver is still
+// unmapping what the build freed).
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[64];
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; }     // (never destroyed: streams outlive static teardown order)
+static hipError_t pool_get(int device, hipStream_t *out) {
+    if (device >= 0 && device < 64) {
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lock(sp.mu);
+        if (!sp.idle[device].empty()) { *out = sp.idle[device].back(); sp.idle[device].pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void pool_put(int device, hipStream_t s) {
+    if (!s) return;
+    if (device >= 0 && device < 64) {
+        (void)hipStreamSynchronize(s);
+        StreamPool &sp = stream_pool();
+        std::lock_guard<std::mutex> lock(sp.mu);
+        if (sp.idle[device].size() < 8) { sp.idle[device].push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 int use_device(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -93,6 +120,14 @@ int use_device(int device) {
                 (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
                 (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
                 (void)hipFree(d);
+            }
+            for (int i = 0; i < 2; ++i) {
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+                (void)pqv::touch_build(st);
+                int dev = -1;
+                (void)hipGetDevice(&dev);
+                pool_put(dev, st);
             }
             (void)hipGetLastError();
         });
@@ -177,12 +212,28 @@ int use_device(int device) { return ::use_device(device); }
 // ---------------------------------------------------------------------------------------
 // handles
 // ---------------------------------------------------------------------------------------
+// the device copy of the inverted lists a build leaves behind (40 MB per 10 M rows, freed with the index): a searcher made on the
+// same device takes its row ids from it instead of uploading them again
+struct DevRows {
+    void *p = nullptr;
+    int device = -1;
+    uint64_t n = 0;
+    ~DevRows() { if (p) { int cur = -1; (void)hipGetDevice(&cur); if (hipSetDevice(device) == hipSuccess) (void)hipFree(p); if (cur >= 0) (void)hipSetDevice(cur); } }
+};
 struct pqv_index {
     uint32_t dim = 0;
     uint32_t n_clusters = 0;
     std::vector<float> centroids;     // [n_clusters * dim]
     std::vector<uint64_t> list_off;   // [n_clusters + 1]
-    std::vector<uint32_t> list_rows;  // concatenated inverted lists
+    // concatenated inverted lists; the vector is shared with the searchers made from this index (they keep it for the host-side
+    // calls -- candidate rows, replays -- without copying 4 bytes per row)
+    std::shared_ptr<std::vector<uint32_t>> rows_sp{std::make_shared<std::vector<uint32_t>>()};
+    std::vector<uint32_t> &list_rows{*rows_sp};
+    std::shared_ptr<DevRows> d_rows;  // see DevRows
+    uint64_t permutation_of = 0;      // != 0: list_rows is a permutation of [0, permutation_of) by construction (a build's result)
+    pqv_index() = default;
+    pqv_index(const pqv_index &) = delete;
+    pqv_index &operator=(const pqv_index &) = delete;
 };
 
 // pinned staging buffers of the streaming upload (pqv_corpus_write_rows): a buffer is free, being filled by a caller, or in
@@ -265,10 +316,11 @@ struct pqv_searcher {
     uint64_t max_list_len = 0;
     pqv_corpus *corpus = nullptr;          // borrowed
     std::vector<uint64_t> h_list_off;      // host copy for candidate_rows
-    std::vector<uint32_t> h_list_rows;
+    std::shared_ptr<const std::vector<uint32_t>> h_rows_sp;   // the index' lists (shared, not copied)
     DevBuf d_cent_t;                   // [dim/4][kc_pad] float4 transpose of the centroids (probe_rows_kernel), dim % 4 == 0
     uint32_t kc_pad = 0;
-    DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats, d_row_norm2;   // |x|^2 per storage row (MFMA screen)
+    DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats;
+    mutable DevBuf d_row_norm2;            // |x|^2 per storage row (f32 / f16 MFMA screens; see norms_done)
     const float *d_mat = nullptr;          // row storage the re-rank reads
     const uint32_t *d_row_of = nullptr;    // list position -> storage row (ROW_ORDER layout, and the images-only IVF layout)
     const uint32_t *d_final_ids = nullptr; // storage row -> file row id (IVF layout with its own f32 copy)
@@ -292,13 +344,18 @@ struct pqv_searcher {
     mutable DevBuf d_mat_blk_op[3], d_blk_off;
     // f16 operands for the wide screened path: values * f16_scale rounded to f16; possible when the stored rows
     // are finite and the power-of-two scale and its square are representable
-    bool f16_ok = false;
-    float f16_scale = 1.0f;
+    mutable bool f16_ok = false;
+    mutable float f16_scale = 1.0f;
+    // The rows' squared norms and their maximum (-> f16_ok / f16_scale) are one pass over the corpus that the int8 screen never
+    // reads: where the int8 copy is built at creation they are left to the first call that needs them (ensure_row_norms).
+    mutable bool norms_done = false;
+    mutable std::mutex norms_mu;
+    uint64_t n_storage = 0;
     // int8 operands (rows of a multiple of 256 dims): per LIST the images of (x - centre_c) * S_c -- the IVF residual:
     // centre_c the per-dimension mid-range of the list's rows, S_c mapping the list's largest |x - centre_c| component
     // to 127 -- per row |xi|^2 and an upper bound of the residual norm, per list a radius >= |x - centre_c| (see
     // kernels_layout.hip: block_rows_i8_kernel); built with the blocked copy (ensure_blocked_copy)
-    bool i8_ok = false;
+    mutable bool i8_ok = false;
     // i8_residual: the per-list (residual) form pays where the lists are much tighter than the corpus (clustered data:
     // a per-list scale twice the global one halves the bound's slack); where they are not (uniform data) the one-centre
     // form gives the same bound with ONE image per query instead of one per probed pair -- 0.45 GB less traffic per
@@ -349,11 +406,12 @@ struct pqv_searcher {
     // timing
     mutable bool timing = false;
     mutable std::vector<hipEvent_t> ev;    // triples: probe-start, rerank-start, rerank-stop, end
-    ~pqv_searcher() {
-        for (auto e : ev) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
+    ~pqv_searcher();
 };
+pqv_searcher::~pqv_searcher() {
+    for (auto e : ev) (void)hipEventDestroy(e);
+    pool_put(device, stream);          // (back to the device's pool: see StreamPool)
+}
 
 // The scratch lane of a call on `stream`: the lane that stream used last, else a free one, else the least
 // recently assigned one.  Resolved ONCE per public entry point (under s->mu) and handed down: a lane taken
@@ -2141,6 +2199,16 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         delete idx;
         return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
     }
+    if (dev_lists && d_rows_sorted.p) {             // the sorted row ids stay on the device for a searcher (PQV_KEEP_DEVICE_LISTS=0: freed here)
+        static const bool keep = [] { const char *e = std::getenv("PQV_KEEP_DEVICE_LISTS"); return !(e && *e == '0'); }();
+        if (keep) {
+            auto dr = std::make_shared<DevRows>();
+            dr->p = d_rows_sorted.p; dr->device = corpus->device; dr->n = n;
+            d_rows_sorted.p = nullptr; d_rows_sorted.bytes = 0;
+            idx->d_rows = std::move(dr);
+        }
+    }
+    idx->permutation_of = n;                        // every row was assigned exactly once
     g_build_stats[3] = t_fa1 - t_fa0; g_build_stats[4] = now_s() - t_fa1; g_build_stats[5] = assign_form > 0.0 ? assign_form : exact_assign ? 0.0 : 1.0;
     g_build_stats[7] = static_cast<double>(sample_size);
     if (verbose()) std::fprintf(stderr, "[pqv] final assignment: %llu rows in %.3f s (+ %.3f s host list build)\n",
@@ -2352,10 +2420,39 @@ bool wide_path_possible(const pqv_searcher *s) { return (s->sdim % 64) == 0 && (
 // large the extra exact evaluations cost more than the stream saves -- measured on the reference's bench shape (1 M x
 // 1024, 1000-row lists): K = 100 int8 2.93 against f16 2.31 ms per step, K = 10 equal; C3 (9766-row lists) K = 10
 // 2.44 against 3.85, K = 100 4.21 against 5.10; 1 M x 768 (976-row lists) K = 10 1.07 against 1.16.
+// squared norms of the rows for the f32 / f16 MFMA screens (indexed by storage row; by list position in the images-only layout) and, in
+// the same pass, the corpus maximum -> power-of-two scale that maps it below 2^14 (f16 operand copy).  Once per searcher.
+int ensure_row_norms(const pqv_searcher *s, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(s->norms_mu);
+    if (s->norms_done) return PQV_OK;
+    DevBuf d_max;
+    HIP_TRY(d_max.alloc(sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
+    HIP_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, s->n_storage) * sizeof(float)));
+    HIP_TRY(pqv::launch_row_norms_max(s->d_mat, s->images_only ? s->d_row_of : nullptr, s->n_storage, s->sdim, s->d_row_norm2.as<float>(),
+                                      d_max.as<uint32_t>(), stream));
+    uint32_t bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, d_max.p, sizeof bits, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float m;
+    std::memcpy(&m, &bits, sizeof m);
+    if (bits < 0x7F800000u) {
+        int e = 0;
+        if (m > 0.0f) (void)std::frexp(m, &e);           // m = f * 2^e, f in [0.5, 1)  =>  m < 2^e
+        const int se = m > 0.0f ? 14 - e : 0;            // scale = 2^se: m * scale < 2^14
+        if (se >= -60 && se <= 60) { s->f16_ok = true; s->f16_scale = std::ldexp(1.0f, se); }
+    }
+    s->norms_done = true;
+    return PQV_OK;
+}
+
+constexpr int kNotFinite = -9001;      // ensure_blocked_copy(op 2) at creation: the rows are not all finite and moderate (the caller falls back)
+
 int screen_op(const pqv_searcher *s, uint32_t k = 1) {
     const uint64_t mean_len = s->n / std::max<uint32_t>(1, s->n_clusters);
     const bool i8_pays = !(k > 32 && mean_len < 4096) || s->opt.screen_i8 > 1;
     if (s->opt.screen_i8 && i8_pays && s->i8_ok && (s->sdim % 256) == 0 && s->sdim >= 256 && static_cast<uint64_t>(64) * s->sdim <= 147456) return 2;
+    if (!s->norms_done && ensure_row_norms(s, s->stream) != PQV_OK) return 0;      // (f16_ok is known only after that pass)
     if (s->opt.screen_f16 && s->f16_ok && (s->sdim % 128) == 0 && s->sdim <= 1024) return 1;
     return 0;
 }
@@ -2390,6 +2487,7 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
         if (ce != hipSuccess) { s->d_blk_off.release(); HIP_TRY(ce); }
     }
     const uint64_t tiles = std::max<uint64_t>(1, boff[kc]);
+    if (op != 2) { if (int rc = ensure_row_norms(s, stream)) return rc; }
     if (op == 2) {
         HIP_TRY(blk.alloc(tiles * 16 * s->sdim));
         HIP_TRY(s->d_row_n2i.ensure(std::max<uint64_t>(1, s->n) * sizeof(int)));
@@ -2415,9 +2513,23 @@ int ensure_blocked_copy(const pqv_searcher *s, int op, hipStream_t stream) {
             HIP_TRY(launch_global_center(kmin, kmax, kc, s->sdim, s->d_list_off.as<uint64_t>(), g_center, g_hs, stream));
             std::vector<float> h_scale(std::max<uint32_t>(1, kc));
             float h_g[2] = {0.0f, 1.0f};
+            std::vector<float> h_gc(s->norms_done ? 0 : s->sdim);
             HIP_TRY(hipMemcpyAsync(h_scale.data(), s->d_list_scale.p, static_cast<size_t>(kc) * sizeof(float), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(h_g, g_hs, sizeof h_g, hipMemcpyDeviceToHost, stream));
+            if (!h_gc.empty()) HIP_TRY(hipMemcpyAsync(h_gc.data(), g_center, h_gc.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (!s->norms_done) {
+                // No pass over the rows' norms has vouched for the data (creation builds this copy first): the per-dimension extremes
+                // do -- every |x_d| <= |mid-range_d| + half range =: m, at most twice the true maximum.  ensure_row_norms' rule is
+                // "finite, and 2^-46 <= max |x_d| < 2^74"; anything within a factor of two of those ends, an infinity or a NaN (it
+                // shows in the extremes) sends the caller to that pass, which decides exactly.
+                float m = 0.0f;
+                bool fin = h_g[0] == h_g[0] && h_g[0] < 1.0e30f;
+                for (float c : h_gc) { fin = fin && c == c; m = std::max(m, std::fabs(c)); }
+                m += h_g[0];
+                if (verbose()) std::fprintf(stderr, "[pqv] int8 copy first: half range %.4g, largest |value| <= %.4g, finite %d\n", h_g[0], m, fin ? 1 : 0);
+                if (!fin || !(m < 9.0e21f) || !(m > 3.0e-14f)) { s->i8_ok = false; return kNotFinite; }
+            }
             // row-weighted median of the list scales (an empty or one-point list says nothing about the data)
             std::vector<std::pair<float, uint64_t>> sc;
             uint64_t rows_total = 0;
@@ -2468,8 +2580,11 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     if (index->dim != corpus->dim)
         return fail(PQV_ERR_INVALID, "index dimension " + std::to_string(index->dim) +
                                          " does not match corpus dimension " + std::to_string(corpus->dim));
-    for (uint32_t r : index->list_rows)
-        if (r >= corpus->n) return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
+    if (index->permutation_of != 0 ? index->permutation_of != corpus->n : false)
+        return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
+    if (index->permutation_of == 0)       // (a build's lists are a permutation of the corpus' rows; anything else is checked)
+        for (uint32_t r : index->list_rows)
+            if (r >= corpus->n) return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
     if (!corpus->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
     if (int rc = use_device(corpus->device)) return rc;
     pqv_searcher *s = new (std::nothrow) pqv_searcher();
@@ -2485,7 +2600,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         else if (up(64) <= lim) s->sdim = up(64);
     }
     s->n = index->list_rows.size(); s->corpus = corpus;
-    s->h_list_off = index->list_off; s->h_list_rows = index->list_rows;
+    s->h_list_off = index->list_off; s->h_rows_sp = index->rows_sp;
     for (uint32_t c = 0; c < index->n_clusters; ++c)
         s->max_list_len = std::max<uint64_t>(s->max_list_len, index->list_off[c + 1] - index->list_off[c]);
     auto cleanup = [&](int code, const std::string &msg) { delete s; return fail(code, msg); };
@@ -2508,10 +2623,12 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         t_last = now;
     };
     mark("validation + host copies");
-    S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    S_TRY(pool_get(s->device, &s->stream));
+    mark("stream");
     S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
     S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
     S_TRY(s->d_ids.alloc(std::max<size_t>(1, index->list_rows.size()) * sizeof(uint32_t)));
+    mark("allocations");
     S_TRY(hipMemcpyAsync(s->d_centroids.p, index->centroids.data(), index->centroids.size() * sizeof(float),
                          hipMemcpyHostToDevice, s->stream));
     S_TRY(hipMemcpyAsync(s->d_list_off.p, index->list_off.data(), index->list_off.size() * sizeof(uint64_t),
@@ -2521,9 +2638,15 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         S_TRY(s->d_cent_t.alloc(static_cast<size_t>(s->kc_pad) * s->dim * sizeof(float)));
         S_TRY(pqv::launch_transpose_rows4(s->d_centroids.as<float>(), s->n_clusters, s->kc_pad, s->dim, s->d_cent_t.p, s->stream));
     }
-    if (!index->list_rows.empty())
-        S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice, s->stream));
+    mark("centroid tables");
+    if (!index->list_rows.empty()) {
+        const DevRows *dr = index->d_rows.get();
+        if (dr && dr->p && dr->device == s->device && dr->n == index->list_rows.size())      // the build's device copy
+            S_TRY(hipMemcpyAsync(s->d_ids.p, dr->p, index->list_rows.size() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+        else
+            S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
+                                 hipMemcpyHostToDevice, s->stream));
+    }
     mark("tables + ids upload");
     // images-only IVF layout: where the wide screened path will serve this searcher (rows of a multiple of 64 dims, lists of
     // >= 192 rows on average) and the caller's matrix stays (no PQV_RELEASE_ROW_ORDER); PQV_IVF_COPY=1 keeps the second copy (A/B)
@@ -2557,35 +2680,34 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     S_TRY(s->d_stats.alloc((8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long)));
     S_TRY(hipMemsetAsync(s->d_stats.p, 0, (8 + 16 * pqv::STATS_SLOTS) * sizeof(unsigned long long), s->stream));
 #endif
-    // squared norms of the rows for the MFMA screen of the batched re-rank (indexed by storage row; by list position in the
-    // images-only layout) and, in the same pass, the corpus maximum -> power-of-two scale that maps it below 2^14 (f16 operand copy)
+    s->n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
+    // The blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide screened path can apply
+    // to this searcher (ensure_blocked_copy rebuilds it if an option changes its form).  int8 form: rows of a multiple of 256 dims,
+    // IVF-ordered rows, finite data.  Where that copy is built right away, ITS first pass (the per-dimension extremes) vouches for the
+    // data and the rows' norms -- 5.5 ms of C3's creation, never read by the int8 screen -- wait for a call that needs them.
+    const bool build_now = wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 192;
+    const bool i8_shape = (s->sdim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0;
+    bool built = false;
     {
-        DevBuf d_max;
-        S_TRY(d_max.alloc(sizeof(uint32_t)));
-        S_TRY(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), s->stream));
-        const uint64_t n_storage = (flags & PQV_LAYOUT_ROW_ORDER) ? corpus->n : s->n;
-        S_TRY(s->d_row_norm2.alloc(std::max<uint64_t>(1, n_storage) * sizeof(float)));
-        S_TRY(pqv::launch_row_norms_max(s->d_mat, s->images_only ? s->d_row_of : nullptr, n_storage, s->sdim, s->d_row_norm2.as<float>(),
-                                        d_max.as<uint32_t>(), s->stream));
-        uint32_t bits = 0;
-        S_TRY(hipMemcpyAsync(&bits, d_max.p, sizeof bits, hipMemcpyDeviceToHost, s->stream));
-        S_TRY(hipStreamSynchronize(s->stream));
-        float m;
-        std::memcpy(&m, &bits, sizeof m);
-        if (bits < 0x7F800000u) {
-            int e = 0;
-            if (m > 0.0f) (void)std::frexp(m, &e);           // m = f * 2^e, f in [0.5, 1)  =>  m < 2^e
-            const int se = m > 0.0f ? 14 - e : 0;            // scale = 2^se: m * scale < 2^14
-            if (se >= -60 && se <= 60) { s->f16_ok = true; s->f16_scale = std::ldexp(1.0f, se); }
+        static const bool eager_norms = [] { const char *e = std::getenv("PQV_EAGER_NORMS"); return e && *e == '1'; }();
+        if (build_now && i8_shape && !eager_norms) {
+            s->i8_ok = true;                                   // (tentatively: screen_op must see it)
+            if (screen_op(s) == 2) {
+                const int rc = ensure_blocked_copy(s, 2, s->stream);
+                if (rc == PQV_OK) built = true;
+                else if (rc != kNotFinite) { delete s; return rc; }
+            }
+            if (!built) s->i8_ok = false;
         }
     }
-    // the blocked MFMA-operand copy of the lists is built here, not inside the first query, whenever the wide
-    // screened path can apply to this searcher (ensure_blocked_copy rebuilds it if an option changes its form)
-    // int8 form of the blocked copy: finite data (f16_ok), rows of a multiple of 256 dims, IVF-ordered rows
-    mark("row norms + maximum");
-    s->i8_ok = s->f16_ok && (s->sdim % 256) == 0 && !(flags & PQV_LAYOUT_ROW_ORDER) && s->n > 0;
-    if (wide_path_possible(s) && s->n / std::max<uint32_t>(1, s->n_clusters) >= 192) {
-        if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
+    mark("int8 copy first");
+    if (!built) {
+        if (int rc = ensure_row_norms(s, s->stream)) { delete s; return rc; }
+        mark("row norms + maximum");
+        s->i8_ok = s->f16_ok && i8_shape;
+        if (build_now) {
+            if (int rc = ensure_blocked_copy(s, screen_op(s), s->stream)) { delete s; return rc; }
+        }
     }
     S_TRY(hipStreamSynchronize(s->stream));
     mark("blocked operand copy");
@@ -3050,6 +3172,7 @@ int enqueue_topk(const pqv_searcher *s, const float *d_queries, uint32_t nq, uin
         ta.slots_per_pair = p.slots_per_pair; ta.slot_base = 0; ta.n_part = p.n_part_rr;
         ta.gthr = sc.s_gthr.as<unsigned long long>();
         ta.part_keys = sc.s_part_keys.as<uint64_t>(); ta.part_vals = sc.s_part_vals.as<uint32_t>();
+        if (p.filter && !(p.quad && p.i8)) { if (int rc = ensure_row_norms(s, stream)) return rc; }    // (the f32 / f16 screens read the rows' norms)
         ta.row_norm2 = s->d_row_norm2.as<float>(); ta.norm_by_pos = s->images_only ? 1 : 0;
         ta.stats = s->d_stats.as<unsigned long long>();
         ta.xcd_swizzle = 0;
@@ -3339,7 +3462,7 @@ int replay_with_clusters(const pqv_searcher *s, Scratch &sc, const float *d_quer
     for (uint32_t c : clusters) {                                        // candidate_rows order
         const uint64_t b = s->h_list_off[c], e = s->h_list_off[c + 1];
         for (uint64_t i = b; i < e && pos < use; ++i, ++pos) {
-            const HeapEnt ent{d[pos], s->h_list_rows[i]};
+            const HeapEnt ent{d[pos], (*s->h_rows_sp)[i]};
             if (heap.size() < k) heap_push(heap, ent);                   // search.rs:119-120
             else if (ent.d < heap[0].d) { heap_pop(heap); heap_push(heap, ent); }   // :121-125
         }
@@ -3831,7 +3954,7 @@ static int pqv_candidate_rows_impl(const pqv_searcher *s, const float *query, ui
     uint64_t o = 0;
     for (uint32_t i = 0; i < got; ++i) {  // probe-rank major, ascending ids inside (index.rs:59-62)
         const uint64_t b = s->h_list_off[clusters[i]], e = s->h_list_off[clusters[i] + 1];
-        std::memcpy(buf + o, s->h_list_rows.data() + b, (e - b) * sizeof(uint32_t));
+        std::memcpy(buf + o, s->h_rows_sp->data() + b, (e - b) * sizeof(uint32_t));
         o += e - b;
     }
     *rows = buf; *n_rows = total;

@@ -1712,3 +1712,37 @@ def test_chunk_major_work_items(pqv, oracle, case):
         _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
         screened[cm] = s.counters()["screened_pairs"]
     assert abs(screened[1] - screened[0]) <= 0.02 * screened[0], screened      # (order-dependent pair pruning, as above)
+
+
+@pytest.mark.parametrize("case", ["finite", "an_infinity", "norms_overflow", "eager"])
+def test_creation_builds_the_int8_copy_first_and_takes_the_norms_on_demand(pqv, oracle, monkeypatch, case):
+    """Creation order of round 6: where the int8 copy is built at creation, its own first pass (the per-dimension extremes) vouches for
+    the data and the pass over the rows' norms waits for a call that reads them -- here the K = 100 call on ~1100-row lists, which
+    screens with f16 operands.  Data that pass cannot vouch for (an infinity, values beyond 2^74) must take
+    the old order: norms first, no int8 copy.  PQV_EAGER_NORMS=1 is the old order by request.  The answers never change."""
+    rng = np.random.default_rng(4242)
+    n, dim, kc, nprobe, nq = 72000, 256, 64, 6, 256
+    data = rng.random((n, dim), dtype=np.float32)
+    if case == "an_infinity":
+        data[123, 7] = np.inf
+    elif case == "norms_overflow":
+        data[789] = np.float32(1e25)                     # finite, but beyond what the f16 / int8 images are scaled for
+    if case == "eager":
+        monkeypatch.setenv("PQV_EAGER_NORMS", "1")
+    queries = (data[rng.integers(1000, n, nq)] * np.float32(1.001)).astype(np.float32)
+    oidx = oracle.build_index(rng.random((n, dim), dtype=np.float32) if case == "an_infinity" else data, n_clusters=kc, workers=1, max_iters=2)
+    s = pqv.Searcher(pqv.Index.from_bytes(oidx.to_bytes()), pqv.Corpus.upload(data))
+    plan10 = s.describe(nq, 10, nprobe)
+    if case in ("finite", "eager"):
+        assert "int8 screen operands" in plan10, plan10
+    else:
+        assert "int8 screen operands" not in plan10, plan10
+    for k in (10, 100, 10):                              # int8 (or its fallback) -> f16 operands (the norms arrive now) -> int8 again
+        rows, dist, nf, nc = s.topk(queries, k, nprobe)
+        orows, odist, onf, onc = oidx.topk_batch(data, queries, k, nprobe)
+        assert (nc == onc).all() and (nf == onf).all()
+        live = ~np.isnan(odist)
+        assert (_bits(dist)[live] == _bits(odist)[live]).all()
+        _assert_topk_equal((rows, dist, nf), (orows, odist, onf), k)
+    if case == "finite":
+        assert "f16 screen operands" in s.describe(nq, 100, nprobe) or "f16" in s.describe(nq, 100, nprobe)
