@@ -393,37 +393,43 @@ hipError_t launch_list_center(const uint32_t *kmin, const uint32_t *kmax, uint32
 // The one-centre form (round 2's): per-dimension min / max over ALL lists -> centre and scale in entry 0 of scratch
 // tables (global_center_kernel), and, if that form is chosen, every list's entry overwritten with them
 // (broadcast_center_kernel) -- block_rows_i8_kernel and the screen kernels then need no second code path.
-__global__ __launch_bounds__(256) void global_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
-                                                           uint32_t n_clusters, uint32_t dim, const uint64_t *__restrict__ list_off,
-                                                           float *__restrict__ g_center, float *__restrict__ g_half_scale) {
-    __shared__ float wm[4];
-    float h = 0.0f;
-    for (uint32_t d = threadIdx.x; d < dim; d += 256) {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (uint32_t c = 0; c < n_clusters; ++c) {
+// (one block per 64 dimensions, sixteen slices of the lists per dimension reduced through LDS; the largest half range through an
+//  atomicMax on its bits -- it is >= 0 --, the scale by a one-thread kernel behind it.  As ONE 256-thread block this was 1 ms of C3's
+//  searcher creation: 1024 x 3 dependent loads per thread.)
+__global__ __launch_bounds__(1024) void global_center_kernel(const uint32_t *__restrict__ kmin, const uint32_t *__restrict__ kmax,
+                                                            uint32_t n_clusters, uint32_t dim, const uint64_t *__restrict__ list_off,
+                                                            float *__restrict__ g_center, float *__restrict__ g_half_scale) {
+    __shared__ uint32_t slo[16][64], shi[16][64];
+    const uint32_t lane = threadIdx.x & 63u, sl = threadIdx.x >> 6, d = blockIdx.x * 64u + lane;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    if (d < dim)
+        for (uint32_t c = sl; c < n_clusters; c += 16) {
             if (list_off[c + 1] == list_off[c]) continue;
             const uint32_t a = kmin[(uint64_t)c * dim + d], b = kmax[(uint64_t)c * dim + d];
             lo = a < lo ? a : lo; hi = b > hi ? b : hi;
         }
-        float ctr = 0.0f;
+    slo[sl][lane] = lo; shi[sl][lane] = hi;
+    __syncthreads();
+    if (sl == 0 && d < dim) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { const uint32_t a = slo[i][lane], b = shi[i][lane]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        float ctr = 0.0f, h = 0.0f;
         if (lo <= hi) {
             const float flo = unsortable_bits(lo), fhi = unsortable_bits(hi);
             ctr = 0.5f * flo + 0.5f * fhi;
-            h = fmaxf(h, fabsf(fmaxf(fhi - ctr, ctr - flo)));
+            h = fabsf(fmaxf(fhi - ctr, ctr - flo));
         }
         g_center[d] = ctr;
+        // (a NaN half range must survive the maximum as the old fmaxf chain's did not need to: its bits are above every number's)
+        atomicMax(reinterpret_cast<uint32_t *>(g_half_scale), __float_as_uint(h) & 0x7FFFFFFFu);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) h = fmaxf(h, __shfl_xor(h, off, 64));
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = h;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        h = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
-        if (!(sc < 1.0e15f)) sc = 1.0e15f;
-        if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
-        g_half_scale[0] = h; g_half_scale[1] = sc;
-    }
+}
+__global__ void global_scale_kernel(float *__restrict__ g_half_scale) {
+    const float h = g_half_scale[0];
+    float sc = h > 0.0f ? 127.0f / (h * 1.000001f) : 1.0f;
+    if (!(sc < 1.0e15f)) sc = 1.0e15f;
+    if (!(sc > 1.0e-30f)) sc = 1.0e-30f;
+    g_half_scale[1] = sc;
 }
 __global__ __launch_bounds__(256) void broadcast_center_kernel(const float *__restrict__ g_center, const float *__restrict__ g_half_scale,
                                                               uint32_t dim, float *__restrict__ center, float *__restrict__ half,
@@ -434,7 +440,10 @@ __global__ __launch_bounds__(256) void broadcast_center_kernel(const float *__re
 }
 hipError_t launch_global_center(const uint32_t *kmin, const uint32_t *kmax, uint32_t n_clusters, uint32_t dim, const uint64_t *list_off,
                                 float *g_center, float *g_half_scale, hipStream_t s) {
-    hipLaunchKernelGGL(global_center_kernel, dim3(1), dim3(256), 0, s, kmin, kmax, n_clusters, dim, list_off, g_center, g_half_scale);
+    hipError_t e = hipMemsetAsync(g_half_scale, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(global_center_kernel, dim3((dim + 63) / 64), dim3(1024), 0, s, kmin, kmax, n_clusters, dim, list_off, g_center, g_half_scale);
+    hipLaunchKernelGGL(global_scale_kernel, dim3(1), dim3(1), 0, s, g_half_scale);
     return hipGetLastError();
 }
 hipError_t launch_broadcast_center(const float *g_center, const float *g_half_scale, uint32_t n_clusters, uint32_t dim, float *center,
