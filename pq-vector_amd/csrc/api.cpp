@@ -220,17 +220,44 @@ struct DevRows {
     uint64_t n = 0;
     ~DevRows() { if (p) { int cur = -1; (void)hipGetDevice(&cur); if (hipSetDevice(device) == hipSuccess) (void)hipFree(p); if (cur >= 0) (void)hipSetDevice(cur); } }
 };
+// The index' lists as its callers see them: the host vector, plus -- after a build -- the device copy it has NOT been downloaded
+// from yet.  A build leaves the lists where it sorted them (4 bytes per row of HBM, freed with the last owner); the host copy is
+// made by the first call that reads it (the blob writer, pqv_index_list_rows, a searcher's host-side calls, a searcher on another
+// device).  Shared by the index and its searchers.
+struct ListRows {
+    std::mutex mu;
+    std::vector<uint32_t> host;
+    std::shared_ptr<DevRows> dev;
+    uint64_t n = 0;
+    bool pending = false;             // host is still empty: dev holds the lists
+    // the host vector, downloaded now if it has to be (nullptr + fail() if that goes wrong)
+    const std::vector<uint32_t> *get() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (pending) {
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            hipError_t e = hipSetDevice(dev->device);
+            if (e == hipSuccess) {
+                try { host.resize(n); } catch (const std::bad_alloc &) { if (cur >= 0) (void)hipSetDevice(cur); (void)fail(PQV_ERR_OOM, "host allocation failed"); return nullptr; }
+                e = hipMemcpy(host.data(), dev->p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            }
+            if (cur >= 0) (void)hipSetDevice(cur);
+            if (e != hipSuccess) { host.clear(); (void)fail(PQV_ERR_HIP, std::string("download of the inverted lists: ") + hipGetErrorString(e)); return nullptr; }
+            pending = false;
+        }
+        return &host;
+    }
+};
 struct pqv_index {
     uint32_t dim = 0;
     uint32_t n_clusters = 0;
     std::vector<float> centroids;     // [n_clusters * dim]
     std::vector<uint64_t> list_off;   // [n_clusters + 1]
-    // concatenated inverted lists; the vector is shared with the searchers made from this index (they keep it for the host-side
-    // calls -- candidate rows, replays -- without copying 4 bytes per row)
-    std::shared_ptr<std::vector<uint32_t>> rows_sp{std::make_shared<std::vector<uint32_t>>()};
-    std::vector<uint32_t> &list_rows{*rows_sp};
-    std::shared_ptr<DevRows> d_rows;  // see DevRows
-    uint64_t permutation_of = 0;      // != 0: list_rows is a permutation of [0, permutation_of) by construction (a build's result)
+    // concatenated inverted lists (see ListRows); `list_rows` is the host vector for the code that FILLS it -- readers go through rows->get()
+    std::shared_ptr<ListRows> rows{std::make_shared<ListRows>()};
+    std::vector<uint32_t> &list_rows{rows->host};
+    uint64_t n_rows() const { return rows->pending ? rows->n : rows->host.size(); }
+    uint64_t permutation_of = 0;      // != 0: the lists are a permutation of [0, permutation_of) by construction (a build's result)
     pqv_index() = default;
     pqv_index(const pqv_index &) = delete;
     pqv_index &operator=(const pqv_index &) = delete;
@@ -316,7 +343,7 @@ struct pqv_searcher {
     uint64_t max_list_len = 0;
     pqv_corpus *corpus = nullptr;          // borrowed
     std::vector<uint64_t> h_list_off;      // host copy for candidate_rows
-    std::shared_ptr<const std::vector<uint32_t>> h_rows_sp;   // the index' lists (shared, not copied)
+    std::shared_ptr<ListRows> h_rows;      // the index' lists (shared, not copied; the host copy is made by the first call that reads it)
     DevBuf d_cent_t;                   // [dim/4][kc_pad] float4 transpose of the centroids (probe_rows_kernel), dim % 4 == 0
     uint32_t kc_pad = 0;
     DevBuf d_centroids, d_list_off, d_ids, d_mat_ivf, d_stats;
@@ -1056,7 +1083,10 @@ extern "C" int pqv_index_from_bytes(const uint8_t *bytes, size_t len, pqv_index 
 static int pqv_index_to_bytes_impl(const pqv_index *idx, uint8_t **buf, size_t *len) {
     if (!idx || !buf || !len) return fail(PQV_ERR_INVALID, "index/buf/len must not be NULL");
     const uint64_t k = idx->n_clusters;
-    const size_t sz = 8 + idx->centroids.size() * 4 + static_cast<size_t>(k) * 4 + idx->list_rows.size() * 4;
+    const std::vector<uint32_t> *rows_p = idx->rows->get();
+    if (!rows_p) return PQV_ERR_HIP;
+    const std::vector<uint32_t> &rows_v = *rows_p;
+    const size_t sz = 8 + idx->centroids.size() * 4 + static_cast<size_t>(k) * 4 + rows_v.size() * 4;
     uint8_t *b = static_cast<uint8_t *>(std::malloc(sz));
     if (!b) return fail(PQV_ERR_OOM, "host allocation failed");
     size_t off = 0;
@@ -1071,7 +1101,7 @@ static int pqv_index_to_bytes_impl(const pqv_index *idx, uint8_t **buf, size_t *
         const uint64_t s = idx->list_off[c], e = idx->list_off[c + 1];
         wr_u32(b + off, static_cast<uint32_t>(e - s));
         off += 4;
-        for (uint64_t i = s; i < e; ++i, off += 4) wr_u32(b + off, idx->list_rows[i]);
+        for (uint64_t i = s; i < e; ++i, off += 4) wr_u32(b + off, rows_v[i]);
     }
     *buf = b;
     *len = sz;
@@ -1113,10 +1143,14 @@ extern "C" int pqv_index_from_parts(uint32_t dim, uint32_t n_clusters, const flo
 
 extern "C" uint32_t pqv_index_dim(const pqv_index *i) { return i ? i->dim : 0; }
 extern "C" uint32_t pqv_index_n_clusters(const pqv_index *i) { return i ? i->n_clusters : 0; }
-extern "C" uint64_t pqv_index_n_rows(const pqv_index *i) { return i ? i->list_rows.size() : 0; }
+extern "C" uint64_t pqv_index_n_rows(const pqv_index *i) { return i ? i->n_rows() : 0; }
 extern "C" const float *pqv_index_centroids(const pqv_index *i) { return i ? i->centroids.data() : nullptr; }
 extern "C" const uint64_t *pqv_index_list_offsets(const pqv_index *i) { return i ? i->list_off.data() : nullptr; }
-extern "C" const uint32_t *pqv_index_list_rows(const pqv_index *i) { return i ? i->list_rows.data() : nullptr; }
+extern "C" const uint32_t *pqv_index_list_rows(const pqv_index *i) {
+    if (!i) return nullptr;
+    const std::vector<uint32_t> *v = i->rows->get();         // (a build's lists are downloaded by the first reader)
+    return v ? v->data() : nullptr;
+}
 extern "C" void pqv_index_free(pqv_index *i) { delete i; }
 
 // ---------------------------------------------------------------------------------------
@@ -2120,7 +2154,7 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     if (n >= (1u << 20)) {
         try {
             warm.t = std::thread([&cluster_of, &rows_buf, n, dev_lists] {
-                try { if (!dev_lists) cluster_of.resize(n); rows_buf.resize(n); } catch (...) { }
+                try { if (!dev_lists) { cluster_of.resize(n); rows_buf.resize(n); } } catch (...) { }
             });
         } catch (const std::system_error &) { }
     }
@@ -2178,10 +2212,13 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
     idx->centroids.resize(k * dim);
     uint32_t h_bad = 0;
     hipError_t e = hipSuccess;
+    static const bool keep_dev = [] { const char *e = std::getenv("PQV_KEEP_DEVICE_LISTS"); return !(e && *e == '0'); }();
     if (dev_lists) {
-        idx->list_rows.resize(n);
         idx->list_off.resize(k + 1);
-        e = hipMemcpyAsync(idx->list_rows.data(), d_rows_sorted.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (!keep_dev) {                            // (the lists are not left on the device: downloaded here)
+            idx->list_rows.resize(n);
+            e = hipMemcpyAsync(idx->list_rows.data(), d_rows_sorted.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(idx->list_off.data(), d_off.p, (k + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, dlists.bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     } else if (!downloaded) {
@@ -2199,14 +2236,16 @@ int build_index_impl(const pqv_corpus *corpus, uint32_t n_clusters, uint32_t max
         delete idx;
         return fail(PQV_ERR_HIP, "internal error: final assignment out of range");
     }
-    if (dev_lists && d_rows_sorted.p) {             // the sorted row ids stay on the device for a searcher (PQV_KEEP_DEVICE_LISTS=0: freed here)
-        static const bool keep = [] { const char *e = std::getenv("PQV_KEEP_DEVICE_LISTS"); return !(e && *e == '0'); }();
-        if (keep) {
-            auto dr = std::make_shared<DevRows>();
-            dr->p = d_rows_sorted.p; dr->device = corpus->device; dr->n = n;
-            d_rows_sorted.p = nullptr; d_rows_sorted.bytes = 0;
-            idx->d_rows = std::move(dr);
-        }
+    if (dev_lists && keep_dev && d_rows_sorted.p) {
+        // The sorted row ids stay where they are: a searcher on this device copies them device to device, and the host copy (40 MB per
+        // 10 M rows: 3.5 ms of download) is made by the first call that reads it (ListRows::get).  PQV_KEEP_DEVICE_LISTS=0: downloaded above.
+        auto dr = std::make_shared<DevRows>();
+        dr->p = d_rows_sorted.p; dr->device = corpus->device; dr->n = n;
+        d_rows_sorted.p = nullptr; d_rows_sorted.bytes = 0;
+        idx->rows->dev = std::move(dr);
+        idx->rows->n = n;
+        idx->rows->host.clear();
+        idx->rows->pending = true;
     }
     idx->permutation_of = n;                        // every row was assigned exactly once
     g_build_stats[3] = t_fa1 - t_fa0; g_build_stats[4] = now_s() - t_fa1; g_build_stats[5] = assign_form > 0.0 ? assign_form : exact_assign ? 0.0 : 1.0;
@@ -2582,9 +2621,12 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
                                          " does not match corpus dimension " + std::to_string(corpus->dim));
     if (index->permutation_of != 0 ? index->permutation_of != corpus->n : false)
         return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
-    if (index->permutation_of == 0)       // (a build's lists are a permutation of the corpus' rows; anything else is checked)
-        for (uint32_t r : index->list_rows)
+    if (index->permutation_of == 0) {     // (a build's lists are a permutation of the corpus' rows; anything else is checked)
+        const std::vector<uint32_t> *rv = index->rows->get();
+        if (!rv) return PQV_ERR_HIP;
+        for (uint32_t r : *rv)
             if (r >= corpus->n) return fail(PQV_ERR_INVALID, "index row id out of range for this corpus");
+    }
     if (!corpus->d_rows) return fail(PQV_ERR_INVALID, "corpus row-order copy was released");
     if (int rc = use_device(corpus->device)) return rc;
     pqv_searcher *s = new (std::nothrow) pqv_searcher();
@@ -2599,8 +2641,8 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         else if (up(128) <= lim) s->sdim = up(128);
         else if (up(64) <= lim) s->sdim = up(64);
     }
-    s->n = index->list_rows.size(); s->corpus = corpus;
-    s->h_list_off = index->list_off; s->h_rows_sp = index->rows_sp;
+    s->n = index->n_rows(); s->corpus = corpus;
+    s->h_list_off = index->list_off; s->h_rows = index->rows;
     for (uint32_t c = 0; c < index->n_clusters; ++c)
         s->max_list_len = std::max<uint64_t>(s->max_list_len, index->list_off[c + 1] - index->list_off[c]);
     auto cleanup = [&](int code, const std::string &msg) { delete s; return fail(code, msg); };
@@ -2627,7 +2669,7 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
     mark("stream");
     S_TRY(s->d_centroids.alloc(index->centroids.size() * sizeof(float)));
     S_TRY(s->d_list_off.alloc(index->list_off.size() * sizeof(uint64_t)));
-    S_TRY(s->d_ids.alloc(std::max<size_t>(1, index->list_rows.size()) * sizeof(uint32_t)));
+    S_TRY(s->d_ids.alloc(std::max<size_t>(1, s->n) * sizeof(uint32_t)));
     mark("allocations");
     S_TRY(hipMemcpyAsync(s->d_centroids.p, index->centroids.data(), index->centroids.size() * sizeof(float),
                          hipMemcpyHostToDevice, s->stream));
@@ -2639,13 +2681,15 @@ static int pqv_searcher_create_impl(const pqv_index *index, pqv_corpus *corpus, 
         S_TRY(pqv::launch_transpose_rows4(s->d_centroids.as<float>(), s->n_clusters, s->kc_pad, s->dim, s->d_cent_t.p, s->stream));
     }
     mark("centroid tables");
-    if (!index->list_rows.empty()) {
-        const DevRows *dr = index->d_rows.get();
-        if (dr && dr->p && dr->device == s->device && dr->n == index->list_rows.size())      // the build's device copy
-            S_TRY(hipMemcpyAsync(s->d_ids.p, dr->p, index->list_rows.size() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-        else
-            S_TRY(hipMemcpyAsync(s->d_ids.p, index->list_rows.data(), index->list_rows.size() * sizeof(uint32_t),
-                                 hipMemcpyHostToDevice, s->stream));
+    if (s->n) {
+        const DevRows *dr = index->rows->dev.get();
+        if (dr && dr->p && dr->device == s->device && dr->n == s->n) {      // the build's device copy
+            S_TRY(hipMemcpyAsync(s->d_ids.p, dr->p, s->n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+        } else {
+            const std::vector<uint32_t> *rv = index->rows->get();
+            if (!rv) { delete s; return PQV_ERR_HIP; }
+            S_TRY(hipMemcpyAsync(s->d_ids.p, rv->data(), s->n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        }
     }
     mark("tables + ids upload");
     // images-only IVF layout: where the wide screened path will serve this searcher (rows of a multiple of 64 dims, lists of
@@ -3459,10 +3503,12 @@ int replay_with_clusters(const pqv_searcher *s, Scratch &sc, const float *d_quer
     std::vector<HeapEnt> heap;
     heap.reserve(static_cast<size_t>(std::min<uint64_t>(k, use)) + 1);
     uint64_t pos = 0;
+    const std::vector<uint32_t> *h_rows = s->h_rows->get();             // (the index' host lists: downloaded by the first call that reads them)
+    if (!h_rows) return PQV_ERR_HIP;
     for (uint32_t c : clusters) {                                        // candidate_rows order
         const uint64_t b = s->h_list_off[c], e = s->h_list_off[c + 1];
         for (uint64_t i = b; i < e && pos < use; ++i, ++pos) {
-            const HeapEnt ent{d[pos], (*s->h_rows_sp)[i]};
+            const HeapEnt ent{d[pos], (*h_rows)[i]};
             if (heap.size() < k) heap_push(heap, ent);                   // search.rs:119-120
             else if (ent.d < heap[0].d) { heap_pop(heap); heap_push(heap, ent); }   // :121-125
         }
@@ -3949,12 +3995,14 @@ static int pqv_candidate_rows_impl(const pqv_searcher *s, const float *query, ui
     if (int rc = pqv_probe(s, query, query_len, nprobe, clusters.data(), &got)) return rc;
     uint64_t total = 0;
     for (uint32_t i = 0; i < got; ++i) total += s->h_list_off[clusters[i] + 1] - s->h_list_off[clusters[i]];
+    const std::vector<uint32_t> *h_rows = s->h_rows->get();             // (downloaded by the first call that reads them)
+    if (!h_rows) return PQV_ERR_HIP;
     uint32_t *buf = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(1, total) * sizeof(uint32_t)));
     if (!buf) return fail(PQV_ERR_OOM, "host allocation failed");
     uint64_t o = 0;
     for (uint32_t i = 0; i < got; ++i) {  // probe-rank major, ascending ids inside (index.rs:59-62)
         const uint64_t b = s->h_list_off[clusters[i]], e = s->h_list_off[clusters[i] + 1];
-        std::memcpy(buf + o, s->h_rows_sp->data() + b, (e - b) * sizeof(uint32_t));
+        std::memcpy(buf + o, h_rows->data() + b, (e - b) * sizeof(uint32_t));
         o += e - b;
     }
     *rows = buf; *n_rows = total;
