@@ -1390,6 +1390,10 @@ struct GemmAssign {
     // round 4: 256 x 256 tiles with the rows on the lane-owned side and centroid images at one global scale (assign_wide_kernel +
     // assign_resolve_kernel); PQV_ASSIGN_TILE=128 keeps round 3's 128 x 256 kernel with its own exact pass (A/B, tests)
     bool wide = true;
+    // The Lloyd iterations assign the SAME rows again and again: with the centring vector kept from the first iteration (any fixed
+    // vector serves the bounds; the first centroid mean is as good as the current one) the rows' images and norms are made once.
+    bool keep_mu = false, mu_set = false;
+    const float *img_rows = nullptr; uint64_t img_n = 0; uint32_t img_dim_p = 0;       // what x16 / xn2 currently hold (single-chunk runs)
     float cmaxs = 0.0f, cn_max = 0.0f, kA = 0.0f;
     std::vector<float> h_cn2;
     unsigned long long exact_rows = 0, exact_evals = 0, rows_total = 0;
@@ -1419,7 +1423,7 @@ struct GemmAssign {
         HIP_TRY(mu.ensure(static_cast<size_t>(dim) * sizeof(float)));
         HIP_TRY(c16.ensure(static_cast<size_t>(kc_pad) * dim_p * sizeof(uint16_t)));
         HIP_TRY(cn2.ensure(static_cast<size_t>(kc_pad) * sizeof(float)));
-        HIP_TRY(launch_col_mean(d_c, kc, dim, mu.as<float>(), stream));
+        if (!(keep_mu && mu_set)) { HIP_TRY(launch_col_mean(d_c, kc, dim, mu.as<float>(), stream)); mu_set = true; img_rows = nullptr; }
         HIP_TRY(launch_center_normalize_f16(d_c, mu.as<float>(), kc, kc_pad, dim, dim_p, cn2.as<float>(), c16.p, stream));
         if (!wide) return finite(cn2.as<float>(), kc, stream, nonfinite);
         // one global scale for the centroid images: 2^8 / max |c - mu| (the norms come back anyway: this is the call's one host check)
@@ -1498,8 +1502,10 @@ struct GemmAssign {
         for (uint64_t r0 = 0; r0 < n; r0 += ch) {
             const uint64_t m = std::min<uint64_t>(ch, n - r0);
             const float *rows = d_rows + r0 * dim;
-            HIP_TRY(launch_center_normalize_f16(rows, mu.as<float>(), m, m, dim, dim_p, xn2.as<float>(), x16.p, stream));
+            const bool have_img = keep_mu && n <= ch && img_rows == d_rows && img_n == n && img_dim_p == dim_p;
+            if (!have_img) HIP_TRY(launch_center_normalize_f16(rows, mu.as<float>(), m, m, dim, dim_p, xn2.as<float>(), x16.p, stream));
             HIP_TRY(launch_nonfinite_flag(xn2.as<float>(), m, flag.as<uint32_t>(), stream));
+            img_rows = n <= ch ? d_rows : nullptr; img_n = n; img_dim_p = dim_p;
             HIP_TRY(hipMemsetAsync(cnt.p, 0, m * sizeof(uint32_t), stream));
             if (wide) {
                 AssignWideArgs w{};
@@ -2031,6 +2037,10 @@ int kmeans_device(const float *d_data, uint64_t n, uint32_t dim, uint32_t k, uin
     GemmAssign gemm;
     const bool use_gemm = GemmAssign::applicable(dim, k);
     const bool use_screen = !use_gemm && ScreenedAssign::applicable(dim, k);
+    {
+        const char *e = std::getenv("PQV_LLOYD_KEEP_IMAGES");
+        gemm.keep_mu = !(e && *e == '0');
+    }
     const bool dev_lists = DeviceLists::applicable(n, k);
     DeviceLists dlists;
     uint32_t h_bad = 0;

@@ -502,7 +502,10 @@ __global__ __launch_bounds__(64 * AW_NWM * NWN, NWN == 4 ? 1 : 2) void assign_wi
 hipError_t launch_assign_wide(const AssignWideArgs &a, hipStream_t s) {
     if (a.m == 0 || a.kc == 0) return hipSuccess;
     if ((a.dim_p % 64) != 0 || (uint64_t)a.dim_p * 2 * 512 >= 0x7FFFFFFFull || (a.kc_pad % AW_BM) != 0 || a.kc_pad < a.kc) return hipErrorInvalidValue;
-    static const bool half = [] { const char *e = getenv("PQV_ASSIGN_SHAPE"); return e && atoi(e) == 128; }();
+    // 256 centroids x 128 rows in 4-wave blocks, two per CU, where the rows make fewer than two rounds of 256-row blocks (the Lloyd
+    // iterations over the 100 k sample: 16.2-16.5 against 17.1-17.3 ms for twenty of them); PQV_ASSIGN_SHAPE=128 / 256 forces a shape
+    static const int shape = [] { const char *e = getenv("PQV_ASSIGN_SHAPE"); return e ? atoi(e) : 0; }();
+    const bool half = shape == 128 || (shape != 256 && a.m < 2ull * 256 * AW_BN);
     if (half) {
         constexpr int BN = 32 * AW_TN * 2;
         const uint64_t blocks = (a.m + BN - 1) / BN;
