@@ -332,3 +332,49 @@ def test_device_kmeanspp_rounds_equal_the_host_walk(n, dim, kc, style, workers):
         assert p.returncode == 0, p.stderr[-2000:]
         got[mode] = [l for l in p.stdout.splitlines() if l.startswith("BLOB")][0]
     assert got["1"] == got["0"]
+
+
+_ENV_SCRIPT = r"""
+import sys, os, hashlib
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import pq_vector_amd as pqv
+rng = np.random.default_rng(99)
+n, dim, kc = 120_000, 256, 128
+data = rng.random((n, dim), dtype=np.float32)
+queries = rng.random((64, dim), dtype=np.float32)
+corpus = pqv.Corpus.upload(data)
+idx = pqv.IndexBuilder(corpus).n_clusters(kc).max_iters(3).seed(3).workers(8).build()
+s = pqv.Searcher(idx, corpus)                                  # made BEFORE anything read the host lists
+rows, dist, nf, nc = s.topk(queries, 10, 8)
+off = np.asarray(idx.list_offsets); lr = np.asarray(idx.list_rows)                # (the host copy is made here at the latest)
+assert off[-1] == n and len(lr) == n and np.array_equal(np.sort(lr), np.arange(n, dtype=lr.dtype))
+blob = idx.to_bytes()
+s2 = pqv.Searcher(pqv.Index.from_bytes(blob), corpus)          # a loaded index: host lists only, validated row by row
+rows2, dist2, nf2, nc2 = s2.topk(queries, 10, 8)
+assert np.array_equal(rows, rows2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32))
+cr = s.candidate_rows(queries[0], 8) if hasattr(s, "candidate_rows") else None   # a host-side call that reads the shared lists
+h = hashlib.sha256(blob); h.update(rows.tobytes()); h.update(dist.tobytes()); h.update(nc.tobytes())
+if cr is not None: h.update(np.asarray(cr).tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.timeout(900)
+def test_round6_build_and_creation_switches_never_change_a_result():
+    """Round 6 moved work around -- the k-means++ pick and the list sort onto the device, the lists' host copy to its first reader, the
+    runtime's one-time set-up to the library's first call, the rows' norms behind the int8 copy, the Lloyd iterations' images out of
+    the loop.  Every switch that restores the old place (and all of them together) must give the same blob, the same answers and the
+    same candidate rows; a searcher made before the host lists exist and one made from the serialised blob must agree."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    switches = [{}, {"PQV_KPP_DEVICE": "0"}, {"PQV_DEVICE_LISTS": "0"}, {"PQV_KEEP_DEVICE_LISTS": "0"}, {"PQV_LAZY_INIT": "1"},
+                {"PQV_EAGER_NORMS": "1"}, {"PQV_LLOYD_KEEP_IMAGES": "0"}, {"PQV_ASSIGN_SHAPE": "256"},
+                {"PQV_KPP_DEVICE": "0", "PQV_DEVICE_LISTS": "0", "PQV_KEEP_DEVICE_LISTS": "0", "PQV_LAZY_INIT": "1", "PQV_EAGER_NORMS": "1",
+                 "PQV_LLOYD_KEEP_IMAGES": "0", "PQV_ASSIGN_SHAPE": "256"}]
+    got = []
+    for sw in switches:
+        p = subprocess.run([sys.executable, "-c", _ENV_SCRIPT], cwd=root, env=dict(os.environ, **sw), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (sw, p.stderr[-2000:])
+        got.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][0])
+    assert len(set(got)) == 1, list(zip(switches, got))
