@@ -1392,6 +1392,7 @@ struct GemmAssign {
     bool wide = true;
     // The Lloyd iterations assign the SAME rows again and again: with the centring vector kept from the first iteration (any fixed
     // vector serves the bounds; the first centroid mean is as good as the current one) the rows' images and norms are made once.
+    std::vector<uint32_t> h_perm; std::vector<float> h_grp;
     bool keep_mu = false, mu_set = false;
     const float *img_rows = nullptr; uint64_t img_n = 0; uint32_t img_dim_p = 0;       // what x16 / xn2 currently hold (single-chunk runs)
     float cmaxs = 0.0f, cn_max = 0.0f, kA = 0.0f;
@@ -1442,11 +1443,13 @@ struct GemmAssign {
         kA = 2.0f / (256.0f * cscale);
         // images in ascending-norm order: a 32-centroid group's own largest norm scales its error bound (a table trained on a
         // sample has a few far-out centroids -- clusters of one or two points -- and the table-wide maximum would loosen every bound)
-        std::vector<uint32_t> perm(kc);
+        std::vector<uint32_t> &perm = h_perm;          // (members: the uploads below need no synchronisation to outlive)
+        std::vector<float> &grp = h_grp;
+        perm.resize(kc);
         for (uint32_t c = 0; c < kc; ++c) perm[c] = c;
         std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return h_cn2[x] < h_cn2[y]; });
         const uint32_t ngrp = kc_pad / 32;
-        std::vector<float> grp(2 * static_cast<size_t>(ngrp), 0.0f);
+        grp.assign(2 * static_cast<size_t>(ngrp), 0.0f);
         for (uint32_t g = 0; g < ngrp; ++g) {
             float gm = 0.0f;
             for (uint32_t s = g * 32; s < std::min(kc, (g + 1) * 32); ++s) gm = std::max(gm, h_cn2[perm[s]]);
@@ -1457,8 +1460,7 @@ struct GemmAssign {
         HIP_TRY(hipMemcpyAsync(d_perm.p, perm.data(), static_cast<size_t>(kc) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_grp.p, grp.data(), grp.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         HIP_TRY(launch_center_normalize_f16(d_c, mu.as<float>(), kc, kc_pad, dim, dim_p, cn2.as<float>(), c16.p, stream, cscale, d_perm.as<uint32_t>()));
-        HIP_TRY(hipStreamSynchronize(stream));          // perm / grp are host vectors of this scope
-        return PQV_OK;
+        return PQV_OK;          // (perm / grp are members: a later call rewrites them only after its own synchronisation on the norms)
     }
     // cluster[0 .. n) for rows d_rows[0 .. n); *fallback = true if a row norm is not finite (the caller re-runs its old path)
     // h_out (optional): the assignment is also copied to this host array, chunk by chunk on a second stream, each copy behind
