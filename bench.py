@@ -751,7 +751,12 @@ def build_record(n, dim, kc, build_s):
     peak = 2500.0 if gemm else 157.3
     return {"seconds": build_s, "vectors_per_s": n / build_s,
             "phases_s": {"kmeans_pp": kpp, "lloyd": lloyd, "lloyd_iterations": int(iters), "final_assignment": fa,
-                         "host_list_build": host, "sample_rows": int(sample)},
+                         "host_list_build": host, "sample_rows": int(sample),
+                         "kmeans_pp_us_per_round": kpp / max(1, kc - 1) * 1e6,
+                         "note": "k-means++: the rounds run back to back on the device (csrc/kernels_kpp.hip: the pick's sequential f32 sums "
+                                 "evaluated exactly in parallel) where the int8 round screen applies, else a host round trip per centroid; "
+                                 "the inverted lists are sorted on the device and their host copy is made by the first call that reads it "
+                                 "(host_list_build is the host counting sort: 0 unless PQV_DEVICE_LISTS=0)"},
             "roofline": {"bound": "mfma",
                          "kernel": ("final assignment: center_normalize_f16_kernel + assign_wide_kernel (f16 contraction against all centroids, "
                                     "256 x 256 tiles) + assign_resolve_kernel (exact order where two or more candidates remain)") if gemm else
